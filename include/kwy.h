@@ -1,0 +1,99 @@
+/*
+ * include/kwy.h -- C ABI of libkwy.so, the MI355X (gfx950) implementation of
+ * kwiiyatta's per-utterance conversion hot path.
+ *
+ * The reference (Iselix/kwiiyatta) has no native code: its replaceable seam is
+ * the set of third-party calls it makes.  Every entry
+ * point below replaces one of those calls; the comment on each names the
+ * reference call site.  Conventions:
+ *
+ *   - all arrays are float64, C-contiguous, caller-allocated; the library never
+ *     retains or frees a caller pointer
+ *   - `kwy_<op>`      takes HOST pointers (what a ctypes/numpy binding passes);
+ *                     it stages through HBM, runs the HIP kernels and copies
+ *                     the result back (synchronous on return)
+ *   - `kwy_<op>_dev`  takes DEVICE pointers; work is enqueued on the context's
+ *                     HIP stream and NOT synchronised (call kwy_ctx_sync)
+ *   - return value: 0 on success, a negative KWY_E* code otherwise;
+ *     kwy_last_error(ctx) gives a message.  No C++ exception crosses the ABI.
+ *   - a kwy_ctx owns one HIP stream plus its device scratch; calls on one
+ *     context are serialised, different contexts run concurrently
+ *     (one context per utterance stream / per Python thread).
+ *   - There is NO CPU fallback: without a HIP device kwy_ctx_create fails.
+ */
+#ifndef KWY_H_
+#define KWY_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KWY_OK 0
+#define KWY_EINVAL (-1)   /* bad argument                               -> ValueError   */
+#define KWY_EHIP (-2)     /* HIP runtime / launch failure               -> RuntimeError */
+#define KWY_ENOMEM (-3)   /* device allocation failed                   -> MemoryError  */
+#define KWY_ENODEV (-4)   /* no usable HIP device                       -> RuntimeError */
+#define KWY_ENUMERIC (-5) /* numerical failure (e.g. covariance not PD) -> ValueError   */
+
+typedef struct kwy_ctx kwy_ctx;
+
+/* ---- context --------------------------------------------------------------- */
+int kwy_version(void);
+/* device: HIP device ordinal.  stream: an existing hipStream_t to enqueue on
+ * (e.g. torch's current stream), or NULL to let the context create its own. */
+int kwy_ctx_create(int device, void *stream, kwy_ctx **out);
+void kwy_ctx_destroy(kwy_ctx *ctx);
+int kwy_ctx_sync(kwy_ctx *ctx);
+void *kwy_ctx_stream(kwy_ctx *ctx);
+const char *kwy_last_error(kwy_ctx *ctx);
+/* error text when kwy_ctx_create itself failed (no context to ask) */
+const char *kwy_create_error(void);
+
+/* ---- sizes (pure host arithmetic, no device needed) -------------------------- */
+/* pyworld.get_cheaptrick_fft_size(fs, f0_floor)      kwiiyatta/vocoder/world.py:96 */
+int kwy_cheaptrick_fft_size(int fs, double f0_floor);
+/* number of frames pyworld.dio returns               kwiiyatta/vocoder/world.py:35 */
+int64_t kwy_dio_frames(int fs, int64_t x_length, double frame_period_ms);
+/* output length of pyworld.synthesize                kwiiyatta/vocoder/world.py:86 */
+int64_t kwy_synth_length(int64_t f0_length, double frame_period_ms, int fs);
+
+/* ---- WORLD analysis ----------------------------------------------------------- */
+/* pyworld.cheaptrick(x, f0, t, fs, q1, f0_floor, fft_size)
+ *                                                    kwiiyatta/vocoder/world.py:45
+ * fft_size <= 0: derive from (fs, f0_floor).  out: T x (fft_size/2+1).
+ * out_div: the result is divided by this value (pass fs to fold the
+ * `spectrum_envelope /= fs` of world.py:50 into the kernel; 1.0 = pyworld). */
+int kwy_cheaptrick(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+                   const double *temporal_positions, const double *f0, int64_t f0_length,
+                   double q1, double f0_floor, int fft_size, double out_div, double *out);
+int kwy_cheaptrick_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+                       const double *temporal_positions, const double *f0, int64_t f0_length,
+                       double q1, double f0_floor, int fft_size, double out_div, double *out);
+
+/* pyworld.d4c(x, f0, t, fs, threshold, fft_size)     kwiiyatta/vocoder/world.py:55
+ * out: T x (fft_size/2+1). */
+int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+            const double *temporal_positions, const double *f0, int64_t f0_length,
+            double threshold, int fft_size, double *out);
+int kwy_d4c_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+                const double *temporal_positions, const double *f0, int64_t f0_length,
+                double threshold, int fft_size, double *out);
+
+/* ---- WORLD synthesis ------------------------------------------------------------ */
+/* pyworld.synthesize(f0, sp, ap, fs, frame_period)   kwiiyatta/vocoder/world.py:86-92
+ * sp_mul: every spectrogram value is multiplied by this before use (pass fs to
+ * fold `spectrum_envelope * fs` of world.py:88; 1.0 = pyworld).
+ * y: kwy_synth_length(...) samples. */
+int kwy_synthesize(kwy_ctx *ctx, const double *f0, int64_t f0_length, const double *sp,
+                   const double *ap, int fft_size, double frame_period_ms, int fs,
+                   double sp_mul, int64_t y_length, double *y);
+int kwy_synthesize_dev(kwy_ctx *ctx, const double *f0, int64_t f0_length, const double *sp,
+                       const double *ap, int fft_size, double frame_period_ms, int fs,
+                       double sp_mul, int64_t y_length, double *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KWY_H_ */

@@ -1,0 +1,153 @@
+"""ctypes binding of ``libkwy.so`` (include/kwy.h), the gfx950 HIP library.
+
+There is no CPU fallback: importing this module without the built shared
+object raises ImportError, and creating a context without a HIP device raises
+RuntimeError (``libkwy: no HIP device available``).
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libkwy.so')
+
+if not os.path.exists(_SO):
+    raise ImportError(
+        f'{_SO} is missing: build the HIP extension first '
+        f'(python -c "import __graft_entry__ as g; g.build()" or kwiiyatta_amd/csrc/build.sh). '
+        f'kwiiyatta_amd has no CPU fallback.')
+
+lib = ctypes.CDLL(_SO)
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_vp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+
+KWY_OK, KWY_EINVAL, KWY_EHIP, KWY_ENOMEM, KWY_ENODEV, KWY_ENUMERIC = 0, -1, -2, -3, -4, -5
+
+# name -> (restype, argtypes); mirrors include/kwy.h line by line
+SIGNATURES = {
+    'kwy_version': (c_int, []),
+    'kwy_ctx_create': (c_int, [c_int, c_vp, ctypes.POINTER(c_vp)]),
+    'kwy_ctx_destroy': (None, [c_vp]),
+    'kwy_ctx_sync': (c_int, [c_vp]),
+    'kwy_ctx_stream': (c_vp, [c_vp]),
+    'kwy_last_error': (ctypes.c_char_p, [c_vp]),
+    'kwy_create_error': (ctypes.c_char_p, []),
+    'kwy_cheaptrick_fft_size': (c_int, [c_int, c_dbl]),
+    'kwy_dio_frames': (c_i64, [c_int, c_i64, c_dbl]),
+    'kwy_synth_length': (c_i64, [c_i64, c_dbl, c_int]),
+    'kwy_cheaptrick': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl, c_int,
+                               c_dbl, c_vp]),
+    'kwy_cheaptrick_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl,
+                                   c_int, c_dbl, c_vp]),
+    'kwy_d4c': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_int, c_vp]),
+    'kwy_d4c_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_int, c_vp]),
+    'kwy_dio': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_dbl,
+                        c_vp, c_vp]),
+    'kwy_stonemask': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp]),
+    'kwy_synthesize': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_i64,
+                               c_vp]),
+    'kwy_synthesize_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl,
+                                   c_i64, c_vp]),
+    'kwy_sp2mc': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_dbl, c_vp]),
+    'kwy_sp2mc_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_dbl, c_vp]),
+    'kwy_mc2sp': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_vp]),
+    'kwy_mc2sp_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_vp]),
+    'kwy_fastdtw': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'kwy_fastdtw_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'kwy_gmm_mlpg_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+}
+
+MISSING = []
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _f = getattr(lib, _name)
+    except AttributeError:
+        MISSING.append(_name)
+        continue
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+class Context:
+    """One HIP stream + device scratch (``kwy_ctx``).  Calls on one context are
+    serialised; use one context per thread / utterance stream."""
+
+    def __init__(self, device=0, stream=None):
+        h = c_vp()
+        rc = lib.kwy_ctx_create(int(device), c_vp(stream) if stream else None, ctypes.byref(h))
+        if rc != KWY_OK:
+            msg = lib.kwy_create_error().decode()
+            raise RuntimeError(msg or f'kwy_ctx_create failed ({rc})')
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            lib.kwy_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self, lib.kwy_ctx_sync(self.handle))
+
+    def error(self):
+        return lib.kwy_last_error(self.handle).decode()
+
+
+def check(ctx, rc):
+    if rc == KWY_OK:
+        return
+    msg = ctx.error() if ctx is not None else ''
+    if rc in (KWY_EINVAL, KWY_ENUMERIC):
+        raise ValueError(msg or 'invalid argument')
+    if rc == KWY_ENOMEM:
+        raise MemoryError(msg or 'device out of memory')
+    raise RuntimeError(msg or f'libkwy error {rc}')
+
+
+_tls = threading.local()
+_default_device = 0
+
+
+def set_default_device(device):
+    global _default_device
+    _default_device = int(device)
+    _tls.ctx = None
+
+
+def default_context():
+    """Per-thread default context on the default device (LOCAL_RANK-agnostic;
+    multi-GPU drivers call set_default_device(local_rank))."""
+    ctx = getattr(_tls, 'ctx', None)
+    if ctx is None or ctx.handle is None or ctx.device != _default_device:
+        ctx = Context(_default_device)
+        _tls.ctx = ctx
+    return ctx
+
+
+def as_f64(a, name='ndarray'):
+    """pyworld's input contract (reference tests/kwiiyatta/vocoder/test_world.py:21-40)."""
+    a = np.asarray(a)
+    if not a.flags['C_CONTIGUOUS']:
+        raise ValueError('ndarray is not C-contiguous')
+    if a.dtype != np.float64:
+        raise ValueError(f"Buffer dtype mismatch, expected 'double' but got {a.dtype!s}")
+    return a
+
+
+def ptr(a):
+    return c_vp(a.ctypes.data)

@@ -1,0 +1,72 @@
+"""pyworld-shaped front-end of the HIP WORLD kernels.
+
+Same names, argument meaning, defaults and error behaviour as the pyworld 0.2.8
+functions the reference calls (/root/reference/kwiiyatta/vocoder/world.py:35-96):
+float64 C-contiguous inputs (``ValueError('ndarray is not C-contiguous')``
+otherwise), freshly allocated numpy outputs.
+"""
+import numpy as np
+
+from .. import _lib
+from .._lib import lib, ptr
+
+default_frame_period = 5.0
+default_f0_floor = 71.0
+default_f0_ceil = 800.0
+
+
+def get_cheaptrick_fft_size(fs, f0_floor=default_f0_floor):
+    return lib.kwy_cheaptrick_fft_size(int(fs), float(f0_floor))
+
+
+def get_cheaptrick_f0_floor(fs, fft_size):
+    return 3.0 * fs / (fft_size - 3.0)
+
+
+def cheaptrick(x, f0, temporal_positions, fs, q1=-0.15, f0_floor=default_f0_floor,
+               fft_size=None, ctx=None, out_div=1.0):
+    x = _lib.as_f64(x)
+    f0 = _lib.as_f64(f0)
+    t = _lib.as_f64(temporal_positions)
+    if len(t) != len(f0):
+        raise ValueError('f0 and temporal_positions must have the same length')
+    if fft_size is None:
+        fft_size = get_cheaptrick_fft_size(fs, f0_floor)
+    ctx = ctx or _lib.default_context()
+    out = np.empty((len(f0), fft_size // 2 + 1))
+    _lib.check(ctx, lib.kwy_cheaptrick(ctx.handle, ptr(x), len(x), int(fs), ptr(t), ptr(f0),
+                                       len(f0), float(q1), float(f0_floor), int(fft_size),
+                                       float(out_div), ptr(out)))
+    return out
+
+
+def d4c(x, f0, temporal_positions, fs, threshold=0.85, fft_size=None, ctx=None):
+    x = _lib.as_f64(x)
+    f0 = _lib.as_f64(f0)
+    t = _lib.as_f64(temporal_positions)
+    if len(t) != len(f0):
+        raise ValueError('f0 and temporal_positions must have the same length')
+    if fft_size is None:
+        fft_size = get_cheaptrick_fft_size(fs, default_f0_floor)
+    ctx = ctx or _lib.default_context()
+    out = np.empty((len(f0), fft_size // 2 + 1))
+    _lib.check(ctx, lib.kwy_d4c(ctx.handle, ptr(x), len(x), int(fs), ptr(t), ptr(f0), len(f0),
+                                float(threshold), int(fft_size), ptr(out)))
+    return out
+
+
+def synthesize(f0, spectrogram, aperiodicity, fs, frame_period=default_frame_period, ctx=None,
+               sp_mul=1.0):
+    f0 = _lib.as_f64(f0)
+    sp = _lib.as_f64(spectrogram)
+    ap = _lib.as_f64(aperiodicity)
+    if sp.ndim != 2 or sp.shape != ap.shape or sp.shape[0] != len(f0):
+        raise ValueError('f0, spectrogram and aperiodicity shapes do not match')
+    fft_size = (sp.shape[1] - 1) * 2
+    y_length = int(len(f0) * frame_period * fs / 1000)
+    ctx = ctx or _lib.default_context()
+    y = np.empty(y_length)
+    _lib.check(ctx, lib.kwy_synthesize(ctx.handle, ptr(f0), len(f0), ptr(sp), ptr(ap), fft_size,
+                                       float(frame_period), int(fs), float(sp_mul), y_length,
+                                       ptr(y)))
+    return y

@@ -1,0 +1,305 @@
+// kwy_cheaptrick.hip -- CheapTrick spectral envelope on gfx950.
+//
+// Replaces pyworld.cheaptrick (reference call site kwiiyatta/vocoder/world.py:45;
+// algorithm: Morise 2015, as shipped with pyworld 0.2.8).  One 256-thread
+// workgroup per analysis frame; the whole frame lives in LDS:
+//
+//   F0-adaptive Hanning window of x (coalesced HBM reads of the framed audio)
+//   -> real FFT (half-length complex Stockham FFT in LDS) -> power spectrum
+//   -> DC correction -> linear smoothing (mirrored cumulative sum + 2 lerps)
+//   -> + |randn|*eps -> log -> FFT -> smoothing/recovery lifter -> inverse FFT
+//   -> exp -> HBM (coalesced, K doubles per frame)
+//
+// Algorithmic HBM bytes per frame: hop*8 (audio) + 16 (f0, t) in, K*8 out.
+// The serial xorshift "randn" stream of the CPU algorithm is reproduced with
+// per-frame jump-ahead (see kwy_ctx.hip).
+#include "kwy_internal.hpp"
+
+#define CT_EPS 0.00000000000000022204460492503131
+#define CT_DEFAULT_F0 500.0
+
+// per-frame draw counts: window length + K
+__global__ void k_ct_counts(const double *__restrict__ f0, int64_t T, int fs, double f0_floor_eff,
+                            int K, uint32_t *__restrict__ counts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  double cf0 = f0[i] <= f0_floor_eff ? CT_DEFAULT_F0 : f0[i];
+  int half = kwy_matlab_round(1.5 * fs / cf0);
+  counts[i] = (uint32_t)(2 * half + 1 + K);
+}
+
+// y(x) on the regular grid x0 + shift*j (WORLD interp1Q); delta of the last node is 0
+__device__ __forceinline__ double ct_interp1q(double x0, double shift, const double *y, int x_length,
+                                              double xi) {
+  double r = (xi - x0) / shift;
+  int base = (int)r;
+  double frac = r - base;
+  double y0 = y[base];
+  double dy = (base >= x_length - 1) ? 0.0 : y[base + 1] - y0;
+  return y0 + dy * frac;
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
+    const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
+    const double *__restrict__ f0, double q1, double f0_floor_eff,
+    const uint32_t *__restrict__ ebase, const uint4 *__restrict__ poly,
+    const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN, double out_div,
+    double *__restrict__ out) {
+  constexpr int N = 1 << LOG2N;
+  constexpr int H = N / 2;
+  constexpr int K = H + 1;
+  constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;  // draws owned per thread
+
+  extern __shared__ double smem[];
+  kwy_c *bufA = (kwy_c *)smem;           // H+1 complex
+  kwy_c *bufB = bufA + (H + 1);          // H+1 complex
+  double *red = (double *)(bufB + (H + 1));  // 8
+  double *tot = red + 8;                 // KWY_THREADS
+  uint32_t *e = (uint32_t *)(tot + KWY_THREADS);  // KWY_EBASE_WORDS
+
+  const int tid = threadIdx.x;
+  const int64_t frame = blockIdx.x;
+  const double f0v = f0[frame];
+  const double cf0 = f0v <= f0_floor_eff ? CT_DEFAULT_F0 : f0v;
+  const double pos = tpos[frame];
+  const int half = kwy_matlab_round(1.5 * fs / cf0);
+  const int wl = 2 * half + 1;
+  const int origin = kwy_matlab_round(pos * fs + 0.001);
+
+  // ---- noise: this thread owns draws [C*tid, C*tid + C) of the frame's stream
+  for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
+  __syncthreads();
+  kwy_rng rng = kwy_rng_combine(e, poly[tid]);
+  double nz[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) nz[j] = kwy_rng_randn(rng);
+
+  // ---- F0-adaptive window (thread owns samples i = C*tid + j < wl)
+  double wv[C];
+  double sumsq = 0.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int i = C * tid + j;
+    double position = (i - half) / 1.5 / fs;
+    double w = 0.5 * cos(KWY_PI * position * cf0) + 0.5;
+    wv[j] = w;
+    if (i < wl) sumsq += w * w;
+  }
+  const double average = sqrt(kwy_block_sum(sumsq, red));
+  double *A = (double *)bufA;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int i = C * tid + j;
+    if (i < wl) {
+      double wn = wv[j] / average;
+      wv[j] = wn;
+      int idx = min(x_length - 1, max(0, origin + i - half));
+      double v = x[idx] * wn;
+      v = v + nz[j] * 0.000000000000001;
+      A[i] = v;
+      s1 += v;
+      s2 += wn;
+    }
+  }
+  const double t1 = kwy_block_sum(s1, red);
+  const double t2 = kwy_block_sum(s2, red);
+  const double coef = t1 / t2;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int i = C * tid + j;
+    if (i < wl) A[i] -= wv[j] * coef;
+  }
+  for (int i = wl + tid; i < N; i += KWY_THREADS) A[i] = 0.0;
+
+  // ---- power spectrum
+  kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
+  kwy_c *Yc = (X == bufA) ? bufB : bufA;
+  double *P = (double *)Yc;  // K doubles
+  double *S = (double *)X;   // scratch after P is formed (N+2 doubles)
+  for (int k = tid; k <= H; k += KWY_THREADS) {
+    kwy_c v = X[k];
+    P[k] = v.x * v.x + v.y * v.y;
+  }
+  __syncthreads();
+
+  // ---- DC correction
+  {
+    const int upper_limit = 2 + (int)(cf0 * N / fs);
+    const int nrep = upper_limit - 1;
+    const double shift = -(double)fs / N;
+    for (int k = tid; k < nrep; k += KWY_THREADS)
+      S[k] = ct_interp1q(cf0, shift, P, upper_limit + 1, (double)k * fs / N);
+    __syncthreads();
+    for (int k = tid; k < nrep; k += KWY_THREADS) P[k] = P[k] + S[k];
+    __syncthreads();
+  }
+
+  // ---- linear smoothing, width 2 f0 / 3
+  {
+    const double width = cf0 * 2.0 / 3.0;
+    int boundary = (int)(width * N / fs) + 1;
+    if (boundary > H / 2) boundary = H / 2;  // guards LDS only; f0 > 3fs/8 is outside WORLD's domain
+    const int L = H + boundary * 2 + 1;
+    for (int i = tid; i < L; i += KWY_THREADS) {
+      double m;
+      if (i < boundary) m = P[boundary - i];
+      else if (i < H + boundary) m = P[i - boundary];
+      else m = P[H - (i - (H + boundary))];
+      S[i] = m * fs / N;
+    }
+    __syncthreads();
+    kwy_block_cumsum(S, L, tot);
+    const double origin_of_mirroring_axis = -(boundary - 0.5) * fs / N;
+    const double dfi = (double)fs / N;
+    for (int k = tid; k <= H; k += KWY_THREADS) {
+      double fa = (double)k / N * fs - width / 2.0;
+      double low = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
+      fa += width;
+      double high = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
+      P[k] = (high - low) / width;
+    }
+    __syncthreads();
+  }
+
+  // ---- infinitesimal noise: draw wl + k belongs to bin k
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int k = C * tid + j - wl;
+    if (k >= 0 && k <= H) P[k] = P[k] + fabs(nz[j]) * CT_EPS;
+  }
+  __syncthreads();
+
+  // ---- log spectrum, mirrored, into the other buffer
+  double *Lg = S;  // N doubles in buffer X
+  for (int k = tid; k <= H; k += KWY_THREADS) {
+    double v = log(P[k]);
+    Lg[k] = v;
+    if (k >= 1 && k < H) Lg[N - k] = v;
+  }
+  __syncthreads();
+  kwy_c *Cx = kwy_rfft_lds(X, Yc, LOG2N - 1, twH, twN);
+  kwy_c *Co = (Cx == bufA) ? bufB : bufA;
+
+  // ---- smoothing + recovery lifter
+  for (int k = tid; k <= H; k += KWY_THREADS) {
+    double sl, cl;
+    if (k == 0) {
+      sl = 1.0;
+      cl = (1.0 - 2.0 * q1) + 2.0 * q1;
+    } else {
+      double quefrency = (double)k / fs;
+      sl = sin(KWY_PI * cf0 * quefrency) / (KWY_PI * cf0 * quefrency);
+      cl = (1.0 - 2.0 * q1) + 2.0 * q1 * cos(2.0 * KWY_PI * quefrency * cf0);
+    }
+    Cx[k] = {Cx[k].x * sl * cl / N, 0.0};
+  }
+  kwy_c *W = kwy_irfft_lds(Cx, Co, LOG2N - 1, twH, twN);
+  const double *wr = (const double *)W;
+  double *o = out + frame * K;
+  if (out_div == 1.0) {
+    for (int k = tid; k <= H; k += KWY_THREADS) o[k] = exp(wr[k]);
+  } else {
+    for (int k = tid; k <= H; k += KWY_THREADS) o[k] = exp(wr[k]) / out_div;
+  }
+}
+
+template <int LOG2N>
+static int launch_ct(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                     const double *f0, int64_t T, double q1, double floor_eff,
+                     const uint32_t *ebase, double out_div, double *out) {
+  constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
+  constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;
+  const kwy_c *twH, *twN;
+  const uint4 *poly;
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
+  KWY_TRY(kwy_get_poly(ctx, 12ull * C, &poly));
+  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * (8 + KWY_THREADS) +
+               sizeof(uint32_t) * KWY_EBASE_WORDS;
+  KWY_HIP(hipFuncSetAttribute((const void *)k_cheaptrick<LOG2N>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_cheaptrick<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x,
+                     (int)x_length, fs, t, f0, q1, floor_eff, ebase, poly, twH, twN, out_div, out);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static size_t ct_scratch_bytes(int64_t T) {
+  return kwy_pad(sizeof(uint32_t) * T) + kwy_pad(sizeof(uint64_t) * (T + 1)) +
+         kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * T);
+}
+
+// device-pointer core; the arena must already have room (ct_scratch_bytes)
+static int cheaptrick_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                           const double *f0, int64_t T, double q1, int fft_size, double out_div,
+                           double *out) {
+  const int log2n = kwy_ilog2(fft_size);
+  if ((1 << log2n) != fft_size || log2n < 9 || log2n > 12) {
+    ctx->err = "cheaptrick: fft_size must be a power of two in [512, 4096]";
+    return KWY_EINVAL;
+  }
+  const int K = fft_size / 2 + 1;
+  const double floor_eff = 3.0 * fs / (fft_size - 3.0);
+  uint32_t *counts = kwy_arena<uint32_t>(ctx, T);
+  uint64_t *offsets = kwy_arena<uint64_t>(ctx, T + 1);
+  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * T);
+  if (!counts || !offsets || !ebase) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
+  hipLaunchKernelGGL(k_ct_counts, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, f0, T,
+                     fs, floor_eff, K, counts);
+  KWY_HIP(hipGetLastError());
+  KWY_TRY(kwy_launch_scan(ctx, counts, offsets, T));
+  KWY_TRY(kwy_launch_ebase(ctx, offsets, nullptr, T, ebase));
+  switch (log2n) {
+    case 9: return launch_ct<9>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
+    case 10: return launch_ct<10>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
+    case 11: return launch_ct<11>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
+    default: return launch_ct<12>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
+  }
+}
+
+static int ct_check(kwy_ctx *ctx, const void *x, int64_t x_length, int fs, const void *t,
+                    const void *f0, int64_t T, const void *out, int *fft_size, double f0_floor) {
+  if (!ctx) return KWY_EINVAL;
+  if (!x || !t || !f0 || !out || x_length <= 0 || T <= 0 || fs <= 0 || x_length > 0x7fffffff) {
+    ctx->err = "cheaptrick: bad argument";
+    return KWY_EINVAL;
+  }
+  if (*fft_size <= 0) {
+    if (!(f0_floor > 0)) { ctx->err = "cheaptrick: f0_floor must be positive"; return KWY_EINVAL; }
+    *fft_size = kwy_cheaptrick_fft_size(fs, f0_floor);
+  }
+  return KWY_OK;
+}
+
+extern "C" int kwy_cheaptrick_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+                                  const double *t, const double *f0, int64_t T, double q1,
+                                  double f0_floor, int fft_size, double out_div, double *out) {
+  KWY_TRY(ct_check(ctx, x, x_length, fs, t, f0, T, out, &fft_size, f0_floor));
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, ct_scratch_bytes(T)));
+  return cheaptrick_core(ctx, x, x_length, fs, t, f0, T, q1, fft_size, out_div, out);
+}
+
+extern "C" int kwy_cheaptrick(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+                              const double *t, const double *f0, int64_t T, double q1,
+                              double f0_floor, int fft_size, double out_div, double *out) {
+  KWY_TRY(ct_check(ctx, x, x_length, fs, t, f0, T, out, &fft_size, f0_floor));
+  KWY_HIP(hipSetDevice(ctx->device));
+  const int K = fft_size / 2 + 1;
+  for (int64_t i = 0; i < T; ++i)
+    if (!(f0[i] < fs * 0.375)) { ctx->err = "cheaptrick: f0 must be below 3*fs/8"; return KWY_EINVAL; }
+  size_t bx = kwy_pad(sizeof(double) * x_length), bt = kwy_pad(sizeof(double) * T);
+  size_t bo = kwy_pad(sizeof(double) * T * K);
+  KWY_TRY(kwy_arena_begin(ctx, ct_scratch_bytes(T) + bx + 2 * bt + bo));
+  double *dx = kwy_arena<double>(ctx, x_length), *dt = kwy_arena<double>(ctx, T);
+  double *df0 = kwy_arena<double>(ctx, T), *dout = kwy_arena<double>(ctx, (size_t)T * K);
+  KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * x_length, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dt, t, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(df0, f0, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
+  KWY_TRY(cheaptrick_core(ctx, dx, x_length, fs, dt, df0, T, q1, fft_size, out_div, dout));
+  KWY_HIP(hipMemcpyAsync(out, dout, sizeof(double) * T * K, hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}

@@ -1,0 +1,541 @@
+// kwy_d4c.hip -- D4C band aperiodicity (with the "LoveTrain" voicing gate) on gfx950.
+//
+// Replaces pyworld.d4c (reference call site kwiiyatta/vocoder/world.py:55;
+// algorithm: Morise 2016, as shipped with pyworld 0.2.8).  Two frame-parallel
+// kernels, one 256-thread workgroup per frame, everything staged in LDS:
+//
+//   k_d4c_lovetrain : Blackman-windowed frame -> power spectrum -> ratio of the
+//                     cumulative power at 4 kHz / 7.9 kHz  (voicing gate)
+//   k_d4c_body      : for gated frames: 2 temporal centroids (2 FFTs each),
+//                     smoothed power spectrum, static group delay, then per
+//                     3 kHz band a Nuttall-windowed FFT, an in-LDS sort and the
+//                     energy ratio; finally the band values are interpolated to
+//                     the K output bins.  Ungated frames write 1 - 1e-12.
+//
+// Algorithmic HBM bytes per frame: hop*8 + 16 in, K*8 out.
+#include <math.h>
+
+#include <vector>
+
+#include "kwy_internal.hpp"
+
+#define D4C_SAFE 0.000000000001
+#define D4C_FLOOR_F0 47.0
+#define D4C_FREQ_INTERVAL 3000.0
+#define D4C_UPPER_LIMIT 15000.0
+#define D4C_MAX_BANDS 8
+
+enum { D4C_HANNING = 1, D4C_BLACKMAN = 2 };
+
+__device__ __forceinline__ double d4c_window(int type, int i, int half, double ratio, int fs, double cf0) {
+  double position = (2.0 * (i - half) / ratio) / fs;
+  if (type == D4C_HANNING) return 0.5 * cos(KWY_PI * position * cf0) + 0.5;
+  return 0.42 + 0.5 * cos(KWY_PI * position * cf0) + 0.08 * cos(KWY_PI * position * cf0 * 2);
+}
+
+__device__ __forceinline__ double d4c_interp1q(double x0, double shift, const double *y, int x_length,
+                                               double xi) {
+  double r = (xi - x0) / shift;
+  int base = (int)r;
+  double frac = r - base;
+  double y0 = y[base];
+  double dy = (base >= x_length - 1) ? 0.0 : y[base + 1] - y0;
+  return y0 + dy * frac;
+}
+
+// WORLD DCCorrection in place on P[0..H]; S: scratch
+__device__ inline void d4c_dc_correction(double *P, double *S, double cf0, int fs, int N) {
+  const int upper_limit = 2 + (int)(cf0 * N / fs);
+  const int nrep = upper_limit - 1;
+  const double shift = -(double)fs / N;
+  for (int k = threadIdx.x; k < nrep; k += KWY_THREADS)
+    S[k] = d4c_interp1q(cf0, shift, P, upper_limit + 1, (double)k * fs / N);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nrep; k += KWY_THREADS) P[k] = P[k] + S[k];
+  __syncthreads();
+}
+
+// WORLD LinearSmoothing: in[0..H] -> out[0..H] (out may alias in); S: scratch of >= H+2b+1
+__device__ inline void d4c_linear_smoothing(const double *in, double *out, double *S, double *tot,
+                                            double width, int fs, int N) {
+  const int H = N / 2;
+  int boundary = (int)(width * N / fs) + 1;
+  if (boundary > H / 2) boundary = H / 2;  // LDS guard; outside WORLD's domain anyway
+  const int L = H + boundary * 2 + 1;
+  for (int i = threadIdx.x; i < L; i += KWY_THREADS) {
+    double m;
+    if (i < boundary) m = in[boundary - i];
+    else if (i < H + boundary) m = in[i - boundary];
+    else m = in[H - (i - (H + boundary))];
+    S[i] = m * fs / N;
+  }
+  __syncthreads();
+  kwy_block_cumsum(S, L, tot);
+  const double origin = -(boundary - 0.5) * fs / N;
+  const double dfi = (double)fs / N;
+  for (int k = threadIdx.x; k <= H; k += KWY_THREADS) {
+    double fa = (double)k / N * fs - width / 2.0;
+    double low = d4c_interp1q(origin, dfi, S, L, fa);
+    fa += width;
+    double high = d4c_interp1q(origin, dfi, S, L, fa);
+    out[k] = (high - low) / width;
+  }
+  __syncthreads();
+}
+
+// per-frame draw counts for the LoveTrain pass
+__global__ void k_d4c_lt_counts(const double *__restrict__ f0, int64_t T, int fs,
+                                uint32_t *__restrict__ counts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  double f = f0[i];
+  if (f == 0.0) { counts[i] = 0; return; }
+  double cf0 = f > 40.0 ? f : 40.0;
+  counts[i] = (uint32_t)(kwy_matlab_round(1.5 * fs / cf0) * 2 + 1);
+}
+
+// per-frame draw counts for the general body (0 for ungated frames)
+__global__ void k_d4c_body_counts(const double *__restrict__ f0, const double *__restrict__ ap0,
+                                  int64_t T, int fs, double threshold,
+                                  uint32_t *__restrict__ counts) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  double f = f0[i];
+  if (f == 0.0 || ap0[i] <= threshold) { counts[i] = 0; return; }
+  double cf0 = f > D4C_FLOOR_F0 ? f : D4C_FLOOR_F0;
+  counts[i] = (uint32_t)(3 * (kwy_matlab_round(2.0 * fs / cf0) * 2 + 1));
+}
+
+// ------------------------------------------------------------------ LoveTrain
+template <int LOG2N>
+__global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
+    const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
+    const double *__restrict__ f0, const uint32_t *__restrict__ ebase,
+    const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
+    double *__restrict__ ap0) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  constexpr int C = N / KWY_THREADS;
+  extern __shared__ double smem[];
+  kwy_c *bufA = (kwy_c *)smem;
+  kwy_c *bufB = bufA + (H + 1);
+  double *red = (double *)(bufB + (H + 1));
+  uint32_t *e = (uint32_t *)(red + 8);
+
+  const int tid = threadIdx.x;
+  const int64_t frame = blockIdx.x;
+  const double f0v = f0[frame];
+  if (f0v == 0.0) {
+    if (tid == 0) ap0[frame] = 0.0;
+    return;
+  }
+  const double cf0 = f0v > 40.0 ? f0v : 40.0;
+  const int half = kwy_matlab_round(3.0 * fs / cf0 / 2.0);
+  const int wl = 2 * half + 1;
+  const int origin = kwy_matlab_round(tpos[frame] * fs + 0.001);
+
+  for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
+  __syncthreads();
+  kwy_rng rng = kwy_rng_combine(e, poly[tid]);
+
+  double *A = (double *)bufA;
+  double wv[C], vv[C];
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int i = C * tid + j;
+    double nzv = kwy_rng_randn(rng);
+    double w = d4c_window(D4C_BLACKMAN, i, half, 3.0, fs, cf0);
+    int idx = min(x_length - 1, max(0, origin + i - half));
+    double v = x[idx] * w;
+    v = v + nzv * D4C_SAFE;
+    wv[j] = w; vv[j] = v;
+    if (i < wl) { s1 += v; s2 += w; }
+  }
+  const double t1 = kwy_block_sum(s1, red);
+  const double t2 = kwy_block_sum(s2, red);
+  const double coef = t1 / t2;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int i = C * tid + j;
+    A[i] = (i < wl) ? vv[j] - wv[j] * coef : 0.0;
+  }
+  kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
+
+  const int boundary0 = (int)ceil(100.0 * N / fs);
+  const int boundary1 = (int)ceil(4000.0 * N / fs);
+  const int boundary2 = (int)ceil(7900.0 * N / fs);
+  double c1 = 0.0, c2 = 0.0;
+  for (int k = boundary0 + 1 + tid; k <= boundary2 && k <= H; k += KWY_THREADS) {
+    kwy_c v = X[k];
+    double p = v.x * v.x + v.y * v.y;
+    c2 += p;
+    if (k <= boundary1) c1 += p;
+  }
+  const double n1 = kwy_block_sum(c1, red);
+  const double n2 = kwy_block_sum(c2, red);
+  if (tid == 0) ap0[frame] = n1 / n2;
+}
+
+// ------------------------------------------------------------------ general body
+struct d4c_params {
+  int x_length, fs, K, fft_size, nbands, window_length;
+  double threshold;
+};
+
+// Windowed, DC-removed frame into A (N reals).  Thread t owns the draws
+// [C*t, C*t+C) of the frame's 3*wl draws; window `which` uses draws
+// [which*wl, (which+1)*wl).  If `make_ramp`, also normalises to unit power and
+// writes A[i]*(i+1) into R.
+template <int N, int C>
+__device__ inline void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
+                                        double pos, int type, int which, const double (&nz)[C],
+                                        double *A, double *R, bool make_ramp, double *red) {
+  const int tid = threadIdx.x;
+  const int half = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0);
+  const int wl = 2 * half + 1;
+  const int origin = kwy_matlab_round(pos * p.fs + 0.001);
+  __syncthreads();
+  for (int i = tid; i < N; i += KWY_THREADS) A[i] = 0.0;
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int d = C * tid + j - which * wl;
+    if (d >= 0 && d < wl) {
+      double w = d4c_window(type, d, half, 4.0, p.fs, cf0);
+      int idx = min(p.x_length - 1, max(0, origin + d - half));
+      double v = x[idx] * w;
+      v = v + nz[j] * D4C_SAFE;
+      A[d] = v;
+      s1 += v; s2 += w;
+    }
+  }
+  const double t1 = kwy_block_sum(s1, red);
+  const double t2 = kwy_block_sum(s2, red);
+  const double coef = t1 / t2;
+  double pw = 0.0;
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    int d = C * tid + j - which * wl;
+    if (d >= 0 && d < wl) {
+      double w = d4c_window(type, d, half, 4.0, p.fs, cf0);
+      double v = A[d] - w * coef;
+      A[d] = v;
+      pw += v * v;
+    }
+  }
+  if (make_ramp) {
+    const double power = kwy_block_sum(pw, red);
+    const double sq = sqrt(power);
+    for (int i = tid; i < N; i += KWY_THREADS) {
+      double v = (i < wl) ? A[i] / sq : 0.0;
+      A[i] = v;
+      R[i] = v * (i + 1.0);
+    }
+  }
+  __syncthreads();
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(KWY_THREADS) void k_d4c_body(
+    const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
+    const double *__restrict__ ap0, d4c_params p, const uint32_t *__restrict__ ebase,
+    const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
+    const double *__restrict__ nuttall, double *__restrict__ out) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  constexpr int C = 3 * N / KWY_THREADS;  // draws per thread (3 windows, each shorter than N)
+  extern __shared__ double smem[];
+  kwy_c *buf0 = (kwy_c *)smem;
+  kwy_c *buf1 = buf0 + (H + 1);
+  kwy_c *buf2 = buf1 + (H + 1);
+  double *Dv = (double *)(buf2 + (H + 1));  // H+1: centroid sum, later group delay
+  double *red = Dv + (H + 2);               // 8
+  double *tot = red + 8;                    // KWY_THREADS
+  double *coarse = tot + KWY_THREADS;       // D4C_MAX_BANDS + 2
+  uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);
+
+  const int tid = threadIdx.x;
+  const int64_t frame = blockIdx.x;
+  const double f0v = f0[frame];
+  double *o = out + frame * p.K;
+  if (f0v == 0.0 || ap0[frame] <= p.threshold) {
+    for (int k = tid; k < p.K; k += KWY_THREADS) o[k] = 1.0 - D4C_SAFE;
+    return;
+  }
+  const double cf0 = f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0;
+  const double pos = tpos[frame];
+
+  for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
+  __syncthreads();
+  kwy_rng rng = kwy_rng_combine(e, poly[tid]);
+  double nz[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) nz[j] = kwy_rng_randn(rng);
+
+  // ---- static centroid: two temporal centroids at pos -+ 0.25/f0
+  for (int which = 0; which < 2; ++which) {
+    double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
+    d4c_frame_window<N, C>(x, p, cf0, cpos, D4C_BLACKMAN, which, nz, (double *)buf0, (double *)buf1,
+                           true, red);
+    // X1 = rfft(buf0) using buf2 as scratch; X2 = rfft(buf1) using the buffer X1 left free
+    kwy_c *X1 = kwy_rfft_lds(buf0, buf2, LOG2N - 1, twH, twN);
+    kwy_c *F = (X1 == buf0) ? buf2 : buf0;
+    kwy_c *X2 = kwy_rfft_lds(buf1, F, LOG2N - 1, twH, twN);
+    for (int k = tid; k <= H; k += KWY_THREADS) {
+      double c = X2[k].x * X1[k].x + X1[k].y * X2[k].y;
+      Dv[k] = which == 0 ? c : Dv[k] + c;
+    }
+    __syncthreads();
+  }
+  d4c_dc_correction(Dv, (double *)buf0, cf0, p.fs, N);
+
+  // ---- smoothed power spectrum
+  d4c_frame_window<N, C>(x, p, cf0, pos, D4C_HANNING, 2, nz, (double *)buf0, nullptr, false, red);
+  kwy_c *Xs = kwy_rfft_lds(buf0, buf1, LOG2N - 1, twH, twN);
+  double *P = (double *)buf2;
+  for (int k = tid; k <= H; k += KWY_THREADS) {
+    kwy_c v = Xs[k];
+    P[k] = v.x * v.x + v.y * v.y;
+  }
+  __syncthreads();
+  double *S = (double *)buf0;
+  double *G2 = (double *)buf1;
+  d4c_dc_correction(P, S, cf0, p.fs, N);
+  d4c_linear_smoothing(P, P, S, tot, cf0, p.fs, N);
+
+  // ---- static group delay
+  for (int k = tid; k <= H; k += KWY_THREADS) Dv[k] = Dv[k] / P[k];
+  __syncthreads();
+  d4c_linear_smoothing(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N);
+  d4c_linear_smoothing(Dv, G2, S, tot, cf0, p.fs, N);
+  for (int k = tid; k <= H; k += KWY_THREADS) Dv[k] = Dv[k] - G2[k];
+  __syncthreads();
+
+  // ---- coarse aperiodicity per band
+  const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
+  const int half_window_length = p.window_length / 2;
+  for (int b = 0; b < p.nbands; ++b) {
+    const int center = (int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs);
+    double *A = (double *)buf0;
+    for (int j = tid; j < N; j += KWY_THREADS)
+      A[j] = (j <= half_window_length * 2) ? Dv[center - half_window_length + j] * nuttall[j] : 0.0;
+    kwy_c *Xb = kwy_rfft_lds(buf0, buf1, LOG2N - 1, twH, twN);
+    double *Q = (double *)buf2;  // N slots: power spectrum padded with +inf for the sort
+    for (int k = tid; k < N; k += KWY_THREADS) {
+      double v = INFINITY;
+      if (k <= H) { kwy_c c = Xb[k]; v = c.x * c.x + c.y * c.y; }
+      Q[k] = v;
+    }
+    __syncthreads();
+    // bitonic sort ascending of N values
+    for (int size = 2; size <= N; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < N / 2; t += KWY_THREADS) {
+          int lo = 2 * t - (t & (stride - 1));
+          int hi = lo + stride;
+          bool up = ((lo & size) == 0);
+          double a = Q[lo], c = Q[hi];
+          if ((a > c) == up) { Q[lo] = c; Q[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    double cs = 0.0, ca = 0.0;
+    for (int k = tid; k <= H; k += KWY_THREADS) {
+      double v = Q[k];
+      ca += v;
+      if (k <= H - boundary - 1) cs += v;
+    }
+    const double nsmall = kwy_block_sum(cs, red);
+    const double nall = kwy_block_sum(ca, red);
+    if (tid == 0) {
+      double c = 10 * log10(nsmall / nall);
+      c = c + (cf0 - 100) / 50.0;
+      coarse[b + 1] = c < 0.0 ? c : 0.0;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    coarse[0] = -60.0;
+    coarse[p.nbands + 1] = -D4C_SAFE;
+  }
+  __syncthreads();
+
+  // ---- interp1 of the (nbands+2)-point contour onto the K output bins
+  const int nn = p.nbands + 2;
+  for (int k = tid; k < p.K; k += KWY_THREADS) {
+    double xi = (double)k * p.fs / p.fft_size;
+    int seg = 0;  // number of nodes <= xi
+    for (int j = 0; j < nn; ++j) {
+      double xj = (j <= p.nbands) ? j * D4C_FREQ_INTERVAL : p.fs / 2.0;
+      if (xj <= xi) seg = j + 1;
+    }
+    if (seg < 1) seg = 1;
+    if (seg > nn - 1) seg = nn - 1;
+    double xa = (seg - 1 <= p.nbands) ? (seg - 1) * D4C_FREQ_INTERVAL : p.fs / 2.0;
+    double xb = (seg <= p.nbands) ? seg * D4C_FREQ_INTERVAL : p.fs / 2.0;
+    double s = (xi - xa) / (xb - xa);
+    double v = coarse[seg - 1] + s * (coarse[seg] - coarse[seg - 1]);
+    o[k] = pow(10.0, v / 20.0);
+  }
+}
+
+// ------------------------------------------------------------------ host side
+template <int LOG2N>
+static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                     const double *f0, int64_t T, const uint32_t *ebase, double *ap0) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  const kwy_c *twH, *twN;
+  const uint4 *poly;
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
+  KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
+  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
+  KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_d4c_lovetrain<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream,
+                     x, (int)x_length, fs, t, f0, ebase, poly, twH, twN, ap0);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+template <int LOG2N>
+static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const double *f0,
+                       const double *ap0, const d4c_params &p, int64_t T, const uint32_t *ebase,
+                       const double *nuttall, double *out) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  const kwy_c *twH, *twN;
+  const uint4 *poly;
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
+  KWY_TRY(kwy_get_poly(ctx, 12ull * (3 * N / KWY_THREADS), &poly));
+  size_t lds = sizeof(kwy_c) * 3 * (H + 1) +
+               sizeof(double) * ((H + 2) + 8 + KWY_THREADS + D4C_MAX_BANDS + 2) +
+               sizeof(uint32_t) * KWY_EBASE_WORDS;
+  KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x, t,
+                     f0, ap0, p, ebase, poly, twH, twN, nuttall, out);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static int get_nuttall(kwy_ctx *ctx, int window_length, const double **out) {
+  std::string key = "nuttall:" + std::to_string(window_length);
+  auto it = ctx->d_mats.find(key);
+  if (it == ctx->d_mats.end()) {
+    std::vector<double> h(window_length);
+    for (int i = 0; i < window_length; ++i) {
+      double tmp = i / (window_length - 1.0);
+      h[i] = 0.355768 - 0.487396 * cos(2.0 * KWY_PI * tmp) + 0.144232 * cos(4.0 * KWY_PI * tmp) -
+             0.012604 * cos(6.0 * KWY_PI * tmp);
+    }
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(double) * window_length));
+    KWY_HIP(hipMemcpy(d, h.data(), sizeof(double) * window_length, hipMemcpyHostToDevice));
+    it = ctx->d_mats.emplace(key, d).first;
+  }
+  *out = it->second;
+  return KWY_OK;
+}
+
+static size_t d4c_scratch_bytes(int64_t T) {
+  return 2 * (kwy_pad(sizeof(uint32_t) * T) + kwy_pad(sizeof(uint64_t) * (T + 1))) +
+         kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * T) + kwy_pad(sizeof(double) * T);
+}
+
+static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                    const double *f0, int64_t T, double threshold, int fft_size, double *out) {
+  const int n4 = (int)pow(2.0, 1.0 + (int)(log(4.0 * fs / D4C_FLOOR_F0 + 1) / 0.69314718055994529));
+  const int nl = (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / 40.0 + 1) / 0.69314718055994529));
+  const int l4 = kwy_ilog2(n4), ll = kwy_ilog2(nl);
+  if (l4 < 10 || l4 > 12 || ll < 10 || ll > 12) {
+    ctx->err = "d4c: sampling rate outside the supported range (8 kHz .. 48 kHz)";
+    return KWY_EINVAL;
+  }
+  d4c_params p;
+  p.x_length = (int)x_length;
+  p.fs = fs;
+  p.fft_size = fft_size;
+  p.K = fft_size / 2 + 1;
+  double lim = fs / 2.0 - D4C_FREQ_INTERVAL;
+  if (lim > D4C_UPPER_LIMIT) lim = D4C_UPPER_LIMIT;
+  p.nbands = (int)(lim / D4C_FREQ_INTERVAL);
+  if (p.nbands < 0) p.nbands = 0;
+  if (p.nbands > D4C_MAX_BANDS) { ctx->err = "d4c: too many bands"; return KWY_EINVAL; }
+  p.window_length = (int)(D4C_FREQ_INTERVAL * n4 / fs) * 2 + 1;
+  p.threshold = threshold;
+
+  uint32_t *counts = kwy_arena<uint32_t>(ctx, T);
+  uint64_t *offs_lt = kwy_arena<uint64_t>(ctx, T + 1);
+  uint64_t *offs_b = kwy_arena<uint64_t>(ctx, T + 1);
+  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * T);
+  double *ap0 = kwy_arena<double>(ctx, T);
+  if (!counts || !offs_lt || !offs_b || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
+  const double *nuttall;
+  KWY_TRY(get_nuttall(ctx, p.window_length, &nuttall));
+  const unsigned gb = (unsigned)((T + 255) / 256);
+
+  // LoveTrain pass
+  hipLaunchKernelGGL(k_d4c_lt_counts, dim3(gb), dim3(256), 0, ctx->stream, f0, T, fs, counts);
+  KWY_HIP(hipGetLastError());
+  KWY_TRY(kwy_launch_scan(ctx, counts, offs_lt, T));
+  KWY_TRY(kwy_launch_ebase(ctx, offs_lt, nullptr, T, ebase));
+  switch (ll) {
+    case 10: KWY_TRY(launch_lt<10>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
+    case 11: KWY_TRY(launch_lt<11>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
+    default: KWY_TRY(launch_lt<12>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
+  }
+  // general body; its noise continues where the LoveTrain pass stopped (offs_lt[T])
+  hipLaunchKernelGGL(k_d4c_body_counts, dim3(gb), dim3(256), 0, ctx->stream, f0, ap0, T, fs,
+                     threshold, counts);
+  KWY_HIP(hipGetLastError());
+  KWY_TRY(kwy_launch_scan(ctx, counts, offs_b, T));
+  KWY_TRY(kwy_launch_ebase(ctx, offs_b, offs_lt + T, T, ebase));
+  switch (l4) {
+    case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
+    case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
+    default: return launch_body<12>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
+  }
+}
+
+static int d4c_check(kwy_ctx *ctx, const void *x, int64_t x_length, int fs, const void *t,
+                     const void *f0, int64_t T, const void *out, int *fft_size) {
+  if (!ctx) return KWY_EINVAL;
+  if (!x || !t || !f0 || !out || x_length <= 0 || T <= 0 || fs <= 0 || x_length > 0x7fffffff) {
+    ctx->err = "d4c: bad argument";
+    return KWY_EINVAL;
+  }
+  if (*fft_size <= 0) *fft_size = kwy_cheaptrick_fft_size(fs, 71.0);
+  return KWY_OK;
+}
+
+extern "C" int kwy_d4c_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                           const double *f0, int64_t T, double threshold, int fft_size,
+                           double *out) {
+  KWY_TRY(d4c_check(ctx, x, x_length, fs, t, f0, T, out, &fft_size));
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, d4c_scratch_bytes(T)));
+  return d4c_core(ctx, x, x_length, fs, t, f0, T, threshold, fft_size, out);
+}
+
+extern "C" int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                       const double *f0, int64_t T, double threshold, int fft_size, double *out) {
+  KWY_TRY(d4c_check(ctx, x, x_length, fs, t, f0, T, out, &fft_size));
+  KWY_HIP(hipSetDevice(ctx->device));
+  for (int64_t i = 0; i < T; ++i)
+    if (!(f0[i] >= 0.0 && f0[i] < fs * 0.2)) { ctx->err = "d4c: f0 must lie in [0, fs/5)"; return KWY_EINVAL; }
+  const int K = fft_size / 2 + 1;
+  size_t bx = kwy_pad(sizeof(double) * x_length), bt = kwy_pad(sizeof(double) * T);
+  size_t bo = kwy_pad(sizeof(double) * T * K);
+  KWY_TRY(kwy_arena_begin(ctx, d4c_scratch_bytes(T) + bx + 2 * bt + bo));
+  double *dx = kwy_arena<double>(ctx, x_length), *dt = kwy_arena<double>(ctx, T);
+  double *df0 = kwy_arena<double>(ctx, T), *dout = kwy_arena<double>(ctx, (size_t)T * K);
+  KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * x_length, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dt, t, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(df0, f0, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
+  KWY_TRY(d4c_core(ctx, dx, x_length, fs, dt, df0, T, threshold, fft_size, dout));
+  KWY_HIP(hipMemcpyAsync(out, dout, sizeof(double) * T * K, hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}

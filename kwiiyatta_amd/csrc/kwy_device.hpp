@@ -1,0 +1,270 @@
+// kwy_device.hpp -- device-side building blocks shared by the gfx950 kernels:
+//   * WORLD's xorshift128 "randn" stream with GF(2) jump-ahead, so that every
+//     frame / pulse draws exactly the numbers the serial CPU algorithm would
+//   * block-wide f64 reductions and scans (64-wide wavefronts)
+//   * LDS-resident double-precision Stockham FFTs (radix-4 + one radix-2 pass)
+//     and the half-length real-FFT packing around them
+// Written for CDNA4 only (wave64, 160 KB LDS); no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define KWY_THREADS 256
+#define KWY_WAVES (KWY_THREADS / 64)
+#define KWY_PI 3.1415926535897932384
+
+// ---------------------------------------------------------------- xorshift128
+struct kwy_rng {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ void kwy_rng_seed(kwy_rng &r) {
+  r.x = 123456789u; r.y = 362436069u; r.z = 521288629u; r.w = 88675123u;
+}
+
+__device__ __forceinline__ uint32_t kwy_rng_step(kwy_rng &r) {
+  uint32_t t = r.x ^ (r.x << 11);
+  r.x = r.y; r.y = r.z; r.z = r.w;
+  r.w = (r.w ^ (r.w >> 19)) ^ (t ^ (t >> 8));
+  return r.w;
+}
+
+// one "randn" = 12 generator steps (sum of 12 uniforms, WORLD matlabfunctions)
+__device__ __forceinline__ double kwy_rng_randn(kwy_rng &r) {
+  uint32_t tmp = kwy_rng_step(r) >> 4;
+#pragma unroll
+  for (int i = 0; i < 11; ++i) tmp += kwy_rng_step(r) >> 4;
+  return tmp / 268435456.0 - 6.0;
+}
+
+// Wavefront-cooperative jump: all 64 lanes hold the same state s[4]; on return
+// every lane holds T^steps s.  pow2: [64][128] columns of T^(2^k) (uint4 each).
+__device__ inline void kwy_wave_jump(uint32_t (&s)[4], uint64_t steps, const uint4 *__restrict__ pow2) {
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; steps != 0; ++k, steps >>= 1) {
+    if (!(steps & 1)) continue;
+    // lane l owns state bits l and l+64 (words l>>5 and 2+(l>>5))
+    const uint32_t wlo = lane < 32 ? s[0] : s[1];
+    const uint32_t whi = lane < 32 ? s[2] : s[3];
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    uint32_t m = 0u - ((wlo >> (lane & 31)) & 1u);
+    uint4 c = pow2[k * 128 + lane];
+    o0 ^= c.x & m; o1 ^= c.y & m; o2 ^= c.z & m; o3 ^= c.w & m;
+    m = 0u - ((whi >> (lane & 31)) & 1u);
+    c = pow2[k * 128 + 64 + lane];
+    o0 ^= c.x & m; o1 ^= c.y & m; o2 ^= c.z & m; o3 ^= c.w & m;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      o0 ^= __shfl_xor(o0, d); o1 ^= __shfl_xor(o1, d);
+      o2 ^= __shfl_xor(o2, d); o3 ^= __shfl_xor(o3, d);
+    }
+    s[0] = o0; s[1] = o1; s[2] = o2; s[3] = o3;
+  }
+}
+
+// e[0..130]: the extended word sequence of a start state S0 (e0..e3 = x,y,z,w,
+// e[4+i] = output of step i+1), so that T^i S0 = (e[i], e[i+1], e[i+2], e[i+3]).
+#define KWY_EBASE_WORDS 132
+__device__ inline void kwy_rng_ebase(kwy_rng s, uint32_t *e) {
+  e[0] = s.x; e[1] = s.y; e[2] = s.z; e[3] = s.w;
+  for (int i = 4; i < 131; ++i) e[i] = kwy_rng_step(s);
+  e[131] = 0;
+}
+
+// state = sum_i c_i T^i S0 with c = coefficients of x^n mod P(x) (P = the
+// characteristic polynomial of T); e[] lives in LDS.
+__device__ __forceinline__ void kwy_rng_combine_word(kwy_rng &r, const uint32_t *e, uint32_t bits,
+                                                      uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+#pragma unroll 8
+  for (int b = 0; b < 32; ++b) {
+    uint32_t w3 = e[b + 3];
+    uint32_t m = 0u - ((bits >> b) & 1u);
+    r.x ^= w0 & m; r.y ^= w1 & m; r.z ^= w2 & m; r.w ^= w3 & m;
+    w0 = w1; w1 = w2; w2 = w3;
+  }
+}
+
+__device__ __forceinline__ kwy_rng kwy_rng_combine(const uint32_t *e, uint4 c) {
+  kwy_rng r = {0, 0, 0, 0};
+  uint32_t w0 = e[0], w1 = e[1], w2 = e[2];
+  kwy_rng_combine_word(r, e, c.x, w0, w1, w2);
+  kwy_rng_combine_word(r, e + 32, c.y, w0, w1, w2);
+  kwy_rng_combine_word(r, e + 64, c.z, w0, w1, w2);
+  kwy_rng_combine_word(r, e + 96, c.w, w0, w1, w2);
+  return r;
+}
+
+// ------------------------------------------------------------ block reductions
+__device__ __forceinline__ double kwy_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;
+}
+
+// sum over the whole block; every thread gets the result. red: >= KWY_WAVES doubles.
+__device__ __forceinline__ double kwy_block_sum(double v, double *red) {
+  v = kwy_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int i = 1; i < KWY_WAVES; ++i) s += red[i];
+  return s;
+}
+
+// in-place inclusive prefix sum of buf[0..L) (LDS).  Thread t owns the
+// contiguous chunk [t*chunk, (t+1)*chunk).  tot: KWY_THREADS doubles of LDS.
+__device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
+  const int t = threadIdx.x;
+  const int chunk = (L + KWY_THREADS - 1) / KWY_THREADS;
+  const int b0 = t * chunk;
+  const int b1 = min(L, b0 + chunk);
+  double run = 0.0;
+  for (int i = b0; i < b1; ++i) { run += buf[i]; buf[i] = run; }
+  tot[t] = run;
+  __syncthreads();
+  if (t < 64) {  // wave 0 scans the 256 chunk totals, 4 per lane
+    double a0 = tot[4 * t], a1 = tot[4 * t + 1], a2 = tot[4 * t + 2], a3 = tot[4 * t + 3];
+    a1 += a0; a2 += a1; a3 += a2;
+    double inc = a3;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      double u = __shfl_up(inc, o);
+      if (t >= o) inc += u;
+    }
+    double excl = inc - a3;  // sum of lanes before this one
+    // exclusive offsets per chunk
+    tot[4 * t] = excl; tot[4 * t + 1] = excl + a0; tot[4 * t + 2] = excl + a1; tot[4 * t + 3] = excl + a2;
+  }
+  __syncthreads();
+  const double off = tot[t];
+  if (t > 0)
+    for (int i = b0; i < b1; ++i) buf[i] += off;
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------- LDS FFTs
+struct kwy_c { double x, y; };  // complex double (16 B, LDS b128 accesses)
+
+__device__ __forceinline__ kwy_c cadd(kwy_c a, kwy_c b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ kwy_c csub(kwy_c a, kwy_c b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ kwy_c cmul(kwy_c a, kwy_c b) {
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+
+// One Stockham radix-4 pass over H points: x -> y, sub-transform stride s.
+// tw: H-entry table exp(-2 pi i k / H).  INV conjugates the twiddles.
+template <bool INV>
+__device__ __forceinline__ void kwy_fft_r4(const kwy_c *__restrict__ x, kwy_c *__restrict__ y,
+                                           int H, int s, int log2s,
+                                           const kwy_c *__restrict__ tw) {
+  const int Q = H >> 2;
+  for (int j = threadIdx.x; j < Q; j += KWY_THREADS) {
+    const int q = j & (s - 1);
+    const int p = j >> log2s;
+    kwy_c a = x[j], b = x[j + Q], c = x[j + 2 * Q], d = x[j + 3 * Q];
+    kwy_c apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+    kwy_c jb = INV ? kwy_c{bmd.y, -bmd.x} : kwy_c{-bmd.y, bmd.x};  // = +-i*(b-d), sign folded below
+    // forward: y1 = amc - i*bmd, y3 = amc + i*bmd ; inverse: swapped
+    kwy_c y0 = cadd(apc, bpd);
+    kwy_c y1 = csub(amc, jb);
+    kwy_c y2 = csub(apc, bpd);
+    kwy_c y3 = cadd(amc, jb);
+    const int ps = p << log2s;
+    kwy_c w1 = tw[ps], w2 = tw[2 * ps], w3 = tw[3 * ps];
+    if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+    const int o = q + ((4 * p) << log2s);
+    y[o] = y0;
+    y[o + s] = cmul(w1, y1);
+    y[o + 2 * s] = cmul(w2, y2);
+    y[o + 3 * s] = cmul(w3, y3);
+  }
+}
+
+// final radix-2 pass (sub-transform size 2, no twiddle), s = H/2
+__device__ __forceinline__ void kwy_fft_r2(const kwy_c *__restrict__ x, kwy_c *__restrict__ y, int H) {
+  const int s = H >> 1;
+  for (int q = threadIdx.x; q < s; q += KWY_THREADS) {
+    kwy_c a = x[q], b = x[q + s];
+    y[q] = cadd(a, b);
+    y[q + s] = csub(a, b);
+  }
+}
+
+// Complex FFT of H = 2^log2H points held in LDS buffer a; b is a scratch buffer
+// of the same size.  Returns the buffer that holds the (natural order) result.
+// Unnormalised in both directions.  Ends with a barrier.
+template <bool INV>
+__device__ inline kwy_c *kwy_fft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ tw) {
+  const int H = 1 << log2H;
+  kwy_c *src = a, *dst = b;
+  int log2s = 0;
+  __syncthreads();
+  for (int rem = log2H; rem >= 2; rem -= 2) {
+    kwy_fft_r4<INV>(src, dst, H, 1 << log2s, log2s, tw);
+    __syncthreads();
+    kwy_c *t = src; src = dst; dst = t;
+    log2s += 2;
+  }
+  if (log2H & 1) {
+    kwy_fft_r2(src, dst, H);
+    __syncthreads();
+    kwy_c *t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
+// Real FFT of N = 2H reals.  `a` holds the N reals (viewed as H packed complex),
+// `b` is scratch; both need room for H+1 complex.  twH: H-entry table for the
+// H-point transform, twN: table exp(-2 pi i k / N) for k < H.
+// Returns the buffer holding X[0..H] (H+1 complex bins).
+__device__ inline kwy_c *kwy_rfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ twH,
+                                      const kwy_c *__restrict__ twN) {
+  const int H = 1 << log2H;
+  kwy_c *z = kwy_fft_lds<false>(a, b, log2H, twH);
+  kwy_c *o = (z == a) ? b : a;
+  for (int k = threadIdx.x; k <= H; k += KWY_THREADS) {
+    kwy_c r;
+    if (k == 0) {
+      r = {z[0].x + z[0].y, 0.0};
+    } else if (k == H) {
+      r = {z[0].x - z[0].y, 0.0};
+    } else {
+      kwy_c A = z[k];
+      kwy_c B = {z[H - k].x, -z[H - k].y};
+      double er = 0.5 * (A.x + B.x), ei = 0.5 * (A.y + B.y);
+      double dr = 0.5 * (A.x - B.x), di = 0.5 * (A.y - B.y);
+      double orr = di, oi = -dr;
+      kwy_c w = twN[k];
+      r = {er + (orr * w.x - oi * w.y), ei + (orr * w.y + oi * w.x)};
+    }
+    o[k] = r;
+  }
+  __syncthreads();
+  return o;
+}
+
+// Inverse of the above (unnormalised c2r: result = N * true inverse).
+// `a` holds X[0..H]; returns the buffer whose first N doubles are the signal.
+__device__ inline kwy_c *kwy_irfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ twH,
+                                       const kwy_c *__restrict__ twN) {
+  const int H = 1 << log2H;
+  __syncthreads();
+  for (int k = threadIdx.x; k < H; k += KWY_THREADS) {
+    double ar = a[k].x, ai = (k == 0) ? 0.0 : a[k].y;
+    double br = a[H - k].x, bi = (k == 0) ? 0.0 : -a[H - k].y;
+    double er = ar + br, ei = ai + bi;
+    double dr = ar - br, di = ai - bi;
+    kwy_c w = twN[k];
+    double wr = w.x, wi = -w.y;
+    double orr = dr * wr - di * wi, oi = dr * wi + di * wr;
+    b[k] = {er - oi, ei + orr};
+  }
+  return kwy_fft_lds<true>(b, a, log2H, twH);
+}
+
+__device__ __forceinline__ int kwy_matlab_round(double x) {
+  return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5);
+}

@@ -1,0 +1,74 @@
+// kwy_internal.hpp -- host-side internals of libkwy.so (context, scratch arena,
+// constant tables).  Not part of the ABI (see include/kwy.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/kwy.h"
+#include "kwy_device.hpp"
+
+struct kwy_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // scratch arena (grow-only bump allocator, reset at the start of every call)
+  char *arena = nullptr;
+  size_t arena_cap = 0, arena_off = 0;
+
+  // constant tables
+  uint4 *d_pow2 = nullptr;                 // [64][128] columns of T^(2^k)
+  kwy_c *d_tw[20] = {nullptr};             // d_tw[l]: exp(-2 pi i k / 2^l), k < 2^l
+  std::map<uint64_t, uint4 *> d_poly;      // stride(steps) -> x^(stride*t) mod P, t < 256
+  std::map<std::string, double *> d_mats;  // cached host-built matrices (mcep etc.)
+};
+
+#define KWY_HIP(call)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+      return e_ == hipErrorOutOfMemory ? KWY_ENOMEM : KWY_EHIP;                    \
+    }                                                                              \
+  } while (0)
+
+#define KWY_TRY(call)              \
+  do {                             \
+    int rc_ = (call);              \
+    if (rc_ != KWY_OK) return rc_; \
+  } while (0)
+
+// --- arena ------------------------------------------------------------------
+// Reserve `bytes` of scratch for the current call (must be called once, before
+// any kwy_arena_alloc of the call); grows the arena if needed.
+int kwy_arena_begin(kwy_ctx *ctx, size_t bytes);
+void *kwy_arena_alloc(kwy_ctx *ctx, size_t bytes);
+template <typename T>
+static inline T *kwy_arena(kwy_ctx *ctx, size_t n) {
+  return (T *)kwy_arena_alloc(ctx, n * sizeof(T));
+}
+static inline size_t kwy_pad(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// --- tables -----------------------------------------------------------------
+int kwy_get_twiddles(kwy_ctx *ctx, int log2n, const kwy_c **out);
+int kwy_get_poly(kwy_ctx *ctx, uint64_t stride_steps, const uint4 **out);
+
+// --- shared small kernels (kwy_ctx.hip) --------------------------------------
+// offsets[i] = sum_{j<i} counts[j] (u32 -> u64), single block
+int kwy_launch_scan(kwy_ctx *ctx, const uint32_t *counts, uint64_t *offsets, int64_t n);
+// ebase[i][0..131] for the generator state after 12*(*base + offsets[i]) steps
+// (base_draws: device pointer to a draw count, or NULL for 0)
+int kwy_launch_ebase(kwy_ctx *ctx, const uint64_t *offsets, const uint64_t *base_draws, int64_t n,
+                     uint32_t *ebase);
+
+static inline int kwy_ilog2(int n) {
+  int l = 0;
+  while ((1 << l) < n) ++l;
+  return l;
+}

@@ -1,0 +1,663 @@
+// kwy_synth.hip -- WORLD pulse-synchronous overlap-add synthesis on gfx950.
+//
+// Replaces pyworld.synthesize (reference call site kwiiyatta/vocoder/world.py:86-92;
+// algorithm: Morise et al. 2016 "WORLD", synthesis.cpp as shipped with pyworld 0.2.8).
+//
+//   time base   : per-sample f0/vuv interpolation, phase accumulation as a
+//                 device-wide f64 scan (tile sums -> scan -> tile rescan),
+//                 pulse detection + ordered compaction          (5 tiny kernels)
+//   noise       : pulse p starts (idx[p]-idx[0]) draws into the serial randn
+//                 stream -> per-pulse jump-ahead                    (1 kernel)
+//   per pulse   : one 256-thread workgroup: interpolate the two neighbouring
+//                 spectral/aperiodicity frames (coalesced HBM reads), build the
+//                 minimum-phase periodic and aperiodic responses with LDS FFTs,
+//                 and overlap-add the 2*(K-1) samples into y with f64 atomics.
+//
+// Algorithmic HBM bytes per frame: 2*K*8 + 8 in, hop*8 out.
+#include <math.h>
+
+#include <vector>
+
+#include "kwy_internal.hpp"
+
+#define SYN_SAFE 0.000000000001
+#define SYN_DEFAULT_F0 500.0
+#define SYN_TILE_PER_THREAD 8
+#define SYN_TILE (KWY_THREADS * SYN_TILE_PER_THREAD)
+#define SYN_TWO_PI (2.0 * KWY_PI)
+
+struct syn_params {
+  int64_t T, y_length;
+  int fs, fft_size;
+  double frame_period;  // seconds
+  double lowest_f0;
+  double sp_mul;
+};
+
+// per-sample phase increment and vuv (synthesis.cpp GetTimeBase + interp1/histc)
+__device__ __forceinline__ double syn_increment(const double *__restrict__ f0, const syn_params &p,
+                                                int64_t n, double *vuv_out) {
+  const double fp = p.frame_period;
+  const double xi = n / (double)p.fs;
+  int64_t g = (int64_t)(xi / fp);
+  if (g > p.T) g = p.T;
+  while (g + 1 <= p.T && (g + 1) * fp <= xi) ++g;
+  while (g > 0 && g * fp > xi) --g;
+  int64_t k = g + 1;  // number of nodes <= xi, clamped to [1, T]
+  if (k < 1) k = 1;
+  if (k > p.T) k = p.T;
+  const double xa = (k - 1) * fp, xb = k * fp;
+  const double s = (xi - xa) / (xb - xa);
+  auto cf = [&](int64_t j) -> double {
+    if (j < p.T) { double v = f0[j]; return v < p.lowest_f0 ? 0.0 : v; }
+    double a = f0[p.T - 1], b = f0[p.T - 2];
+    a = a < p.lowest_f0 ? 0.0 : a;
+    b = b < p.lowest_f0 ? 0.0 : b;
+    return a * 2 - b;
+  };
+  auto cv = [&](int64_t j) -> double {
+    if (j < p.T) { double v = f0[j]; return v < p.lowest_f0 ? 0.0 : 1.0; }
+    double a = f0[p.T - 1] < p.lowest_f0 ? 0.0 : 1.0;
+    double b = f0[p.T - 2] < p.lowest_f0 ? 0.0 : 1.0;
+    return a * 2 - b;
+  };
+  const double fa = cf(k - 1), fb = cf(k);
+  const double va = cv(k - 1), vb = cv(k);
+  double f = fa + s * (fb - fa);
+  double v = va + s * (vb - va);
+  v = v > 0.5 ? 1.0 : 0.0;
+  if (v == 0.0) f = SYN_DEFAULT_F0;
+  *vuv_out = v;
+  return 2.0 * KWY_PI * f / p.fs;
+}
+
+__device__ __forceinline__ int syn_block_exscan_int(int v, int *sh, int *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
+  }
+  __syncthreads();
+  if (lane == 63) sh[wv] = inc;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < KWY_WAVES; ++i) {
+    if (i < wv) woff += sh[i];
+    tot += sh[i];
+  }
+  *total = tot;
+  return woff + (inc - v);
+}
+
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_scan_counts(int *__restrict__ cnt, int nt,
+                                                                int *__restrict__ npulse) {
+  __shared__ int tot[KWY_THREADS];
+  const int t = threadIdx.x;
+  const int chunk = (nt + KWY_THREADS - 1) / KWY_THREADS;
+  const int b0 = t * chunk, b1 = min(nt, b0 + chunk);
+  int run = 0;
+  for (int i = b0; i < b1; ++i) run += cnt[i];
+  tot[t] = run;
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int i = 0; i < KWY_THREADS; ++i) { int v = tot[i]; tot[i] = acc; acc += v; }
+    npulse[0] = acc;
+  }
+  __syncthreads();
+  run = tot[t];
+  for (int i = b0; i < b1; ++i) { int v = cnt[i]; cnt[i] = run; run += v; }
+}
+
+// phase A: per-sample phase increment 2*pi*f0/fs and vuv flag
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_inc(const double *__restrict__ f0, syn_params p,
+                                                        double *__restrict__ inc,
+                                                        unsigned char *__restrict__ vuv8) {
+  const int64_t n = (int64_t)blockIdx.x * KWY_THREADS + threadIdx.x;
+  if (n >= p.y_length) return;
+  double vuv;
+  inc[n] = syn_increment(f0, p, n, &vuv);
+  vuv8[n] = vuv > 0.5 ? 1 : 0;
+}
+
+// phase B: the running phase  tp[n] = fl(tp[n-1] + inc[n])  EXACTLY as the serial
+// CPU loop rounds it, but computed with block-wide scans.
+//
+// While tp stays inside one binade [2^k, 2^(k+1)) every addition rounds to a
+// multiple of u = 2^(k-52):  fl(m*u + c) = (m + rn(c/u))*u, where rn is
+// round-to-nearest-even on the integer m + c/u.  Only an exact tie
+// (frac(c/u) == 1/2) depends on the running value, and then only on the parity
+// of m.  So each sample is a map {parity in} -> {integer delta}; such maps
+// compose associatively and can be scanned.  The few additions that carry tp
+// into the next binade are done with a real f64 add, after which the scan
+// restarts in the new binade.  (Pulse positions are decided by these roundings
+// whenever the period is an exact number of samples, e.g. the 500 Hz default of
+// unvoiced segments at 16/48 kHz, so this is needed for parity.)
+#define SYN_PH_THREADS 1024
+#define SYN_PH_PER_THREAD 4
+#define SYN_PH_TILE (SYN_PH_THREADS * SYN_PH_PER_THREAD)
+
+struct syn_ff { long long d0, d1; };  // delta when the incoming mantissa is even / odd
+
+__device__ __forceinline__ syn_ff syn_ff_compose(syn_ff g, syn_ff f) {  // g first, then f
+  syn_ff h;
+  h.d0 = g.d0 + ((g.d0 & 1) ? f.d1 : f.d0);
+  h.d1 = g.d1 + (((g.d1 + 1) & 1) ? f.d1 : f.d0);
+  return h;
+}
+
+// c / 2^(k-52) split into integer part + rounding class, as a parity map.
+__device__ __forceinline__ syn_ff syn_ff_make(double c, int k) {
+  syn_ff r = {0, 0};
+  if (!(c > 0.0)) return r;
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(c);
+  const int e = (int)((bits >> 52) & 0x7ff) - 1023;
+  const unsigned long long mant = (bits & 0xfffffffffffffULL) | 0x10000000000000ULL;
+  const int s = k - e;  // c/u = mant * 2^(-s)
+  if (s <= 0) {
+    long long v = (s > -10) ? (long long)(mant << (-s)) : (1LL << 62);  // forces the binade check to trip
+    r.d0 = r.d1 = v;
+    return r;
+  }
+  if (s > 54) return r;  // c < u/4: never moves the sum
+  if (s == 54) return r; // mant < 2^53 = half of 2^54: below half
+  const long long kint = (long long)(mant >> s);
+  const unsigned long long rem = mant & ((1ULL << s) - 1ULL);
+  const unsigned long long half = 1ULL << (s - 1);
+  if (rem < half) { r.d0 = r.d1 = kint; }
+  else if (rem > half) { r.d0 = r.d1 = kint + 1; }
+  else { r.d0 = kint + (kint & 1); r.d1 = kint + ((kint + 1) & 1); }  // tie: to even
+  return r;
+}
+
+__global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__restrict__ inc,
+                                                             int64_t y_length,
+                                                             double *__restrict__ wrap) {
+  __shared__ syn_ff wtot[SYN_PH_THREADS / 64];
+  __shared__ int s_cross;
+  __shared__ double s_tp;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double tp = 0.0;  // running phase (uniform across the block)
+  for (int64_t tile0 = 0; tile0 < y_length; tile0 += SYN_PH_TILE) {
+    const int tile_n = (int)min((int64_t)SYN_PH_TILE, y_length - tile0);
+    double c[SYN_PH_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
+      int i = tid * SYN_PH_PER_THREAD + j;
+      c[j] = i < tile_n ? inc[tile0 + i] : 0.0;
+    }
+    int pos = 0;  // first element of the tile not yet produced
+    while (pos < tile_n) {
+      if (tid == 0) s_cross = tile_n;
+      __syncthreads();
+      int cross;
+      if (tp == 0.0) {
+        cross = pos;  // 0 + c: plain add
+      } else {
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
+        const int k = (int)((tb >> 52) & 0x7ff) - 1023;
+        const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
+        syn_ff f[SYN_PH_PER_THREAD];
+        syn_ff mine = {0, 0};
+#pragma unroll
+        for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
+          int i = tid * SYN_PH_PER_THREAD + j;
+          f[j] = (i >= pos && i < tile_n) ? syn_ff_make(c[j], k) : syn_ff{0, 0};
+          mine = syn_ff_compose(mine, f[j]);
+        }
+        // ordered inclusive scan of the per-thread maps
+        syn_ff incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          syn_ff u;
+          u.d0 = __shfl_up(incl.d0, o);
+          u.d1 = __shfl_up(incl.d1, o);
+          if (lane >= o) incl = syn_ff_compose(u, incl);
+        }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        syn_ff pre = {0, 0};
+        for (int w = 0; w < wv; ++w) pre = syn_ff_compose(pre, wtot[w]);
+        // exclusive prefix for this thread = pre o (incl of previous lane)
+        syn_ff prev;
+        prev.d0 = __shfl_up(incl.d0, 1);
+        prev.d1 = __shfl_up(incl.d1, 1);
+        if (lane == 0) prev = syn_ff{0, 0};
+        const syn_ff excl = syn_ff_compose(pre, prev);
+        long long m = m_in + ((m_in & 1) ? excl.d1 : excl.d0);
+        int my_cross = tile_n;
+        double tpv[SYN_PH_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
+          int i = tid * SYN_PH_PER_THREAD + j;
+          if (i >= pos && i < tile_n) {
+            m += (m & 1) ? f[j].d1 : f[j].d0;
+            if ((m >> 53) != 0 && my_cross == tile_n) my_cross = i;
+            tpv[j] = ldexp((double)m, k - 52);
+          } else {
+            tpv[j] = 0.0;
+          }
+        }
+        if (my_cross < tile_n) atomicMin(&s_cross, my_cross);
+        __syncthreads();
+        cross = s_cross;
+#pragma unroll
+        for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
+          int i = tid * SYN_PH_PER_THREAD + j;
+          if (i >= pos && i < cross) {
+            wrap[tile0 + i] = fmod(tpv[j], SYN_TWO_PI);
+            if (i == cross - 1) s_tp = tpv[j];
+          }
+        }
+        __syncthreads();
+        if (cross > pos) tp = s_tp;
+      }
+      if (cross < tile_n) {
+        // this addition leaves the binade (or starts from 0): do it for real
+        tp = tp + inc[tile0 + cross];
+        if (tid == 0) wrap[tile0 + cross] = fmod(tp, SYN_TWO_PI);
+        pos = cross + 1;
+      } else {
+        pos = tile_n;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ bool syn_is_pulse(const double *__restrict__ wrap, int64_t n, int64_t y_length) {
+  return n < y_length - 1 && fabs(wrap[n + 1] - wrap[n]) > KWY_PI;
+}
+
+// phase D: pulses per tile
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_count(const double *__restrict__ wrap,
+                                                                int64_t y_length, int *__restrict__ cnt) {
+  __shared__ int sh[KWY_WAVES];
+  const int64_t base = (int64_t)blockIdx.x * SYN_TILE + (int64_t)threadIdx.x * SYN_TILE_PER_THREAD;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < SYN_TILE_PER_THREAD; ++j) c += syn_is_pulse(wrap, base + j, y_length) ? 1 : 0;
+  int tot;
+  (void)syn_block_exscan_int(c, sh, &tot);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+
+// phase E: ordered pulse list
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_emit(const double *__restrict__ wrap,
+                                                               int64_t y_length, int fs,
+                                                               const int *__restrict__ tile_off,
+                                                               int cap, int32_t *__restrict__ pidx,
+                                                               double *__restrict__ pshift) {
+  __shared__ int sh[KWY_WAVES];
+  const int64_t base = (int64_t)blockIdx.x * SYN_TILE + (int64_t)threadIdx.x * SYN_TILE_PER_THREAD;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < SYN_TILE_PER_THREAD; ++j) c += syn_is_pulse(wrap, base + j, y_length) ? 1 : 0;
+  int tot;
+  int pos = tile_off[blockIdx.x] + syn_block_exscan_int(c, sh, &tot);
+#pragma unroll
+  for (int j = 0; j < SYN_TILE_PER_THREAD; ++j) {
+    int64_t n = base + j;
+    if (syn_is_pulse(wrap, n, y_length)) {
+      if (pos < cap) {
+        double y1 = wrap[n] - SYN_TWO_PI;
+        double y2 = wrap[n + 1];
+        double xx = -y1 / (y2 - y1);
+        pidx[pos] = (int32_t)n;
+        pshift[pos] = xx / fs;
+      }
+      ++pos;
+    }
+  }
+}
+
+// per-pulse generator state: (idx[p] - idx[0]) draws into the stream
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_ebase(const int32_t *__restrict__ pidx,
+                                                          const int *__restrict__ npulse, int cap,
+                                                          const uint4 *__restrict__ pow2,
+                                                          uint32_t *__restrict__ ebase) {
+  __shared__ uint32_t sh[KWY_WAVES][KWY_EBASE_WORDS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int P = min(npulse[0], cap);
+  for (int p = blockIdx.x * KWY_WAVES + wv; p < P; p += gridDim.x * KWY_WAVES) {
+    uint64_t steps = 12ull * (uint64_t)(pidx[p] - pidx[0]);
+    uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+    kwy_wave_jump(s, steps, pow2);
+    if (lane == 0) {
+      kwy_rng r = {s[0], s[1], s[2], s[3]};
+      kwy_rng_ebase(r, sh[wv]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int i = lane; i < KWY_EBASE_WORDS; i += 64) ebase[(int64_t)p * KWY_EBASE_WORDS + i] = sh[wv][i];
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Minimum-phase spectrum (common.cpp GetMinimumPhaseSpectrum).  bufL holds the
+// half log-spectrum L[0..H] as reals; bufS is scratch.  Returns the buffer
+// holding M[0..H].  (The ~1e-17 imaginary rounding residue of the real
+// cepstrum that the CPU code carries along is dropped.)
+template <int LOG2N>
+__device__ inline kwy_c *syn_min_phase(kwy_c *bufL, kwy_c *bufS, const kwy_c *__restrict__ twH,
+                                       const kwy_c *__restrict__ twN) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  double *L = (double *)bufL;
+  __syncthreads();
+  for (int i = H + 1 + threadIdx.x; i < N; i += KWY_THREADS) L[i] = L[N - i];
+  kwy_c *C = kwy_rfft_lds(bufL, bufS, LOG2N - 1, twH, twN);
+  kwy_c *F = (C == bufL) ? bufS : bufL;
+  double *r = (double *)F;
+  for (int n = threadIdx.x; n < N; n += KWY_THREADS) {
+    double v = 0.0;
+    if (n <= H) {
+      v = C[n].x;
+      if (n >= 1 && n < H) v *= 2.0;
+    }
+    r[n] = v;
+  }
+  kwy_c *R = kwy_rfft_lds(F, C, LOG2N - 1, twH, twN);
+  for (int k = threadIdx.x; k <= H; k += KWY_THREADS) {
+    double tmp = exp(R[k].x / N);
+    double ph = R[k].y / N;
+    R[k] = {tmp * cos(ph), tmp * sin(ph)};
+  }
+  __syncthreads();
+  return R;
+}
+
+__device__ __forceinline__ double syn_safe_ap(double x) {
+  return fmax(0.001, fmin(0.999999999999, x));
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse(
+    const double *__restrict__ sp, const double *__restrict__ ap, syn_params p,
+    const int32_t *__restrict__ pidx, const double *__restrict__ pshift,
+    const unsigned char *__restrict__ vuv8, const int *__restrict__ npulse, int cap,
+    const uint32_t *__restrict__ ebase, const uint4 *__restrict__ poly,
+    const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
+    const double *__restrict__ dc_remover, double *__restrict__ y) {
+  constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
+  constexpr int C = N / KWY_THREADS;  // draws / output samples per thread
+  extern __shared__ double smem[];
+  kwy_c *bufA = (kwy_c *)smem;
+  kwy_c *bufB = bufA + (H + 1);
+  kwy_c *Nz = bufB + (H + 1);              // noise spectrum
+  double *env = (double *)(Nz + (H + 1));  // K
+  double *ratio = env + K + 1;             // K
+  double *red = ratio + K + 1;             // 8
+  uint32_t *e = (uint32_t *)(red + 8);
+
+  const int tid = threadIdx.x;
+  const int P = min(npulse[0], cap);
+  for (int pp = blockIdx.x; pp < P; pp += gridDim.x) {
+    const int idx = pidx[pp];
+    const int nxt = pidx[min(P - 1, pp + 1)];
+    const int noise_size = nxt - idx;
+    __syncthreads();
+    if (noise_size <= 0) continue;  // last pulse: zero response
+    const int ns_used = min(noise_size, N);
+    const double current_vuv = vuv8[idx] ? 1.0 : 0.0;
+    const double current_time = idx / (double)p.fs;
+    const double shift = pshift[pp];
+
+    for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[(int64_t)pp * KWY_EBASE_WORDS + i];
+
+    // ---- spectral envelope / aperiodic ratio at the pulse time
+    int fl = (int)floor(current_time / p.frame_period);
+    int ce = (int)ceil(current_time / p.frame_period);
+    if (fl > p.T - 1) fl = (int)p.T - 1;
+    if (ce > p.T - 1) ce = (int)p.T - 1;
+    const double interpolation = current_time / p.frame_period - fl;
+    const double *s0 = sp + (int64_t)fl * K, *s1 = sp + (int64_t)ce * K;
+    const double *a0 = ap + (int64_t)fl * K, *a1 = ap + (int64_t)ce * K;
+    for (int k = tid; k < K; k += KWY_THREADS) {
+      double ev, rv;
+      if (fl == ce) {
+        ev = fabs(s0[k] * p.sp_mul);
+        rv = syn_safe_ap(a0[k]);
+      } else {
+        ev = (1.0 - interpolation) * fabs(s0[k] * p.sp_mul) + interpolation * fabs(s1[k] * p.sp_mul);
+        rv = (1.0 - interpolation) * syn_safe_ap(a0[k]) + interpolation * syn_safe_ap(a1[k]);
+      }
+      env[k] = ev;
+      ratio[k] = rv * rv;
+    }
+    __syncthreads();
+
+    // ---- periodic response (kept in registers: sample i = tid + 256*m)
+    double per[C];
+#pragma unroll
+    for (int m = 0; m < C; ++m) per[m] = 0.0;
+    if (current_vuv > 0.5 && !(ratio[0] > 0.999)) {
+      double *L = (double *)bufA;
+      for (int k = tid; k <= H; k += KWY_THREADS)
+        L[k] = log(env[k] * (1.0 - ratio[k]) + SYN_SAFE) / 2.0;
+      kwy_c *M = syn_min_phase<LOG2N>(bufA, bufB, twH, twN);
+      kwy_c *O = (M == bufA) ? bufB : bufA;
+      const double coefficient = 2.0 * KWY_PI * shift * p.fs / N;
+      for (int k = tid; k <= H; k += KWY_THREADS) {
+        double re = M[k].x, im = M[k].y;
+        double re2 = cos(coefficient * k);
+        double im2 = sqrt(1.0 - re2 * re2);
+        M[k] = {re * re2 + im * im2, im * re2 - re * im2};
+      }
+      kwy_c *W = kwy_irfft_lds(M, O, LOG2N - 1, twH, twN);
+      const double *w = (const double *)W;
+      double part = 0.0;
+      for (int i = tid; i < H; i += KWY_THREADS) part += w[i];
+      const double dc_component = kwy_block_sum(part, red);
+#pragma unroll
+      for (int m = 0; m < C; ++m) {
+        int i = tid + KWY_THREADS * m;
+        double v = (i < H) ? -dc_component * dc_remover[i] : w[i - H] - dc_component * dc_remover[i];
+        per[m] = v;
+      }
+      __syncthreads();
+    }
+
+    // ---- aperiodic response
+    {
+      kwy_rng rng = kwy_rng_combine(e, poly[tid]);
+      double *A = (double *)bufA;
+      double nv[C];
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        int d = C * tid + j;
+        double v = kwy_rng_randn(rng);
+        nv[j] = v;
+        if (d < ns_used) sum += v;
+      }
+      const double average = kwy_block_sum(sum, red) / noise_size;
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        int d = C * tid + j;
+        A[d] = (d < ns_used) ? nv[j] - average : 0.0;
+      }
+      kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
+      for (int k = tid; k <= H; k += KWY_THREADS) Nz[k] = X[k];
+      __syncthreads();
+      double *L = (double *)bufA;
+      if (current_vuv != 0.0) {
+        for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k] * ratio[k]) / 2.0;
+      } else {
+        for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k]) / 2.0;
+      }
+      kwy_c *M = syn_min_phase<LOG2N>(bufA, bufB, twH, twN);
+      kwy_c *O = (M == bufA) ? bufB : bufA;
+      for (int k = tid; k <= H; k += KWY_THREADS) {
+        kwy_c a = M[k], b = Nz[k];
+        M[k] = {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+      }
+      kwy_c *W = kwy_irfft_lds(M, O, LOG2N - 1, twH, twN);
+      const double *w = (const double *)W;
+      const double sqrt_noise_size = sqrt((double)noise_size);
+      const int64_t offset = (int64_t)idx - H + 1;
+#pragma unroll
+      for (int m = 0; m < C; ++m) {
+        int i = tid + KWY_THREADS * m;
+        double aper = (i < H) ? w[i + H] : w[i - H];
+        double r = (per[m] * sqrt_noise_size + aper) / N;
+        int64_t n = offset + i;
+        if (n >= 0 && n < p.y_length) unsafeAtomicAdd(&y[n], r);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static int get_dc_remover(kwy_ctx *ctx, int fft_size, const double **out) {
+  std::string key = "dcrem:" + std::to_string(fft_size);
+  auto it = ctx->d_mats.find(key);
+  if (it == ctx->d_mats.end()) {
+    std::vector<double> h(fft_size);
+    double dc_component = 0.0;
+    for (int i = 0; i < fft_size / 2; ++i) {
+      h[i] = 0.5 - 0.5 * cos(2.0 * KWY_PI * (i + 1.0) / (1.0 + fft_size));
+      h[fft_size - i - 1] = h[i];
+      dc_component += h[i] * 2.0;
+    }
+    for (int i = 0; i < fft_size / 2; ++i) {
+      h[i] /= dc_component;
+      h[fft_size - i - 1] = h[i];
+    }
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(double) * fft_size));
+    KWY_HIP(hipMemcpy(d, h.data(), sizeof(double) * fft_size, hipMemcpyHostToDevice));
+    it = ctx->d_mats.emplace(key, d).first;
+  }
+  *out = it->second;
+  return KWY_OK;
+}
+
+template <int LOG2N>
+static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const syn_params &p,
+                        const int32_t *pidx, const double *pshift, const unsigned char *vuv8,
+                        const int *npulse, int cap, const uint32_t *ebase, const double *dcrem,
+                        double *y) {
+  constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
+  const kwy_c *twH, *twN;
+  const uint4 *poly;
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
+  KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
+  size_t lds = sizeof(kwy_c) * 3 * (H + 1) + sizeof(double) * (2 * (K + 1) + 8) +
+               sizeof(uint32_t) * KWY_EBASE_WORDS;
+  KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int grid = cap < 2048 ? cap : 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
+                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, y);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static int syn_pulse_cap(int64_t y_length) { return (int)(y_length / 8 + 16); }
+
+static size_t syn_scratch_bytes(int64_t y_length) {
+  int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
+  int cap = syn_pulse_cap(y_length);
+  return kwy_pad(sizeof(int) * (nt + 1)) + 2 * kwy_pad(sizeof(double) * y_length) +
+         kwy_pad(y_length) + kwy_pad(sizeof(int32_t) * cap) + kwy_pad(sizeof(double) * cap) +
+         kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * (size_t)cap) + kwy_pad(64);
+}
+
+static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp, const double *ap,
+                      int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length,
+                      double *y) {
+  const int log2n = kwy_ilog2(fft_size);
+  if ((1 << log2n) != fft_size || log2n < 9 || log2n > 12) {
+    ctx->err = "synthesize: fft_size must be a power of two in [512, 4096]";
+    return KWY_EINVAL;
+  }
+  KWY_HIP(hipMemsetAsync(y, 0, sizeof(double) * y_length, ctx->stream));
+  if (y_length < 2 || T < 2) return KWY_OK;
+  syn_params p;
+  p.T = T; p.y_length = y_length; p.fs = fs; p.fft_size = fft_size;
+  p.frame_period = frame_period_ms / 1000.0;
+  p.lowest_f0 = fs / fft_size + 1.0;  // integer division, as upstream
+  p.sp_mul = sp_mul;
+  const int nt = (int)((y_length + SYN_TILE - 1) / SYN_TILE);
+  const int cap = syn_pulse_cap(y_length);
+  double *incr = kwy_arena<double>(ctx, y_length);
+  int *tile_cnt = kwy_arena<int>(ctx, nt + 1);
+  double *wrap = kwy_arena<double>(ctx, y_length);
+  unsigned char *vuv8 = kwy_arena<unsigned char>(ctx, y_length);
+  int32_t *pidx = kwy_arena<int32_t>(ctx, cap);
+  double *pshift = kwy_arena<double>(ctx, cap);
+  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * cap);
+  int *npulse = kwy_arena<int>(ctx, 16);
+  if (!incr || !tile_cnt || !wrap || !vuv8 || !pidx || !pshift || !ebase || !npulse) {
+    ctx->err = "synthesize: scratch arena too small";
+    return KWY_ENOMEM;
+  }
+  const double *dcrem;
+  KWY_TRY(get_dc_remover(ctx, fft_size, &dcrem));
+
+  hipLaunchKernelGGL(k_syn_inc, dim3((unsigned)((y_length + KWY_THREADS - 1) / KWY_THREADS)),
+                     dim3(KWY_THREADS), 0, ctx->stream, f0, p, incr, vuv8);
+  hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream, incr, y_length, wrap);
+  hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, tile_cnt);
+  hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, tile_cnt, nt, npulse);
+  hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, fs,
+                     tile_cnt, cap, pidx, pshift);
+  hipLaunchKernelGGL(k_syn_ebase, dim3(512), dim3(KWY_THREADS), 0, ctx->stream, pidx, npulse, cap,
+                     ctx->d_pow2, ebase);
+  KWY_HIP(hipGetLastError());
+  switch (log2n) {
+    case 9: return launch_pulse<9>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, y);
+    case 10: return launch_pulse<10>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, y);
+    case 11: return launch_pulse<11>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, y);
+    default: return launch_pulse<12>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, y);
+  }
+}
+
+static int syn_check(kwy_ctx *ctx, const void *f0, int64_t T, const void *sp, const void *ap,
+                     int fft_size, double frame_period_ms, int fs, int64_t y_length, const void *y) {
+  if (!ctx) return KWY_EINVAL;
+  if (!f0 || !sp || !ap || !y || T <= 0 || fs <= 0 || fft_size <= 0 || !(frame_period_ms > 0) ||
+      y_length < 0 || y_length > 0x7fffffff) {
+    ctx->err = "synthesize: bad argument";
+    return KWY_EINVAL;
+  }
+  return KWY_OK;
+}
+
+extern "C" int kwy_synthesize_dev(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp,
+                                  const double *ap, int fft_size, double frame_period_ms, int fs,
+                                  double sp_mul, int64_t y_length, double *y) {
+  KWY_TRY(syn_check(ctx, f0, T, sp, ap, fft_size, frame_period_ms, fs, y_length, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  if (y_length == 0) return KWY_OK;
+  KWY_TRY(kwy_arena_begin(ctx, syn_scratch_bytes(y_length)));
+  return synth_core(ctx, f0, T, sp, ap, fft_size, frame_period_ms, fs, sp_mul, y_length, y);
+}
+
+extern "C" int kwy_synthesize(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp,
+                              const double *ap, int fft_size, double frame_period_ms, int fs,
+                              double sp_mul, int64_t y_length, double *y) {
+  KWY_TRY(syn_check(ctx, f0, T, sp, ap, fft_size, frame_period_ms, fs, y_length, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  if (y_length == 0) return KWY_OK;
+  for (int64_t i = 0; i < T; ++i)
+    if (!(f0[i] >= 0.0 && f0[i] < fs / 12.0)) { ctx->err = "synthesize: f0 must lie in [0, fs/12)"; return KWY_EINVAL; }
+  const int K = fft_size / 2 + 1;
+  size_t bf = kwy_pad(sizeof(double) * T), bs = kwy_pad(sizeof(double) * T * K);
+  size_t by = kwy_pad(sizeof(double) * y_length);
+  KWY_TRY(kwy_arena_begin(ctx, syn_scratch_bytes(y_length) + bf + 2 * bs + by));
+  double *df0 = kwy_arena<double>(ctx, T), *dsp = kwy_arena<double>(ctx, (size_t)T * K);
+  double *dap = kwy_arena<double>(ctx, (size_t)T * K), *dy = kwy_arena<double>(ctx, y_length);
+  KWY_HIP(hipMemcpyAsync(df0, f0, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dsp, sp, sizeof(double) * T * K, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dap, ap, sizeof(double) * T * K, hipMemcpyHostToDevice, ctx->stream));
+  KWY_TRY(synth_core(ctx, df0, T, dsp, dap, fft_size, frame_period_ms, fs, sp_mul, y_length, dy));
+  KWY_HIP(hipMemcpyAsync(y, dy, sizeof(double) * y_length, hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}

@@ -1,0 +1,188 @@
+"""GPU parity tests proper: the HIP WORLD kernels, called through the C ABI
+(libkwy.so via ctypes), against the CPU oracle on identical inputs.
+
+Tolerances (float64 path; north_star: output within 1e-4 RMS of the CPU path):
+  * spectral envelope: max |d| / max|ref| per utterance <= 1e-8, and the
+    log-spectral distance per bin <= 1e-3 on bins that are within 100 dB of the
+    frame maximum, and sum|d| / sum|ref| <= 1e-9.  (CheapTrick's linear smoothing differences two cumulative
+    sums; bins far below the frame's total power are conditioned like
+    eps * total / local in ANY summation order, CPU included, so elementwise
+    agreement on dead bins is not a meaningful target.)
+  * aperiodicity: max abs <= 1e-4 (values live in [0, 1])
+  * waveform: RMS <= 1e-9 given identical features (pulse positions, noise
+    stream and overlap-add are reproduced exactly; only FFT rounding differs).
+"""
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from conftest import CLB_WAV, SLT_WAV, clb_variant
+
+pytestmark = pytest.mark.gpu
+
+
+def load(path):
+    fs, d = wavfile.read(path)
+    return fs, np.ascontiguousarray(d.astype(np.float64) / 2 ** 15)
+
+
+@pytest.fixture(scope='module')
+def ko():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope='module')
+def kw():
+    from kwiiyatta_amd.backend import world
+    return world
+
+
+def f0_track(ko, x, fs):
+    f0, t = ko.dio(x, fs)
+    return ko.stonemask(x, f0, t, fs), t
+
+
+def check_spectrum(got, ref):
+    assert got.shape == ref.shape
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.abs(ref).max() <= 1e-8
+    assert np.abs(got - ref).sum() / np.abs(ref).sum() <= 1e-9
+    live = ref >= ref.max(axis=1, keepdims=True) * 1e-10
+    lsd = np.abs(np.log(got[live]) - np.log(ref[live]))
+    assert lsd.max() <= 1e-3, lsd.max()
+
+
+CASES = [CLB_WAV, SLT_WAV, clb_variant('22'), clb_variant('44'), clb_variant('48')]
+
+
+@pytest.mark.parametrize('path', CASES)
+def test_cheaptrick_parity(ko, kw, path):
+    fs, x = load(path)
+    f0, t = f0_track(ko, x, fs)
+    check_spectrum(kw.cheaptrick(x, f0, t, fs), ko.cheaptrick(x, f0, t, fs))
+
+
+@pytest.mark.parametrize('path', CASES)
+def test_d4c_parity(ko, kw, path):
+    fs, x = load(path)
+    f0, t = f0_track(ko, x, fs)
+    got, ref = kw.d4c(x, f0, t, fs), ko.d4c(x, f0, t, fs)
+    assert got.shape == ref.shape
+    # same frames pass the LoveTrain gate
+    assert np.array_equal(got[:, 0] < 0.99, ref[:, 0] < 0.99)
+    assert np.abs(got - ref).max() <= 1e-4
+    assert np.median(np.abs(got - ref)) <= 1e-6
+
+
+@pytest.mark.parametrize('path', [CLB_WAV, clb_variant('22'), clb_variant('48')])
+def test_synthesis_parity(ko, kw, path):
+    fs, x = load(path)
+    f0, t = f0_track(ko, x, fs)
+    sp, ap = ko.cheaptrick(x, f0, t, fs), ko.d4c(x, f0, t, fs)
+    got, ref = kw.synthesize(f0, sp, ap, fs, 5.0), ko.synthesize(f0, sp, ap, fs, 5.0)
+    assert got.shape == ref.shape
+    rms = np.sqrt(np.mean((got - ref) ** 2))
+    assert rms <= 1e-9, rms
+    assert np.abs(got - ref).max() <= 1e-8
+
+
+def test_analysis_synthesis_end_to_end_rms(ko, kw):
+    """GPU analyse -> GPU synthesise vs oracle analyse -> oracle synthesise:
+    the north-star criterion (waveform within 1e-4 RMS)."""
+    fs, x = load(clb_variant('48'))
+    f0, t = f0_track(ko, x, fs)
+    y_gpu = kw.synthesize(f0, kw.cheaptrick(x, f0, t, fs), kw.d4c(x, f0, t, fs), fs, 5.0)
+    y_ref = ko.synthesize(f0, ko.cheaptrick(x, f0, t, fs), ko.d4c(x, f0, t, fs), fs, 5.0)
+    rms = np.sqrt(np.mean((y_gpu - y_ref) ** 2))
+    assert rms <= 1e-4, rms
+    assert rms <= 1e-6 * np.sqrt(np.mean(y_ref ** 2)) * 1e3
+
+
+@pytest.mark.parametrize('frame_period', [3, 5, 8])
+def test_frame_periods(ko, kw, frame_period):
+    fs, x = load(CLB_WAV)
+    f0, t = ko.dio(x, fs, frame_period=frame_period)
+    f0 = ko.stonemask(x, f0, t, fs)
+    check_spectrum(kw.cheaptrick(x, f0, t, fs), ko.cheaptrick(x, f0, t, fs))
+    sp, ap = ko.cheaptrick(x, f0, t, fs), ko.d4c(x, f0, t, fs)
+    got = kw.synthesize(f0, sp, ap, fs, float(frame_period))
+    ref = ko.synthesize(f0, sp, ap, fs, float(frame_period))
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-9
+
+
+def test_options(ko, kw):
+    """q1 / fft_size / threshold keyword paths (reference call sites
+    tests/kwiiyatta/test_vocoder.py:429-430, view/qt/kwiieiya.py:84)."""
+    fs, x = load(CLB_WAV)
+    f0, t = f0_track(ko, x, fs)
+    check_spectrum(kw.cheaptrick(x, f0, t, fs, q1=-0.09, fft_size=2048),
+                   ko.cheaptrick(x, f0, t, fs, q1=-0.09, fft_size=2048))
+    for thr in (0.0, 0.5, 0.95):
+        got, ref = kw.d4c(x, f0, t, fs, threshold=thr), ko.d4c(x, f0, t, fs, threshold=thr)
+        assert np.abs(got - ref).max() <= 1e-4
+    got, ref = kw.d4c(x, f0, t, fs, fft_size=2048), ko.d4c(x, f0, t, fs, fft_size=2048)
+    assert got.shape == (len(f0), 1025) and np.abs(got - ref).max() <= 1e-4
+
+
+def test_edge_inputs(ko, kw):
+    fs = 16000
+    rng = np.random.default_rng(0)
+    # all-unvoiced, digital silence, one-frame and clipped-window inputs
+    x = rng.standard_normal(4000) * 0.01
+    f0 = np.zeros(51)
+    t = np.arange(51) * 0.005
+    check_spectrum(kw.cheaptrick(x, f0, t, fs), ko.cheaptrick(x, f0, t, fs))
+    assert np.array_equal(kw.d4c(x, f0, t, fs), ko.d4c(x, f0, t, fs))
+    xs = np.zeros(4000)
+    got, ref = kw.cheaptrick(xs, f0, t, fs), ko.cheaptrick(xs, f0, t, fs)
+    assert np.abs(np.log(got) - np.log(ref)).max() <= 1e-6   # spectrum of the noise floor itself
+    sp = ko.cheaptrick(x, f0, t, fs)
+    ap = ko.d4c(x, f0, t, fs)
+    assert np.sqrt(np.mean((kw.synthesize(f0, sp, ap, fs) - ko.synthesize(f0, sp, ap, fs)) ** 2)) <= 1e-12
+    # very short signal, frames beyond the end of x
+    x1 = rng.standard_normal(90) * 0.1
+    f01 = np.array([0.0, 120.0, 0.0]); t1 = np.arange(3) * 0.005
+    check_spectrum(kw.cheaptrick(x1, f01, t1, fs), ko.cheaptrick(x1, f01, t1, fs))
+
+
+def test_contiguity_contract(kw):
+    """pyworld raises ValueError('ndarray is not C-contiguous')
+    (reference tests/kwiiyatta/vocoder/test_world.py:21-40)."""
+    x = np.zeros(2000)
+    f0 = np.zeros(10); t = np.arange(10) * 0.005
+    with pytest.raises(ValueError) as e:
+        kw.cheaptrick(x[::2], f0, t, 16000)
+    assert str(e.value) == 'ndarray is not C-contiguous'
+    with pytest.raises(ValueError) as e:
+        kw.d4c(x[::2], f0, t, 16000)
+    assert str(e.value) == 'ndarray is not C-contiguous'
+    sp = np.ones((10, 513)); ap = np.ones((10, 513))
+    with pytest.raises(ValueError) as e:
+        kw.synthesize(f0[::2], sp[::2], ap[::2], 16000)
+    assert str(e.value) == 'ndarray is not C-contiguous'
+
+
+def test_full_size_config2(ko, kw):
+    """BASELINE config 2: one 48 kHz / 10 s synthetic utterance (T=2001, K=1025),
+    analyse + synthesise, against the oracle at full size."""
+    from kwiiyatta_amd.synthetic import make_utterance
+    fs = 48000
+    x, f0, t = make_utterance(seed=1234, fs=fs, seconds=10.0)
+    assert len(f0) == 2001
+    sp, ap = kw.cheaptrick(x, f0, t, fs), kw.d4c(x, f0, t, fs)
+    assert sp.shape == (2001, 1025) and ap.shape == (2001, 1025)
+    sp_ref, ap_ref = ko.cheaptrick(x, f0, t, fs), ko.d4c(x, f0, t, fs)
+    check_spectrum(sp, sp_ref)
+    assert np.abs(ap - ap_ref).max() <= 1e-4
+    y = kw.synthesize(f0, sp, ap, fs, 5.0)
+    assert len(y) == 480240
+    y_ref = ko.synthesize(f0, sp_ref, ap_ref, fs, 5.0)
+    rms = np.sqrt(np.mean((y - y_ref) ** 2))
+    assert rms <= 1e-4, rms
+    # size-independent properties: amplitude scaling and determinism
+    sp2 = kw.cheaptrick(x * 0.5, f0, t, fs)
+    live = sp >= sp.max(axis=1, keepdims=True) * 1e-10
+    assert np.abs(sp2[live] / sp[live] - 0.25).max() <= 1e-6
+    assert np.array_equal(sp, kw.cheaptrick(x, f0, t, fs))
+    assert ((ap > 0) & (ap <= 1)).all()
