@@ -93,6 +93,41 @@ int kwy_synthesize_dev(kwy_ctx *ctx, const double *f0, int64_t f0_length, const 
                        const double *ap, int fft_size, double frame_period_ms, int fs,
                        double sp_mul, int64_t y_length, double *y);
 
+/* ---- mel-cepstrum ---------------------------------------------------------------- */
+/* pysptk.sp2mc(spec, order, alpha) row-wise          kwiiyatta/vocoder/mcep.py:71
+ * sp: T x K (K = fftlen/2+1), mc: T x (order+1). */
+int kwy_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int K, int order, double alpha,
+              double *mc);
+int kwy_sp2mc_dev(kwy_ctx *ctx, const double *sp, int64_t T, int K, int order, double alpha,
+                  double *mc);
+/* pysptk.mc2sp(mc, alpha, fftlen) row-wise           kwiiyatta/vocoder/mcep.py:65 */
+int kwy_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, int fftlen,
+              double *sp);
+int kwy_mc2sp_dev(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha,
+                  int fftlen, double *sp);
+
+/* ---- alignment -------------------------------------------------------------------- */
+/* fastdtw.fastdtw(x, y, radius, dist=2) -> (dist, path)
+ *                                                    kwiiyatta/vocoder/align.py:71
+ * x: Tx x dim, y: Ty x dim; path: capacity (Tx+Ty) x 2 int32, *path_len pairs written. */
+int kwy_fastdtw(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty,
+                int dim, int radius, double *dist, int32_t *path, int64_t *path_len);
+int kwy_fastdtw_dev(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty,
+                    int dim, int radius, double *dist, int32_t *path, int64_t *path_len);
+
+/* ---- converter apply ---------------------------------------------------------------- */
+/* delta_features(X, DELTA_WINDOWS) + MLPG(gmm, windows, diff).transform(X)[:, :d]
+ *                         kwiiyatta/converter/delta.py:39-50, gmm.py:28-34
+ * x: T x d static features.  GMM: M components over the joint (2*3d)-dim
+ * static+delta+delta2 space (source | target), full covariances.
+ * y: T x d converted static features. */
+int kwy_gmm_mlpg(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
+                 const double *weights, const double *means, const double *covs, int diff,
+                 double *y);
+int kwy_gmm_mlpg_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
+                     const double *weights, const double *means, const double *covs, int diff,
+                     double *y);
+
 #ifdef __cplusplus
 }
 #endif

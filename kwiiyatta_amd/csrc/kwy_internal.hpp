@@ -27,6 +27,7 @@ struct kwy_ctx {
   kwy_c *d_tw[20] = {nullptr};             // d_tw[l]: exp(-2 pi i k / 2^l), k < 2^l
   std::map<uint64_t, uint4 *> d_poly;      // stride(steps) -> x^(stride*t) mod P, t < 256
   std::map<std::string, double *> d_mats;  // cached host-built matrices (mcep etc.)
+  std::map<std::string, int64_t> i_vals;   // small cached integers that go with them
 };
 
 #define KWY_HIP(call)                                                              \

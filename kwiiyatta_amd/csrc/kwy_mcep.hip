@@ -1,0 +1,262 @@
+// kwy_mcep.hip -- spectral envelope <-> mel-cepstrum on gfx950.
+//
+// Replaces pysptk.sp2mc / pysptk.mc2sp (reference call sites
+// kwiiyatta/vocoder/mcep.py:71 and :65; pysptk 0.1.16 / SPTK `freqt`):
+//
+//   sp2mc: c = irfft(log P); c[0] /= 2; mc = freqt(c, order, alpha)
+//   mc2sp: c = freqt(mc, fftlen/2, -alpha); c[0] *= 2; mirror; exp(real(rfft(c)))
+//
+// SPTK's freqt is a linear recursion, so it is applied as a small dense matrix
+// (built once per (alpha, sizes) on the host with the same recursion and cached
+// in HBM): one workgroup per frame does the FFT in LDS and the matrix product
+// from L2-resident coefficients.  Both kernels stream each frame once:
+// sp2mc reads K*8 B and writes (order+1)*8 B per frame; mc2sp the reverse.
+#include <math.h>
+
+#include <vector>
+
+#include "kwy_internal.hpp"
+
+#define MC_MAX_ORDER 63  // order+1 <= 64 coefficients
+
+// ---- host: freqt as a matrix ---------------------------------------------------
+// One freqt step with zero input: g <- B g  (SPTK freqt inner loop with c1[-i] = 0)
+static void freqt_step0(std::vector<double> &g, std::vector<double> &d, int m2, double a) {
+  const double b = 1 - a * a;
+  if (0 <= m2) { d[0] = g[0]; g[0] = a * d[0]; }
+  if (1 <= m2) { d[1] = g[1]; g[1] = b * d[0] + a * d[1]; }
+  for (int j = 2; j <= m2; ++j) { d[j] = g[j]; g[j] = d[j - 1] + a * (d[j] - g[j - 1]); }
+}
+
+// F[n][j] (n < ncols, j <= m2): response of output j to a unit input at index n.
+// Input n is injected and then transformed n more times, so F[n] = B^n e0.
+static void freqt_matrix(int ncols, int m2, double a, std::vector<double> &F) {
+  F.assign((size_t)ncols * (m2 + 1), 0.0);
+  std::vector<double> g(m2 + 1, 0.0), d(m2 + 1, 0.0);
+  g[0] = 1.0;
+  for (int n = 0; n < ncols; ++n) {
+    for (int j = 0; j <= m2; ++j) F[(size_t)n * (m2 + 1) + j] = g[j];
+    freqt_step0(g, d, m2, a);
+  }
+}
+
+// ---- sp2mc -----------------------------------------------------------------------
+// F: [ncut][MC_STRIDE] with MC_STRIDE = 64 doubles per cepstral index
+#define MC_STRIDE 64
+template <int LOG2N>
+__global__ __launch_bounds__(KWY_THREADS) void k_sp2mc(const double *__restrict__ sp, int order,
+                                                      const double *__restrict__ F, int ncut,
+                                                      const kwy_c *__restrict__ twH,
+                                                      const kwy_c *__restrict__ twN,
+                                                      double *__restrict__ mc) {
+  constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
+  extern __shared__ double smem[];
+  kwy_c *bufA = (kwy_c *)smem;
+  kwy_c *bufB = bufA + (H + 1);
+  double *part = (double *)(bufB + (H + 1));  // 4 x 64 partial sums
+  const int tid = threadIdx.x;
+  const int64_t frame = blockIdx.x;
+  const double *p = sp + frame * K;
+  for (int k = tid; k <= H; k += KWY_THREADS) bufA[k] = {log(p[k]), 0.0};
+  kwy_c *W = kwy_irfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
+  const double *c = (const double *)W;  // N * cepstrum (unnormalised c2r)
+  // mc[j] = sum_n F[n][j] * c[n]; thread (j = tid & 63, part = tid >> 6) strides n by 4
+  const int j = tid & 63, q = tid >> 6;
+  double acc = 0.0;
+  if (j <= order) {
+    for (int n = q; n < ncut; n += 4) {
+      double cn = c[n] / N;
+      if (n == 0) cn /= 2.0;
+      acc += F[(size_t)n * MC_STRIDE + j] * cn;
+    }
+  }
+  part[q * 64 + j] = acc;
+  __syncthreads();
+  if (tid <= order) mc[frame * (order + 1) + tid] = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];
+}
+
+// ---- mc2sp -----------------------------------------------------------------------
+// F2T: [order+1][H+1]: cepstrum index n <- mel-cepstral coefficient m
+template <int LOG2N>
+__global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict__ mc, int order,
+                                                      const double *__restrict__ F2T,
+                                                      const kwy_c *__restrict__ twH,
+                                                      const kwy_c *__restrict__ twN,
+                                                      double *__restrict__ sp) {
+  constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
+  extern __shared__ double smem[];
+  kwy_c *bufA = (kwy_c *)smem;
+  kwy_c *bufB = bufA + (H + 1);
+  double *m = (double *)(bufB + (H + 1));  // order+1
+  const int tid = threadIdx.x;
+  const int64_t frame = blockIdx.x;
+  if (tid <= order) m[tid] = mc[frame * (order + 1) + tid];
+  __syncthreads();
+  double *sym = (double *)bufA;
+  for (int n = tid; n <= H; n += KWY_THREADS) {
+    double acc = 0.0;
+    for (int i = 0; i <= order; ++i) acc += F2T[(size_t)i * K + n] * m[i];
+    if (n == 0) acc *= 2.0;
+    sym[n] = acc;
+    if (n >= 1 && n < H) sym[N - n] = acc;
+  }
+  kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
+  double *o = sp + frame * K;
+  for (int k = tid; k <= H; k += KWY_THREADS) o[k] = exp(X[k].x);
+}
+
+// ---- host side ----------------------------------------------------------------------
+static int get_sp2mc_matrix(kwy_ctx *ctx, int N, int order, double alpha, const double **out, int *ncut) {
+  char key[96];
+  snprintf(key, sizeof(key), "sp2mc:%d:%d:%.17g", N, order, alpha);
+  std::string cnt_key = std::string(key) + ":ncut";
+  auto it = ctx->d_mats.find(key);
+  if (it == ctx->d_mats.end()) {
+    std::vector<double> F;
+    freqt_matrix(N, order, alpha, F);
+    // columns beyond ncut contribute < 1e-40 of a unit cepstral value: drop them
+    int nc = N;
+    while (nc > 1) {
+      double mx = 0.0;
+      for (int j = 0; j <= order; ++j) mx = fmax(mx, fabs(F[(size_t)(nc - 1) * (order + 1) + j]));
+      if (mx > 1e-40) break;
+      --nc;
+    }
+    std::vector<double> Fp((size_t)nc * MC_STRIDE, 0.0);
+    for (int n = 0; n < nc; ++n)
+      for (int j = 0; j <= order; ++j) Fp[(size_t)n * MC_STRIDE + j] = F[(size_t)n * (order + 1) + j];
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(double) * Fp.size()));
+    KWY_HIP(hipMemcpy(d, Fp.data(), sizeof(double) * Fp.size(), hipMemcpyHostToDevice));
+    it = ctx->d_mats.emplace(key, d).first;
+    ctx->i_vals[cnt_key] = nc;
+  }
+  *out = it->second;
+  *ncut = (int)ctx->i_vals[cnt_key];
+  return KWY_OK;
+}
+
+static int get_mc2sp_matrix(kwy_ctx *ctx, int N, int order, double alpha, const double **out) {
+  char key[96];
+  snprintf(key, sizeof(key), "mc2sp:%d:%d:%.17g", N, order, alpha);
+  auto it = ctx->d_mats.find(key);
+  if (it == ctx->d_mats.end()) {
+    const int H = N / 2, K = H + 1;
+    std::vector<double> F;  // [order+1][H+1]: input index i -> outputs 0..H
+    freqt_matrix(order + 1, H, -alpha, F);
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(order + 1) * K));
+    KWY_HIP(hipMemcpy(d, F.data(), sizeof(double) * (size_t)(order + 1) * K, hipMemcpyHostToDevice));
+    it = ctx->d_mats.emplace(key, d).first;
+  }
+  *out = it->second;
+  return KWY_OK;
+}
+
+template <int LOG2N>
+static int launch_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int order, const double *F, int ncut,
+                        double *mc) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  const kwy_c *twH, *twN;
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
+  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 256;
+  KWY_HIP(hipFuncSetAttribute((const void *)k_sp2mc<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_sp2mc<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, sp, order, F,
+                     ncut, twH, twN, mc);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+template <int LOG2N>
+static int launch_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, const double *F2T, double *sp) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  const kwy_c *twH, *twN;
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
+  KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
+  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 64;
+  KWY_HIP(hipFuncSetAttribute((const void *)k_mc2sp<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, mc, order, F2T,
+                     twH, twN, sp);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static int mcep_check(kwy_ctx *ctx, const void *a, const void *b, int64_t T, int K, int order, double alpha,
+                      int *log2n) {
+  if (!ctx) return KWY_EINVAL;
+  const int N = 2 * (K - 1);
+  const int l = kwy_ilog2(N);
+  if (!a || !b || T <= 0 || K < 2 || (1 << l) != N || l < 9 || l > 13) {
+    ctx->err = "mcep: spectrum length must be 2^n+1 with 512 <= 2^(n+1) <= 8192";
+    return KWY_EINVAL;
+  }
+  if (order < 1 || order > MC_MAX_ORDER || order > N / 2) { ctx->err = "mcep: order out of range"; return KWY_EINVAL; }
+  if (!(fabs(alpha) < 1.0)) { ctx->err = "mcep: |alpha| must be < 1"; return KWY_EINVAL; }
+  *log2n = l;
+  return KWY_OK;
+}
+
+extern "C" int kwy_sp2mc_dev(kwy_ctx *ctx, const double *sp, int64_t T, int K, int order, double alpha,
+                             double *mc) {
+  int l;
+  KWY_TRY(mcep_check(ctx, sp, mc, T, K, order, alpha, &l));
+  KWY_HIP(hipSetDevice(ctx->device));
+  const double *F;
+  int ncut;
+  KWY_TRY(get_sp2mc_matrix(ctx, 1 << l, order, alpha, &F, &ncut));
+  switch (l) {
+    case 9: return launch_sp2mc<9>(ctx, sp, T, order, F, ncut, mc);
+    case 10: return launch_sp2mc<10>(ctx, sp, T, order, F, ncut, mc);
+    case 11: return launch_sp2mc<11>(ctx, sp, T, order, F, ncut, mc);
+    case 12: return launch_sp2mc<12>(ctx, sp, T, order, F, ncut, mc);
+    default: return launch_sp2mc<13>(ctx, sp, T, order, F, ncut, mc);
+  }
+}
+
+extern "C" int kwy_mc2sp_dev(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, int fftlen,
+                             double *sp) {
+  int l;
+  KWY_TRY(mcep_check(ctx, mc, sp, T, fftlen / 2 + 1, order, alpha, &l));
+  KWY_HIP(hipSetDevice(ctx->device));
+  const double *F2T;
+  KWY_TRY(get_mc2sp_matrix(ctx, 1 << l, order, alpha, &F2T));
+  switch (l) {
+    case 9: return launch_mc2sp<9>(ctx, mc, T, order, F2T, sp);
+    case 10: return launch_mc2sp<10>(ctx, mc, T, order, F2T, sp);
+    case 11: return launch_mc2sp<11>(ctx, mc, T, order, F2T, sp);
+    case 12: return launch_mc2sp<12>(ctx, mc, T, order, F2T, sp);
+    default: return launch_mc2sp<13>(ctx, mc, T, order, F2T, sp);
+  }
+}
+
+extern "C" int kwy_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int K, int order, double alpha,
+                         double *mc) {
+  int l;
+  KWY_TRY(mcep_check(ctx, sp, mc, T, K, order, alpha, &l));
+  KWY_HIP(hipSetDevice(ctx->device));
+  size_t bs = kwy_pad(sizeof(double) * T * K), bm = kwy_pad(sizeof(double) * T * (order + 1));
+  KWY_TRY(kwy_arena_begin(ctx, bs + bm));
+  double *dsp = kwy_arena<double>(ctx, (size_t)T * K), *dmc = kwy_arena<double>(ctx, (size_t)T * (order + 1));
+  KWY_HIP(hipMemcpyAsync(dsp, sp, sizeof(double) * T * K, hipMemcpyHostToDevice, ctx->stream));
+  KWY_TRY(kwy_sp2mc_dev(ctx, dsp, T, K, order, alpha, dmc));
+  KWY_HIP(hipMemcpyAsync(mc, dmc, sizeof(double) * T * (order + 1), hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}
+
+extern "C" int kwy_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, int fftlen,
+                         double *sp) {
+  int l;
+  const int K = fftlen / 2 + 1;
+  KWY_TRY(mcep_check(ctx, mc, sp, T, K, order, alpha, &l));
+  KWY_HIP(hipSetDevice(ctx->device));
+  size_t bs = kwy_pad(sizeof(double) * T * K), bm = kwy_pad(sizeof(double) * T * (order + 1));
+  KWY_TRY(kwy_arena_begin(ctx, bs + bm));
+  double *dsp = kwy_arena<double>(ctx, (size_t)T * K), *dmc = kwy_arena<double>(ctx, (size_t)T * (order + 1));
+  KWY_HIP(hipMemcpyAsync(dmc, mc, sizeof(double) * T * (order + 1), hipMemcpyHostToDevice, ctx->stream));
+  KWY_TRY(kwy_mc2sp_dev(ctx, dmc, T, order, alpha, fftlen, dsp));
+  KWY_HIP(hipMemcpyAsync(sp, dsp, sizeof(double) * T * K, hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}

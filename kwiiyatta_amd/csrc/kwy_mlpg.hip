@@ -1,0 +1,391 @@
+// kwy_mlpg.hip -- GMM-based spectral mapping with MLPG on gfx950.
+//
+// Replaces, for the converter-apply step of the reference
+// (kwiiyatta/converter/delta.py:39-50 and gmm.py:28-34):
+//     X  = nnmnkwii.preprocessing.delta_features(x, DELTA_WINDOWS)
+//     y  = nnmnkwii.baseline.gmm.MLPG(gmm, windows=DELTA_WINDOWS, diff).transform(X)[:, :d]
+//
+// Kernels:
+//   k_gmm_prep   one workgroup per mixture: Cholesky of S_xx in LDS, its inverse,
+//                A = S_yx S_xx^-1, diagonal conditional variance, log-normaliser
+//   k_delta      static + delta + delta-delta features (3-tap correlations)
+//   k_gmm_logp   (frame tile x mixture) workgroups: ||L^-1 (x - mu)||^2 from LDS
+//   k_gmm_cond   per frame: arg-max mixture, conditional mean E and variance D
+//   k_mlpg_build per (frame, dim): the pentadiagonal normal equations W'PW, W'P mu
+//   k_mlpg_solve per static dim: banded Cholesky + two triangular sweeps
+//
+// Algorithmic HBM bytes per frame: d*8 in, d*8 out (+ the GMM once per call).
+#include <math.h>
+
+#include "kwy_internal.hpp"
+
+#define ML_TILE 64  // frames per k_gmm_logp workgroup
+
+struct ml_dims { int d, D, M; int64_t T; };
+
+// ---- per-mixture preparation -----------------------------------------------------
+// layout of the prepared model (doubles), per mixture m:
+//   Z   [D*D]  lower-triangular inverse of chol(S_xx)   (row j: Z[j][0..j])
+//   A   [D*D]  S_yx S_xx^-1
+//   mux [D], muy [D], dvar [D], cst [1] (+ padding)
+__host__ __device__ static inline size_t ml_model_stride(int D) { return (size_t)2 * D * D + 3 * D + 8; }
+
+__global__ __launch_bounds__(KWY_THREADS) void k_gmm_prep(const double *__restrict__ weights,
+                                                         const double *__restrict__ means,
+                                                         const double *__restrict__ covs, int D, int diff,
+                                                         double *__restrict__ model, int *__restrict__ status) {
+  extern __shared__ double smem[];
+  double *L = smem;          // D x D
+  double *Z = L + D * D;     // D x D
+  double *W = Z + D * D;     // D x D
+  const int tid = threadIdx.x, m = blockIdx.x, D2 = 2 * D;
+  const double *C = covs + (size_t)m * D2 * D2;
+  double *out = model + (size_t)m * ml_model_stride(D);
+  double *oZ = out, *oA = oZ + D * D, *omux = oA + D * D, *omuy = omux + D, *odv = omuy + D, *ocst = odv + D;
+
+  auto Sxx = [&](int i, int j) { return C[(size_t)i * D2 + j]; };
+  auto Sxy = [&](int i, int j) { return diff ? C[(size_t)i * D2 + D + j] - C[(size_t)i * D2 + j] : C[(size_t)i * D2 + D + j]; };
+  auto Syx = [&](int i, int j) { return diff ? Sxy(j, i) : C[(size_t)(D + i) * D2 + j]; };
+  auto Syy = [&](int i, int j) {
+    double v = C[(size_t)(D + i) * D2 + D + j];
+    if (diff) v = C[(size_t)i * D2 + j] + v - C[(size_t)i * D2 + D + j] - C[(size_t)(D + i) * D2 + j];
+    return v;
+  };
+
+  for (int e = tid; e < D * D; e += KWY_THREADS) L[e] = Sxx(e / D, e % D);
+  __syncthreads();
+  // right-looking Cholesky (same subtraction order per entry as the textbook left-looking form)
+  for (int j = 0; j < D; ++j) {
+    const double piv = L[j * D + j];
+    if (!(piv > 0.0)) { if (tid == 0) atomicExch(status, 1); return; }
+    const double dj = sqrt(piv);
+    __syncthreads();
+    if (tid == 0) L[j * D + j] = dj;
+    for (int i = j + 1 + tid; i < D; i += KWY_THREADS) L[i * D + j] = L[i * D + j] / dj;
+    __syncthreads();
+    const int rem = D - j - 1;
+    for (int e = tid; e < rem * rem; e += KWY_THREADS) {
+      int i = j + 1 + e / rem, k = j + 1 + e % rem;
+      if (k <= i) L[i * D + k] -= L[i * D + j] * L[k * D + j];
+    }
+    __syncthreads();
+  }
+  // Z = L^-1 (lower): column c by thread c
+  for (int c = tid; c < D; c += KWY_THREADS) {
+    for (int i = 0; i < D; ++i) {
+      double v = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) v -= L[i * D + k] * Z[k * D + c];
+      Z[i * D + c] = (i < c) ? 0.0 : v / L[i * D + i];
+    }
+  }
+  __syncthreads();
+  // W = S_yx Z'   (W[r][j] = sum_i Syx[r][i] Z[j][i])
+  for (int e = tid; e < D * D; e += KWY_THREADS) {
+    int r = e / D, j = e % D;
+    double v = 0.0;
+    for (int i = 0; i <= j; ++i) v += Syx(r, i) * Z[j * D + i];
+    W[e] = v;
+  }
+  __syncthreads();
+  // A = W Z       (A[r][c] = sum_j W[r][j] Z[j][c])
+  for (int e = tid; e < D * D; e += KWY_THREADS) {
+    int r = e / D, c = e % D;
+    double v = 0.0;
+    for (int j = c; j < D; ++j) v += W[r * D + j] * Z[j * D + c];
+    oA[e] = v;
+    oZ[e] = Z[e];
+  }
+  for (int i = tid; i < D; i += KWY_THREADS) {
+    double mx = means[(size_t)m * D2 + i], my = means[(size_t)m * D2 + D + i];
+    omux[i] = mx;
+    omuy[i] = diff ? my - mx : my;
+    odv[i] = Syy(i, i) - Syx(i, i) / Sxx(i, i) * Sxy(i, i);
+  }
+  if (tid == 0) {
+    double ld = 0.0;
+    for (int i = 0; i < D; ++i) ld -= log(L[i * D + i]);
+    ocst[0] = -0.5 * (D * log(2.0 * KWY_PI)) + ld + log(weights[m]);
+  }
+}
+
+// ---- delta features -----------------------------------------------------------------
+// DELTA_WINDOWS (kwiiyatta/converter/delta.py:8-12): [1], [-0.5, 0, 0.5], [1, -2, 1]
+__global__ void k_delta(const double *__restrict__ x, ml_dims dm, double *__restrict__ X) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= dm.T * dm.d) return;
+  const int64_t t = e / dm.d;
+  const int c = (int)(e % dm.d);
+  const double xm = t > 0 ? x[(t - 1) * dm.d + c] : 0.0;
+  const double x0 = x[t * dm.d + c];
+  const double xp = t + 1 < dm.T ? x[(t + 1) * dm.d + c] : 0.0;
+  double *o = X + t * dm.D;
+  o[c] = 0.0 + x0 * 1.0;
+  double s = 0.0;
+  if (t > 0) s += xm * -0.5;
+  s += x0 * 0.0;
+  if (t + 1 < dm.T) s += xp * 0.5;
+  o[dm.d + c] = s;
+  s = 0.0;
+  if (t > 0) s += xm * 1.0;
+  s += x0 * -2.0;
+  if (t + 1 < dm.T) s += xp * 1.0;
+  o[2 * dm.d + c] = s;
+}
+
+// ---- log p(x_t | m) up to the shared constant -------------------------------------------
+__global__ __launch_bounds__(KWY_THREADS) void k_gmm_logp(const double *__restrict__ X, ml_dims dm,
+                                                         const double *__restrict__ model,
+                                                         double *__restrict__ logp) {
+  extern __shared__ double smem[];
+  const int D = dm.D, DP = D + 1;
+  double *Z = smem;               // D x D
+  double *dt = Z + D * D;         // ML_TILE x DP
+  double *qp = dt + ML_TILE * DP; // 4 x ML_TILE
+  const int tid = threadIdx.x, m = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * ML_TILE;
+  const double *mod = model + (size_t)m * ml_model_stride(D);
+  const double *mZ = mod, *mux = mod + 2 * D * D;
+  for (int e = tid; e < D * D; e += KWY_THREADS) Z[e] = mZ[e];
+  for (int e = tid; e < ML_TILE * D; e += KWY_THREADS) {
+    int tl = e / D, i = e % D;
+    int64_t t = t0 + tl;
+    dt[tl * DP + i] = t < dm.T ? X[t * D + i] - mux[i] : 0.0;
+  }
+  __syncthreads();
+  const int tl = tid & 63, jg = tid >> 6;
+  const int per = (D + 3) / 4;
+  const int j0 = jg * per, j1 = min(D, j0 + per);
+  double q = 0.0;
+  const double *drow = dt + tl * DP;
+  for (int j = j0; j < j1; ++j) {
+    double y = 0.0;
+    const double *zr = Z + j * D;
+    for (int i = 0; i <= j; ++i) y += drow[i] * zr[i];
+    q += y * y;
+  }
+  qp[jg * ML_TILE + tl] = q;
+  __syncthreads();
+  if (tid < ML_TILE) {
+    int64_t t = t0 + tid;
+    if (t < dm.T) {
+      double qq = ((qp[tid] + qp[ML_TILE + tid]) + qp[2 * ML_TILE + tid]) + qp[3 * ML_TILE + tid];
+      logp[t * dm.M + m] = mod[2 * D * D + 3 * D] - 0.5 * qq;
+    }
+  }
+}
+
+// ---- arg-max mixture, conditional mean / variance --------------------------------------------
+__global__ __launch_bounds__(128) void k_gmm_cond(const double *__restrict__ X, ml_dims dm,
+                                                 const double *__restrict__ model,
+                                                 const double *__restrict__ logp,
+                                                 double *__restrict__ E, double *__restrict__ Dv,
+                                                 int *__restrict__ mix) {
+  __shared__ int s_m;
+  __shared__ double dsh[256];
+  const int64_t t = blockIdx.x;
+  const int tid = threadIdx.x, D = dm.D;
+  if (tid == 0) {
+    int bm = 0;
+    double best = -INFINITY;
+    for (int m = 0; m < dm.M; ++m) {
+      double lp = logp[t * dm.M + m];
+      if (lp > best) { best = lp; bm = m; }
+    }
+    s_m = bm;
+    mix[t] = bm;
+  }
+  __syncthreads();
+  const double *mod = model + (size_t)s_m * ml_model_stride(D);
+  const double *A = mod + D * D, *mux = A + D * D, *muy = mux + D, *dvar = muy + D;
+  for (int i = tid; i < D; i += blockDim.x) dsh[i] = X[t * D + i] - mux[i];
+  __syncthreads();
+  for (int i = tid; i < D; i += blockDim.x) {
+    double v = muy[i];
+    const double *ar = A + (size_t)i * D;
+    for (int k = 0; k < D; ++k) v += ar[k] * dsh[k];
+    E[t * D + i] = v;
+    Dv[t * D + i] = dvar[i];
+  }
+}
+
+// ---- MLPG: normal equations ---------------------------------------------------------------------
+// band[t][c][0..2] = P[t][t], P[t][t-1], P[t][t-2];  rhs[t][c]
+__device__ __forceinline__ double ml_wcoef(int w, int k) {  // window w at offset k in [-1, 1]
+  if (w == 0) return k == 0 ? 1.0 : 0.0;
+  if (w == 1) return k == -1 ? -0.5 : (k == 0 ? 0.0 : 0.5);
+  return k == 0 ? -2.0 : 1.0;
+}
+
+__global__ void k_mlpg_build(const double *__restrict__ E, const double *__restrict__ Dv, ml_dims dm,
+                             double *__restrict__ band, double *__restrict__ rhs) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= dm.T * dm.d) return;
+  const int64_t a = e / dm.d;
+  const int c = (int)(e % dm.d);
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, b = 0.0;
+  for (int w = 0; w < 3; ++w) {
+    const int l = w == 0 ? 0 : 1;
+    for (int64_t t = a - l; t <= a + l; ++t) {  // frames whose window touches row a (ascending t)
+      if (t < 0 || t >= dm.T) continue;
+      const int k1 = (int)(a - t);
+      const double prec = 1 / Dv[t * dm.D + w * dm.d + c];
+      const double bm = prec * E[t * dm.D + w * dm.d + c];
+      const double ca = ml_wcoef(w, k1);
+      b += ca * bm;
+      for (int k2 = -l; k2 <= k1; ++k2) {
+        const int64_t cc = t + k2;
+        if (cc < 0 || cc >= dm.T) continue;
+        const double v = ca * prec * ml_wcoef(w, k2);
+        const int off = (int)(a - cc);
+        if (off == 0) p0 += v; else if (off == 1) p1 += v; else p2 += v;
+      }
+    }
+  }
+  band[(a * dm.d + c) * 3 + 0] = p0;
+  band[(a * dm.d + c) * 3 + 1] = p1;
+  band[(a * dm.d + c) * 3 + 2] = p2;
+  rhs[a * dm.d + c] = b;
+}
+
+// ---- MLPG: banded Cholesky + forward/backward sweeps, one thread per static dimension ----------------
+__global__ void k_mlpg_solve(double *__restrict__ band, double *__restrict__ rhs, ml_dims dm,
+                             double *__restrict__ y, int *__restrict__ status) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= dm.d) return;
+  const int d = dm.d;
+  const int64_t T = dm.T;
+  // L[t][0] diag, L[t][1] = L[t][t-1], L[t][2] = L[t][t-2]; z = L^-1 b
+  double l1_0 = 0, l1_1 = 0, z1 = 0;  // row t-1: diag, sub1; z[t-1]
+  double l2_0 = 0, z2 = 0;            // row t-2: diag; z[t-2]
+  for (int64_t t = 0; t < T; ++t) {
+    double *br = band + (t * d + c) * 3;
+    double p0 = br[0], p1 = br[1], p2 = br[2];
+    double L2 = 0.0, L1 = 0.0;
+    if (t >= 2) L2 = p2 / l2_0;
+    if (t >= 1) {
+      double v = p1;
+      if (t >= 2) v -= L2 * l1_1;  // L[t][t-2] * L[t-1][t-2]
+      L1 = v / l1_0;
+    }
+    double v = p0;
+    if (t >= 2) v -= L2 * L2;
+    if (t >= 1) v -= L1 * L1;
+    if (!(v > 0.0)) { atomicExch(status, 2); v = 1.0; }
+    const double L0 = sqrt(v);
+    double zz = rhs[t * d + c];
+    if (t >= 1) zz -= L1 * z1;
+    if (t >= 2) zz -= L2 * z2;
+    zz = zz / L0;
+    br[0] = L0; br[1] = L1; br[2] = L2;
+    rhs[t * d + c] = zz;
+    l2_0 = l1_0; z2 = z1;
+    l1_0 = L0; l1_1 = L1; z1 = zz;
+  }
+  double y1 = 0, y2 = 0, n1_1 = 0, n2_2 = 0, n1_2 = 0;  // y[t+1], y[t+2]; L[t+1][1], L[t+2][2]
+  for (int64_t t = T - 1; t >= 0; --t) {
+    const double *br = band + (t * d + c) * 3;
+    double v = rhs[t * d + c];
+    if (t + 1 < T) v -= n1_1 * y1;
+    if (t + 2 < T) v -= n2_2 * y2;
+    v = v / br[0];
+    y[t * d + c] = v;
+    n2_2 = n1_2;       // L[t+1][2] becomes L[(t-1)+2][2]
+    y2 = y1;
+    n1_1 = br[1]; n1_2 = br[2];
+    y1 = v;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+static size_t ml_scratch_bytes(int64_t T, int d, int M) {
+  const int D = 3 * d;
+  return kwy_pad(sizeof(double) * ml_model_stride(D) * M) + 3 * kwy_pad(sizeof(double) * T * D) +
+         kwy_pad(sizeof(double) * T * M) + kwy_pad(sizeof(int) * T) + kwy_pad(sizeof(double) * T * d * 3) +
+         kwy_pad(sizeof(double) * T * d) + kwy_pad(64);
+}
+
+static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,
+                     const double *means, const double *covs, int diff, double *y, int **status_out) {
+  const int D = 3 * d;
+  ml_dims dm = {d, D, M, T};
+  double *model = kwy_arena<double>(ctx, ml_model_stride(D) * M);
+  double *X = kwy_arena<double>(ctx, (size_t)T * D);
+  double *E = kwy_arena<double>(ctx, (size_t)T * D);
+  double *Dv = kwy_arena<double>(ctx, (size_t)T * D);
+  double *logp = kwy_arena<double>(ctx, (size_t)T * M);
+  int *mix = kwy_arena<int>(ctx, T);
+  double *band = kwy_arena<double>(ctx, (size_t)T * d * 3);
+  double *rhs = kwy_arena<double>(ctx, (size_t)T * d);
+  int *status = kwy_arena<int>(ctx, 16);
+  if (!model || !X || !E || !Dv || !logp || !mix || !band || !rhs || !status) {
+    ctx->err = "gmm_mlpg: scratch arena too small";
+    return KWY_ENOMEM;
+  }
+  *status_out = status;
+  KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
+  size_t lds_prep = sizeof(double) * 3 * D * D;
+  size_t lds_logp = sizeof(double) * (D * D + ML_TILE * (D + 1) + 4 * ML_TILE);
+  if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024) { ctx->err = "gmm_mlpg: feature dimension too large"; return KWY_EINVAL; }
+  KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
+  hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
+                     diff, model, status);
+  const unsigned ge = (unsigned)((T * d + 255) / 256);
+  hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, x, dm, X);
+  hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)((T + ML_TILE - 1) / ML_TILE), M), dim3(KWY_THREADS), lds_logp,
+                     ctx->stream, X, dm, model, logp);
+  hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
+  hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band, rhs);
+  hipLaunchKernelGGL(k_mlpg_solve, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, band, rhs, dm, y, status);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static int ml_check(kwy_ctx *ctx, const void *x, int64_t T, int d, int M, const void *w, const void *mu,
+                    const void *cv, const void *y) {
+  if (!ctx) return KWY_EINVAL;
+  if (!x || !w || !mu || !cv || !y || T <= 0 || d <= 0 || M <= 0 || 3 * d > 255) {
+    ctx->err = "gmm_mlpg: bad argument";
+    return KWY_EINVAL;
+  }
+  return KWY_OK;
+}
+
+extern "C" int kwy_gmm_mlpg_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
+                                const double *weights, const double *means, const double *covs, int diff,
+                                double *y) {
+  KWY_TRY(ml_check(ctx, x, T, d, M, weights, means, covs, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, ml_scratch_bytes(T, d, M)));
+  int *status;
+  return mlpg_core(ctx, x, T, d, M, weights, means, covs, diff, y, &status);
+}
+
+extern "C" int kwy_gmm_mlpg(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,
+                            const double *means, const double *covs, int diff, double *y) {
+  KWY_TRY(ml_check(ctx, x, T, d, M, weights, means, covs, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  const int D2 = 6 * d;
+  size_t bx = kwy_pad(sizeof(double) * T * d), bw = kwy_pad(sizeof(double) * M);
+  size_t bm = kwy_pad(sizeof(double) * M * D2), bc = kwy_pad(sizeof(double) * (size_t)M * D2 * D2);
+  KWY_TRY(kwy_arena_begin(ctx, ml_scratch_bytes(T, d, M) + 2 * bx + bw + bm + bc));
+  double *dx = kwy_arena<double>(ctx, (size_t)T * d), *dy = kwy_arena<double>(ctx, (size_t)T * d);
+  double *dw = kwy_arena<double>(ctx, M), *dmu = kwy_arena<double>(ctx, (size_t)M * D2);
+  double *dcv = kwy_arena<double>(ctx, (size_t)M * D2 * D2);
+  KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * T * d, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dw, weights, sizeof(double) * M, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dmu, means, sizeof(double) * M * D2, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dcv, covs, sizeof(double) * (size_t)M * D2 * D2, hipMemcpyHostToDevice, ctx->stream));
+  int *status;
+  KWY_TRY(mlpg_core(ctx, dx, T, d, M, dw, dmu, dcv, diff, dy, &status));
+  int hstatus = 0;
+  KWY_HIP(hipMemcpyAsync(y, dy, sizeof(double) * T * d, hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  if (hstatus != 0) {
+    ctx->err = hstatus == 1 ? "gmm_mlpg: source covariance is not positive definite"
+                            : "gmm_mlpg: MLPG system is not positive definite";
+    return KWY_ENUMERIC;
+  }
+  return KWY_OK;
+}
