@@ -81,6 +81,17 @@ int kwy_d4c_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
                 const double *temporal_positions, const double *f0, int64_t f0_length,
                 double threshold, int fft_size, double *out);
 
+/* pyworld.dio(x, fs, f0_floor, f0_ceil, channels_in_octave, frame_period, speed,
+ *             allowed_range) -> (f0, t)              kwiiyatta/vocoder/world.py:35
+ * only speed == 1 (pyworld's default, the only value kwiiyatta uses). */
+int kwy_dio(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, double f0_floor,
+            double f0_ceil, double channels_in_octave, double frame_period_ms, int speed,
+            double allowed_range, double *temporal_positions, double *f0);
+/* pyworld.stonemask(x, f0, t, fs)                    kwiiyatta/vocoder/world.py:39 */
+int kwy_stonemask(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+                  const double *temporal_positions, const double *f0, int64_t f0_length,
+                  double *refined_f0);
+
 /* ---- WORLD synthesis ------------------------------------------------------------ */
 /* pyworld.synthesize(f0, sp, ap, fs, frame_period)   kwiiyatta/vocoder/world.py:86-92
  * sp_mul: every spectrogram value is multiplied by this before use (pass fs to

@@ -70,3 +70,39 @@ def synthesize(f0, spectrogram, aperiodicity, fs, frame_period=default_frame_per
                                        float(frame_period), int(fs), float(sp_mul), y_length,
                                        ptr(y)))
     return y
+
+
+def code_aperiodicity(aperiodicity, fs):
+    raise NotImplementedError('WORLD aperiodicity band coding (cross-sampling-rate resampling, '
+                              'SURVEY.md 8(f)-3) is not implemented in kwiiyatta_amd yet')
+
+
+def decode_aperiodicity(coded_aperiodicity, fs, fft_size):
+    raise NotImplementedError('WORLD aperiodicity band decoding (cross-sampling-rate resampling, '
+                              'SURVEY.md 8(f)-3) is not implemented in kwiiyatta_amd yet')
+
+
+def dio(x, fs, f0_floor=default_f0_floor, f0_ceil=default_f0_ceil, channels_in_octave=2.0,
+        frame_period=default_frame_period, speed=1, allowed_range=0.1, ctx=None):
+    x = _lib.as_f64(x)
+    ctx = ctx or _lib.default_context()
+    T = lib.kwy_dio_frames(int(fs), len(x), float(frame_period))
+    f0 = np.empty(T)
+    t = np.empty(T)
+    _lib.check(ctx, lib.kwy_dio(ctx.handle, ptr(x), len(x), int(fs), float(f0_floor), float(f0_ceil),
+                                float(channels_in_octave), float(frame_period), int(speed),
+                                float(allowed_range), ptr(t), ptr(f0)))
+    return f0, t
+
+
+def stonemask(x, f0, temporal_positions, fs, ctx=None):
+    x = _lib.as_f64(x)
+    f0 = _lib.as_f64(f0)
+    t = _lib.as_f64(temporal_positions)
+    if len(t) != len(f0):
+        raise ValueError('f0 and temporal_positions must have the same length')
+    ctx = ctx or _lib.default_context()
+    out = np.empty(len(f0))
+    _lib.check(ctx, lib.kwy_stonemask(ctx.handle, ptr(x), len(x), int(fs), ptr(t), ptr(f0), len(f0),
+                                      ptr(out)))
+    return out
