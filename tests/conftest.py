@@ -35,3 +35,54 @@ def round_equal(expect, actual, sig_dig=2):
 def gpu_ctx():
     from kwiiyatta_amd import _lib
     return _lib.default_context()
+
+
+def _install_oracle_backend(monkeypatch):
+    """Route the pyworld/pysptk/fastdtw/nnmnkwii-shaped backend modules to the CPU
+    oracle, so the HOST logic of the package can be exercised without a GPU.
+    Test-only: the product never does this."""
+    import numpy as np
+    from oracle import oracle as ko
+    from kwiiyatta_amd.backend import dtw, mlpg, sptk, world
+
+    def cheaptrick(x, f0, t, fs, q1=-0.15, f0_floor=71.0, fft_size=None, ctx=None, out_div=1.0):
+        sp = ko.cheaptrick(x, f0, t, fs, q1=q1, f0_floor=f0_floor, fft_size=fft_size)
+        if out_div != 1.0:
+            sp /= out_div
+        return sp
+
+    def synthesize(f0, sp, ap, fs, frame_period=5.0, ctx=None, sp_mul=1.0):
+        return ko.synthesize(f0, np.ascontiguousarray(sp * sp_mul) if sp_mul != 1.0 else sp, ap, fs,
+                             frame_period)
+
+    class OracleMLPG:
+        def __init__(self, gmm, windows=None, swap=False, diff=False, ctx=None):
+            self.gmm, self.diff = gmm, diff
+            self.static_dim = gmm.means_.shape[1] // 6
+
+        def transform(self, src):
+            d = self.static_dim
+            return ko.gmm_mlpg(np.ascontiguousarray(src[:, :d]), self.gmm.weights_, self.gmm.means_,
+                               self.gmm.covariances_, diff=self.diff)
+
+    monkeypatch.setattr(world, 'dio', lambda x, fs, ctx=None, **kw: ko.dio(x, fs, **kw))
+    monkeypatch.setattr(world, 'stonemask', lambda x, f0, t, fs, ctx=None: ko.stonemask(x, f0, t, fs))
+    monkeypatch.setattr(world, 'cheaptrick', cheaptrick)
+    monkeypatch.setattr(world, 'd4c', lambda x, f0, t, fs, ctx=None, **kw: ko.d4c(x, f0, t, fs, **kw))
+    monkeypatch.setattr(world, 'synthesize', synthesize)
+    monkeypatch.setattr(sptk, 'sp2mc', lambda sp, order, alpha, ctx=None: ko.sp2mc(sp, order, alpha))
+    monkeypatch.setattr(sptk, 'mc2sp', lambda mc, alpha, fftlen, ctx=None: ko.mc2sp(mc, alpha, fftlen))
+    monkeypatch.setattr(dtw, 'fastdtw', lambda x, y, radius=1, dist=2, ctx=None: ko.fastdtw(x, y, radius, dist))
+    monkeypatch.setattr(mlpg, 'MLPG', OracleMLPG)
+    from kwiiyatta_amd.converter import gmm as gmm_mod
+    monkeypatch.setattr(gmm_mod, 'MLPG', OracleMLPG)
+
+
+@pytest.fixture(params=['oracle', pytest.param('hip', marks=pytest.mark.gpu)])
+def kwiiyatta(request, monkeypatch):
+    """The host package, with its numerics served either by the CPU oracle
+    (host-logic tests, no GPU) or by the HIP kernels (-m gpu)."""
+    import kwiiyatta_amd
+    if request.param == 'oracle':
+        _install_oracle_backend(monkeypatch)
+    return kwiiyatta_amd

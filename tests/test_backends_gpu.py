@@ -1,0 +1,164 @@
+"""GPU parity of the remaining hot-path kernels against the CPU oracle, through
+the C ABI: mel-cepstrum (sp2mc/mc2sp), FastDTW, GMM+MLPG conversion, and the
+f0 front-end (DIO, StoneMask).
+
+Tolerances: mel-cepstrum 1e-12 relative (same algorithm, different summation
+order); FastDTW path and distance bit-exact (integer path, identical distance
+arithmetic); MLPG 1e-10 relative; DIO f0 1e-8 Hz with identical voicing
+decisions (direct FIR instead of FFT filtering); StoneMask 1e-10 relative."""
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+from conftest import CLB_WAV, SLT_WAV, clb_variant
+
+pytestmark = pytest.mark.gpu
+
+
+def load(path):
+    fs, d = wavfile.read(path)
+    return fs, np.ascontiguousarray(d.astype(np.float64) / 2 ** 15)
+
+
+@pytest.fixture(scope='module')
+def ko():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope='module')
+def clb(ko):
+    fs, x = load(CLB_WAV)
+    f0, t = ko.dio(x, fs)
+    f0 = ko.stonemask(x, f0, t, fs)
+    sp = ko.cheaptrick(x, f0, t, fs) / fs
+    return dict(fs=fs, x=x, f0=f0, t=t, sp=sp)
+
+
+@pytest.mark.parametrize('order', [24, 36, 48])
+def test_sp2mc_mc2sp(ko, clb, order):
+    from kwiiyatta_amd.backend import sptk
+    alpha = sptk.mcepalpha(clb['fs'])
+    assert alpha == pytest.approx(ko.mcepalpha(clb['fs']), abs=1e-12)
+    ref = ko.sp2mc(clb['sp'], order, alpha)
+    got = sptk.sp2mc(clb['sp'], order, alpha)
+    assert got.shape == ref.shape == (len(clb['f0']), order + 1)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    fftlen = (clb['sp'].shape[1] - 1) * 2
+    ref2 = ko.mc2sp(ref, alpha, fftlen)
+    got2 = sptk.mc2sp(ref, alpha, fftlen)
+    assert np.max(np.abs(got2 - ref2) / ref2) <= 1e-11
+    # 1-D input is handled like pysptk's apply-along-last-axis
+    assert np.allclose(sptk.sp2mc(clb['sp'][5], order, alpha), got[5], rtol=0, atol=0)
+
+
+def test_mcep_48k(ko):
+    from kwiiyatta_amd.backend import sptk
+    fs, x = load(clb_variant('48'))
+    f0, t = ko.dio(x, fs)
+    sp = ko.cheaptrick(x, f0, t, fs) / fs
+    alpha = sptk.mcepalpha(fs)
+    assert abs(alpha - 0.554) < 1e-9
+    ref = ko.sp2mc(sp, 24, alpha)
+    got = sptk.sp2mc(sp, 24, alpha)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.max(np.abs(sptk.mc2sp(ref, alpha, 2048) / ko.mc2sp(ref, alpha, 2048) - 1)) <= 1e-11
+
+
+def _series(rng, T, dim, warp):
+    t = np.linspace(0, 1, T) ** warp
+    base = np.stack([np.sin(2 * np.pi * (k + 1) * t * 3 + k) for k in range(dim)], 1)
+    return base + 0.05 * rng.standard_normal((T, dim))
+
+
+@pytest.mark.parametrize('Tx,Ty,dim,radius', [
+    (1, 1, 2, 1), (2, 5, 3, 1), (20, 17, 3, 32), (33, 34, 4, 32), (35, 70, 4, 32), (70, 90, 5, 1),
+    (300, 350, 26, 32), (737, 801, 25, 1), (2201, 2401, 26, 32), (2401, 2201, 26, 32)])
+def test_fastdtw_bit_exact(ko, Tx, Ty, dim, radius):
+    from kwiiyatta_amd.backend import dtw
+    rng = np.random.default_rng(Tx * 7919 + Ty)
+    x, y = _series(rng, Tx, dim, 1.0), _series(rng, Ty, dim, 1.3)
+    d_ref, p_ref = ko.fastdtw(x, y, radius=radius, dist=2)
+    d_got, p_got = dtw.fastdtw(x, y, radius=radius, dist=2)
+    assert p_got == p_ref
+    assert d_got == d_ref
+    # path properties: monotone, unit steps, end points
+    p = np.array(p_got)
+    assert tuple(p[0]) == (0, 0) and tuple(p[-1]) == (Tx - 1, Ty - 1)
+    dp = np.diff(p, axis=0)
+    assert ((dp >= 0) & (dp <= 1)).all() and (dp.sum(axis=1) >= 1).all()
+
+
+def test_fastdtw_ties_and_1d(ko):
+    """Exact ties (integer-valued, repeated frames) exercise the predecessor order."""
+    from kwiiyatta_amd.backend import dtw
+    x = np.array([0, 0, 1, 1, 2, 2, 2, 3, 0, 0, 5, 5, 5, 1], dtype=np.float64)
+    y = np.array([0, 1, 1, 1, 2, 3, 3, 0, 5, 1, 1], dtype=np.float64)
+    for r in (1, 2, 32):
+        assert dtw.fastdtw(x, y, radius=r, dist=2) == ko.fastdtw(x, y, radius=r, dist=2)
+    xx = np.tile(x, 20)[:, None] * np.ones((1, 3))
+    yy = np.tile(y, 23)[:, None] * np.ones((1, 3))
+    assert dtw.fastdtw(xx, yy, radius=1, dist=2) == ko.fastdtw(xx, yy, radius=1, dist=2)
+
+
+@pytest.mark.parametrize('M', [1, 4, 16])
+@pytest.mark.parametrize('diff', [False, True])
+def test_gmm_mlpg(ko, clb, M, diff):
+    from sklearn.mixture import GaussianMixture
+    from kwiiyatta_amd.backend import mlpg
+    alpha = ko.mcepalpha(clb['fs'])
+    mc = ko.sp2mc(clb['sp'], 24, alpha)[:, 1:]
+    rng = np.random.default_rng(0)
+    X = ko.delta_features(mc, ko.DELTA_WINDOWS)
+    assert np.array_equal(mlpg.delta_features(mc, mlpg.DELTA_WINDOWS), X)
+    Y = X @ (np.eye(72) + 0.05 * rng.standard_normal((72, 72))) + 0.1 * rng.standard_normal(X.shape)
+    gmm = GaussianMixture(n_components=M, covariance_type='full', max_iter=15, random_state=0,
+                          reg_covar=1e-4).fit(np.hstack([X, Y]))
+    ref, mix_ref = ko.gmm_mlpg(mc, gmm.weights_, gmm.means_, gmm.covariances_, diff=diff, return_mix=True)
+    got = mlpg.MLPG(gmm, windows=mlpg.DELTA_WINDOWS, diff=diff).transform(X)
+    assert got.shape == ref.shape == mc.shape
+    assert np.abs(got - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1.0)
+    if M > 1:
+        assert len(np.unique(mix_ref)) > 1   # the selection step is exercised
+
+
+def test_gmm_mlpg_errors(clb):
+    from kwiiyatta_amd.backend import mlpg
+
+    class G:  # indefinite source covariance -> ValueError, not garbage
+        covariance_type = 'full'
+        weights_ = np.array([1.0])
+        means_ = np.zeros((1, 12))
+        covariances_ = -np.eye(12)[None]
+    with pytest.raises(ValueError):
+        mlpg.MLPG(G()).transform(np.zeros((5, 2)))
+
+
+@pytest.mark.parametrize('path', [CLB_WAV, SLT_WAV, clb_variant('22'), clb_variant('48')])
+@pytest.mark.parametrize('frame_period', [5.0, 3.0])
+def test_dio_stonemask(ko, path, frame_period):
+    from kwiiyatta_amd.backend import world
+    fs, x = load(path)
+    f0_ref, t_ref = ko.dio(x, fs, frame_period=frame_period)
+    f0_got, t_got = world.dio(x, fs, frame_period=frame_period)
+    assert np.array_equal(t_got, t_ref)
+    assert np.array_equal(f0_got > 0, f0_ref > 0)
+    assert np.abs(f0_got - f0_ref).max() <= 1e-8
+    s_ref = ko.stonemask(x, f0_ref, t_ref, fs)
+    s_got = world.stonemask(x, f0_ref, t_ref, fs)
+    assert np.abs(s_got - s_ref).max() <= 1e-10 * s_ref.max()
+
+
+def test_dio_short_and_silent(ko):
+    from kwiiyatta_amd.backend import world
+    fs = 16000
+    x = np.zeros(3000)
+    f0, t = world.dio(x, fs)
+    f0r, tr = ko.dio(x, fs)
+    assert np.array_equal(f0, f0r) and np.array_equal(t, tr) and not f0.any()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(800) * 0.1      # shorter than the voiced-range minimum
+    f0, t = world.dio(x, fs)
+    f0r, tr = ko.dio(x, fs)
+    assert np.array_equal(t, tr) and np.array_equal(f0, f0r)
+    assert np.array_equal(world.stonemask(x, f0, t, fs), ko.stonemask(x, f0r, tr, fs))
