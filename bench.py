@@ -1,11 +1,17 @@
 #!/usr/bin/env python
-"""Benchmark of the kwiiyatta hot path on MI355X.
+"""Benchmark of kwiiyatta's per-utterance conversion hot path on MI355X.
 
-`python bench.py --gpus N --steps K --warmup W` (N>1: launched under
-torch.distributed.run, one rank per GPU).  A step = one pass of the hot path
-over one batch of synthetic 48 kHz / 10 s utterances that are already resident
-in HBM; utterances are independent, so ranks shard them with no collective
-(weak scaling: per-GPU batch fixed).  Rank 0 prints one JSON line.
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one batch of synthetic 48 kHz utterance
+pairs that are already resident in HBM.  Default workload = BASELINE config 3:
+analyse source and target (CheapTrick + D4C over given f0 tracks), pad, sp2mc,
+DTW-align source onto target (FastDTW, radius 32), convert with a 64-component
+GMM (delta + MLPG), mc2sp, WORLD synthesis.  Pairs are independent: each pair
+runs on its own HIP stream, ranks shard pairs with NO collective on the data
+path (weak scaling: pairs per GPU fixed); only the timing is reduced (MAX).
+One frame = 5 ms of SOURCE audio (240 samples).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -19,37 +25,74 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FS = 48000
-SECONDS = 10.0
 FRAME_PERIOD = 5.0
+METRIC = 'frames/sec end-to-end analyse->align->convert->synth, 48 kHz 5 ms hop'
 
 
-def cpu_baseline(x, f0, t, seconds_budget=20.0):
-    """The CPU oracle ("port" of the reference's pyworld path) timed on one host
-    core over a bounded sample of the same workload."""
+def make_pair(index, seconds):
+    from kwiiyatta_amd.synthetic import make_utterance
+    src = make_utterance(seed=1234 + 2 * index, fs=FS, seconds=seconds)
+    tgt = make_utterance(seed=4321 + 2 * index, fs=FS, seconds=seconds, time_warp=1.1, formant_scale=1.12)
+    return src, tgt
+
+
+def cpu_baseline_pair(src, tgt, gmm, budget_s=25.0):
+    """The CPU oracle (C restatement of the reference's pyworld / pysptk /
+    fastdtw / nnmnkwii path), one thread, on a bounded sample: the first 2.0 s of
+    the source and 2.2 s of the target of the same workload."""
     from oracle import oracle as ko
-    frames = int(200 * 2.0) + 1          # first 2 s of the utterance
-    n = int(FS * 2.0)
-    xs, f0s, ts = np.ascontiguousarray(x[:n]), np.ascontiguousarray(f0[:frames]), np.ascontiguousarray(t[:frames])
+    from kwiiyatta_amd.vocoder.align import project_path_iter
+
+    def cut(u, sec):
+        x, f0, t = u
+        n, T = int(FS * sec), int(sec * 1000 / FRAME_PERIOD) + 1
+        return np.ascontiguousarray(x[:n]), np.ascontiguousarray(f0[:T]), np.ascontiguousarray(t[:T])
+
+    (xs, f0s, ts), (xt, f0t, tt) = cut(src, 2.0), cut(tgt, 2.2)
+    alpha = ko.mcepalpha(FS)
+    P, K = 100, 1025
+    rng = np.random.RandomState(0)
     reps, t0 = 0, time.perf_counter()
     while True:
-        sp = ko.cheaptrick(xs, f0s, ts, FS)
-        ap = ko.d4c(xs, f0s, ts, FS)
-        ko.synthesize(f0s, sp, ap, FS, FRAME_PERIOD)
+        feats = []
+        for x, f0, t in ((xs, f0s, ts), (xt, f0t, tt)):
+            sp = ko.cheaptrick(x, f0, t, FS) / FS
+            ap = ko.d4c(x, f0, t, FS)
+            sil = lambda: np.abs(rng.normal(0, 2.220446049250313e-16 / FS, (P, K)))  # noqa: E731
+            sp_pad = np.ascontiguousarray(np.concatenate((sil(), sp, sil())))
+            ap_pad = np.concatenate((np.full((P, K), 1 - 1e-12), ap, np.full((P, K), 1 - 1e-12)))
+            f0_pad = np.r_[np.zeros(P), f0, np.zeros(P)]
+            mc = ko.sp2mc(sp_pad, 24, alpha)
+            feat = np.hstack((np.zeros((len(mc), 2)), mc[:, 1:]))
+            feat[:, 0][mc[:, 0] >= mc[:, 0].max() - 1.636] = 9.4
+            feat[:, 1][f0_pad > 0] = 9.0
+            feats.append((sp_pad, ap_pad, mc, feat))
+        _, path = ko.fastdtw(feats[0][3], feats[1][3], radius=32, dist=2)
+        idx = np.fromiter(project_path_iter(np.array(path), trim=True, trim_len=P), dtype=np.int64)
+        mc_al, ap_al = feats[0][2][idx], np.ascontiguousarray(feats[0][1][idx])
+        y = ko.gmm_mlpg(np.ascontiguousarray(mc_al[:, 1:]), gmm.weights_, gmm.means_, gmm.covariances_)
+        sp_conv = ko.mc2sp(np.hstack((mc_al[:, :1], y)), alpha, 2048)
+        ko.synthesize(f0t, np.ascontiguousarray(sp_conv * FS), ap_al, FS, FRAME_PERIOD)
         reps += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or reps >= 8:
+        if el > budget_s or reps >= 6:
             break
+    frames = len(f0s)
     return {'value': reps * frames / el, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{reps}x first 2 s (401 frames) of the utterance: cheaptrick+d4c+synthesize, '
-                      f'oracle/liboracle.so (C restatement of pyworld 0.2.8), 1 thread'}
+            'sample': f'{reps}x the first 2.0 s of one source (401 frames) + 2.2 s of its target through the '
+                      f'same analyse->align->convert->synth path on oracle/liboracle.so '
+                      f'(C restatement of pyworld 0.2.8 / pysptk / fastdtw / nnmnkwii), 1 thread'}
 
 
 def main():
     ap_ = argparse.ArgumentParser()
     ap_.add_argument('--gpus', type=int, default=1)
-    ap_.add_argument('--steps', type=int, default=20)
-    ap_.add_argument('--warmup', type=int, default=3)
-    ap_.add_argument('--batch', type=int, default=8, help='utterances per GPU per step')
+    ap_.add_argument('--steps', type=int, default=10)
+    ap_.add_argument('--warmup', type=int, default=2)
+    ap_.add_argument('--batch', type=int, default=8, help='utterance pairs per GPU per step (one stream each)')
+    ap_.add_argument('--seconds', type=float, default=10.0, help='source utterance length')
+    ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
+    ap_.add_argument('--components', type=int, default=64)
     ap_.add_argument('--no-cpu-baseline', action='store_true')
     args = ap_.parse_args()
 
@@ -64,50 +107,39 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    from kwiiyatta_amd import _lib
-    from kwiiyatta_amd._lib import lib, c_vp
-    from kwiiyatta_amd.synthetic import make_utterance
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.parallel import shard_indices
 
-    # distinct utterances per rank (seed = global utterance index); a few base
-    # signals are generated on the host and reused round-robin inside the batch
-    nbase = min(args.batch, 2)
-    base = [make_utterance(seed=1234 + rank * args.batch + i, fs=FS, seconds=SECONDS) for i in range(nbase)]
-    T = len(base[0][1])
-    N = len(base[0][0])
-    fft = lib.kwy_cheaptrick_fft_size(FS, 71.0)
-    K = fft // 2 + 1
-    ylen = lib.kwy_synth_length(T, FRAME_PERIOD, FS)
+    # global utterance indices of this rank (weak scaling: `batch` per rank)
+    mine = shard_indices(world * args.batch, rank, world)
+    nbase = min(len(mine), 2)      # distinct host-generated signals, reused round-robin
+    base = [make_pair(mine[i], args.seconds) for i in range(nbase)]
+    gmm = pl.synthetic_gmm(order=24, components=args.components, seed=0) if args.workload == 'pair' else None
+    dgmm = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev) if gmm is not None else None
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.batch)]
-    ctxs = [_lib.Context(local_rank, stream=s.cuda_stream) for s in streams]
-    bufs = []
-    for i in range(args.batch):
-        x, f0, t = base[i % nbase]
-        bufs.append(dict(
-            x=torch.from_numpy(x).to(dev), f0=torch.from_numpy(f0).to(dev), t=torch.from_numpy(t).to(dev),
-            sp=torch.empty((T, K), dtype=torch.float64, device=dev),
-            ap=torch.empty((T, K), dtype=torch.float64, device=dev),
-            y=torch.empty(ylen, dtype=torch.float64, device=dev)))
+    pipes = []
+    for i in range(len(mine)):
+        src, tgt = base[i % nbase]
+        if args.workload == 'pair':
+            pipes.append(pl.PairPipeline(local_rank, FS, src, tgt, dgmm))
+        else:
+            pipes.append(pl.UtterancePipeline(local_rank, FS, src))
     torch.cuda.synchronize()
 
-    def p(tensor):
-        return c_vp(tensor.data_ptr())
-
     def step():
-        for ctx, b in zip(ctxs, bufs):
-            h = ctx.handle
-            _lib.check(ctx, lib.kwy_cheaptrick_dev(h, p(b['x']), N, FS, p(b['t']), p(b['f0']), T, -0.15, 71.0, fft, float(FS), p(b['sp'])))
-            _lib.check(ctx, lib.kwy_d4c_dev(h, p(b['x']), N, FS, p(b['t']), p(b['f0']), T, 0.85, fft, p(b['ap'])))
-            _lib.check(ctx, lib.kwy_synthesize_dev(h, p(b['f0']), T, p(b['sp']), p(b['ap']), fft, FRAME_PERIOD, FS, float(FS), ylen, p(b['y'])))
+        for p in pipes:
+            p.run()
 
     def sync_all():
-        for ctx in ctxs:
-            ctx.sync()
+        for p in pipes:
+            p.sync()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     sync_all()
+    for p in pipes:
+        p.ctx.profile(True)
     if world > 1:
         dist.barrier()
     sync_all()
@@ -123,30 +155,83 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
-    frames_total = world * args.batch * T * args.steps
+    frames_rank = sum(p.frames for p in pipes) * args.steps
+    if world > 1:
+        ft = torch.tensor([frames_rank], dtype=torch.float64, device=dev)
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        frames_total = float(ft.item())
+    else:
+        frames_total = float(frames_rank)
     value = frames_total / el
 
     if rank == 0:
-        # per-frame algorithmic bytes of the timed path: analyse 18 336 + synth 18 328
-        bytes_per_frame = (240 * 8 + 16 + 2 * K * 8) + (2 * K * 8 + 8 + 240 * 8)
+        T = pipes[0].frames
+        K = pipes[0].K
+        # dominant kernel: D4C general body (rocprofv3 --stats: profiles/).  Algorithmic bytes per
+        # launch = frames x (hop*8 + 16 in, K*8 out)   [SURVEY.md 8(d), D4C share of "analyse"]
+        dom = 'k_d4c_body'
+        tot_ms, launches, dom_bytes = 0.0, 0, 0.0
+        kernel_ms = {}
+        names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_syn_phase', 'k_syn_pulse', 'k_sp2mc',
+                 'k_mc2sp', 'k_dtw_dist', 'k_dtw_dp', 'k_gmm_logp', 'k_mlpg_solve']
+        for p in pipes:
+            for nme in names:
+                ms, n = p.ctx.profile_read(nme)
+                if n:
+                    a = kernel_ms.setdefault(nme, [0.0, 0])
+                    a[0] += ms
+                    a[1] += n
+        if dom in kernel_ms:
+            tot_ms, launches = kernel_ms[dom]
+        frames_per_launch = (2001 if args.workload == 'utterance' else (pipes[0].src.T + pipes[0].tgt.T) / 2.0)
+        if args.workload == 'utterance':
+            frames_per_launch = T
+        bytes_per_launch = frames_per_launch * (240 * 8 + 16 + K * 8)
+        avg_s = (tot_ms / launches) * 1e-3 if launches else float('nan')
+        achieved = bytes_per_launch / avg_s / 1e9 if launches else None
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': (achieved / 8000.0) if achieved else None, 'traffic': None,
+                    'avg_launch_ms': tot_ms / launches if launches else None, 'launches': launches,
+                    'algorithmic_bytes_per_launch': bytes_per_launch,
+                    'note': 'f64 FFT/LDS-bound kernel; HBM fraction is reported as asked, see DESIGN.md'}
+        # whole-path algorithmic bytes per source frame
+        path_bytes = 36664 if args.workload == 'utterance' else 81000
         out = {
-            'metric': 'frames/sec end-to-end analyse->align->convert->synth, 48 kHz 5 ms hop',
-            'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1000.0 * el / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'config2: 48 kHz 10 s utterances (T=2001, K=1025): CheapTrick + D4C + WORLD synthesis '
-                                   '(align/convert stages not in this round-1 line yet)',
-                       'utterances_per_gpu': args.batch, 'frames_per_utterance': T,
-                       'streams_per_gpu': args.batch, 'parallelism': f'utterance-sharded x{world}'},
+            'metric': METRIC, 'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1000.0 * el / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': ('config3: 48 kHz source (10 s, T=2001) + target (11 s, T=2201) pairs: CheapTrick+D4C of '
+                             'both, pad, sp2mc, FastDTW(radius 32) align, GMM(%d comp, D=144)+MLPG convert, mc2sp, '
+                             'WORLD synthesis' % args.components) if args.workload == 'pair' else
+                            'config2: 48 kHz 10 s utterances (T=2001, K=1025): CheapTrick + D4C + WORLD synthesis',
+                'pairs_per_gpu' if args.workload == 'pair' else 'utterances_per_gpu': args.batch,
+                'source_frames_per_pair': T, 'streams_per_gpu': args.batch,
+                'parallelism': f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective'},
             'real_time_factor': value / 200.0,
-            'hbm_fraction_whole_path': value / world * bytes_per_frame / 8e12,
-            'roofline': None,
+            'hbm_fraction_whole_path': value / world * path_bytes / 8e12,
+            'kernel_ms_per_launch': {k: v[0] / v[1] for k, v in sorted(kernel_ms.items())},
+            'roofline': roofline,
             'cpu_baseline': None,
         }
         if not args.no_cpu_baseline and world == 1:
-            x, f0, t = base[0]
-            out['cpu_baseline'] = cpu_baseline(x, f0, t)
+            if args.workload == 'pair':
+                out['cpu_baseline'] = cpu_baseline_pair(base[0][0], base[0][1], gmm)
+            else:
+                from oracle import oracle as ko
+                x, f0, t = base[0][0]
+                n, Tc = int(FS * 2.0), 401
+                xs, f0s, ts = np.ascontiguousarray(x[:n]), np.ascontiguousarray(f0[:Tc]), np.ascontiguousarray(t[:Tc])
+                reps, t1 = 0, time.perf_counter()
+                while time.perf_counter() - t1 < 15 and reps < 8:
+                    sp = ko.cheaptrick(xs, f0s, ts, FS)
+                    apv = ko.d4c(xs, f0s, ts, FS)
+                    ko.synthesize(f0s, sp, apv, FS, FRAME_PERIOD)
+                    reps += 1
+                out['cpu_baseline'] = {'value': reps * Tc / (time.perf_counter() - t1), 'unit': 'frames/s',
+                                       'cores': 1, 'kind': 'port',
+                                       'sample': f'{reps}x first 2 s (401 frames): cheaptrick+d4c+synthesize, '
+                                                 f'oracle/liboracle.so, 1 thread'}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -47,6 +47,13 @@ int kwy_ctx_create(int device, void *stream, kwy_ctx **out);
 void kwy_ctx_destroy(kwy_ctx *ctx);
 int kwy_ctx_sync(kwy_ctx *ctx);
 void *kwy_ctx_stream(kwy_ctx *ctx);
+/* Per-kernel timing: when enabled, the main kernels are bracketed by HIP events
+ * on the context's stream.  kwy_ctx_profile_read synchronises the stream and
+ * returns the summed duration [ms] and launch count of `kernel` since the last
+ * read (kernel names as in rocprofv3, without template arguments, e.g.
+ * "k_d4c_body"). */
+int kwy_ctx_profile(kwy_ctx *ctx, int enable);
+int kwy_ctx_profile_read(kwy_ctx *ctx, const char *kernel, double *total_ms, int64_t *count);
 const char *kwy_last_error(kwy_ctx *ctx);
 /* error text when kwy_ctx_create itself failed (no context to ask) */
 const char *kwy_create_error(void);
@@ -125,6 +132,23 @@ int kwy_fastdtw(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int6
                 int dim, int radius, double *dist, int32_t *path, int64_t *path_len);
 int kwy_fastdtw_dev(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty,
                     int dim, int radius, double *dist, int32_t *path, int64_t *path_len);
+
+/* Device-side glue that keeps a source/target pair resident in HBM between the
+ * stages (used by the batched pipeline; the host API does these in numpy):
+ * DTW feature rows [power, voicing, mc1..mcN] -- make_feature(power='binalize',
+ * power_pivot='max', vuv='f0')                      kwiiyatta/vocoder/align.py:20-58
+ * mc: T x ncoef, out: T x (ncoef+1). */
+int kwy_align_features_dev(kwy_ctx *ctx, const double *mc, int64_t T, int ncoef, const double *f0,
+                           double power_weight, double power_threshold, double vuv_weight,
+                           double *out);
+/* project_path_iter(path, trim, trim_len): one x index per y frame
+ *                                                    kwiiyatta/vocoder/align.py:99-120
+ * path / path_len as produced by kwy_fastdtw_dev (device); trim_len = 0: no trimming. */
+int kwy_align_project_dev(kwy_ctx *ctx, const int32_t *path, const int64_t *path_len, int trim_len,
+                          int32_t *idx, int64_t idx_capacity, int64_t *n_out);
+/* Feature.__getitem__(list): dst[i] = src[idx[i]]    kwiiyatta/vocoder/abc/feature.py:170-194 */
+int kwy_gather_rows_dev(kwy_ctx *ctx, const double *src, int64_t src_rows, int width,
+                        const int32_t *idx, int64_t n, double *dst);
 
 /* ---- converter apply ---------------------------------------------------------------- */
 /* delta_features(X, DELTA_WINDOWS) + MLPG(gmm, windows, diff).transform(X)[:, :d]

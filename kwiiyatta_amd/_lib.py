@@ -19,6 +19,29 @@ if not os.path.exists(_SO):
         f'(python -c "import __graft_entry__ as g; g.build()" or kwiiyatta_amd/csrc/build.sh). '
         f'kwiiyatta_amd has no CPU fallback.')
 
+
+
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7; the image also has
+    /opt/rocm's.  Both have the same SONAME, so whichever is loaded first serves
+    the whole process -- and torch only works with its own.  Load torch's copy
+    first (without importing torch) so that libkwy.so and torch share one HIP
+    runtime regardless of import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+_preload_hip_runtime()
 lib = ctypes.CDLL(_SO)
 
 c_dp = ctypes.POINTER(ctypes.c_double)
@@ -38,6 +61,8 @@ SIGNATURES = {
     'kwy_ctx_destroy': (None, [c_vp]),
     'kwy_ctx_sync': (c_int, [c_vp]),
     'kwy_ctx_stream': (c_vp, [c_vp]),
+    'kwy_ctx_profile': (c_int, [c_vp, c_int]),
+    'kwy_ctx_profile_read': (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     'kwy_last_error': (ctypes.c_char_p, [c_vp]),
     'kwy_create_error': (ctypes.c_char_p, []),
     'kwy_cheaptrick_fft_size': (c_int, [c_int, c_dbl]),
@@ -62,6 +87,9 @@ SIGNATURES = {
     'kwy_mc2sp_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_vp]),
     'kwy_fastdtw': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'kwy_fastdtw_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'kwy_align_features_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_dbl, c_dbl, c_dbl, c_vp]),
+    'kwy_align_project_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp]),
+    'kwy_gather_rows_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp]),
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_mlpg_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
 }
@@ -103,6 +131,15 @@ class Context:
 
     def sync(self):
         check(self, lib.kwy_ctx_sync(self.handle))
+
+    def profile(self, enable=True):
+        check(self, lib.kwy_ctx_profile(self.handle, int(bool(enable))))
+
+    def profile_read(self, kernel):
+        """(total_ms, launches) of `kernel` since the last read; synchronises the stream."""
+        ms, n = c_dbl(), c_i64()
+        check(self, lib.kwy_ctx_profile_read(self.handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def error(self):
         return lib.kwy_last_error(self.handle).decode()

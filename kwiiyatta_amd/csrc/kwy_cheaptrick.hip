@@ -220,8 +220,8 @@ static int launch_ct(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
                sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_cheaptrick<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_cheaptrick<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x,
-                     (int)x_length, fs, t, f0, q1, floor_eff, ebase, poly, twH, twN, out_div, out);
+  KWY_PROF(ctx, "k_cheaptrick", hipLaunchKernelGGL(k_cheaptrick<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x,
+                     (int)x_length, fs, t, f0, q1, floor_eff, ebase, poly, twH, twN, out_div, out));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

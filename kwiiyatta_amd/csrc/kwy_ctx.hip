@@ -328,6 +328,8 @@ void kwy_ctx_destroy(kwy_ctx *ctx) {
     if (p) (void)hipFree(p);
   for (auto &kv : ctx->d_poly) (void)hipFree(kv.second);
   for (auto &kv : ctx->d_mats) (void)hipFree(kv.second);
+  for (auto &kv : ctx->prof_events)
+    for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -335,6 +337,32 @@ void kwy_ctx_destroy(kwy_ctx *ctx) {
 int kwy_ctx_sync(kwy_ctx *ctx) {
   if (!ctx) return KWY_EINVAL;
   KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}
+
+int kwy_ctx_profile(kwy_ctx *ctx, int enable) {
+  if (!ctx) return KWY_EINVAL;
+  ctx->prof = enable != 0;
+  return KWY_OK;
+}
+
+int kwy_ctx_profile_read(kwy_ctx *ctx, const char *kernel, double *total_ms, int64_t *count) {
+  if (!ctx || !kernel || !total_ms || !count) return KWY_EINVAL;
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  int64_t n = 0;
+  auto it = ctx->prof_events.find(kernel);
+  if (it != ctx->prof_events.end()) {
+    for (auto &ev : it->second) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { tot += ms; ++n; }
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    ctx->prof_events.erase(it);
+  }
+  *total_ms = tot;
+  *count = n;
   return KWY_OK;
 }
 

@@ -393,8 +393,8 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_d4c_lovetrain<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream,
-                     x, (int)x_length, fs, t, f0, ebase, poly, twH, twN, ap0);
+  KWY_PROF(ctx, "k_d4c_lovetrain", hipLaunchKernelGGL(k_d4c_lovetrain<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream,
+                     x, (int)x_length, fs, t, f0, ebase, poly, twH, twN, ap0));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -414,8 +414,8 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
                sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x, t,
-                     f0, ap0, p, ebase, poly, twH, twN, nuttall, out);
+  KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x, t,
+                     f0, ap0, p, ebase, poly, twH, twN, nuttall, out));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

@@ -289,10 +289,10 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     hipLaunchKernelGGL(k_dtw_window, dim3((len_x + 255) / 256), dim3(256), 0, ctx->stream, cpath, clen, radius,
                        len_x, len_y, lo, hi, width);
     KWY_TRY(kwy_launch_scan(ctx, width, off, len_x));
-    hipLaunchKernelGGL(k_dtw_dist, dim3(len_x), dim3(KWY_THREADS), sizeof(double) * dim, ctx->stream, xs[l],
-                       ys[l], dim, lo, hi, off, cap, dist, status);
-    hipLaunchKernelGGL(k_dtw_dp, dim3(1), dim3(64), dp_lds, ctx->stream, len_x, len_y, lo, hi, off, cap,
-                       dist, pred, bnd_lds ? (double *)nullptr : bnd, opath, rev, olen, d_dist, status);
+    KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3(len_x), dim3(KWY_THREADS), sizeof(double) * dim, ctx->stream, xs[l],
+                       ys[l], dim, lo, hi, off, cap, dist, status));
+    KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp, dim3(1), dim3(64), dp_lds, ctx->stream, len_x, len_y, lo, hi, off, cap,
+                       dist, pred, bnd_lds ? (double *)nullptr : bnd, opath, rev, olen, d_dist, status));
     cpath = opath;
     clen = olen;
   }

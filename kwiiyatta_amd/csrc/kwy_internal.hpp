@@ -28,6 +28,10 @@ struct kwy_ctx {
   std::map<uint64_t, uint4 *> d_poly;      // stride(steps) -> x^(stride*t) mod P, t < 256
   std::map<std::string, double *> d_mats;  // cached host-built matrices (mcep etc.)
   std::map<std::string, int64_t> i_vals;   // small cached integers that go with them
+
+  // optional per-kernel timing with HIP events on this context's stream
+  bool prof = false;
+  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 };
 
 #define KWY_HIP(call)                                                              \
@@ -44,6 +48,28 @@ struct kwy_ctx {
     int rc_ = (call);              \
     if (rc_ != KWY_OK) return rc_; \
   } while (0)
+
+// --- profiling ---------------------------------------------------------------
+// KWY_PROF(ctx, "kernel", launch-statement): brackets the launch with two HIP
+// events when profiling is on (kwy_ctx_profile); otherwise just launches.
+struct kwy_prof_scope {
+  kwy_ctx *ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char *name;
+  kwy_prof_scope(kwy_ctx *c, const char *n) : ctx(c), name(n) {
+    if (ctx->prof) {
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+      (void)hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~kwy_prof_scope() {
+    if (a && b) {
+      (void)hipEventRecord(b, ctx->stream);
+      ctx->prof_events[name].push_back({a, b});
+    }
+  }
+};
+#define KWY_PROF(ctx, name, stmt) do { kwy_prof_scope ps_(ctx, name); stmt; } while (0)
 
 // --- arena ------------------------------------------------------------------
 // Reserve `bytes` of scratch for the current call (must be called once, before

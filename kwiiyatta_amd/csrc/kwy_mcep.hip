@@ -162,8 +162,8 @@ static int launch_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int order, co
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 256;
   KWY_HIP(hipFuncSetAttribute((const void *)k_sp2mc<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_sp2mc<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, sp, order, F,
-                     ncut, twH, twN, mc);
+  KWY_PROF(ctx, "k_sp2mc", hipLaunchKernelGGL(k_sp2mc<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, sp, order, F,
+                     ncut, twH, twN, mc));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -176,8 +176,8 @@ static int launch_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, co
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 64;
   KWY_HIP(hipFuncSetAttribute((const void *)k_mc2sp<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, mc, order, F2T,
-                     twH, twN, sp);
+  KWY_PROF(ctx, "k_mc2sp", hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, mc, order, F2T,
+                     twH, twN, sp));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

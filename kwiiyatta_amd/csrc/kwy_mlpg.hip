@@ -332,11 +332,11 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
                      diff, model, status);
   const unsigned ge = (unsigned)((T * d + 255) / 256);
   hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, x, dm, X);
-  hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)((T + ML_TILE - 1) / ML_TILE), M), dim3(KWY_THREADS), lds_logp,
-                     ctx->stream, X, dm, model, logp);
+  KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)((T + ML_TILE - 1) / ML_TILE), M), dim3(KWY_THREADS), lds_logp,
+                     ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
   hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band, rhs);
-  hipLaunchKernelGGL(k_mlpg_solve, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, band, rhs, dm, y, status);
+  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, band, rhs, dm, y, status));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

@@ -552,8 +552,8 @@ static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = cap < 2048 ? cap : 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
-                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, y);
+  KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
+                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, y));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -602,7 +602,7 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
 
   hipLaunchKernelGGL(k_syn_inc, dim3((unsigned)((y_length + KWY_THREADS - 1) / KWY_THREADS)),
                      dim3(KWY_THREADS), 0, ctx->stream, f0, p, incr, vuv8);
-  hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream, incr, y_length, wrap);
+  KWY_PROF(ctx, "k_syn_phase", hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream, incr, y_length, wrap));
   hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, tile_cnt);
   hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, tile_cnt, nt, npulse);
   hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, fs,

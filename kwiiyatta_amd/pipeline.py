@@ -1,0 +1,215 @@
+"""HBM-resident batch pipeline for the per-utterance conversion hot path.
+
+The Python API of the package (kwiiyatta_amd.analyze_wav / align / convert /
+synthesize) takes and returns numpy arrays like the reference, so every stage
+crosses PCIe.  For batch conversion the whole source/target pair stays on the
+device instead: one `PairPipeline` owns the buffers of one pair and one HIP
+stream (a `kwy_ctx`), and `run()` only ENQUEUES kernels -- no host
+synchronisation, no allocation -- so several pipelines overlap on one GPU
+(utterance-per-stream) and ranks shard pairs with no collective
+(utterance-per-GPU).
+
+Stage order (the flow of `kwiieiya --carrier`
+followed by `kwiiyatta`'s conversion):
+
+  analyse source and target      CheapTrick + D4C (f0 tracks given)
+  pad 100 silent frames          kwiiyatta.pad_silence
+  sp2mc                          mel-cepstra of both padded features
+  DTW features + FastDTW         make_feature(vuv='f0'), radius 32
+  project path, gather rows      source frames on the target's time axis
+  convert                        delta + GMM posterior + MLPG (c0 kept)
+  mc2sp + WORLD synthesis        with the target's f0
+
+torch is used for device memory, streams and strided copies only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, c_vp
+
+EPS = 2.220446049250313e-16
+SAFE_GUARD_MINIMUM = 1e-12
+PAD_LEN = 100
+POWER_WEIGHT, POWER_THRESHOLD, VUV_WEIGHT = 9.4, 1.636, 9.0
+
+
+def _p(t):
+    return c_vp(t.data_ptr())
+
+
+class DeviceGMM:
+    """Joint GMM parameters resident in HBM (weights (M,), means (M, 2D), covs (M, 2D, 2D))."""
+
+    def __init__(self, weights, means, covs, device):
+        self.M = len(weights)
+        self.D2 = means.shape[1]
+        self.weights = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float64)).to(device)
+        self.means = torch.from_numpy(np.ascontiguousarray(means, dtype=np.float64)).to(device)
+        self.covs = torch.from_numpy(np.ascontiguousarray(covs, dtype=np.float64)).to(device)
+
+
+class _Side:
+    """Buffers of one analysed utterance, stored with PAD_LEN silent frames on both ends."""
+
+    def __init__(self, x, f0, t, fs, K, order, dev):
+        self.N, self.T = len(x), len(f0)
+        self.Tp = self.T + 2 * PAD_LEN
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.x = torch.from_numpy(x).to(dev)
+        self.f0 = torch.from_numpy(f0).to(dev)
+        self.t = torch.from_numpy(t).to(dev)
+        self.f0_pad = torch.zeros(self.Tp, **f64)
+        self.f0_pad[PAD_LEN:PAD_LEN + self.T] = self.f0
+        self.sp_pad = torch.zeros((self.Tp, K), **f64)
+        self.ap_pad = torch.full((self.Tp, K), 1 - SAFE_GUARD_MINIMUM, **f64)
+        self.mc_pad = torch.empty((self.Tp, order + 1), **f64)
+        self.feat = torch.empty((self.Tp, order + 2), **f64)
+        # views of the un-padded middle part (the kernels write straight into them)
+        self.sp = self.sp_pad[PAD_LEN:PAD_LEN + self.T]
+        self.ap = self.ap_pad[PAD_LEN:PAD_LEN + self.T]
+
+    def silence_rows(self):
+        return self.sp_pad[:PAD_LEN], self.sp_pad[PAD_LEN + self.T:]
+
+
+class PairPipeline:
+    def __init__(self, device_index, fs, source, target, gmm, order=24, radius=32, frame_period=5.0,
+                 stream=None):
+        """source / target: (x, f0, timeaxis) numpy triples; gmm: DeviceGMM over 2*3*order dims."""
+        self.dev = torch.device('cuda', device_index)
+        self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
+        self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
+        self.K = self.fft // 2 + 1
+        from .backend import sptk
+        self.alpha = sptk.mcepalpha(self.fs)
+        self.gmm = gmm
+        assert gmm.D2 == 6 * order
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        with torch.cuda.stream(self.stream):
+            self.src = _Side(*source, self.fs, self.K, order, self.dev)
+            self.tgt = _Side(*target, self.fs, self.K, order, self.dev)
+            Tt = self.tgt.T
+            cap = self.src.Tp + self.tgt.Tp + 2
+            self.path = torch.zeros((cap, 2), dtype=torch.int32, device=self.dev)
+            self.path_len = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.dist = torch.zeros(1, **f64)
+            self.idx = torch.zeros(self.tgt.Tp, dtype=torch.int32, device=self.dev)
+            self.n_idx = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.sp_al = torch.empty((Tt, self.K), **f64)     # not needed by the conversion flow itself,
+            self.ap_al = torch.empty((Tt, self.K), **f64)     # kept: align() gathers every feature array
+            self.mc_al = torch.empty((Tt, order + 1), **f64)
+            self.mc_x = torch.empty((Tt, order), **f64)
+            self.mc_y = torch.empty((Tt, order), **f64)
+            self.mc_conv = torch.empty((Tt, order + 1), **f64)
+            self.sp_conv = torch.empty((Tt, self.K), **f64)
+            self.ylen = lib.kwy_synth_length(Tt, self.frame_period, self.fs)
+            self.wave = torch.empty(self.ylen, **f64)
+        self.stream.synchronize()
+        self.frames = self.src.T   # the metric counts source frames
+
+    def _silence(self):
+        # kwiiyatta.pad_silence: |N(0, EPS/fs)| spectra on the padding frames
+        for side in (self.src, self.tgt):
+            for rows in side.silence_rows():
+                rows.normal_(0.0, EPS / self.fs).abs_()
+
+    def _chk(self, rc):
+        _lib.check(self.ctx, rc)
+
+    def run(self):
+        """Enqueue one pass of the hot path on this pipeline's stream (asynchronous)."""
+        h, fs, fft, K, order = self.ctx.handle, self.fs, self.fft, self.K, self.order
+        with torch.cuda.stream(self.stream):
+            for s in (self.src, self.tgt):
+                self._chk(lib.kwy_cheaptrick_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, -0.15, 71.0,
+                                                 fft, float(fs), _p(s.sp)))
+                self._chk(lib.kwy_d4c_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft, _p(s.ap)))
+            self._silence()
+            for s in (self.src, self.tgt):
+                self._chk(lib.kwy_sp2mc_dev(h, _p(s.sp_pad), s.Tp, K, order, self.alpha, _p(s.mc_pad)))
+                self._chk(lib.kwy_align_features_dev(h, _p(s.mc_pad), s.Tp, order + 1, _p(s.f0_pad),
+                                                     POWER_WEIGHT, POWER_THRESHOLD, VUV_WEIGHT, _p(s.feat)))
+            self._chk(lib.kwy_fastdtw_dev(h, _p(self.src.feat), self.src.Tp, _p(self.tgt.feat), self.tgt.Tp,
+                                          order + 2, self.radius, _p(self.dist), _p(self.path),
+                                          _p(self.path_len)))
+            self._chk(lib.kwy_align_project_dev(h, _p(self.path), _p(self.path_len), PAD_LEN, _p(self.idx),
+                                                self.tgt.Tp, _p(self.n_idx)))
+            Tt = self.tgt.T
+            for src_arr, dst, w in ((self.src.sp_pad, self.sp_al, K), (self.src.ap_pad, self.ap_al, K),
+                                    (self.src.mc_pad, self.mc_al, order + 1)):
+                self._chk(lib.kwy_gather_rows_dev(h, _p(src_arr), self.src.Tp, w, _p(self.idx), Tt, _p(dst)))
+            self.mc_x.copy_(self.mc_al[:, 1:])
+            g = self.gmm
+            self._chk(lib.kwy_gmm_mlpg_dev(h, _p(self.mc_x), Tt, order, g.M, _p(g.weights), _p(g.means),
+                                           _p(g.covs), 0, _p(self.mc_y)))
+            self.mc_conv[:, 0].copy_(self.mc_al[:, 0])
+            self.mc_conv[:, 1:].copy_(self.mc_y)
+            self._chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), Tt, order, self.alpha, fft, _p(self.sp_conv)))
+            self._chk(lib.kwy_synthesize_dev(h, _p(self.tgt.f0), Tt, _p(self.sp_conv), _p(self.ap_al), fft,
+                                             self.frame_period, fs, float(fs), self.ylen, _p(self.wave)))
+
+    def sync(self):
+        self.ctx.sync()
+
+
+class UtterancePipeline:
+    """analyse -> resynthesise of one utterance (BASELINE config 2), HBM-resident."""
+
+    def __init__(self, device_index, fs, utterance, frame_period=5.0, stream=None):
+        self.dev = torch.device('cuda', device_index)
+        self.fs, self.frame_period = int(fs), float(frame_period)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
+        self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
+        self.K = self.fft // 2 + 1
+        x, f0, t = utterance
+        self.N, self.T = len(x), len(f0)
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        with torch.cuda.stream(self.stream):
+            self.x, self.f0, self.t = (torch.from_numpy(a).to(self.dev) for a in (x, f0, t))
+            self.sp = torch.empty((self.T, self.K), **f64)
+            self.ap = torch.empty((self.T, self.K), **f64)
+            self.ylen = lib.kwy_synth_length(self.T, self.frame_period, self.fs)
+            self.wave = torch.empty(self.ylen, **f64)
+        self.stream.synchronize()
+        self.frames = self.T
+
+    def run(self):
+        h, fs, fft = self.ctx.handle, self.fs, self.fft
+        chk = lambda rc: _lib.check(self.ctx, rc)  # noqa: E731
+        chk(lib.kwy_cheaptrick_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), self.T, -0.15, 71.0, fft,
+                                   float(fs), _p(self.sp)))
+        chk(lib.kwy_d4c_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), self.T, 0.85, fft, _p(self.ap)))
+        chk(lib.kwy_synthesize_dev(h, _p(self.f0), self.T, _p(self.sp), _p(self.ap), fft, self.frame_period, fs,
+                                   float(fs), self.ylen, _p(self.wave)))
+
+    def sync(self):
+        self.ctx.sync()
+
+
+def synthetic_gmm(order=24, components=64, seed=0, n_frames=16000):
+    """A fixed joint GMM for the benchmark: scikit-learn's
+    GaussianMixture fitted on seed-0 synthetic joint static+delta features."""
+    from sklearn.mixture import GaussianMixture
+    from .backend.mlpg import DELTA_WINDOWS, delta_features
+    rng = np.random.default_rng(seed)
+    d = order
+    # smooth random trajectories with a mel-cepstrum-like decay over the coefficients
+    scale = 1.0 / (1.0 + np.arange(d)) ** 0.7
+    walk = np.cumsum(rng.standard_normal((n_frames, d)), axis=0) * 0.05
+    src = (walk - walk.mean(0)) * scale + rng.standard_normal((n_frames, d)) * 0.02 * scale
+    mix = np.eye(d) + 0.08 * rng.standard_normal((d, d))
+    tgt = src @ mix + 0.05 * scale + rng.standard_normal((n_frames, d)) * 0.02 * scale
+    joint = np.hstack([delta_features(src, DELTA_WINDOWS), delta_features(tgt, DELTA_WINDOWS)])
+    import warnings
+    gmm = GaussianMixture(n_components=components, covariance_type='full', max_iter=2, random_state=seed,
+                          reg_covar=1e-4)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')   # two EM iterations on purpose: a fixed model, not a fit
+        gmm.fit(joint)
+    return gmm
