@@ -64,22 +64,30 @@ Poly g_P;  // characteristic polynomial of T (degree 128)
 
 Poly poly_mulmod(const Poly &a, const Poly &b) {
   Poly r = {{0, 0, 0, 0}};
-  for (int i = 0; i < 128; ++i) {
-    if (!poly_bit(a, i)) continue;
-    // r ^= b << i
-    int ws = i >> 6, bs = i & 63;
-    for (int w = 0; w < 2; ++w) {
-      uint64_t v = b.w[w];
-      if (!v) continue;
-      r.w[w + ws] ^= v << bs;
-      if (bs && w + ws + 1 < 4) r.w[w + ws + 1] ^= v >> (64 - bs);
+  for (int w = 0; w < 2; ++w) {
+    uint64_t bits = a.w[w];
+    while (bits) {
+      const int i = __builtin_ctzll(bits) + 64 * w;
+      bits &= bits - 1;
+      const int ws = i >> 6, bs = i & 63;  // r ^= b << i
+      for (int q = 0; q < 2; ++q) {
+        const uint64_t v = b.w[q];
+        if (!v) continue;
+        r.w[q + ws] ^= v << bs;
+        if (bs && q + ws + 1 < 4) r.w[q + ws + 1] ^= v >> (64 - bs);
+      }
     }
   }
+  // reduce modulo P (degree 128): P = x^128 + (g_P.w[1], g_P.w[0])
   for (int i = 254; i >= 128; --i) {
     if (!poly_bit(r, i)) continue;
-    int sh = i - 128;
-    for (int j = 0; j <= 128; ++j)
-      if (poly_bit(g_P, j)) poly_flip(r, j + sh);
+    const int sh = i - 128, ws = sh >> 6, bs = sh & 63;
+    for (int q = 0; q < 3; ++q) {
+      const uint64_t v = g_P.w[q];
+      if (!v) continue;
+      r.w[q + ws] ^= v << bs;
+      if (bs && q + ws + 1 < 4) r.w[q + ws + 1] ^= v >> (64 - bs);
+    }
   }
   return r;
 }
@@ -267,6 +275,30 @@ int kwy_get_poly(kwy_ctx *ctx, uint64_t stride_steps, const uint4 **out) {
     KWY_HIP(hipMalloc((void **)&d, sizeof(uint4) * KWY_THREADS));
     KWY_HIP(hipMemcpy(d, h.data(), sizeof(uint4) * KWY_THREADS, hipMemcpyHostToDevice));
     it = ctx->d_poly.emplace(stride_steps, d).first;
+  }
+  *out = it->second;
+  return KWY_OK;
+}
+
+int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, const uint4 **out) {
+  const uint64_t key = 0x8000000000000000ull | (uint64_t)max_c;
+  auto it = ctx->d_poly.find(key);
+  if (it == ctx->d_poly.end()) {
+    std::vector<uint4> h((size_t)max_c * KWY_THREADS);
+    for (int c = 1; c <= max_c; ++c) {
+      Poly step = poly_xpow(12ull * c);
+      Poly cur = {{1, 0, 0, 0}};
+      for (int t = 0; t < KWY_THREADS; ++t) {
+        uint4 &o = h[(size_t)(c - 1) * KWY_THREADS + t];
+        o.x = (uint32_t)cur.w[0]; o.y = (uint32_t)(cur.w[0] >> 32);
+        o.z = (uint32_t)cur.w[1]; o.w = (uint32_t)(cur.w[1] >> 32);
+        cur = poly_mulmod(cur, step);
+      }
+    }
+    uint4 *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(uint4) * h.size()));
+    KWY_HIP(hipMemcpy(d, h.data(), sizeof(uint4) * h.size(), hipMemcpyHostToDevice));
+    it = ctx->d_poly.emplace(key, d).first;
   }
   *out = it->second;
   return KWY_OK;

@@ -135,30 +135,37 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
 
   for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
   __syncthreads();
-  kwy_rng rng = kwy_rng_combine(e, poly[tid]);
-
+  // this thread draws the c noise values [c*tid, c*tid + c) of the frame (c adapts to the window)
+  const int c = (wl + KWY_THREADS - 1) / KWY_THREADS;
+  kwy_rng rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
   double *A = (double *)bufA;
-  double wv[C], vv[C];
-  double s1 = 0.0, s2 = 0.0;
+  double *NZ = (double *)bufB;  // noise, then the window values
 #pragma unroll
   for (int j = 0; j < C; ++j) {
-    int i = C * tid + j;
-    double nzv = kwy_rng_randn(rng);
-    double w = d4c_window(D4C_BLACKMAN, i, half, 3.0, fs, cf0);
-    int idx = min(x_length - 1, max(0, origin + i - half));
-    double v = x[idx] * w;
-    v = v + nzv * D4C_SAFE;
-    wv[j] = w; vv[j] = v;
-    if (i < wl) { s1 += v; s2 += w; }
+    if (j < c) {
+      int d = c * tid + j;
+      double nzv = kwy_rng_randn(rng);
+      if (d < wl) NZ[d] = nzv;
+    }
+  }
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < N; i += KWY_THREADS) {
+    double v = 0.0;
+    if (i < wl) {
+      double w = d4c_window(D4C_BLACKMAN, i, half, 3.0, fs, cf0);
+      int idx = min(x_length - 1, max(0, origin + i - half));
+      v = x[idx] * w;
+      v = v + NZ[i] * D4C_SAFE;
+      NZ[i] = w;
+      s1 += v; s2 += w;
+    }
+    A[i] = v;
   }
   const double t1 = kwy_block_sum(s1, red);
   const double t2 = kwy_block_sum(s2, red);
   const double coef = t1 / t2;
-#pragma unroll
-  for (int j = 0; j < C; ++j) {
-    int i = C * tid + j;
-    A[i] = (i < wl) ? vv[j] - wv[j] * coef : 0.0;
-  }
+  for (int i = tid; i < wl; i += KWY_THREADS) A[i] -= NZ[i] * coef;
   kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
 
   const int boundary0 = (int)ceil(100.0 * N / fs);
@@ -182,47 +189,47 @@ struct d4c_params {
   double threshold;
 };
 
-// Windowed, DC-removed frame into A (N reals).  Thread t owns the draws
-// [C*t, C*t+C) of the frame's 3*wl draws; window `which` uses draws
-// [which*wl, (which+1)*wl).  If `make_ramp`, also normalises to unit power and
-// writes A[i]*(i+1) into R.
+// Windowed, DC-removed frame into A (N reals).  Thread t holds the draws
+// [c*t, c*t+c) of the frame's 3*wl draws in nz[]; window `which` uses draws
+// [which*wl, (which+1)*wl): they are scattered into the LDS scratch NZ first, so
+// that the window itself is evaluated with a balanced, strided thread mapping.
+// If `make_ramp`, also normalises to unit power and writes A[i]*(i+1) into R.
 template <int N, int C>
 __device__ inline void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
-                                        double pos, int type, int which, const double (&nz)[C],
-                                        double *A, double *R, bool make_ramp, double *red) {
+                                        double pos, int type, int which, int c, const double (&nz)[C],
+                                        double *A, double *R, double *NZ, bool make_ramp, double *red) {
   const int tid = threadIdx.x;
   const int half = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0);
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(pos * p.fs + 0.001);
   __syncthreads();
-  for (int i = tid; i < N; i += KWY_THREADS) A[i] = 0.0;
-  __syncthreads();
-  double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int j = 0; j < C; ++j) {
-    int d = C * tid + j - which * wl;
-    if (d >= 0 && d < wl) {
-      double w = d4c_window(type, d, half, 4.0, p.fs, cf0);
-      int idx = min(p.x_length - 1, max(0, origin + d - half));
-      double v = x[idx] * w;
-      v = v + nz[j] * D4C_SAFE;
-      A[d] = v;
+    int d = c * tid + j - which * wl;
+    if (j < c && d >= 0 && d < wl) NZ[d] = nz[j];
+  }
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = tid; i < N; i += KWY_THREADS) {
+    double v = 0.0;
+    if (i < wl) {
+      double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
+      int idx = min(p.x_length - 1, max(0, origin + i - half));
+      v = x[idx] * w;
+      v = v + NZ[i] * D4C_SAFE;
+      NZ[i] = w;
       s1 += v; s2 += w;
     }
+    A[i] = v;
   }
   const double t1 = kwy_block_sum(s1, red);
   const double t2 = kwy_block_sum(s2, red);
   const double coef = t1 / t2;
   double pw = 0.0;
-#pragma unroll
-  for (int j = 0; j < C; ++j) {
-    int d = C * tid + j - which * wl;
-    if (d >= 0 && d < wl) {
-      double w = d4c_window(type, d, half, 4.0, p.fs, cf0);
-      double v = A[d] - w * coef;
-      A[d] = v;
-      pw += v * v;
-    }
+  for (int i = tid; i < wl; i += KWY_THREADS) {
+    double v = A[i] - NZ[i] * coef;
+    A[i] = v;
+    pw += v * v;
   }
   if (make_ramp) {
     const double power = kwy_block_sum(pw, red);
@@ -253,6 +260,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_body(
   double *tot = red + 8;                    // KWY_THREADS
   double *coarse = tot + KWY_THREADS;       // D4C_MAX_BANDS + 2
   uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);
+  uint32_t *hist = e + KWY_EBASE_WORDS;     // KWY_WAVES*256 + 4
 
   const int tid = threadIdx.x;
   const int64_t frame = blockIdx.x;
@@ -267,30 +275,33 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_body(
 
   for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
   __syncthreads();
-  kwy_rng rng = kwy_rng_combine(e, poly[tid]);
+  const int wl4 = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0) * 2 + 1;
+  const int c = (3 * wl4 + KWY_THREADS - 1) / KWY_THREADS;  // draws per thread, <= C
+  kwy_rng rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
   double nz[C];
 #pragma unroll
-  for (int j = 0; j < C; ++j) nz[j] = kwy_rng_randn(rng);
+  for (int j = 0; j < C; ++j) nz[j] = (j < c) ? kwy_rng_randn(rng) : 0.0;
 
   // ---- static centroid: two temporal centroids at pos -+ 0.25/f0
   for (int which = 0; which < 2; ++which) {
     double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-    d4c_frame_window<N, C>(x, p, cf0, cpos, D4C_BLACKMAN, which, nz, (double *)buf0, (double *)buf1,
-                           true, red);
+    d4c_frame_window<N, C>(x, p, cf0, cpos, D4C_BLACKMAN, which, c, nz, (double *)buf0, (double *)buf1,
+                           (double *)buf2, true, red);
     // X1 = rfft(buf0) using buf2 as scratch; X2 = rfft(buf1) using the buffer X1 left free
     kwy_c *X1 = kwy_rfft_lds(buf0, buf2, LOG2N - 1, twH, twN);
     kwy_c *F = (X1 == buf0) ? buf2 : buf0;
     kwy_c *X2 = kwy_rfft_lds(buf1, F, LOG2N - 1, twH, twN);
     for (int k = tid; k <= H; k += KWY_THREADS) {
-      double c = X2[k].x * X1[k].x + X1[k].y * X2[k].y;
-      Dv[k] = which == 0 ? c : Dv[k] + c;
+      double cen = X2[k].x * X1[k].x + X1[k].y * X2[k].y;
+      Dv[k] = which == 0 ? cen : Dv[k] + cen;
     }
     __syncthreads();
   }
   d4c_dc_correction(Dv, (double *)buf0, cf0, p.fs, N);
 
   // ---- smoothed power spectrum
-  d4c_frame_window<N, C>(x, p, cf0, pos, D4C_HANNING, 2, nz, (double *)buf0, nullptr, false, red);
+  d4c_frame_window<N, C>(x, p, cf0, pos, D4C_HANNING, 2, c, nz, (double *)buf0, nullptr, (double *)buf2,
+                         false, red);
   kwy_c *Xs = kwy_rfft_lds(buf0, buf1, LOG2N - 1, twH, twN);
   double *P = (double *)buf2;
   for (int k = tid; k <= H; k += KWY_THREADS) {
@@ -320,38 +331,20 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_body(
     for (int j = tid; j < N; j += KWY_THREADS)
       A[j] = (j <= half_window_length * 2) ? Dv[center - half_window_length + j] * nuttall[j] : 0.0;
     kwy_c *Xb = kwy_rfft_lds(buf0, buf1, LOG2N - 1, twH, twN);
-    double *Q = (double *)buf2;  // N slots: power spectrum padded with +inf for the sort
-    for (int k = tid; k < N; k += KWY_THREADS) {
-      double v = INFINITY;
-      if (k <= H) { kwy_c c = Xb[k]; v = c.x * c.x + c.y * c.y; }
-      Q[k] = v;
+    double *Q = (double *)buf2;  // power spectrum of the band
+    for (int k = tid; k <= H; k += KWY_THREADS) {
+      kwy_c cc = Xb[k];
+      Q[k] = cc.x * cc.x + cc.y * cc.y;
     }
     __syncthreads();
-    // bitonic sort ascending of N values
-    for (int size = 2; size <= N; size <<= 1) {
-      for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int t = tid; t < N / 2; t += KWY_THREADS) {
-          int lo = 2 * t - (t & (stride - 1));
-          int hi = lo + stride;
-          bool up = ((lo & size) == 0);
-          double a = Q[lo], c = Q[hi];
-          if ((a > c) == up) { Q[lo] = c; Q[hi] = a; }
-        }
-        __syncthreads();
-      }
-    }
-    double cs = 0.0, ca = 0.0;
-    for (int k = tid; k <= H; k += KWY_THREADS) {
-      double v = Q[k];
-      ca += v;
-      if (k <= H - boundary - 1) cs += v;
-    }
-    const double nsmall = kwy_block_sum(cs, red);
-    const double nall = kwy_block_sum(ca, red);
+    // CPU: sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
+    double nsmall, nall;
+    kwy_block_smallest_sum<(H + 1 + KWY_THREADS - 1) / KWY_THREADS>(Q, H + 1, H - boundary, hist, red, &nsmall,
+                                                                     &nall);
     if (tid == 0) {
-      double c = 10 * log10(nsmall / nall);
-      c = c + (cf0 - 100) / 50.0;
-      coarse[b + 1] = c < 0.0 ? c : 0.0;
+      double cv = 10 * log10(nsmall / nall);
+      cv = cv + (cf0 - 100) / 50.0;
+      coarse[b + 1] = cv < 0.0 ? cv : 0.0;
     }
     __syncthreads();
   }
@@ -389,7 +382,7 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
+  KWY_TRY(kwy_get_poly_multi(ctx, N / KWY_THREADS, &poly));
   size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -408,10 +401,10 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly(ctx, 12ull * (3 * N / KWY_THREADS), &poly));
+  KWY_TRY(kwy_get_poly_multi(ctx, 3 * N / KWY_THREADS, &poly));
   size_t lds = sizeof(kwy_c) * 3 * (H + 1) +
                sizeof(double) * ((H + 2) + 8 + KWY_THREADS + D4C_MAX_BANDS + 2) +
-               sizeof(uint32_t) * KWY_EBASE_WORDS;
+               sizeof(uint32_t) * (KWY_EBASE_WORDS + KWY_WAVES * 256 + 4);
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x, t,

@@ -145,6 +145,84 @@ __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
   __syncthreads();
 }
 
+// Sum of the m smallest of n non-negative doubles v[0..n) (LDS), and the sum of
+// all of them, without sorting: an MSB-first radix select (8 rounds of 8 bits on
+// the IEEE bit patterns, which order like the values for x >= 0) finds the m-th
+// smallest value v*; then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.
+// hist: KWY_WAVES*256 + 4 uint32 of LDS; red: >= KWY_WAVES doubles.  n <= KWY_THREADS * RMAX.
+template <int RMAX>
+__device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uint32_t *hist, double *red,
+                                              double *sum_small, double *sum_all) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned long long key[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    int i = tid + KWY_THREADS * r;
+    key[r] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;
+  }
+  uint32_t *ctl = hist + KWY_WAVES * 256;  // [0] digit, [1] new rank
+  unsigned long long prefix = 0ull;
+  int kk = m;  // 1-based rank of the wanted element among the still-matching keys
+  for (int round = 0; round < 8; ++round) {
+    const int shift = 56 - 8 * round;
+    for (int b = tid; b < KWY_WAVES * 256; b += KWY_THREADS) hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      int i = tid + KWY_THREADS * r;
+      bool match = i < n && (round == 0 || (key[r] >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (match) atomicAdd(&hist[wv * 256 + (int)((key[r] >> shift) & 255ull)], 1u);
+    }
+    __syncthreads();
+    if (wv == 0) {
+      uint32_t c[4];
+      uint32_t tot = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t a = 0;
+#pragma unroll
+        for (int w = 0; w < KWY_WAVES; ++w) a += hist[w * 256 + 4 * lane + q];
+        c[q] = a;
+        tot += a;
+      }
+      uint32_t inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+      }
+      uint32_t before = inc - tot;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((uint32_t)kk > before && (uint32_t)kk <= before + c[q]) {
+          ctl[0] = 4 * lane + q;
+          ctl[1] = (uint32_t)kk - before;
+        }
+        before += c[q];
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)ctl[0] << shift;
+    kk = (int)ctl[1];
+    __syncthreads();
+  }
+  const double vstar = __longlong_as_double((long long)prefix);
+  double s_less = 0.0, s_all = 0.0;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    int i = tid + KWY_THREADS * r;
+    if (i < n) {
+      double x = __longlong_as_double((long long)key[r]);
+      s_all += x;
+      if (key[r] < prefix) s_less += x;
+    }
+  }
+  const double t_less = kwy_block_sum(s_less, red);
+  const double t_all = kwy_block_sum(s_all, red);
+  *sum_small = t_less + (double)kk * vstar;
+  *sum_all = t_all;
+}
+
 // ------------------------------------------------------------------- LDS FFTs
 struct kwy_c { double x, y; };  // complex double (16 B, LDS b128 accesses)
 
