@@ -24,6 +24,7 @@
 
 #define DTW_PAD 128          // slack cells before/after the band storage
 #define DTW_BT_BYTES 49152   // LDS budget for staged predecessor codes
+#define DTW_BT_ROWS 512      // rows per back-trace group
 
 __global__ void k_dtw_halve(const double *__restrict__ in, int n_out, int dim, double *__restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,12 +85,35 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(const double *__restri
   }
 }
 
+// lane l <- lane l-1 across the whole wavefront (DPP wave_shr:1, no LDS round trip);
+// lane 0 keeps its own value.
+__device__ __forceinline__ double dtw_wave_shr1(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// value of lane `idx` (wave-uniform index) broadcast to all lanes (v_readlane, scalar path)
+__device__ __forceinline__ double dtw_readlane(double v, int idx) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), idx);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), idx);
+  return __hiloint2double(hi, lo);
+}
+
+// Packed predecessor codes: 2 bits per cell, 32 cells per 64-bit word; row i owns the
+// words starting at (off[i] >> 5) + i (rows never share a word).
+__device__ __forceinline__ uint64_t dtw_word_base(const uint64_t *__restrict__ off, int i) {
+  return (off[i] >> 5) + (uint64_t)i;
+}
+
 // The DP + back-trace of one level, one wavefront.
+template <bool BND_LDS>
 __global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32_t *__restrict__ lo,
                                               const int32_t *__restrict__ hi,
                                               const uint64_t *__restrict__ off, uint64_t cap,
                                               const double *__restrict__ dist,
-                                              unsigned char *__restrict__ pred,
+                                              unsigned long long *__restrict__ predw,
                                               double *__restrict__ bnd_global /* 2 x (len_y+2) or null */,
                                               int32_t *__restrict__ path, int32_t *__restrict__ rev,
                                               int64_t *__restrict__ path_len, double *__restrict__ out_dist,
@@ -99,69 +123,85 @@ __global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32
   const int lane = threadIdx.x;
   if (*status != 0) { if (lane == 0) { *path_len = 0; *out_dist = NAN; } return; }
   const double INF = INFINITY;
-  const bool bnd_lds = (bnd_global == nullptr);
-  double *bnd = bnd_lds ? (double *)(bt + DTW_BT_BYTES) : bnd_global;
-  double *b_prev = bnd, *b_next = bnd + (len_y + 2);
+  constexpr bool bnd_lds = BND_LDS;
+  // boundary rows are indexed by j + 1 (entry 0 is column -1)
+  double *const lds_rows = (double *)(bt + DTW_BT_BYTES);
+#define B_PREV(ix) (BND_LDS ? lds_rows[o_prev + (ix)] : bnd_global[o_prev + (ix)])
+#define B_NEXT(ix) (BND_LDS ? lds_rows[o_next + (ix)] : bnd_global[o_next + (ix)])
+  int o_prev = 0, o_next = len_y + 2;
+  for (int j = lane; j < len_y + 2; j += 64) B_PREV(j) = INF;
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) B_PREV(0) = 0.0;  // D[-1][-1] = 0: the origin of the recurrence
   double last_val = INF;
   for (int i0 = 0; i0 < len_x; i0 += 64) {
     const int i = i0 + lane;
     const bool valid = i < len_x;
     const int rl = valid ? lo[i] : 0, rh = valid ? hi[i] : -1;
     const int rw = rh - rl;  // last valid index of the row
+    const int rwc = rw > 0 ? rw : 0;
     const int ilast = min(i0 + 63, len_x - 1);
     const int jmin = lo[i0], jmax = hi[ilast];
-    for (int j = lane; j < len_y + 2; j += 64) b_next[j] = INF;
+    for (int j = lane; j < len_y + 2; j += 64) B_NEXT(j) = INF;
     __builtin_amdgcn_wave_barrier();
+    if (bnd_lds) __threadfence_block(); else __threadfence();
     const double *drow = dist + DTW_PAD + (valid ? off[i] : 0);
-    unsigned char *prow = pred + DTW_PAD + (valid ? off[i] : 0);
+    unsigned long long *pwrow = predw + (valid ? dtw_word_base(off, i) : 0);
     double v1 = INF, v2 = INF;  // this lane's values at the two previous steps
     const int nsteps = (jmax - jmin + 1) + 63;
     const int shift = lane + rl - jmin;  // this lane's row index at step s is s - shift
+    unsigned long long pw = 0ull;        // predecessor codes of the current 32-cell word
+    double up0_prev = B_PREV(jmin);      // lane 0: D[i0-1][jmin-1] (column j-1 of the first step)
     // software prefetch of the lane's distances, 8 steps per block
     double curd[8], nxtd[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      int idx = u - shift;
-      curd[u] = (valid && idx >= 0 && idx <= rw) ? drow[idx] : 0.0;
+      curd[u] = drow[min(max(u - shift, 0), rwc)];
     }
-    for (int s0 = 0; s0 < nsteps; s0 += 8) {
+    for (int c0 = 0; c0 < nsteps; c0 += 64) {
+      // the boundary row values lane 0 will need in the next 64 steps: one LDS read per lane
+      const int jb = jmin + c0 + lane;
+      const double bchunk = (jb >= -1 && jb <= len_y) ? B_PREV(jb + 1) : INF;
+      for (int s0 = c0; s0 < min(c0 + 64, nsteps); s0 += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        int idx = s0 + 8 + u - shift;
-        nxtd[u] = (valid && idx >= 0 && idx <= rw) ? drow[idx] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int s = s0 + u;
-        const int j = jmin + s - lane;
-        const bool act = valid && j >= rl && j <= rh && s < nsteps;
-        double up = __shfl_up(v1, 1), dg = __shfl_up(v2, 1);
-        if (lane == 0) {
-          if (i0 == 0) { up = INF; dg = (j == 0) ? 0.0 : INF; }
-          else { up = (j >= 0 && j < len_y) ? b_prev[j] : INF; dg = (j >= 1 && j <= len_y) ? b_prev[j - 1] : INF; }
+        for (int u = 0; u < 8; ++u) {
+          nxtd[u] = drow[min(max(s0 + 8 + u - shift, 0), rwc)];
         }
-        double cur = INF;
-        if (act) {
-          const double dt = curd[u];
-          const double c0 = up + dt, c1 = v1 + dt, c2 = dg + dt;
-          double best = c0; unsigned char pb = 0;
-          if (c1 < best) { best = c1; pb = 1; }
-          if (c2 < best) { best = c2; pb = 2; }
-          cur = best;
-          prow[j - rl] = pb;
-          if (i == ilast) b_next[j] = cur;
-          if (i == len_x - 1 && j == len_y - 1) last_val = cur;
-        }
-        v2 = v1;
-        v1 = cur;
-      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) curd[u] = nxtd[u];
+        for (int u = 0; u < 8; ++u) {
+          const int s = s0 + u;
+          const int j = jmin + s - lane;
+          const int pos = s - shift;
+          const bool act = pos >= 0 && pos <= rw;
+          double up = dtw_wave_shr1(v1), dg = dtw_wave_shr1(v2);
+          const double bup = dtw_readlane(bchunk, (s - c0) & 63);
+          if (lane == 0) { up = bup; dg = up0_prev; }
+          up0_prev = bup;
+          double cur = INF;
+          if (act) {
+            const double dt = curd[u];
+            const double c0v = up + dt, c1v = v1 + dt, c2v = dg + dt;
+            double best = c0v; unsigned long long pb = 0ull;
+            if (c1v < best) { best = c1v; pb = 1ull; }
+            if (c2v < best) { best = c2v; pb = 2ull; }
+            cur = best;
+            pw |= pb << (2 * (pos & 31));
+            if ((pos & 31) == 31 || pos == rw) { pwrow[pos >> 5] = pw; pw = 0ull; }
+            if (i == ilast) B_NEXT(j + 1) = cur;
+            if (i == len_x - 1 && j == len_y - 1) last_val = cur;
+          }
+          v2 = v1;
+          v1 = cur;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) curd[u] = nxtd[u];
+      }
     }
     __builtin_amdgcn_wave_barrier();
     if (bnd_lds) __threadfence_block(); else __threadfence();
-    double *t = b_prev; b_prev = b_next; b_next = t;
+    { int t = o_prev; o_prev = o_next; o_next = t; }
   }
+#undef B_PREV
+#undef B_NEXT
   // broadcast D[len_x-1][len_y-1] (held by the lane of the last row)
   {
     const int owner = (len_x - 1) & 63;
@@ -170,19 +210,27 @@ __global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32
   }
   __threadfence();  // predecessor codes written above are read back below through global memory
 
-  // ---- back-trace, staged through LDS in groups of rows
+  // ---- back-trace, staged through LDS in groups of rows (codes AND row descriptors,
+  //      so that the serial walk of lane 0 never waits on global memory)
+  unsigned long long *btw = (unsigned long long *)bt;
+  const uint64_t bt_words = DTW_BT_BYTES / 8;
+  __shared__ int g_lo[DTW_BT_ROWS], g_hi[DTW_BT_ROWS];
+  __shared__ unsigned int g_wb[DTW_BT_ROWS];
   int ci = len_x - 1, cj = len_y - 1, n = 0;
   while (ci >= 0) {
-    // rows [r0, ci] whose codes fit in the LDS budget
+    // rows [r0, ci]: at most DTW_BT_ROWS rows whose code words fit in the LDS budget
     int r0 = ci;
-    uint64_t bytes = (uint64_t)(hi[ci] - lo[ci] + 1);
-    while (r0 > 0 && bytes + (uint64_t)(hi[r0 - 1] - lo[r0 - 1] + 1) <= DTW_BT_BYTES) {
-      --r0;
-      bytes += (uint64_t)(hi[r0] - lo[r0] + 1);
-    }
-    const uint64_t base = off[r0];
-    if (bytes <= DTW_BT_BYTES) {
-      for (uint64_t b = lane; b < bytes; b += 64) bt[b] = pred[DTW_PAD + base + b];
+    const uint64_t wend = dtw_word_base(off, ci) + (uint64_t)((hi[ci] - lo[ci]) >> 5) + 1;
+    while (r0 > 0 && ci - (r0 - 1) < DTW_BT_ROWS && wend - dtw_word_base(off, r0 - 1) <= bt_words) --r0;
+    const uint64_t wbase = dtw_word_base(off, r0);
+    const uint64_t nw = wend - wbase;
+    const bool staged = nw <= bt_words;
+    if (staged)
+      for (uint64_t b = lane; b < nw; b += 64) btw[b] = predw[wbase + b];
+    for (int r = r0 + lane; r <= ci; r += 64) {
+      g_lo[r - r0] = lo[r];
+      g_hi[r - r0] = hi[r];
+      g_wb[r - r0] = (unsigned int)(dtw_word_base(off, r) - wbase);
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -191,10 +239,13 @@ __global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32
       while (i >= r0) {
         rev[2 * m] = i; rev[2 * m + 1] = j; ++m;
         if (i == 0 && j == 0) { i = -1; break; }
-        unsigned char pb;
-        if (j < lo[i] || j > hi[i]) pb = 0;
-        else if (bytes <= DTW_BT_BYTES) pb = bt[off[i] - base + (uint64_t)(j - lo[i])];
-        else pb = pred[DTW_PAD + off[i] + (uint64_t)(j - lo[i])];
+        unsigned int pb = 0;
+        const int l = g_lo[i - r0];
+        if (j >= l && j <= g_hi[i - r0]) {
+          const unsigned int w = g_wb[i - r0] + (unsigned int)((j - l) >> 5);
+          const unsigned long long word = staged ? btw[w] : predw[wbase + w];
+          pb = (unsigned int)(word >> (2 * ((j - l) & 31))) & 3u;
+        }
         if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
         if (j < 0) { i = -1; break; }
       }
@@ -231,7 +282,7 @@ static size_t dtw_scratch_bytes(int64_t Tx, int64_t Ty, int dim, int radius, boo
     tot += kwy_pad(sizeof(double) * (size_t)lx * dim) + kwy_pad(sizeof(double) * (size_t)ly * dim);
   }
   uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
-  tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_PAD)) + kwy_pad(cap + 2 * DTW_PAD);
+  tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_PAD)) + kwy_pad(8 * (cap / 32 + Tx + 64));
   tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1));
   tot += kwy_pad(sizeof(double) * 2 * (Ty + 2));
   tot += 3 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
@@ -258,7 +309,7 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   }
   const uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
   double *dist = kwy_arena<double>(ctx, cap + 2 * DTW_PAD);
-  unsigned char *pred = kwy_arena<unsigned char>(ctx, cap + 2 * DTW_PAD);
+  unsigned long long *pred = kwy_arena<unsigned long long>(ctx, cap / 32 + Tx + 64);
   int32_t *lo = kwy_arena<int32_t>(ctx, Tx), *hi = kwy_arena<int32_t>(ctx, Tx);
   uint32_t *width = kwy_arena<uint32_t>(ctx, Tx);
   uint64_t *off = kwy_arena<uint64_t>(ctx, Tx + 1);
@@ -277,7 +328,8 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   const size_t bnd_bytes = sizeof(double) * 2 * (Ty + 2);
   const bool bnd_lds = DTW_BT_BYTES + bnd_bytes <= 150 * 1024;
   const size_t dp_lds = DTW_BT_BYTES + (bnd_lds ? bnd_bytes : 0);
-  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
 
   const int32_t *cpath = nullptr;
   const int64_t *clen = nullptr;
@@ -291,8 +343,14 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     KWY_TRY(kwy_launch_scan(ctx, width, off, len_x));
     KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3(len_x), dim3(KWY_THREADS), sizeof(double) * dim, ctx->stream, xs[l],
                        ys[l], dim, lo, hi, off, cap, dist, status));
-    KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp, dim3(1), dim3(64), dp_lds, ctx->stream, len_x, len_y, lo, hi, off, cap,
-                       dist, pred, bnd_lds ? (double *)nullptr : bnd, opath, rev, olen, d_dist, status));
+    if (bnd_lds)
+      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<true>, dim3(1), dim3(64), dp_lds, ctx->stream, len_x, len_y,
+                                                     lo, hi, off, cap, dist, pred, (double *)nullptr, opath, rev, olen,
+                                                     d_dist, status));
+    else
+      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<false>, dim3(1), dim3(64), dp_lds, ctx->stream, len_x, len_y,
+                                                     lo, hi, off, cap, dist, pred, bnd, opath, rev, olen, d_dist,
+                                                     status));
     cpath = opath;
     clen = olen;
   }

@@ -173,16 +173,125 @@ __device__ __forceinline__ syn_ff syn_ff_make(double c, int k) {
   return r;
 }
 
+// ordered exclusive scan of one map per thread over the workgroup (NW waves);
+// returns the composition of all earlier threads' maps, *total = the whole block's.
+template <int NW>
+__device__ __forceinline__ syn_ff syn_ff_block_exscan(syn_ff mine, syn_ff *wtot, syn_ff *total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  syn_ff incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    syn_ff u;
+    u.d0 = __shfl_up(incl.d0, o);
+    u.d1 = __shfl_up(incl.d1, o);
+    if (lane >= o) incl = syn_ff_compose(u, incl);
+  }
+  __syncthreads();
+  if (lane == 63) wtot[wv] = incl;
+  __syncthreads();
+  syn_ff pre = {0, 0}, all = {0, 0};
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    if (w < wv) pre = syn_ff_compose(pre, wtot[w]);
+    all = syn_ff_compose(all, wtot[w]);
+  }
+  syn_ff prev;
+  prev.d0 = __shfl_up(incl.d0, 1);
+  prev.d1 = __shfl_up(incl.d1, 1);
+  if (lane == 0) prev = syn_ff{0, 0};
+  *total = all;
+  return syn_ff_compose(pre, prev);
+}
+
+__device__ __forceinline__ int syn_exponent(double v) {
+  return (int)(((unsigned long long)__double_as_longlong(v) >> 52) & 0x7ff) - 1023;
+}
+
+#define SYN_TL_PER_THREAD (SYN_PH_TILE / KWY_THREADS)  // 16 samples per thread in the parallel phases
+#define SYN_SLOW (-100000)
+
+// phase B1: plain f64 sum of every tile's increments (an estimate of where each tile starts)
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_sums(const double *__restrict__ inc, int64_t y_length,
+                                                              double *__restrict__ tsum) {
+  __shared__ double red[8];
+  const int64_t tile0 = (int64_t)blockIdx.x * SYN_PH_TILE;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < SYN_PH_TILE; i += KWY_THREADS)
+    if (tile0 + i < y_length) s += inc[tile0 + i];
+  s = kwy_block_sum(s, red);
+  if (threadIdx.x == 0) tsum[blockIdx.x] = s;
+}
+
+// phase B2: per tile, guess the binade from the estimated start/end phase; if the tile safely stays
+// inside one binade, reduce its samples to ONE parity map (summary); otherwise mark it slow.
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_summary(const double *__restrict__ inc,
+                                                                 int64_t y_length,
+                                                                 const double *__restrict__ tsum, int ntiles,
+                                                                 long long *__restrict__ summ /* 3 per tile */) {
+  __shared__ syn_ff wtot[KWY_WAVES];
+  __shared__ double s_lo;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    double lo = 0.0;
+    for (int i = 0; i < t; ++i) lo += tsum[i];
+    s_lo = lo;
+  }
+  __syncthreads();
+  const double lo = s_lo, hi = lo + tsum[t];
+  int k = SYN_SLOW;
+  if (lo > 0.0) {
+    const int ka = syn_exponent(lo * (1.0 - 1e-9)), kb = syn_exponent(hi * (1.0 + 1e-9));
+    if (ka == kb) k = ka;
+  }
+  long long *o = summ + 3 * (int64_t)t;
+  if (k == SYN_SLOW) {
+    if (tid == 0) { o[0] = 0; o[1] = 0; o[2] = SYN_SLOW; }
+    return;
+  }
+  const int64_t tile0 = (int64_t)t * SYN_PH_TILE;
+  syn_ff mine = {0, 0};
+#pragma unroll
+  for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
+    int64_t n = tile0 + tid * SYN_TL_PER_THREAD + j;
+    if (n < y_length) mine = syn_ff_compose(mine, syn_ff_make(inc[n], k));
+  }
+  syn_ff all;
+  (void)syn_ff_block_exscan<KWY_WAVES>(mine, wtot, &all);
+  if (tid == 0) { o[0] = all.d0; o[1] = all.d1; o[2] = k; }
+}
+
+// phase B3: the serial chain over tiles.  Fast tiles cost a few scalar operations (apply the
+// summary to the exact running phase); slow tiles (binade changes, the very beginning) are
+// produced here, sample by sample exactly, with workgroup-wide scans.
 __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__restrict__ inc,
                                                              int64_t y_length,
+                                                             const long long *__restrict__ summ,
+                                                             double *__restrict__ tin,
                                                              double *__restrict__ wrap) {
   __shared__ syn_ff wtot[SYN_PH_THREADS / 64];
   __shared__ int s_cross;
   __shared__ double s_tp;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x;
   double tp = 0.0;  // running phase (uniform across the block)
-  for (int64_t tile0 = 0; tile0 < y_length; tile0 += SYN_PH_TILE) {
+  int tix = 0;
+  for (int64_t tile0 = 0; tile0 < y_length; tile0 += SYN_PH_TILE, ++tix) {
     const int tile_n = (int)min((int64_t)SYN_PH_TILE, y_length - tile0);
+    // ---- fast tile?
+    {
+      const long long d0 = summ[3 * tix], d1 = summ[3 * tix + 1];
+      const int k = (int)summ[3 * tix + 2];
+      if (k != SYN_SLOW && tp > 0.0 && syn_exponent(tp) == k) {
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
+        const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
+        const long long m_out = m_in + ((m_in & 1) ? d1 : d0);
+        if ((m_out >> 53) == 0) {
+          if (tid == 0) tin[tix] = tp;
+          tp = ldexp((double)m_out, k - 52);
+          continue;
+        }
+      }
+      if (tid == 0) tin[tix] = -1.0;  // produced here
+    }
     double c[SYN_PH_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
@@ -197,8 +306,8 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
       if (tp == 0.0) {
         cross = pos;  // 0 + c: plain add
       } else {
+        const int k = syn_exponent(tp);
         const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
-        const int k = (int)((tb >> 52) & 0x7ff) - 1023;
         const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
         syn_ff f[SYN_PH_PER_THREAD];
         syn_ff mine = {0, 0};
@@ -208,25 +317,8 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
           f[j] = (i >= pos && i < tile_n) ? syn_ff_make(c[j], k) : syn_ff{0, 0};
           mine = syn_ff_compose(mine, f[j]);
         }
-        // ordered inclusive scan of the per-thread maps
-        syn_ff incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          syn_ff u;
-          u.d0 = __shfl_up(incl.d0, o);
-          u.d1 = __shfl_up(incl.d1, o);
-          if (lane >= o) incl = syn_ff_compose(u, incl);
-        }
-        if (lane == 63) wtot[wv] = incl;
-        __syncthreads();
-        syn_ff pre = {0, 0};
-        for (int w = 0; w < wv; ++w) pre = syn_ff_compose(pre, wtot[w]);
-        // exclusive prefix for this thread = pre o (incl of previous lane)
-        syn_ff prev;
-        prev.d0 = __shfl_up(incl.d0, 1);
-        prev.d1 = __shfl_up(incl.d1, 1);
-        if (lane == 0) prev = syn_ff{0, 0};
-        const syn_ff excl = syn_ff_compose(pre, prev);
+        syn_ff all;
+        const syn_ff excl = syn_ff_block_exscan<SYN_PH_THREADS / 64>(mine, wtot, &all);
         long long m = m_in + ((m_in & 1) ? excl.d1 : excl.d0);
         int my_cross = tile_n;
         double tpv[SYN_PH_PER_THREAD];
@@ -264,6 +356,37 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
         pos = tile_n;
       }
       __syncthreads();
+    }
+  }
+}
+
+// phase B4: fast tiles, in parallel: every sample's exact phase from the tile's exact start
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_apply(const double *__restrict__ inc, int64_t y_length,
+                                                               const double *__restrict__ tin,
+                                                               double *__restrict__ wrap) {
+  __shared__ syn_ff wtot[KWY_WAVES];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const double tp = tin[t];
+  if (!(tp > 0.0)) return;  // produced by the chain kernel
+  const int k = syn_exponent(tp);
+  const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
+  const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
+  const int64_t base = (int64_t)t * SYN_PH_TILE + (int64_t)tid * SYN_TL_PER_THREAD;
+  syn_ff f[SYN_TL_PER_THREAD];
+  syn_ff mine = {0, 0};
+#pragma unroll
+  for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
+    f[j] = (base + j < y_length) ? syn_ff_make(inc[base + j], k) : syn_ff{0, 0};
+    mine = syn_ff_compose(mine, f[j]);
+  }
+  syn_ff all;
+  const syn_ff excl = syn_ff_block_exscan<KWY_WAVES>(mine, wtot, &all);
+  long long m = m_in + ((m_in & 1) ? excl.d1 : excl.d0);
+#pragma unroll
+  for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
+    if (base + j < y_length) {
+      m += (m & 1) ? f[j].d1 : f[j].d0;
+      wrap[base + j] = fmod(ldexp((double)m, k - 52), SYN_TWO_PI);
     }
   }
 }
@@ -563,7 +686,7 @@ static int syn_pulse_cap(int64_t y_length) { return (int)(y_length / 8 + 16); }
 static size_t syn_scratch_bytes(int64_t y_length) {
   int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
   int cap = syn_pulse_cap(y_length);
-  return kwy_pad(sizeof(int) * (nt + 1)) + 2 * kwy_pad(sizeof(double) * y_length) +
+  return kwy_pad(sizeof(int) * (nt + 1)) + 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) +
          kwy_pad(y_length) + kwy_pad(sizeof(int32_t) * cap) + kwy_pad(sizeof(double) * cap) +
          kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * (size_t)cap) + kwy_pad(64);
 }
@@ -586,6 +709,9 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
   const int nt = (int)((y_length + SYN_TILE - 1) / SYN_TILE);
   const int cap = syn_pulse_cap(y_length);
   double *incr = kwy_arena<double>(ctx, y_length);
+  const size_t npt_alloc = (size_t)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE) + 1;
+  double *ph_tsum = kwy_arena<double>(ctx, npt_alloc), *ph_tin = kwy_arena<double>(ctx, npt_alloc);
+  long long *ph_summ = kwy_arena<long long>(ctx, 3 * npt_alloc);
   int *tile_cnt = kwy_arena<int>(ctx, nt + 1);
   double *wrap = kwy_arena<double>(ctx, y_length);
   unsigned char *vuv8 = kwy_arena<unsigned char>(ctx, y_length);
@@ -593,7 +719,7 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
   double *pshift = kwy_arena<double>(ctx, cap);
   uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * cap);
   int *npulse = kwy_arena<int>(ctx, 16);
-  if (!incr || !tile_cnt || !wrap || !vuv8 || !pidx || !pshift || !ebase || !npulse) {
+  if (!incr || !ph_tsum || !ph_tin || !ph_summ || !tile_cnt || !wrap || !vuv8 || !pidx || !pshift || !ebase || !npulse) {
     ctx->err = "synthesize: scratch arena too small";
     return KWY_ENOMEM;
   }
@@ -602,7 +728,16 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
 
   hipLaunchKernelGGL(k_syn_inc, dim3((unsigned)((y_length + KWY_THREADS - 1) / KWY_THREADS)),
                      dim3(KWY_THREADS), 0, ctx->stream, f0, p, incr, vuv8);
-  KWY_PROF(ctx, "k_syn_phase", hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream, incr, y_length, wrap));
+  {
+    const int npt = (int)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE);
+    hipLaunchKernelGGL(k_syn_tile_sums, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum);
+    hipLaunchKernelGGL(k_syn_tile_summary, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum,
+                       npt, ph_summ);
+    KWY_PROF(ctx, "k_syn_phase", hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream,
+                                                      incr, y_length, ph_summ, ph_tin, wrap));
+    hipLaunchKernelGGL(k_syn_tile_apply, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tin,
+                       wrap);
+  }
   hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, tile_cnt);
   hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, tile_cnt, nt, npulse);
   hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, fs,
