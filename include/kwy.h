@@ -53,6 +53,9 @@ void *kwy_ctx_stream(kwy_ctx *ctx);
  * read (kernel names as in rocprofv3, without template arguments, e.g.
  * "k_d4c_body"). */
 int kwy_ctx_profile(kwy_ctx *ctx, int enable);
+/* Diagnostic only: a device buffer of >= 64 int64 that instrumented kernels fill with
+ * clock64() stamps for the workgroup whose index is stored in element 63 (NULL = off). */
+int kwy_ctx_debug_buffer(kwy_ctx *ctx, void *device_buffer);
 int kwy_ctx_profile_read(kwy_ctx *ctx, const char *kernel, double *total_ms, int64_t *count);
 const char *kwy_last_error(kwy_ctx *ctx);
 /* error text when kwy_ctx_create itself failed (no context to ask) */

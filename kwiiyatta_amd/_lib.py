@@ -62,6 +62,7 @@ SIGNATURES = {
     'kwy_ctx_sync': (c_int, [c_vp]),
     'kwy_ctx_stream': (c_vp, [c_vp]),
     'kwy_ctx_profile': (c_int, [c_vp, c_int]),
+    'kwy_ctx_debug_buffer': (c_int, [c_vp, c_vp]),
     'kwy_ctx_profile_read': (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     'kwy_last_error': (ctypes.c_char_p, [c_vp]),
     'kwy_create_error': (ctypes.c_char_p, []),

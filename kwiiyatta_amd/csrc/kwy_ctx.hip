@@ -280,16 +280,16 @@ int kwy_get_poly(kwy_ctx *ctx, uint64_t stride_steps, const uint4 **out) {
   return KWY_OK;
 }
 
-int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, const uint4 **out) {
-  const uint64_t key = 0x8000000000000000ull | (uint64_t)max_c;
+int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, int nthreads, const uint4 **out) {
+  const uint64_t key = 0x8000000000000000ull | ((uint64_t)nthreads << 32) | (uint64_t)max_c;
   auto it = ctx->d_poly.find(key);
   if (it == ctx->d_poly.end()) {
-    std::vector<uint4> h((size_t)max_c * KWY_THREADS);
+    std::vector<uint4> h((size_t)max_c * nthreads);
     for (int c = 1; c <= max_c; ++c) {
       Poly step = poly_xpow(12ull * c);
       Poly cur = {{1, 0, 0, 0}};
-      for (int t = 0; t < KWY_THREADS; ++t) {
-        uint4 &o = h[(size_t)(c - 1) * KWY_THREADS + t];
+      for (int t = 0; t < nthreads; ++t) {
+        uint4 &o = h[(size_t)(c - 1) * nthreads + t];
         o.x = (uint32_t)cur.w[0]; o.y = (uint32_t)(cur.w[0] >> 32);
         o.z = (uint32_t)cur.w[1]; o.w = (uint32_t)(cur.w[1] >> 32);
         cur = poly_mulmod(cur, step);
@@ -369,6 +369,12 @@ void kwy_ctx_destroy(kwy_ctx *ctx) {
 int kwy_ctx_sync(kwy_ctx *ctx) {
   if (!ctx) return KWY_EINVAL;
   KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}
+
+int kwy_ctx_debug_buffer(kwy_ctx *ctx, void *device_buffer) {
+  if (!ctx) return KWY_EINVAL;
+  ctx->dbg = device_buffer;
   return KWY_OK;
 }
 

@@ -30,7 +30,10 @@ enum { D4C_HANNING = 1, D4C_BLACKMAN = 2 };
 __device__ __forceinline__ double d4c_window(int type, int i, int half, double ratio, int fs, double cf0) {
   double position = (2.0 * (i - half) / ratio) / fs;
   if (type == D4C_HANNING) return 0.5 * cos(KWY_PI * position * cf0) + 0.5;
-  return 0.42 + 0.5 * cos(KWY_PI * position * cf0) + 0.08 * cos(KWY_PI * position * cf0 * 2);
+  // Blackman: the second harmonic through the double-angle identity (one cos instead of two;
+  // differs from cos(2x) by <= 2 ulp of the window value)
+  const double c1 = cos(KWY_PI * position * cf0);
+  return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
 }
 
 __device__ __forceinline__ double d4c_interp1q(double x0, double shift, const double *y, int x_length,
@@ -44,25 +47,27 @@ __device__ __forceinline__ double d4c_interp1q(double x0, double shift, const do
 }
 
 // WORLD DCCorrection in place on P[0..H]; S: scratch
+template <int NT>
 __device__ inline void d4c_dc_correction(double *P, double *S, double cf0, int fs, int N) {
   const int upper_limit = 2 + (int)(cf0 * N / fs);
   const int nrep = upper_limit - 1;
   const double shift = -(double)fs / N;
-  for (int k = threadIdx.x; k < nrep; k += KWY_THREADS)
+  for (int k = threadIdx.x; k < nrep; k += NT)
     S[k] = d4c_interp1q(cf0, shift, P, upper_limit + 1, (double)k * fs / N);
   __syncthreads();
-  for (int k = threadIdx.x; k < nrep; k += KWY_THREADS) P[k] = P[k] + S[k];
+  for (int k = threadIdx.x; k < nrep; k += NT) P[k] = P[k] + S[k];
   __syncthreads();
 }
 
 // WORLD LinearSmoothing: in[0..H] -> out[0..H] (out may alias in); S: scratch of >= H+2b+1
+template <int NT>
 __device__ inline void d4c_linear_smoothing(const double *in, double *out, double *S, double *tot,
                                             double width, int fs, int N) {
   const int H = N / 2;
   int boundary = (int)(width * N / fs) + 1;
   if (boundary > H / 2) boundary = H / 2;  // LDS guard; outside WORLD's domain anyway
   const int L = H + boundary * 2 + 1;
-  for (int i = threadIdx.x; i < L; i += KWY_THREADS) {
+  for (int i = threadIdx.x; i < L; i += NT) {
     double m;
     if (i < boundary) m = in[boundary - i];
     else if (i < H + boundary) m = in[i - boundary];
@@ -70,10 +75,10 @@ __device__ inline void d4c_linear_smoothing(const double *in, double *out, doubl
     S[i] = m * fs / N;
   }
   __syncthreads();
-  kwy_block_cumsum(S, L, tot);
+  kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
   const double dfi = (double)fs / N;
-  for (int k = threadIdx.x; k <= H; k += KWY_THREADS) {
+  for (int k = threadIdx.x; k <= H; k += NT) {
     double fa = (double)k / N * fs - width / 2.0;
     double low = d4c_interp1q(origin, dfi, S, L, fa);
     fa += width;
@@ -194,7 +199,7 @@ struct d4c_params {
 // [which*wl, (which+1)*wl): they are scattered into the LDS scratch NZ first, so
 // that the window itself is evaluated with a balanced, strided thread mapping.
 // If `make_ramp`, also normalises to unit power and writes A[i]*(i+1) into R.
-template <int N, int C>
+template <int N, int C, int NT>
 __device__ inline void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
                                         double pos, int type, int which, int c, const double (&nz)[C],
                                         double *A, double *R, double *NZ, bool make_ramp, double *red) {
@@ -210,7 +215,7 @@ __device__ inline void d4c_frame_window(const double *__restrict__ x, const d4c_
   }
   __syncthreads();
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < N; i += KWY_THREADS) {
+  for (int i = tid; i < N; i += NT) {
     double v = 0.0;
     if (i < wl) {
       double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
@@ -222,19 +227,19 @@ __device__ inline void d4c_frame_window(const double *__restrict__ x, const d4c_
     }
     A[i] = v;
   }
-  const double t1 = kwy_block_sum(s1, red);
-  const double t2 = kwy_block_sum(s2, red);
+  const double t1 = kwy_block_sum<NT>(s1, red);
+  const double t2 = kwy_block_sum<NT>(s2, red);
   const double coef = t1 / t2;
   double pw = 0.0;
-  for (int i = tid; i < wl; i += KWY_THREADS) {
+  for (int i = tid; i < wl; i += NT) {
     double v = A[i] - NZ[i] * coef;
     A[i] = v;
     pw += v * v;
   }
   if (make_ramp) {
-    const double power = kwy_block_sum(pw, red);
+    const double power = kwy_block_sum<NT>(pw, red);
     const double sq = sqrt(power);
-    for (int i = tid; i < N; i += KWY_THREADS) {
+    for (int i = tid; i < N; i += NT) {
       double v = (i < wl) ? A[i] / sq : 0.0;
       A[i] = v;
       R[i] = v * (i + 1.0);
@@ -243,104 +248,119 @@ __device__ inline void d4c_frame_window(const double *__restrict__ x, const d4c_
   __syncthreads();
 }
 
+#define D4C_NT 512  // threads of the general-body workgroup: 8 wavefronts share one frame's LDS
 template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS) void k_d4c_body(
+__global__ __launch_bounds__(D4C_NT) void k_d4c_body(
     const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
     const double *__restrict__ ap0, d4c_params p, const uint32_t *__restrict__ ebase,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    const double *__restrict__ nuttall, double *__restrict__ out) {
+    const double *__restrict__ nuttall, double *__restrict__ out, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
-  constexpr int C = 3 * N / KWY_THREADS;  // draws per thread (3 windows, each shorter than N)
+  constexpr int NT = D4C_NT;
+  constexpr int C = 3 * N / NT;
+#define D4C_STAMP(n) do { if (dbg && threadIdx.x == 0 && blockIdx.x == (unsigned)dbg[63]) dbg[n] = clock64(); } while (0)  // draws per thread (3 windows, each shorter than N)
   extern __shared__ double smem[];
   kwy_c *buf0 = (kwy_c *)smem;
   kwy_c *buf1 = buf0 + (H + 1);
   kwy_c *buf2 = buf1 + (H + 1);
   double *Dv = (double *)(buf2 + (H + 1));  // H+1: centroid sum, later group delay
   double *red = Dv + (H + 2);               // 8
-  double *tot = red + 8;                    // KWY_THREADS
-  double *coarse = tot + KWY_THREADS;       // D4C_MAX_BANDS + 2
+  double *tot = red + 8;                    // NT
+  double *coarse = tot + NT;       // D4C_MAX_BANDS + 2
   uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);
-  uint32_t *hist = e + KWY_EBASE_WORDS;     // KWY_WAVES*256 + 4
+  uint32_t *hist = e + KWY_EBASE_WORDS;     // (NT/64)*256 + 8
 
   const int tid = threadIdx.x;
   const int64_t frame = blockIdx.x;
   const double f0v = f0[frame];
   double *o = out + frame * p.K;
   if (f0v == 0.0 || ap0[frame] <= p.threshold) {
-    for (int k = tid; k < p.K; k += KWY_THREADS) o[k] = 1.0 - D4C_SAFE;
+    for (int k = tid; k < p.K; k += NT) o[k] = 1.0 - D4C_SAFE;
     return;
   }
   const double cf0 = f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0;
   const double pos = tpos[frame];
 
-  for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
+  D4C_STAMP(0);
+  for (int i = tid; i < KWY_EBASE_WORDS; i += NT) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
   __syncthreads();
   const int wl4 = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0) * 2 + 1;
-  const int c = (3 * wl4 + KWY_THREADS - 1) / KWY_THREADS;  // draws per thread, <= C
-  kwy_rng rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
+  const int c = (3 * wl4 + NT - 1) / NT;  // draws per thread, <= C
+  kwy_rng rng = kwy_rng_combine(e, poly[(c - 1) * NT + tid]);
   double nz[C];
 #pragma unroll
   for (int j = 0; j < C; ++j) nz[j] = (j < c) ? kwy_rng_randn(rng) : 0.0;
 
+  D4C_STAMP(1);
   // ---- static centroid: two temporal centroids at pos -+ 0.25/f0
   for (int which = 0; which < 2; ++which) {
     double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-    d4c_frame_window<N, C>(x, p, cf0, cpos, D4C_BLACKMAN, which, c, nz, (double *)buf0, (double *)buf1,
+    d4c_frame_window<N, C, NT>(x, p, cf0, cpos, D4C_BLACKMAN, which, c, nz, (double *)buf0, (double *)buf1,
                            (double *)buf2, true, red);
+    D4C_STAMP(2 + which * 2);
     // X1 = rfft(buf0) using buf2 as scratch; X2 = rfft(buf1) using the buffer X1 left free
-    kwy_c *X1 = kwy_rfft_lds(buf0, buf2, LOG2N - 1, twH, twN);
+    kwy_c *X1 = kwy_rfft_lds<NT>(buf0, buf2, LOG2N - 1, twH, twN);
     kwy_c *F = (X1 == buf0) ? buf2 : buf0;
-    kwy_c *X2 = kwy_rfft_lds(buf1, F, LOG2N - 1, twH, twN);
-    for (int k = tid; k <= H; k += KWY_THREADS) {
+    kwy_c *X2 = kwy_rfft_lds<NT>(buf1, F, LOG2N - 1, twH, twN);
+    for (int k = tid; k <= H; k += NT) {
       double cen = X2[k].x * X1[k].x + X1[k].y * X2[k].y;
       Dv[k] = which == 0 ? cen : Dv[k] + cen;
     }
     __syncthreads();
+    D4C_STAMP(3 + which * 2);
   }
-  d4c_dc_correction(Dv, (double *)buf0, cf0, p.fs, N);
+  d4c_dc_correction<NT>(Dv, (double *)buf0, cf0, p.fs, N);
 
+  D4C_STAMP(6);
   // ---- smoothed power spectrum
-  d4c_frame_window<N, C>(x, p, cf0, pos, D4C_HANNING, 2, c, nz, (double *)buf0, nullptr, (double *)buf2,
+  d4c_frame_window<N, C, NT>(x, p, cf0, pos, D4C_HANNING, 2, c, nz, (double *)buf0, nullptr, (double *)buf2,
                          false, red);
-  kwy_c *Xs = kwy_rfft_lds(buf0, buf1, LOG2N - 1, twH, twN);
+  D4C_STAMP(7);
+  kwy_c *Xs = kwy_rfft_lds<NT>(buf0, buf1, LOG2N - 1, twH, twN);
+  D4C_STAMP(8);
   double *P = (double *)buf2;
-  for (int k = tid; k <= H; k += KWY_THREADS) {
+  for (int k = tid; k <= H; k += NT) {
     kwy_c v = Xs[k];
     P[k] = v.x * v.x + v.y * v.y;
   }
   __syncthreads();
   double *S = (double *)buf0;
   double *G2 = (double *)buf1;
-  d4c_dc_correction(P, S, cf0, p.fs, N);
-  d4c_linear_smoothing(P, P, S, tot, cf0, p.fs, N);
+  d4c_dc_correction<NT>(P, S, cf0, p.fs, N);
+  d4c_linear_smoothing<NT>(P, P, S, tot, cf0, p.fs, N);
 
+  D4C_STAMP(9);
   // ---- static group delay
-  for (int k = tid; k <= H; k += KWY_THREADS) Dv[k] = Dv[k] / P[k];
+  for (int k = tid; k <= H; k += NT) Dv[k] = Dv[k] / P[k];
   __syncthreads();
-  d4c_linear_smoothing(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N);
-  d4c_linear_smoothing(Dv, G2, S, tot, cf0, p.fs, N);
-  for (int k = tid; k <= H; k += KWY_THREADS) Dv[k] = Dv[k] - G2[k];
+  d4c_linear_smoothing<NT>(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N);
+  d4c_linear_smoothing<NT>(Dv, G2, S, tot, cf0, p.fs, N);
+  for (int k = tid; k <= H; k += NT) Dv[k] = Dv[k] - G2[k];
   __syncthreads();
 
+  D4C_STAMP(10);
   // ---- coarse aperiodicity per band
   const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
   const int half_window_length = p.window_length / 2;
   for (int b = 0; b < p.nbands; ++b) {
     const int center = (int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs);
     double *A = (double *)buf0;
-    for (int j = tid; j < N; j += KWY_THREADS)
+    for (int j = tid; j < N; j += NT)
       A[j] = (j <= half_window_length * 2) ? Dv[center - half_window_length + j] * nuttall[j] : 0.0;
-    kwy_c *Xb = kwy_rfft_lds(buf0, buf1, LOG2N - 1, twH, twN);
+    if (b == 0) D4C_STAMP(11);
+    kwy_c *Xb = kwy_rfft_lds<NT>(buf0, buf1, LOG2N - 1, twH, twN);
+    if (b == 0) D4C_STAMP(12);
     double *Q = (double *)buf2;  // power spectrum of the band
-    for (int k = tid; k <= H; k += KWY_THREADS) {
+    for (int k = tid; k <= H; k += NT) {
       kwy_c cc = Xb[k];
       Q[k] = cc.x * cc.x + cc.y * cc.y;
     }
     __syncthreads();
     // CPU: sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
     double nsmall, nall;
-    kwy_block_smallest_sum<(H + 1 + KWY_THREADS - 1) / KWY_THREADS>(Q, H + 1, H - boundary, hist, red, &nsmall,
+    kwy_block_smallest_sum<(H + 1 + NT - 1) / NT, NT>(Q, H + 1, H - boundary, hist, red, &nsmall,
                                                                      &nall);
+    if (b == 0) D4C_STAMP(13);
     if (tid == 0) {
       double cv = 10 * log10(nsmall / nall);
       cv = cv + (cf0 - 100) / 50.0;
@@ -354,9 +374,10 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_body(
   }
   __syncthreads();
 
+  D4C_STAMP(14);
   // ---- interp1 of the (nbands+2)-point contour onto the K output bins
   const int nn = p.nbands + 2;
-  for (int k = tid; k < p.K; k += KWY_THREADS) {
+  for (int k = tid; k < p.K; k += NT) {
     double xi = (double)k * p.fs / p.fft_size;
     int seg = 0;  // number of nodes <= xi
     for (int j = 0; j < nn; ++j) {
@@ -369,8 +390,10 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_body(
     double xb = (seg <= p.nbands) ? seg * D4C_FREQ_INTERVAL : p.fs / 2.0;
     double s = (xi - xa) / (xb - xa);
     double v = coarse[seg - 1] + s * (coarse[seg] - coarse[seg - 1]);
-    o[k] = pow(10.0, v / 20.0);
+    o[k] = exp10(v / 20.0);
   }
+  D4C_STAMP(15);
+#undef D4C_STAMP
 }
 
 // ------------------------------------------------------------------ host side
@@ -382,7 +405,7 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly_multi(ctx, N / KWY_THREADS, &poly));
+  KWY_TRY(kwy_get_poly_multi(ctx, N / KWY_THREADS, KWY_THREADS, &poly));
   size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -401,14 +424,14 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly_multi(ctx, 3 * N / KWY_THREADS, &poly));
+  KWY_TRY(kwy_get_poly_multi(ctx, 3 * N / D4C_NT, D4C_NT, &poly));
   size_t lds = sizeof(kwy_c) * 3 * (H + 1) +
-               sizeof(double) * ((H + 2) + 8 + KWY_THREADS + D4C_MAX_BANDS + 2) +
-               sizeof(uint32_t) * (KWY_EBASE_WORDS + KWY_WAVES * 256 + 4);
+               sizeof(double) * ((H + 2) + 8 + D4C_NT + D4C_MAX_BANDS + 2) +
+               sizeof(uint32_t) * (KWY_EBASE_WORDS + (D4C_NT / 64) * 256 + 8);
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x, t,
-                     f0, ap0, p, ebase, poly, twH, twN, nuttall, out));
+  KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(D4C_NT), lds, ctx->stream, x, t,
+                     f0, ap0, p, ebase, poly, twH, twN, nuttall, out, (long long *)ctx->dbg));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

@@ -102,7 +102,8 @@ __device__ __forceinline__ double kwy_wave_sum(double v) {
   return v;
 }
 
-// sum over the whole block; every thread gets the result. red: >= KWY_WAVES doubles.
+// sum over the whole block of NT threads; every thread gets the result. red: >= NT/64 doubles.
+template <int NT = KWY_THREADS>
 __device__ __forceinline__ double kwy_block_sum(double v, double *red) {
   v = kwy_wave_sum(v);
   __syncthreads();
@@ -110,33 +111,38 @@ __device__ __forceinline__ double kwy_block_sum(double v, double *red) {
   __syncthreads();
   double s = red[0];
 #pragma unroll
-  for (int i = 1; i < KWY_WAVES; ++i) s += red[i];
+  for (int i = 1; i < NT / 64; ++i) s += red[i];
   return s;
 }
 
 // in-place inclusive prefix sum of buf[0..L) (LDS).  Thread t owns the
-// contiguous chunk [t*chunk, (t+1)*chunk).  tot: KWY_THREADS doubles of LDS.
+// contiguous chunk [t*chunk, (t+1)*chunk).  tot: NT doubles of LDS.
+template <int NT = KWY_THREADS>
 __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
+  constexpr int PER = NT / 64;  // chunk totals scanned per lane of wave 0
   const int t = threadIdx.x;
-  const int chunk = (L + KWY_THREADS - 1) / KWY_THREADS;
+  const int chunk = (L + NT - 1) / NT;
   const int b0 = t * chunk;
   const int b1 = min(L, b0 + chunk);
   double run = 0.0;
   for (int i = b0; i < b1; ++i) { run += buf[i]; buf[i] = run; }
   tot[t] = run;
   __syncthreads();
-  if (t < 64) {  // wave 0 scans the 256 chunk totals, 4 per lane
-    double a0 = tot[4 * t], a1 = tot[4 * t + 1], a2 = tot[4 * t + 2], a3 = tot[4 * t + 3];
-    a1 += a0; a2 += a1; a3 += a2;
-    double inc = a3;
+  if (t < 64) {  // wave 0 scans the NT chunk totals, PER per lane
+    double a[PER];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { acc += tot[PER * t + q]; a[q] = acc; }
+    double inc = acc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       double u = __shfl_up(inc, o);
       if (t >= o) inc += u;
     }
-    double excl = inc - a3;  // sum of lanes before this one
-    // exclusive offsets per chunk
-    tot[4 * t] = excl; tot[4 * t + 1] = excl + a0; tot[4 * t + 2] = excl + a1; tot[4 * t + 3] = excl + a2;
+    const double excl = inc - acc;  // sum of the lanes before this one
+    tot[PER * t] = excl;
+#pragma unroll
+    for (int q = 1; q < PER; ++q) tot[PER * t + q] = excl + a[q - 1];
   }
   __syncthreads();
   const double off = tot[t];
@@ -149,27 +155,28 @@ __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
 // all of them, without sorting: an MSB-first radix select (8 rounds of 8 bits on
 // the IEEE bit patterns, which order like the values for x >= 0) finds the m-th
 // smallest value v*; then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.
-// hist: KWY_WAVES*256 + 4 uint32 of LDS; red: >= KWY_WAVES doubles.  n <= KWY_THREADS * RMAX.
-template <int RMAX>
+// hist: KWY_WAVES*256 + 8 uint32 of LDS (8-byte aligned); red: >= KWY_WAVES doubles.  n <= KWY_THREADS * RMAX.
+template <int RMAX, int NT = KWY_THREADS>
 __device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uint32_t *hist, double *red,
                                               double *sum_small, double *sum_all) {
+  constexpr int NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned long long key[RMAX];
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
-    int i = tid + KWY_THREADS * r;
+    int i = tid + NT * r;
     key[r] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;
   }
-  uint32_t *ctl = hist + KWY_WAVES * 256;  // [0] digit, [1] new rank
+  uint32_t *ctl = hist + NW * 256;  // [0] digit, [1] new rank
   unsigned long long prefix = 0ull;
   int kk = m;  // 1-based rank of the wanted element among the still-matching keys
   for (int round = 0; round < 8; ++round) {
     const int shift = 56 - 8 * round;
-    for (int b = tid; b < KWY_WAVES * 256; b += KWY_THREADS) hist[b] = 0;
+    for (int b = tid; b < NW * 256; b += NT) hist[b] = 0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-      int i = tid + KWY_THREADS * r;
+      int i = tid + NT * r;
       bool match = i < n && (round == 0 || (key[r] >> (shift + 8)) == (prefix >> (shift + 8)));
       if (match) atomicAdd(&hist[wv * 256 + (int)((key[r] >> shift) & 255ull)], 1u);
     }
@@ -181,7 +188,7 @@ __device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uin
       for (int q = 0; q < 4; ++q) {
         uint32_t a = 0;
 #pragma unroll
-        for (int w = 0; w < KWY_WAVES; ++w) a += hist[w * 256 + 4 * lane + q];
+        for (int w = 0; w < NW; ++w) a += hist[w * 256 + 4 * lane + q];
         c[q] = a;
         tot += a;
       }
@@ -197,6 +204,7 @@ __device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uin
         if ((uint32_t)kk > before && (uint32_t)kk <= before + c[q]) {
           ctl[0] = 4 * lane + q;
           ctl[1] = (uint32_t)kk - before;
+          ctl[2] = c[q];  // population of the chosen bin
         }
         before += c[q];
       }
@@ -204,21 +212,35 @@ __device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uin
     __syncthreads();
     prefix |= (unsigned long long)ctl[0] << shift;
     kk = (int)ctl[1];
+    const bool single = ctl[2] == 1u;
     __syncthreads();
+    if (single && round < 7) {
+      // exactly one key carries this prefix: it IS the wanted element, skip the remaining rounds
+      unsigned long long *k64 = (unsigned long long *)(ctl + 4);
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        int i = tid + NT * r;
+        if (i < n && (key[r] >> shift) == (prefix >> shift)) *k64 = key[r];
+      }
+      __syncthreads();
+      prefix = *k64;
+      kk = 1;
+      break;
+    }
   }
   const double vstar = __longlong_as_double((long long)prefix);
   double s_less = 0.0, s_all = 0.0;
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
-    int i = tid + KWY_THREADS * r;
+    int i = tid + NT * r;
     if (i < n) {
       double x = __longlong_as_double((long long)key[r]);
       s_all += x;
       if (key[r] < prefix) s_less += x;
     }
   }
-  const double t_less = kwy_block_sum(s_less, red);
-  const double t_all = kwy_block_sum(s_all, red);
+  const double t_less = kwy_block_sum<NT>(s_less, red);
+  const double t_all = kwy_block_sum<NT>(s_all, red);
   *sum_small = t_less + (double)kk * vstar;
   *sum_all = t_all;
 }
@@ -234,12 +256,12 @@ __device__ __forceinline__ kwy_c cmul(kwy_c a, kwy_c b) {
 
 // One Stockham radix-4 pass over H points: x -> y, sub-transform stride s.
 // tw: H-entry table exp(-2 pi i k / H).  INV conjugates the twiddles.
-template <bool INV>
+template <bool INV, int NT = KWY_THREADS>
 __device__ __forceinline__ void kwy_fft_r4(const kwy_c *__restrict__ x, kwy_c *__restrict__ y,
                                            int H, int s, int log2s,
                                            const kwy_c *__restrict__ tw) {
   const int Q = H >> 2;
-  for (int j = threadIdx.x; j < Q; j += KWY_THREADS) {
+  for (int j = threadIdx.x; j < Q; j += NT) {
     const int q = j & (s - 1);
     const int p = j >> log2s;
     kwy_c a = x[j], b = x[j + Q], c = x[j + 2 * Q], d = x[j + 3 * Q];
@@ -262,9 +284,10 @@ __device__ __forceinline__ void kwy_fft_r4(const kwy_c *__restrict__ x, kwy_c *_
 }
 
 // final radix-2 pass (sub-transform size 2, no twiddle), s = H/2
+template <int NT = KWY_THREADS>
 __device__ __forceinline__ void kwy_fft_r2(const kwy_c *__restrict__ x, kwy_c *__restrict__ y, int H) {
   const int s = H >> 1;
-  for (int q = threadIdx.x; q < s; q += KWY_THREADS) {
+  for (int q = threadIdx.x; q < s; q += NT) {
     kwy_c a = x[q], b = x[q + s];
     y[q] = cadd(a, b);
     y[q + s] = csub(a, b);
@@ -274,20 +297,20 @@ __device__ __forceinline__ void kwy_fft_r2(const kwy_c *__restrict__ x, kwy_c *_
 // Complex FFT of H = 2^log2H points held in LDS buffer a; b is a scratch buffer
 // of the same size.  Returns the buffer that holds the (natural order) result.
 // Unnormalised in both directions.  Ends with a barrier.
-template <bool INV>
+template <bool INV, int NT = KWY_THREADS>
 __device__ inline kwy_c *kwy_fft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ tw) {
   const int H = 1 << log2H;
   kwy_c *src = a, *dst = b;
   int log2s = 0;
   __syncthreads();
   for (int rem = log2H; rem >= 2; rem -= 2) {
-    kwy_fft_r4<INV>(src, dst, H, 1 << log2s, log2s, tw);
+    kwy_fft_r4<INV, NT>(src, dst, H, 1 << log2s, log2s, tw);
     __syncthreads();
     kwy_c *t = src; src = dst; dst = t;
     log2s += 2;
   }
   if (log2H & 1) {
-    kwy_fft_r2(src, dst, H);
+    kwy_fft_r2<NT>(src, dst, H);
     __syncthreads();
     kwy_c *t = src; src = dst; dst = t;
   }
@@ -298,12 +321,13 @@ __device__ inline kwy_c *kwy_fft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c 
 // `b` is scratch; both need room for H+1 complex.  twH: H-entry table for the
 // H-point transform, twN: table exp(-2 pi i k / N) for k < H.
 // Returns the buffer holding X[0..H] (H+1 complex bins).
+template <int NT = KWY_THREADS>
 __device__ inline kwy_c *kwy_rfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ twH,
                                       const kwy_c *__restrict__ twN) {
   const int H = 1 << log2H;
-  kwy_c *z = kwy_fft_lds<false>(a, b, log2H, twH);
+  kwy_c *z = kwy_fft_lds<false, NT>(a, b, log2H, twH);
   kwy_c *o = (z == a) ? b : a;
-  for (int k = threadIdx.x; k <= H; k += KWY_THREADS) {
+  for (int k = threadIdx.x; k <= H; k += NT) {
     kwy_c r;
     if (k == 0) {
       r = {z[0].x + z[0].y, 0.0};
@@ -326,11 +350,12 @@ __device__ inline kwy_c *kwy_rfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c
 
 // Inverse of the above (unnormalised c2r: result = N * true inverse).
 // `a` holds X[0..H]; returns the buffer whose first N doubles are the signal.
+template <int NT = KWY_THREADS>
 __device__ inline kwy_c *kwy_irfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ twH,
                                        const kwy_c *__restrict__ twN) {
   const int H = 1 << log2H;
   __syncthreads();
-  for (int k = threadIdx.x; k < H; k += KWY_THREADS) {
+  for (int k = threadIdx.x; k < H; k += NT) {
     double ar = a[k].x, ai = (k == 0) ? 0.0 : a[k].y;
     double br = a[H - k].x, bi = (k == 0) ? 0.0 : -a[H - k].y;
     double er = ar + br, ei = ai + bi;
@@ -340,7 +365,7 @@ __device__ inline kwy_c *kwy_irfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_
     double orr = dr * wr - di * wi, oi = dr * wi + di * wr;
     b[k] = {er - oi, ei + orr};
   }
-  return kwy_fft_lds<true>(b, a, log2H, twH);
+  return kwy_fft_lds<true, NT>(b, a, log2H, twH);
 }
 
 __device__ __forceinline__ int kwy_matlab_round(double x) {

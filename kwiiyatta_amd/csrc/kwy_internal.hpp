@@ -30,6 +30,7 @@ struct kwy_ctx {
   std::map<std::string, int64_t> i_vals;   // small cached integers that go with them
 
   // optional per-kernel timing with HIP events on this context's stream
+  void *dbg = nullptr;  // optional device buffer for in-kernel cycle stamps (diagnostic builds)
   bool prof = false;
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
 };
@@ -85,8 +86,8 @@ static inline size_t kwy_pad(size_t b) { return (b + 255) & ~(size_t)255; }
 // --- tables -----------------------------------------------------------------
 int kwy_get_twiddles(kwy_ctx *ctx, int log2n, const kwy_c **out);
 int kwy_get_poly(kwy_ctx *ctx, uint64_t stride_steps, const uint4 **out);
-// [max_c][256] table: row c-1 holds x^(12*c*t) mod P, t < 256 (chunk of c draws per thread)
-int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, const uint4 **out);
+// [max_c][nthreads] table: row c-1 holds x^(12*c*t) mod P, t < nthreads (chunk of c draws per thread)
+int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, int nthreads, const uint4 **out);
 
 // --- shared small kernels (kwy_ctx.hip) --------------------------------------
 // offsets[i] = sum_{j<i} counts[j] (u32 -> u64), single block
