@@ -12,12 +12,10 @@
 // All three are index/byte work: HBM-bound row copies and one short serial walk.
 #include "kwy_internal.hpp"
 
-__global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__restrict__ mc, int64_t T,
-                                                               int ncoef, const double *__restrict__ f0,
-                                                               double power_weight, double power_threshold,
-                                                               double vuv_weight, double *__restrict__ out) {
+__global__ __launch_bounds__(KWY_THREADS) void k_align_power_threshold(const double *__restrict__ mc, int64_t T,
+                                                                      int ncoef, double power_threshold,
+                                                                      double *__restrict__ thr_out) {
   __shared__ double red[KWY_WAVES];
-  __shared__ double s_thr;
   const int tid = threadIdx.x;
   double mx = -INFINITY;
   for (int64_t t = tid; t < T; t += KWY_THREADS) mx = fmax(mx, mc[t * ncoef]);
@@ -28,58 +26,99 @@ __global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__
   if (tid == 0) {
     double m = red[0];
     for (int i = 1; i < KWY_WAVES; ++i) m = fmax(m, red[i]);
-    s_thr = m - power_threshold;
+    thr_out[0] = m - power_threshold;
   }
-  __syncthreads();
-  const double thr = s_thr;
+}
+
+__global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__restrict__ mc, int64_t T,
+                                                               int ncoef, const double *__restrict__ f0,
+                                                               const double *__restrict__ thr_in,
+                                                               double power_weight, double vuv_weight,
+                                                               double *__restrict__ out) {
+  const int64_t t = blockIdx.x * 8 + (threadIdx.x >> 5);  // 8 frames per workgroup, 32 lanes per frame
+  if (t >= T) return;
+  const double thr = thr_in[0];
   const int w = ncoef + 1;
-  for (int64_t e = tid; e < T * w; e += KWY_THREADS) {
-    const int64_t t = e / w;
-    const int c = (int)(e % w);
+  for (int c = threadIdx.x & 31; c < w; c += 32) {
     double v;
     if (c == 0) v = mc[t * ncoef] >= thr ? power_weight : 0.0;
     else if (c == 1) v = f0[t] > 0 ? vuv_weight : 0.0;
     else v = mc[t * ncoef + (c - 1)];
-    out[e] = v;
+    out[t * w + c] = v;
   }
 }
 
-// serial walk over the path (one thread): exactly project_path_iter
-__global__ void k_align_project(const int32_t *__restrict__ path, const int64_t *__restrict__ path_len,
-                                int trim_len, int32_t *__restrict__ idx, int64_t cap,
-                                int64_t *__restrict__ n_out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// serial walk over the path, exactly project_path_iter: the wavefront stages path tiles in LDS
+// (coalesced), lane 0 walks them, and the produced indices leave through LDS as well.
+#define AL_TILE 1024
+__global__ __launch_bounds__(64) void k_align_project(const int32_t *__restrict__ path,
+                                                     const int64_t *__restrict__ path_len, int trim_len,
+                                                     int32_t *__restrict__ idx, int64_t cap,
+                                                     int64_t *__restrict__ n_out) {
+  __shared__ int32_t sp[2 * AL_TILE];
+  __shared__ int32_t so[AL_TILE];
+  __shared__ long long st[4];  // prev_x, prev_y, n, stop
+  const int lane = threadIdx.x;
   const int64_t L = *path_len;
-  int64_t n = 0;
-  if (L > 0) {
-    long long prev_x = -1, prev_y = -1;
-    long long len_y = path[2 * (L - 1) + 1] + 1;
-    if (trim_len > 0) { prev_y += trim_len; len_y -= trim_len; }
-    for (int64_t k = 0; k < L; ++k) {
-      long long x = path[2 * k], y = path[2 * k + 1];
-      if (y <= prev_y) continue;
-      if (y - prev_y > 1) {
-        if (y > len_y - 1) y = len_y - 1;
-        const long long diff_x = x - prev_x, diff_y = y - prev_y;
-        for (long long i = 0; i < diff_y; ++i) {
-          // Python floor division; diff_y - 1 >= 1 here unless the clamp made diff_y <= 1
-          long long den = diff_y - 1;
-          long long num = diff_x * i;
-          long long q = den != 0 ? (num >= 0 ? num / den : -((-num + den - 1) / den)) : 0;
-          if (n < cap) idx[n] = (int32_t)(prev_x + q);
-          ++n;
+  if (L <= 0) { if (lane == 0) *n_out = 0; return; }
+  long long len_y = path[2 * (L - 1) + 1] + 1;
+  if (lane == 0) { st[0] = -1; st[1] = -1 + (trim_len > 0 ? trim_len : 0); st[2] = 0; st[3] = 0; }
+  if (trim_len > 0) len_y -= trim_len;
+  int64_t k0 = 0;
+  while (k0 < L) {
+    const int nk = (int)min((int64_t)AL_TILE, L - k0);
+    for (int e = lane; e < 2 * nk; e += 64) sp[e] = path[2 * k0 + e];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // lane 0 consumes path cells until the tile is exhausted or the output tile is full
+    __shared__ int s_used, s_made;
+    if (lane == 0) {
+      long long prev_x = st[0], prev_y = st[1];
+      int made = 0, k = 0;
+      bool stop = false;
+      for (; k < nk && !stop; ++k) {
+        long long x = sp[2 * k], y = sp[2 * k + 1];
+        if (y <= prev_y) continue;
+        if (y - prev_y > 1) {
+          if (y > len_y - 1) y = len_y - 1;
+          const long long diff_x = x - prev_x, diff_y = y - prev_y;
+          if (made + diff_y > AL_TILE) {
+            if (made > 0) break;         // flush what we have, redo this cell next round
+            // a single gap longer than the tile: emit directly
+          }
+          for (long long i = 0; i < diff_y; ++i) {
+            const long long den = diff_y - 1, num = diff_x * i;
+            const long long q = den != 0 ? (num >= 0 ? num / den : -((-num + den - 1) / den)) : 0;
+            if (made < AL_TILE) so[made++] = (int32_t)(prev_x + q);
+          }
+        } else if (y >= len_y) {
+          stop = true;
+          break;
+        } else {
+          if (made >= AL_TILE) break;
+          so[made++] = (int32_t)x;
         }
-      } else if (y >= len_y) {
-        break;
-      } else {
-        if (n < cap) idx[n] = (int32_t)x;
-        ++n;
+        prev_x = x;
+        prev_y = y;
       }
-      prev_x = x;
-      prev_y = y;
+      st[0] = prev_x; st[1] = prev_y;
+      s_used = k; s_made = made;
+      if (stop) st[3] = 1;
     }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int made = s_made, used = s_used;
+    const long long n0 = st[2];
+    for (int e = lane; e < made; e += 64)
+      if (n0 + e < cap) idx[n0 + e] = so[e];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) st[2] = n0 + made;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (st[3]) break;
+    k0 += used > 0 ? used : 1;
   }
-  *n_out = n;
+  if (lane == 0) *n_out = st[2];
 }
 
 __global__ void k_gather_rows(const double *__restrict__ src, int64_t src_rows, int width,
@@ -100,8 +139,12 @@ extern "C" int kwy_align_features_dev(kwy_ctx *ctx, const double *mc, int64_t T,
   if (!ctx) return KWY_EINVAL;
   if (!mc || !f0 || !out || T <= 0 || ncoef < 1) { ctx->err = "align_features: bad argument"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_align_features, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, mc, T, ncoef, f0,
-                     power_weight, power_threshold, vuv_weight, out);
+  KWY_TRY(kwy_arena_begin(ctx, 256));
+  double *thr = kwy_arena<double>(ctx, 8);
+  hipLaunchKernelGGL(k_align_power_threshold, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, mc, T, ncoef,
+                     power_threshold, thr);
+  hipLaunchKernelGGL(k_align_features, dim3((unsigned)((T + 7) / 8)), dim3(KWY_THREADS), 0, ctx->stream, mc, T,
+                     ncoef, f0, thr, power_weight, vuv_weight, out);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

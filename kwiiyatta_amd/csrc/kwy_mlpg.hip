@@ -247,52 +247,88 @@ __global__ void k_mlpg_build(const double *__restrict__ E, const double *__restr
   rhs[a * dm.d + c] = b;
 }
 
-// ---- MLPG: banded Cholesky + forward/backward sweeps, one thread per static dimension ----------------
-__global__ void k_mlpg_solve(double *__restrict__ band, double *__restrict__ rhs, ml_dims dm,
-                             double *__restrict__ y, int *__restrict__ status) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= dm.d) return;
-  const int d = dm.d;
+// ---- MLPG: banded Cholesky + forward/backward sweeps, one lane per static dimension ------------------
+// The recurrence is serial in t, so the wavefront streams the band through LDS in tiles of
+// ML_SOLVE_TILE frames: all 64 lanes load/store a tile coalesced, lanes c < d walk it.
+#define ML_SOLVE_TILE 64
+__global__ __launch_bounds__(64) void k_mlpg_solve(double *__restrict__ band, double *__restrict__ rhs, ml_dims dm,
+                                                  double *__restrict__ y, int *__restrict__ status) {
+  extern __shared__ double sm[];  // band tile [ML_SOLVE_TILE][d][3] followed by rhs tile [ML_SOLVE_TILE][d]
+  const int lane = threadIdx.x, d = dm.d;
   const int64_t T = dm.T;
+  const int c = lane;
+  double *sb = sm, *sr = sm + ML_SOLVE_TILE * d * 3;
   // L[t][0] diag, L[t][1] = L[t][t-1], L[t][2] = L[t][t-2]; z = L^-1 b
   double l1_0 = 0, l1_1 = 0, z1 = 0;  // row t-1: diag, sub1; z[t-1]
   double l2_0 = 0, z2 = 0;            // row t-2: diag; z[t-2]
-  for (int64_t t = 0; t < T; ++t) {
-    double *br = band + (t * d + c) * 3;
-    double p0 = br[0], p1 = br[1], p2 = br[2];
-    double L2 = 0.0, L1 = 0.0;
-    if (t >= 2) L2 = p2 / l2_0;
-    if (t >= 1) {
-      double v = p1;
-      if (t >= 2) v -= L2 * l1_1;  // L[t][t-2] * L[t-1][t-2]
-      L1 = v / l1_0;
+  for (int64_t t0 = 0; t0 < T; t0 += ML_SOLVE_TILE) {
+    const int nt = (int)min((int64_t)ML_SOLVE_TILE, T - t0);
+    for (int e = lane; e < nt * d * 3; e += 64) sb[e] = band[t0 * d * 3 + e];
+    for (int e = lane; e < nt * d; e += 64) sr[e] = rhs[t0 * d + e];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (c < d) {
+      for (int tt = 0; tt < nt; ++tt) {
+        const int64_t t = t0 + tt;
+        double *q = sb + (tt * d + c) * 3;
+        double p0 = q[0], p1 = q[1], p2 = q[2];
+        double L2 = 0.0, L1 = 0.0;
+        if (t >= 2) L2 = p2 / l2_0;
+        if (t >= 1) {
+          double v = p1;
+          if (t >= 2) v -= L2 * l1_1;  // L[t][t-2] * L[t-1][t-2]
+          L1 = v / l1_0;
+        }
+        double v = p0;
+        if (t >= 2) v -= L2 * L2;
+        if (t >= 1) v -= L1 * L1;
+        if (!(v > 0.0)) { atomicExch(status, 2); v = 1.0; }
+        const double L0 = sqrt(v);
+        double zz = sr[tt * d + c];
+        if (t >= 1) zz -= L1 * z1;
+        if (t >= 2) zz -= L2 * z2;
+        zz = zz / L0;
+        q[0] = L0; q[1] = L1; q[2] = L2;
+        sr[tt * d + c] = zz;
+        l2_0 = l1_0; z2 = z1;
+        l1_0 = L0; l1_1 = L1; z1 = zz;
+      }
     }
-    double v = p0;
-    if (t >= 2) v -= L2 * L2;
-    if (t >= 1) v -= L1 * L1;
-    if (!(v > 0.0)) { atomicExch(status, 2); v = 1.0; }
-    const double L0 = sqrt(v);
-    double zz = rhs[t * d + c];
-    if (t >= 1) zz -= L1 * z1;
-    if (t >= 2) zz -= L2 * z2;
-    zz = zz / L0;
-    br[0] = L0; br[1] = L1; br[2] = L2;
-    rhs[t * d + c] = zz;
-    l2_0 = l1_0; z2 = z1;
-    l1_0 = L0; l1_1 = L1; z1 = zz;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int e = lane; e < nt * d * 3; e += 64) band[t0 * d * 3 + e] = sb[e];
+    for (int e = lane; e < nt * d; e += 64) rhs[t0 * d + e] = sr[e];
+    __builtin_amdgcn_wave_barrier();
   }
+  __threadfence();
   double y1 = 0, y2 = 0, n1_1 = 0, n2_2 = 0, n1_2 = 0;  // y[t+1], y[t+2]; L[t+1][1], L[t+2][2]
-  for (int64_t t = T - 1; t >= 0; --t) {
-    const double *br = band + (t * d + c) * 3;
-    double v = rhs[t * d + c];
-    if (t + 1 < T) v -= n1_1 * y1;
-    if (t + 2 < T) v -= n2_2 * y2;
-    v = v / br[0];
-    y[t * d + c] = v;
-    n2_2 = n1_2;       // L[t+1][2] becomes L[(t-1)+2][2]
-    y2 = y1;
-    n1_1 = br[1]; n1_2 = br[2];
-    y1 = v;
+  const int64_t ntiles = (T + ML_SOLVE_TILE - 1) / ML_SOLVE_TILE;
+  for (int64_t ti = ntiles - 1; ti >= 0; --ti) {
+    const int64_t t0 = ti * ML_SOLVE_TILE;
+    const int nt = (int)min((int64_t)ML_SOLVE_TILE, T - t0);
+    for (int e = lane; e < nt * d * 3; e += 64) sb[e] = band[t0 * d * 3 + e];
+    for (int e = lane; e < nt * d; e += 64) sr[e] = rhs[t0 * d + e];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (c < d) {
+      for (int tt = nt - 1; tt >= 0; --tt) {
+        const int64_t t = t0 + tt;
+        const double *q = sb + (tt * d + c) * 3;
+        double v = sr[tt * d + c];
+        if (t + 1 < T) v -= n1_1 * y1;
+        if (t + 2 < T) v -= n2_2 * y2;
+        v = v / q[0];
+        n2_2 = n1_2;  // L[t+1][2] becomes L[(t-1)+2][2]
+        y2 = y1;
+        n1_1 = q[1]; n1_2 = q[2];
+        y1 = v;
+        sr[tt * d + c] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int e = lane; e < nt * d; e += 64) y[t0 * d + e] = sr[e];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -328,6 +364,8 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024) { ctx->err = "gmm_mlpg: feature dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_mlpg_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(double) * ML_SOLVE_TILE * d * 4)));
   hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
                      diff, model, status);
   const unsigned ge = (unsigned)((T * d + 255) / 256);
@@ -336,7 +374,7 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
                      ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
   hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band, rhs);
-  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3((d + 63) / 64), dim3(64), 0, ctx->stream, band, rhs, dm, y, status));
+  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(64), sizeof(double) * ML_SOLVE_TILE * d * 4, ctx->stream, band, rhs, dm, y, status));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -344,7 +382,7 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
 static int ml_check(kwy_ctx *ctx, const void *x, int64_t T, int d, int M, const void *w, const void *mu,
                     const void *cv, const void *y) {
   if (!ctx) return KWY_EINVAL;
-  if (!x || !w || !mu || !cv || !y || T <= 0 || d <= 0 || M <= 0 || 3 * d > 255) {
+  if (!x || !w || !mu || !cv || !y || T <= 0 || d <= 0 || d > 64 || M <= 0) {
     ctx->err = "gmm_mlpg: bad argument";
     return KWY_EINVAL;
   }
