@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Config 5 companion benchmark: the converter fit (EM) on an atr503-sized joint
+feature matrix (n ~ 5e5 frames x 144, 64 full-covariance components).
+
+    python bench_fit.py [--frames N] [--iters K]                      one GPU
+    python -m torch.distributed.run --nproc-per-node G bench_fit.py   G GPUs: frames sharded,
+                                                                     statistics all-reduced (RCCL)
+Prints one JSON line with the time per EM iteration (strong scaling: total frames fixed)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=500000)
+    ap.add_argument('--dim', type=int, default=144)
+    ap.add_argument('--components', type=int, default=64)
+    ap.add_argument('--iters', type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    from kwiiyatta_amd.converter.gmm_fit import HipStats, _all_reduce_sum
+    n_local = args.frames // world
+    rng = np.random.default_rng(1000 + rank)
+    M, D = args.components, args.dim
+    centres = np.random.default_rng(0).standard_normal((M, D)) * 2
+    lab = rng.integers(0, M, n_local)
+    X = centres[lab] + rng.standard_normal((n_local, D))
+    st = HipStats(X, M, device_index=local_rank)
+    st.set_resp_from_labels(lab)
+
+    def m_step():
+        s = _all_reduce_sum(st.sums())
+        st.means_from(s)
+        c = _all_reduce_sum(st.cov())
+        st.finalize(s, c, 1e-6)
+
+    m_step()
+    st.estep(); m_step()        # warm-up iteration
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    st.ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        ll = np.array([st.estep()])
+        _all_reduce_sum(ll)
+        m_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        lp, n1 = st.ctx.profile_read('k_fit_logprob')
+        cv, n2 = st.ctx.profile_read('k_fit_cov')
+        flops = 2.0 * n_local * M * (D * (D + 1) / 2)          # E-step triangular products
+        print(json.dumps({'metric': 'EM iteration time, full-covariance GMM fit', 'value': el / args.iters * 1e3,
+                          'unit': 'ms/iteration', 'n_gpus': world, 'frames_total': n_local * world, 'dim': D,
+                          'components': M, 'higher_is_better': False, 'scaling': 'strong', 'dtype': 'f64',
+                          'k_fit_logprob_ms': lp / max(n1, 1), 'k_fit_cov_ms': cv / max(n2, 1),
+                          'logprob_tflops': flops / (lp / max(n1, 1) * 1e-3) / 1e12 if n1 else None,
+                          'all_reduce_bytes_per_iteration': 8 * (M * (D + 1) + M * D * D + 1)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -166,6 +166,26 @@ int kwy_gmm_mlpg_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
                      const double *weights, const double *means, const double *covs, int diff,
                      double *y);
 
+/* ---- converter fit: EM building blocks --------------------------------------------------------
+ * sklearn.mixture.GaussianMixture(covariance_type='full').fit as used at
+ *                                                    kwiiyatta/converter/gmm.py:14-26
+ * The data are sharded by frames; each call works on the local shard X (n x D, device).
+ * A driver (kwiiyatta_amd/converter/gmm_fit.py) runs, per EM iteration,
+ *   estep -> sums -> [all-reduce stats] -> means -> cov -> [all-reduce sxx] -> finalize
+ * and all-reduces the statistics over RCCL when several GPUs hold shards.
+ * M <= 256, D <= 160 (and (D+1) / (256 / 2^ceil(log2 M)) <= 40). */
+int kwy_gmm_em_estep_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *weights,
+                         const double *means, const double *covs, double *resp /* n x M */,
+                         double *loglik_parts /* ceil(n/256) */, int *status_out);
+int kwy_gmm_em_sums_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
+                        double *stats /* M x (D+1): [sum r, sum r x] */);
+int kwy_gmm_em_means_dev(kwy_ctx *ctx, const double *stats, int D, int M, double *means);
+int kwy_gmm_em_cov_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
+                       const double *means, double *sxx /* M x D x D */);
+int kwy_gmm_em_finalize_dev(kwy_ctx *ctx, const double *stats, const double *sxx, int D, int M,
+                            double reg_covar, double *weights, double *covs);
+int kwy_gmm_em_scratch_bytes(int64_t n, int D, int M, int64_t *bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,12 @@ SIGNATURES = {
     'kwy_align_features_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_dbl, c_dbl, c_dbl, c_vp]),
     'kwy_align_project_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp]),
     'kwy_gather_rows_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp]),
+    'kwy_gmm_em_estep_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'kwy_gmm_em_sums_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    'kwy_gmm_em_means_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    'kwy_gmm_em_cov_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'kwy_gmm_em_finalize_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_vp, c_vp]),
+    'kwy_gmm_em_scratch_bytes': (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_mlpg_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
 }

@@ -1,7 +1,8 @@
 """Joint-density GMM converter (mirrors
-/root/reference/kwiiyatta/converter/gmm.py:9-34).  Apply = GPU (MLPG kernels);
-fit = scikit-learn's GaussianMixture, as in the reference."""
-from sklearn.mixture import GaussianMixture
+/root/reference/kwiiyatta/converter/gmm.py:9-34).  Apply = MLPG kernels, fit = EM
+kernels (GaussianMixtureHIP reproduces sklearn.mixture.GaussianMixture.fit for the
+configuration the reference uses)."""
+from .gmm_fit import GaussianMixtureHIP as GaussianMixture
 
 from ..backend.mlpg import MLPG
 from . import abc, delta

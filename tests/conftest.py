@@ -76,6 +76,8 @@ def _install_oracle_backend(monkeypatch):
     monkeypatch.setattr(mlpg, 'MLPG', OracleMLPG)
     from kwiiyatta_amd.converter import gmm as gmm_mod
     monkeypatch.setattr(gmm_mod, 'MLPG', OracleMLPG)
+    import sklearn.mixture
+    monkeypatch.setattr(gmm_mod, 'GaussianMixture', sklearn.mixture.GaussianMixture)  # the reference's own fit
 
 
 @pytest.fixture(params=['oracle', pytest.param('hip', marks=pytest.mark.gpu)])
