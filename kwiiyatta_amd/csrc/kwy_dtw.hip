@@ -25,6 +25,7 @@
 #define DTW_PAD 128          // slack cells before/after the band storage
 #define DTW_BT_BYTES 49152   // LDS budget for staged predecessor codes
 #define DTW_BT_ROWS 512      // rows per back-trace group
+#define DTW_BT_OUT 1024      // path cells buffered in LDS between flushes
 
 __global__ void k_dtw_halve(const double *__restrict__ in, int n_out, int dim, double *__restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,37 +104,55 @@ __device__ __forceinline__ double dtw_readlane(double v, int idx) {
 
 // Packed predecessor codes: 2 bits per cell, 32 cells per 64-bit word; row i owns the
 // words starting at (off[i] >> 5) + i (rows never share a word).
+// Predecessor codes: 2 bits per cell, 16 cells per 32-bit word.
+// Words are cut at multiples of 16 of the STEP index s (cell (i, j) of strip i0 is handled at
+// step s = j - lo[i0] + (i - i0)), so that all lanes of a wavefront flush their word at the same
+// step: one store instruction per 16 steps instead of a trickle that the in-order memory counter
+// would make every distance prefetch wait for.  A row therefore owns up to width/16 + 2 words.
 __device__ __forceinline__ uint64_t dtw_word_base(const uint64_t *__restrict__ off, int i) {
-  return (off[i] >> 5) + (uint64_t)i;
+  return (off[i] >> 4) + 2ull * (uint64_t)i;
+}
+__device__ __forceinline__ int dtw_row_shift(const int32_t *__restrict__ lo, int i) {
+  const int i0 = i & ~63;
+  return (i - i0) + lo[i] - lo[i0];  // step at which the row's first cell is handled
+}
+__device__ __forceinline__ uint64_t dtw_row_words_end(const uint64_t *__restrict__ off,
+                                                      const int32_t *__restrict__ lo,
+                                                      const int32_t *__restrict__ hi, int i) {
+  const int sh = dtw_row_shift(lo, i);
+  return dtw_word_base(off, i) + (uint64_t)(((sh + hi[i] - lo[i]) >> 4) - (sh >> 4)) + 1;
 }
 
-// The DP + back-trace of one level, one wavefront.
+// The DP + back-trace of one level: ONE workgroup of DTW_WAVES wavefronts.  Strip k (64 rows) is
+// processed by wave k % DTW_WAVES; strip k+1 trails strip k by one 64-step block, synchronised
+// through a progress word in LDS (the boundary row written by strip k is read by strip k+1).
+#define DTW_WAVES 4
 template <bool BND_LDS>
-__global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32_t *__restrict__ lo,
+__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y, const int32_t *__restrict__ lo,
                                               const int32_t *__restrict__ hi,
                                               const uint64_t *__restrict__ off, uint64_t cap,
                                               const double *__restrict__ dist,
-                                              unsigned long long *__restrict__ predw,
-                                              double *__restrict__ bnd_global /* 2 x (len_y+2) or null */,
+                                              uint32_t *__restrict__ predw,
+                                              double *__restrict__ bnd_global /* DTW_WAVES x (len_y+2) or null */,
                                               int32_t *__restrict__ path, int32_t *__restrict__ rev,
                                               int64_t *__restrict__ path_len, double *__restrict__ out_dist,
-                                              const int *__restrict__ status) {
+                                              const int *__restrict__ status, long long *__restrict__ dbg) {
   extern __shared__ unsigned char bt[];  // DTW_BT_BYTES [+ boundary rows]
+  const long long t_start = dbg ? clock64() : 0;
   __shared__ int s_i, s_j, s_n;
-  const int lane = threadIdx.x;
-  if (*status != 0) { if (lane == 0) { *path_len = 0; *out_dist = NAN; } return; }
+  __shared__ volatile long long s_prog[DTW_WAVES];  // (strip << 32) | (last finished column + 1)
+  __shared__ double s_last;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (*status != 0) { if (threadIdx.x == 0) { *path_len = 0; *out_dist = NAN; } return; }
   const double INF = INFINITY;
-  constexpr bool bnd_lds = BND_LDS;
-  // boundary rows are indexed by j + 1 (entry 0 is column -1)
+  const int rowlen = len_y + 2;  // boundary rows are indexed by j + 1 (entry 0 is column -1)
   double *const lds_rows = (double *)(bt + DTW_BT_BYTES);
-#define B_PREV(ix) (BND_LDS ? lds_rows[o_prev + (ix)] : bnd_global[o_prev + (ix)])
-#define B_NEXT(ix) (BND_LDS ? lds_rows[o_next + (ix)] : bnd_global[o_next + (ix)])
-  int o_prev = 0, o_next = len_y + 2;
-  for (int j = lane; j < len_y + 2; j += 64) B_PREV(j) = INF;
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) B_PREV(0) = 0.0;  // D[-1][-1] = 0: the origin of the recurrence
-  double last_val = INF;
-  for (int i0 = 0; i0 < len_x; i0 += 64) {
+#define BROW(buf, ix) (BND_LDS ? lds_rows[(buf) * rowlen + (ix)] : bnd_global[(size_t)(buf) * rowlen + (ix)])
+  if (threadIdx.x < DTW_WAVES) s_prog[threadIdx.x] = -1;
+  __syncthreads();
+  const int nstrips = (len_x + 63) / 64;
+  for (int k = wv; k < nstrips; k += DTW_WAVES) {
+    const int i0 = k * 64;
     const int i = i0 + lane;
     const bool valid = i < len_x;
     const int rl = valid ? lo[i] : 0, rh = valid ? hi[i] : -1;
@@ -141,31 +160,46 @@ __global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32
     const int rwc = rw > 0 ? rw : 0;
     const int ilast = min(i0 + 63, len_x - 1);
     const int jmin = lo[i0], jmax = hi[ilast];
-    for (int j = lane; j < len_y + 2; j += 64) B_NEXT(j) = INF;
-    __builtin_amdgcn_wave_barrier();
-    if (bnd_lds) __threadfence_block(); else __threadfence();
+    // the previous strip's last row: where its boundary values are valid
+    const int plo = k > 0 ? lo[i0 - 1] : 0, phi = k > 0 ? hi[i0 - 1] : -1;
+    const int pbuf = (k + DTW_WAVES - 1) % DTW_WAVES, nbuf = k % DTW_WAVES;
     const double *drow = dist + DTW_PAD + (valid ? off[i] : 0);
-    unsigned long long *pwrow = predw + (valid ? dtw_word_base(off, i) : 0);
+    uint32_t *pwrow = predw + (valid ? dtw_word_base(off, i) : 0);
     double v1 = INF, v2 = INF;  // this lane's values at the two previous steps
     const int nsteps = (jmax - jmin + 1) + 63;
     const int shift = lane + rl - jmin;  // this lane's row index at step s is s - shift
-    unsigned long long pw = 0ull;        // predecessor codes of the current 32-cell word
-    double up0_prev = B_PREV(jmin);      // lane 0: D[i0-1][jmin-1] (column j-1 of the first step)
-    // software prefetch of the lane's distances, 8 steps per block
+    uint32_t pw = 0u;                    // predecessor codes of the current 16-cell word
+    // lane 0's diagonal input at the first step: D[i0-1][jmin-1]
+    double up0_prev = INF;
+    if (k == 0) { if (jmin == 0) up0_prev = 0.0; }  // D[-1][-1] = 0: the origin of the recurrence
     double curd[8], nxtd[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      curd[u] = drow[min(max(u - shift, 0), rwc)];
-    }
+    for (int u = 0; u < 8; ++u) curd[u] = drow[min(max(u - shift, 0), rwc)];
+    bool first_chunk = true;
     for (int c0 = 0; c0 < nsteps; c0 += 64) {
-      // the boundary row values lane 0 will need in the next 64 steps: one LDS read per lane
+      // wait until the previous strip's last row has produced the columns this chunk reads
+      if (k > 0) {
+        const int need = min(jmin + c0 + 63, phi);  // last column we may read (valid ones only)
+        while (true) {
+          const long long pv = s_prog[pbuf];
+          const int ps = (int)(pv >> 32), pc = (int)(pv & 0xffffffffll) - 1;
+          if (ps > k - 1 || (ps == k - 1 && pc >= need)) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (BND_LDS) __threadfence_block(); else __threadfence();
+      }
+      // the boundary values lane 0 needs in the next 64 steps: one read per lane
       const int jb = jmin + c0 + lane;
-      const double bchunk = (jb >= -1 && jb <= len_y) ? B_PREV(jb + 1) : INF;
+      double bchunk = INF;
+      if (k > 0 && jb >= plo && jb <= phi) bchunk = BROW(pbuf, jb + 1);
+      if (first_chunk && k > 0) {
+        const int jd = jmin - 1;
+        up0_prev = (jd >= plo && jd <= phi) ? BROW(pbuf, jd + 1) : INF;
+        first_chunk = false;
+      }
       for (int s0 = c0; s0 < min(c0 + 64, nsteps); s0 += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          nxtd[u] = drow[min(max(s0 + 8 + u - shift, 0), rwc)];
-        }
+        for (int u = 0; u < 8; ++u) nxtd[u] = drow[min(max(s0 + 8 + u - shift, 0), rwc)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int s = s0 + u;
@@ -180,48 +214,60 @@ __global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32
           if (act) {
             const double dt = curd[u];
             const double c0v = up + dt, c1v = v1 + dt, c2v = dg + dt;
-            double best = c0v; unsigned long long pb = 0ull;
-            if (c1v < best) { best = c1v; pb = 1ull; }
-            if (c2v < best) { best = c2v; pb = 2ull; }
+            double best = c0v; uint32_t pb = 0u;
+            if (c1v < best) { best = c1v; pb = 1u; }
+            if (c2v < best) { best = c2v; pb = 2u; }
             cur = best;
-            pw |= pb << (2 * (pos & 31));
-            if ((pos & 31) == 31 || pos == rw) { pwrow[pos >> 5] = pw; pw = 0ull; }
-            if (i == ilast) B_NEXT(j + 1) = cur;
-            if (i == len_x - 1 && j == len_y - 1) last_val = cur;
+            pw |= pb << (2 * (s & 15));
+            if ((s & 15) == 15 || pos == rw) { pwrow[(s >> 4) - (shift >> 4)] = pw; pw = 0u; }
+            if (i == ilast) BROW(nbuf, j + 1) = cur;
+            if (i == len_x - 1 && j == len_y - 1) s_last = cur;
           }
           v2 = v1;
           v1 = cur;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) curd[u] = nxtd[u];
+        // publish how far this strip's last row has got (after its boundary writes)
+        if (BND_LDS) __threadfence_block(); else __threadfence();
+        if (i == ilast) {
+          const int jdone = min(jmin + (s0 + 7) - lane, rh);
+          s_prog[nbuf] = ((long long)k << 32) | (long long)(unsigned int)(jdone + 1 > 0 ? jdone + 1 : 0);
+        }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (bnd_lds) __threadfence_block(); else __threadfence();
-    { int t = o_prev; o_prev = o_next; o_next = t; }
+    if (BND_LDS) __threadfence_block(); else __threadfence();
+    if (i == ilast) s_prog[nbuf] = ((long long)k << 32) | 0x7fffffffll;
   }
-#undef B_PREV
-#undef B_NEXT
-  // broadcast D[len_x-1][len_y-1] (held by the lane of the last row)
-  {
-    const int owner = (len_x - 1) & 63;
-    last_val = __shfl(last_val, owner);
-    if (lane == 0) *out_dist = last_val;
-  }
+#undef BROW
+  __syncthreads();
+  if (wv != 0) return;
+  const long long t_dp = dbg ? clock64() : 0;
+  double last_val = s_last;
+  if (lane == 0) *out_dist = last_val;
   __threadfence();  // predecessor codes written above are read back below through global memory
 
-  // ---- back-trace, staged through LDS in groups of rows (codes AND row descriptors,
-  //      so that the serial walk of lane 0 never waits on global memory)
-  unsigned long long *btw = (unsigned long long *)bt;
-  const uint64_t bt_words = DTW_BT_BYTES / 8;
+  // ---- back-trace, staged through LDS in groups of rows (codes AND row descriptors), with the
+  //      produced cells buffered in LDS too: the serial walk of lane 0 touches no global memory
+  uint32_t *btw = (uint32_t *)bt;
+  const uint64_t bt_words = DTW_BT_BYTES / 4;
   __shared__ int g_lo[DTW_BT_ROWS], g_hi[DTW_BT_ROWS];
   __shared__ unsigned int g_wb[DTW_BT_ROWS];
+  __shared__ int g_sh[DTW_BT_ROWS];
+  __shared__ int g_rev[2 * DTW_BT_OUT];
   int ci = len_x - 1, cj = len_y - 1, n = 0;
   while (ci >= 0) {
     // rows [r0, ci]: at most DTW_BT_ROWS rows whose code words fit in the LDS budget
+    const uint64_t wend = dtw_row_words_end(off, lo, hi, ci);
     int r0 = ci;
-    const uint64_t wend = dtw_word_base(off, ci) + (uint64_t)((hi[ci] - lo[ci]) >> 5) + 1;
-    while (r0 > 0 && ci - (r0 - 1) < DTW_BT_ROWS && wend - dtw_word_base(off, r0 - 1) <= bt_words) --r0;
+    {  // smallest r in [ci - DTW_BT_ROWS + 1, ci] whose words still fit (the predicate is monotone in r)
+      int lo_r = max(0, ci - DTW_BT_ROWS + 1), hi_r = ci;
+      while (lo_r < hi_r) {
+        const int mid = (lo_r + hi_r) >> 1;
+        if (wend - dtw_word_base(off, mid) <= bt_words) hi_r = mid; else lo_r = mid + 1;
+      }
+      r0 = lo_r;
+    }
     const uint64_t wbase = dtw_word_base(off, r0);
     const uint64_t nw = wend - wbase;
     const bool staged = nw <= bt_words;
@@ -231,36 +277,58 @@ __global__ __launch_bounds__(64) void k_dtw_dp(int len_x, int len_y, const int32
       g_lo[r - r0] = lo[r];
       g_hi[r - r0] = hi[r];
       g_wb[r - r0] = (unsigned int)(dtw_word_base(off, r) - wbase);
+      g_sh[r - r0] = dtw_row_shift(lo, r);
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    if (lane == 0) {
-      int i = ci, j = cj, m = n;
-      while (i >= r0) {
-        rev[2 * m] = i; rev[2 * m + 1] = j; ++m;
-        if (i == 0 && j == 0) { i = -1; break; }
-        unsigned int pb = 0;
-        const int l = g_lo[i - r0];
-        if (j >= l && j <= g_hi[i - r0]) {
-          const unsigned int w = g_wb[i - r0] + (unsigned int)((j - l) >> 5);
-          const unsigned long long word = staged ? btw[w] : predw[wbase + w];
-          pb = (unsigned int)(word >> (2 * ((j - l) & 31))) & 3u;
+    bool group_done = false;
+    while (!group_done) {
+      if (lane == 0) {
+        int i = ci, j = cj, m = 0;
+        int crow = -1, l = 0, h = -1, sh = 0;
+        unsigned int wb = 0, cw = 0xffffffffu;
+        uint32_t word = 0u;
+        while (i >= r0 && m < DTW_BT_OUT) {
+          g_rev[2 * m] = i; g_rev[2 * m + 1] = j; ++m;
+          if (i == 0 && j == 0) { i = -1; break; }
+          if (i != crow) { crow = i; l = g_lo[i - r0]; h = g_hi[i - r0]; wb = g_wb[i - r0]; sh = g_sh[i - r0]; cw = 0xffffffffu; }
+          unsigned int pb = 0;
+          if (j >= l && j <= h) {
+            const int st = sh + (j - l);  // the step at which this cell was computed
+            const unsigned int w = wb + (unsigned int)((st >> 4) - (sh >> 4));
+            if (w != cw) {
+              cw = w;
+              if (staged) word = btw[w]; else word = predw[wbase + w];
+            }
+            pb = (word >> (2 * (st & 15))) & 3u;
+          }
+          if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
+          if (j < 0) { i = -1; break; }
         }
-        if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
-        if (j < 0) { i = -1; break; }
+        s_i = i; s_j = j; s_n = m;
       }
-      s_i = i; s_j = j; s_n = m;
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      const int made = s_n;
+      for (int e = lane; e < 2 * made; e += 64) rev[2 * n + e] = g_rev[e];
+      n += made;
+      ci = s_i; cj = s_j;
+      group_done = ci < r0;
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    ci = s_i; cj = s_j; n = s_n;
-    __builtin_amdgcn_wave_barrier();
   }
+  __threadfence();
   for (int k = lane; k < n; k += 64) {
     path[2 * k] = rev[2 * (n - 1 - k)];
     path[2 * k + 1] = rev[2 * (n - 1 - k) + 1];
   }
   if (lane == 0) *path_len = n;
+  if (dbg && lane == 0) {
+    const long long t_end = clock64();
+    atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t_dp - t_start));
+    atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(t_end - t_dp));
+    dbg[2] = t_dp - t_start; dbg[3] = t_end - t_dp; dbg[4] = n;
+  }
 }
 
 // ---- host side -----------------------------------------------------------------------------
@@ -282,9 +350,9 @@ static size_t dtw_scratch_bytes(int64_t Tx, int64_t Ty, int dim, int radius, boo
     tot += kwy_pad(sizeof(double) * (size_t)lx * dim) + kwy_pad(sizeof(double) * (size_t)ly * dim);
   }
   uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
-  tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_PAD)) + kwy_pad(8 * (cap / 32 + Tx + 64));
+  tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_PAD)) + kwy_pad(4 * (cap / 16 + 2 * Tx + 64));
   tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1));
-  tot += kwy_pad(sizeof(double) * 2 * (Ty + 2));
+  tot += kwy_pad(sizeof(double) * 4 * (Ty + 2));
   tot += 3 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
   return tot + 16 * 256;
 }
@@ -309,11 +377,11 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   }
   const uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
   double *dist = kwy_arena<double>(ctx, cap + 2 * DTW_PAD);
-  unsigned long long *pred = kwy_arena<unsigned long long>(ctx, cap / 32 + Tx + 64);
+  uint32_t *pred = kwy_arena<uint32_t>(ctx, cap / 16 + 2 * Tx + 64);
   int32_t *lo = kwy_arena<int32_t>(ctx, Tx), *hi = kwy_arena<int32_t>(ctx, Tx);
   uint32_t *width = kwy_arena<uint32_t>(ctx, Tx);
   uint64_t *off = kwy_arena<uint64_t>(ctx, Tx + 1);
-  double *bnd = kwy_arena<double>(ctx, 2 * (Ty + 2));
+  double *bnd = kwy_arena<double>(ctx, DTW_WAVES * (Ty + 2));
   int32_t *pathA = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
   int32_t *pathB = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
   int32_t *rev = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
@@ -325,7 +393,7 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   }
   *status_out = status;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
-  const size_t bnd_bytes = sizeof(double) * 2 * (Ty + 2);
+  const size_t bnd_bytes = sizeof(double) * DTW_WAVES * (Ty + 2);
   const bool bnd_lds = DTW_BT_BYTES + bnd_bytes <= 150 * 1024;
   const size_t dp_lds = DTW_BT_BYTES + (bnd_lds ? bnd_bytes : 0);
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
@@ -344,13 +412,13 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3(len_x), dim3(KWY_THREADS), sizeof(double) * dim, ctx->stream, xs[l],
                        ys[l], dim, lo, hi, off, cap, dist, status));
     if (bnd_lds)
-      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<true>, dim3(1), dim3(64), dp_lds, ctx->stream, len_x, len_y,
+      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<true>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
                                                      lo, hi, off, cap, dist, pred, (double *)nullptr, opath, rev, olen,
-                                                     d_dist, status));
+                                                     d_dist, status, (long long *)ctx->dbg));
     else
-      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<false>, dim3(1), dim3(64), dp_lds, ctx->stream, len_x, len_y,
+      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<false>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
                                                      lo, hi, off, cap, dist, pred, bnd, opath, rev, olen, d_dist,
-                                                     status));
+                                                     status, (long long *)ctx->dbg));
     cpath = opath;
     clen = olen;
   }
