@@ -89,7 +89,7 @@ def main():
     ap_.add_argument('--gpus', type=int, default=1)
     ap_.add_argument('--steps', type=int, default=10)
     ap_.add_argument('--warmup', type=int, default=2)
-    ap_.add_argument('--batch', type=int, default=8, help='utterance pairs per GPU per step (one stream each)')
+    ap_.add_argument('--batch', type=int, default=32, help='utterance pairs per GPU per step (one stream each)')
     ap_.add_argument('--seconds', type=float, default=10.0, help='source utterance length')
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
     ap_.add_argument('--components', type=int, default=64)
@@ -167,13 +167,9 @@ def main():
     if rank == 0:
         T = pipes[0].frames
         K = pipes[0].K
-        # dominant kernel: D4C general body (rocprofv3 --stats: profiles/).  Algorithmic bytes per
-        # launch = frames x (hop*8 + 16 in, K*8 out)   [SURVEY.md 8(d), D4C share of "analyse"]
-        dom = 'k_d4c_body'
-        tot_ms, launches, dom_bytes = 0.0, 0, 0.0
-        kernel_ms = {}
         names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_syn_phase', 'k_syn_pulse', 'k_sp2mc',
-                 'k_mc2sp', 'k_dtw_dist', 'k_dtw_dp', 'k_gmm_logp', 'k_mlpg_solve']
+                 'k_mc2sp', 'k_dtw_dist', 'k_dtw_dp', 'k_gmm_prep', 'k_gmm_logp', 'k_mlpg_solve', 'k_align_project']
+        kernel_ms = {}
         for p in pipes:
             for nme in names:
                 ms, n = p.ctx.profile_read(nme)
@@ -181,19 +177,36 @@ def main():
                     a = kernel_ms.setdefault(nme, [0.0, 0])
                     a[0] += ms
                     a[1] += n
-        if dom in kernel_ms:
-            tot_ms, launches = kernel_ms[dom]
-        frames_per_launch = (2001 if args.workload == 'utterance' else (pipes[0].src.T + pipes[0].tgt.T) / 2.0)
-        if args.workload == 'utterance':
-            frames_per_launch = T
-        bytes_per_launch = frames_per_launch * (240 * 8 + 16 + K * 8)
+        # Frames one launch of a per-frame kernel processes (pair: source and target utterances alternate).
+        fpl = float(T) if args.workload == 'utterance' else (pipes[0].src.T + pipes[0].tgt.T) / 2.0
+        hop = FS * FRAME_PERIOD / 1000.0
+        # ALGORITHMIC HBM bytes per launch of the whole-chip kernels:
+        # hop new samples + (f0, t) in, one K-bin f64 row out per frame; synthesis reads sp+ap rows, writes hop samples.
+        algo = {'k_d4c_body': fpl * (hop * 8 + 16 + K * 8), 'k_cheaptrick': fpl * (hop * 8 + 16 + K * 8),
+                'k_d4c_lovetrain': fpl * (hop * 8 + 16 + 8), 'k_syn_pulse': fpl * (2 * K * 8 + hop * 8)}
+        # The dominant kernel = the whole-chip kernel with the largest summed duration.  The single-workgroup
+        # serial kernels (k_dtw_dp, k_mlpg_solve, ...) occupy one CU each and overlap with other streams;
+        # they bound latency, not throughput, and are listed in kernel_ms_per_launch.
+        cand = [k for k in algo if k in kernel_ms]
+        dom = max(cand, key=lambda k: kernel_ms[k][0]) if cand else 'k_d4c_body'
+        tot_ms, launches = kernel_ms.get(dom, (0.0, 0))
+        bytes_per_launch = algo[dom]
         avg_s = (tot_ms / launches) * 1e-3 if launches else float('nan')
         achieved = bytes_per_launch / avg_s / 1e9 if launches else None
+        traffic = None
+        try:        # PMC-measured HBM bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) per launch
+            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as fh:
+                pmc = json.load(fh)
+            traffic = pmc['kernels'][dom]['hbm_bytes_per_launch_raw'] * fpl / pmc['frames_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                    'frac': (achieved / 8000.0) if achieved else None, 'traffic': None,
+                    'frac': (achieved / 8000.0) if achieved else None, 'traffic': traffic,
                     'avg_launch_ms': tot_ms / launches if launches else None, 'launches': launches,
                     'algorithmic_bytes_per_launch': bytes_per_launch,
-                    'note': 'f64 FFT/LDS-bound kernel; HBM fraction is reported as asked, see DESIGN.md'}
+                    'note': 'kernel is f64-FFT/LDS bound, not HBM bound; the HBM fraction is reported as asked '
+                            '(DESIGN.md section 5).  traffic = FETCH_SIZE+WRITE_SIZE of profiles/r1_pmc_traffic.json '
+                            'scaled to the frames of one launch; avg_launch_ms is measured while other streams run'}
         # whole-path algorithmic bytes per source frame
         path_bytes = 36664 if args.workload == 'utterance' else 81000
         out = {

@@ -194,81 +194,131 @@ struct d4c_params {
   double threshold;
 };
 
-// Windowed, DC-removed frame into A (N reals).  Thread t holds the draws
-// [c*t, c*t+c) of the frame's 3*wl draws in nz[]; window `which` uses draws
-// [which*wl, (which+1)*wl): they are scattered into the LDS scratch NZ first, so
-// that the window itself is evaluated with a balanced, strided thread mapping.
-// If `make_ramp`, also normalises to unit power and writes A[i]*(i+1) into R.
+// One WORLD window of the frame: x around `pos`, times the window function, plus the
+// safeguard noise, DC removed with the window as weight.  Element i = tid + NT*r
+// stays in av[r] (0 beyond the window); Bd (N doubles of LDS, free on entry) only
+// carries the noise draws from the threads that drew them (thread t holds draws
+// [c*t, c*t+c) of the frame's 3*wl, window `which` uses [which*wl, (which+1)*wl))
+// to the threads that use them.  `normalise` scales to unit power (GetCentroid).
 template <int N, int C, int NT>
-__device__ inline void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
-                                        double pos, int type, int which, int c, const double (&nz)[C],
-                                        double *A, double *R, double *NZ, bool make_ramp, double *red) {
+__device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
+                                                 double pos, int type, int which, int c,
+                                                 const uint32_t (&nzraw)[C], double *Bd, bool normalise,
+                                                 double *red, double (&av)[N / NT]) {
+  constexpr int E = N / NT;
   const int tid = threadIdx.x;
   const int half = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0);
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(pos * p.fs + 0.001);
-  __syncthreads();
 #pragma unroll
   for (int j = 0; j < C; ++j) {
     int d = c * tid + j - which * wl;
-    if (j < c && d >= 0 && d < wl) NZ[d] = nz[j];
+    if (j < c && d >= 0 && d < wl) Bd[d] = nzraw[j] / 268435456.0 - 6.0;
   }
   __syncthreads();
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < N; i += NT) {
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = tid + NT * r;
     double v = 0.0;
     if (i < wl) {
-      double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
+      const double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
       int idx = min(p.x_length - 1, max(0, origin + i - half));
       v = x[idx] * w;
-      v = v + NZ[i] * D4C_SAFE;
-      NZ[i] = w;
+      v = v + Bd[i] * D4C_SAFE;
+      Bd[i] = w;                       // the window value takes the place of the consumed draw
       s1 += v; s2 += w;
     }
-    A[i] = v;
+    av[r] = v;
   }
-  const double t1 = kwy_block_sum<NT>(s1, red);
-  const double t2 = kwy_block_sum<NT>(s2, red);
+  double t1, t2;
+  kwy_block_sum2<NT>(s1, s2, red, &t1, &t2);
   const double coef = t1 / t2;
   double pw = 0.0;
-  for (int i = tid; i < wl; i += NT) {
-    double v = A[i] - NZ[i] * coef;
-    A[i] = v;
-    pw += v * v;
-  }
-  if (make_ramp) {
-    const double power = kwy_block_sum<NT>(pw, red);
-    const double sq = sqrt(power);
-    for (int i = tid; i < N; i += NT) {
-      double v = (i < wl) ? A[i] / sq : 0.0;
-      A[i] = v;
-      R[i] = v * (i + 1.0);
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    if (tid + NT * r < wl) {
+      double v = av[r] - Bd[tid + NT * r] * coef;
+      av[r] = v;
+      pw += v * v;
     }
+  }
+  if (normalise) {
+    const double sq = sqrt(kwy_block_sum<NT>(pw, red));
+#pragma unroll
+    for (int r = 0; r < E; ++r)
+      if (tid + NT * r < wl) av[r] = av[r] / sq;
+  }
+}
+
+// WORLD LinearSmoothing as above, but out[k] = in[k] - smoothed[k] (the last step of the static group delay)
+template <int NT>
+__device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot, double width, int fs, int N) {
+  const int H = N / 2;
+  int boundary = (int)(width * N / fs) + 1;
+  if (boundary > H / 2) boundary = H / 2;
+  const int L = H + boundary * 2 + 1;
+  for (int i = threadIdx.x; i < L; i += NT) {
+    double m;
+    if (i < boundary) m = io[boundary - i];
+    else if (i < H + boundary) m = io[i - boundary];
+    else m = io[H - (i - (H + boundary))];
+    S[i] = m * fs / N;
+  }
+  __syncthreads();
+  kwy_block_cumsum<NT>(S, L, tot);
+  const double origin = -(boundary - 0.5) * fs / N;
+  const double dfi = (double)fs / N;
+  for (int k = threadIdx.x; k <= H; k += NT) {
+    double fa = (double)k / N * fs - width / 2.0;
+    double low = d4c_interp1q(origin, dfi, S, L, fa);
+    fa += width;
+    double high = d4c_interp1q(origin, dfi, S, L, fa);
+    io[k] = io[k] - (high - low) / width;
   }
   __syncthreads();
 }
 
-#define D4C_NT 512  // threads of the general-body workgroup: 8 wavefronts share one frame's LDS
+// General body.  One 512-thread workgroup per frame; the frame lives in ~61 KB of
+// LDS so that two frames share a CU:
+//   Dv  (H+2 doubles)   centroid sum, later the static group delay
+//   B   (H+1 complex)   the one FFT buffer (in-place radix-8 transforms); afterwards the
+//                       power spectrum P = B[0..H] as doubles, the smoothing scratch S
+//                       behind it, and during the band loop the select histograms
+// The spectra themselves never go back to LDS: each thread pulls "its" bins
+// k = tid + NT*r out of the packed half-length transform into registers.
+#define D4C_NT 512
+// doubles of the region shared by B (2H+2), P + S (H+2 + 2H+4) and the select histograms
+__host__ __device__ constexpr int d4c_overlay_doubles(int H) {
+  return (3 * H + 6) > (KWY_SELECT_WORDS(D4C_NT) / 2) ? (3 * H + 6) : (KWY_SELECT_WORDS(D4C_NT) / 2);
+}
 template <int LOG2N>
-__global__ __launch_bounds__(D4C_NT) void k_d4c_body(
+__global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
     const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
     const double *__restrict__ ap0, d4c_params p, const uint32_t *__restrict__ ebase,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     const double *__restrict__ nuttall, double *__restrict__ out, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int NT = D4C_NT;
-  constexpr int C = 3 * N / NT;
-#define D4C_STAMP(n) do { if (dbg && threadIdx.x == 0 && blockIdx.x == (unsigned)dbg[63]) dbg[n] = clock64(); } while (0)  // draws per thread (3 windows, each shorter than N)
+  constexpr int C = 3 * N / NT;            // draws per thread (3 windows, each shorter than N)
+  constexpr int E = N / NT;                // window elements per thread
+  constexpr int RK = (H + 1 + NT - 1) / NT;  // spectrum bins per thread
+#define D4C_STAMP(n) do { if (dbg && threadIdx.x == 0 && blockIdx.x == (unsigned)dbg[63]) dbg[n] = clock64(); } while (0)
   extern __shared__ double smem[];
-  kwy_c *buf0 = (kwy_c *)smem;
-  kwy_c *buf1 = buf0 + (H + 1);
-  kwy_c *buf2 = buf1 + (H + 1);
-  double *Dv = (double *)(buf2 + (H + 1));  // H+1: centroid sum, later group delay
-  double *red = Dv + (H + 2);               // 8
-  double *tot = red + 8;                    // NT
-  double *coarse = tot + NT;       // D4C_MAX_BANDS + 2
-  uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);
-  uint32_t *hist = e + KWY_EBASE_WORDS;     // (NT/64)*256 + 8
+  double *Dv = smem;                         // H+2
+  kwy_c *B = (kwy_c *)(Dv + (H + 2));        // H+1 complex
+  double *Bd = (double *)B;
+  double *P = Bd;                            // H+1 doubles (+1 pad)
+  double *S = Bd + (H + 2);                  // <= 2H+3 doubles: reaches past B, see d4c_body_lds()
+  double *tot = Bd + d4c_overlay_doubles(H);  // NT
+  double *red = tot + NT;                    // 16
+  double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
+  uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);  // KWY_EBASE_WORDS
+  kwy_c *twL = (kwy_c *)(e + KWY_EBASE_WORDS);   // H/16 entries: exp(-2 pi i k / (N/2)), k < N/16
+  uint32_t *hist = (uint32_t *)B;            // KWY_SELECT_WORDS(NT), band loop only
+  // centroid phase only: bins 0..H/2 in Dv (H+2 doubles = H/2+1 complex), the rest behind B
+  kwy_c *X1s = (kwy_c *)Dv;
+  constexpr int XGAP = (H + 1);              // complex elements of B between the two pieces
 
   const int tid = threadIdx.x;
   const int64_t frame = blockIdx.x;
@@ -283,49 +333,91 @@ __global__ __launch_bounds__(D4C_NT) void k_d4c_body(
 
   D4C_STAMP(0);
   for (int i = tid; i < KWY_EBASE_WORDS; i += NT) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
+  for (int i = tid; i < H / 8; i += NT) twL[i] = twH[i];
+  // exp(-2 pi i k / N) of "my" spectrum bins k = tid + NT*r is this times an 8th root of unity
+  const kwy_c twb = twN[tid];
+  constexpr int OCT = 8 * NT / N;
+  // Nuttall window of the band loop (window_length <= 2*NT)
+  double nutr[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) nutr[r] = (tid + NT * r < p.window_length) ? nuttall[tid + NT * r] : 0.0;
   __syncthreads();
   const int wl4 = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0) * 2 + 1;
   const int c = (3 * wl4 + NT - 1) / NT;  // draws per thread, <= C
   kwy_rng rng = kwy_rng_combine(e, poly[(c - 1) * NT + tid]);
-  double nz[C];
+  uint32_t nzraw[C];
 #pragma unroll
-  for (int j = 0; j < C; ++j) nz[j] = (j < c) ? kwy_rng_randn(rng) : 0.0;
+  for (int j = 0; j < C; ++j) nzraw[j] = (j < c) ? kwy_rng_randn_raw(rng) : 0u;
 
   D4C_STAMP(1);
-  // ---- static centroid: two temporal centroids at pos -+ 0.25/f0
+  // ---- static centroid: two temporal centroids at pos -+ 0.25/f0, each Re(X2 conj X1) of the
+  //      normalised window (X1) and the window times its sample index (X2)
+  double cen[RK];
+  double av[E];
   for (int which = 0; which < 2; ++which) {
     double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-    d4c_frame_window<N, C, NT>(x, p, cf0, cpos, D4C_BLACKMAN, which, c, nz, (double *)buf0, (double *)buf1,
-                           (double *)buf2, true, red);
+    d4c_frame_window<N, C, NT>(x, p, cf0, cpos, D4C_BLACKMAN, which, c, nzraw, Bd, true, red, av);
+#pragma unroll
+    for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];   // each thread overwrites the draws it consumed
+    __syncthreads();
     D4C_STAMP(2 + which * 2);
-    // X1 = rfft(buf0) using buf2 as scratch; X2 = rfft(buf1) using the buffer X1 left free
-    kwy_c *X1 = kwy_rfft_lds<NT>(buf0, buf2, LOG2N - 1, twH, twN);
-    kwy_c *F = (X1 == buf0) ? buf2 : buf0;
-    kwy_c *X2 = kwy_rfft_lds<NT>(buf1, F, LOG2N - 1, twH, twN);
-    for (int k = tid; k <= H; k += NT) {
-      double cen = X2[k].x * X1[k].x + X1[k].y * X2[k].y;
-      Dv[k] = which == 0 ? cen : Dv[k] + cen;
+    kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
+    // X1 of "my" bins waits in the LDS that is idle until the centroid is complete (Dv and the
+    // tail of the overlay): written and read back by the same thread, no barrier involved
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+      const int k = tid + NT * r;
+      if (k <= H) X1s[k < H / 2 + 1 ? k : k + XGAP] = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r] * (tid + NT * r + 1.0);
+    __syncthreads();
+    kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+      const int k = tid + NT * r;
+      if (k <= H) {
+        const kwy_c X2 = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
+        const kwy_c X1 = X1s[k < H / 2 + 1 ? k : k + XGAP];
+        const double v = X2.x * X1.x + X1.y * X2.y;
+        cen[r] = which == 0 ? v : cen[r] + v;
+      }
     }
     __syncthreads();
     D4C_STAMP(3 + which * 2);
   }
-  d4c_dc_correction<NT>(Dv, (double *)buf0, cf0, p.fs, N);
+#pragma unroll
+  for (int r = 0; r < RK; ++r)
+    if (tid + NT * r <= H) Dv[tid + NT * r] = cen[r];
+  __syncthreads();
+  d4c_dc_correction<NT>(Dv, Bd, cf0, p.fs, N);
 
   D4C_STAMP(6);
   // ---- smoothed power spectrum
-  d4c_frame_window<N, C, NT>(x, p, cf0, pos, D4C_HANNING, 2, c, nz, (double *)buf0, nullptr, (double *)buf2,
-                         false, red);
-  D4C_STAMP(7);
-  kwy_c *Xs = kwy_rfft_lds<NT>(buf0, buf1, LOG2N - 1, twH, twN);
-  D4C_STAMP(8);
-  double *P = (double *)buf2;
-  for (int k = tid; k <= H; k += NT) {
-    kwy_c v = Xs[k];
-    P[k] = v.x * v.x + v.y * v.y;
-  }
+  d4c_frame_window<N, C, NT>(x, p, cf0, pos, D4C_HANNING, 2, c, nzraw, Bd, false, red, av);
+#pragma unroll
+  for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];
   __syncthreads();
-  double *S = (double *)buf0;
-  double *G2 = (double *)buf1;
+  D4C_STAMP(7);
+  kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
+  D4C_STAMP(8);
+  {
+    double pv[RK];
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+      const int k = tid + NT * r;
+      if (k <= H) {
+        const kwy_c v = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
+        pv[r] = v.x * v.x + v.y * v.y;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RK; ++r)
+      if (tid + NT * r <= H) P[tid + NT * r] = pv[r];
+    __syncthreads();
+  }
   d4c_dc_correction<NT>(P, S, cf0, p.fs, N);
   d4c_linear_smoothing<NT>(P, P, S, tot, cf0, p.fs, N);
 
@@ -334,9 +426,7 @@ __global__ __launch_bounds__(D4C_NT) void k_d4c_body(
   for (int k = tid; k <= H; k += NT) Dv[k] = Dv[k] / P[k];
   __syncthreads();
   d4c_linear_smoothing<NT>(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N);
-  d4c_linear_smoothing<NT>(Dv, G2, S, tot, cf0, p.fs, N);
-  for (int k = tid; k <= H; k += NT) Dv[k] = Dv[k] - G2[k];
-  __syncthreads();
+  d4c_subtract_smoothed<NT>(Dv, S, tot, cf0, p.fs, N);
 
   D4C_STAMP(10);
   // ---- coarse aperiodicity per band
@@ -344,22 +434,29 @@ __global__ __launch_bounds__(D4C_NT) void k_d4c_body(
   const int half_window_length = p.window_length / 2;
   for (int b = 0; b < p.nbands; ++b) {
     const int center = (int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs);
-    double *A = (double *)buf0;
-    for (int j = tid; j < N; j += NT)
-      A[j] = (j <= half_window_length * 2) ? Dv[center - half_window_length + j] * nuttall[j] : 0.0;
-    if (b == 0) D4C_STAMP(11);
-    kwy_c *Xb = kwy_rfft_lds<NT>(buf0, buf1, LOG2N - 1, twH, twN);
-    if (b == 0) D4C_STAMP(12);
-    double *Q = (double *)buf2;  // power spectrum of the band
-    for (int k = tid; k <= H; k += NT) {
-      kwy_c cc = Xb[k];
-      Q[k] = cc.x * cc.x + cc.y * cc.y;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int j = tid + NT * r;
+      Bd[j] = (r < 2 && j <= half_window_length * 2) ? Dv[center - half_window_length + j] * nutr[r < 2 ? r : 0] : 0.0;
     }
     __syncthreads();
-    // CPU: sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
+    if (b == 0) D4C_STAMP(11);
+    kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
+    if (b == 0) D4C_STAMP(12);
+    // CPU: power spectrum, sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
+    unsigned long long key[RK];
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+      const int k = tid + NT * r;
+      key[r] = ~0ull;
+      if (k <= H) {
+        const kwy_c cc = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
+        key[r] = (unsigned long long)__double_as_longlong(cc.x * cc.x + cc.y * cc.y);
+      }
+    }
+    __syncthreads();
     double nsmall, nall;
-    kwy_block_smallest_sum<(H + 1 + NT - 1) / NT, NT>(Q, H + 1, H - boundary, hist, red, &nsmall,
-                                                                     &nall);
+    kwy_block_smallest_sum<RK, NT>(key, H + 1, H - boundary, hist, red, &nsmall, &nall);
     if (b == 0) D4C_STAMP(13);
     if (tid == 0) {
       double cv = 10 * log10(nsmall / nall);
@@ -396,6 +493,14 @@ __global__ __launch_bounds__(D4C_NT) void k_d4c_body(
 #undef D4C_STAMP
 }
 
+template <int LOG2N>
+static constexpr size_t d4c_body_lds() {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  // Dv | overlay (B, or P + S, or the select histograms) | tot | red | coarse | e
+  return sizeof(double) * ((H + 2) + d4c_overlay_doubles(H) + D4C_NT + 16 + D4C_MAX_BANDS + 2) +
+         sizeof(uint32_t) * KWY_EBASE_WORDS + sizeof(kwy_c) * (H / 8);
+}
+
 // ------------------------------------------------------------------ host side
 template <int LOG2N>
 static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
@@ -425,9 +530,7 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   KWY_TRY(kwy_get_poly_multi(ctx, 3 * N / D4C_NT, D4C_NT, &poly));
-  size_t lds = sizeof(kwy_c) * 3 * (H + 1) +
-               sizeof(double) * ((H + 2) + 8 + D4C_NT + D4C_MAX_BANDS + 2) +
-               sizeof(uint32_t) * (KWY_EBASE_WORDS + (D4C_NT / 64) * 256 + 8);
+  size_t lds = d4c_body_lds<LOG2N>();
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(D4C_NT), lds, ctx->stream, x, t,

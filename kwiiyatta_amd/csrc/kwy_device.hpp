@@ -30,12 +30,16 @@ __device__ __forceinline__ uint32_t kwy_rng_step(kwy_rng &r) {
   return r.w;
 }
 
-// one "randn" = 12 generator steps (sum of 12 uniforms, WORLD matlabfunctions)
-__device__ __forceinline__ double kwy_rng_randn(kwy_rng &r) {
+// one "randn" = 12 generator steps (sum of 12 uniforms, WORLD matlabfunctions);
+// the raw integer sum keeps a draw in one register, randn = raw / 2^28 - 6
+__device__ __forceinline__ uint32_t kwy_rng_randn_raw(kwy_rng &r) {
   uint32_t tmp = kwy_rng_step(r) >> 4;
 #pragma unroll
   for (int i = 0; i < 11; ++i) tmp += kwy_rng_step(r) >> 4;
-  return tmp / 268435456.0 - 6.0;
+  return tmp;
+}
+__device__ __forceinline__ double kwy_rng_randn(kwy_rng &r) {
+  return kwy_rng_randn_raw(r) / 268435456.0 - 6.0;
 }
 
 // Wavefront-cooperative jump: all 64 lanes hold the same state s[4]; on return
@@ -151,34 +155,50 @@ __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
   __syncthreads();
 }
 
-// Sum of the m smallest of n non-negative doubles v[0..n) (LDS), and the sum of
-// all of them, without sorting: an MSB-first radix select (8 rounds of 8 bits on
-// the IEEE bit patterns, which order like the values for x >= 0) finds the m-th
-// smallest value v*; then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.
-// hist: KWY_WAVES*256 + 8 uint32 of LDS (8-byte aligned); red: >= KWY_WAVES doubles.  n <= KWY_THREADS * RMAX.
-template <int RMAX, int NT = KWY_THREADS>
-__device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uint32_t *hist, double *red,
-                                              double *sum_small, double *sum_all) {
-  constexpr int NW = NT / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  unsigned long long key[RMAX];
+// sums of two values over the block in one exchange; red: >= 2*NT/64 doubles
+template <int NT = KWY_THREADS>
+__device__ __forceinline__ void kwy_block_sum2(double a, double b, double *red, double *ta, double *tb) {
+  a = kwy_wave_sum(a);
+  b = kwy_wave_sum(b);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[NT / 64 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  double sa = red[0], sb = red[NT / 64];
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    int i = tid + NT * r;
-    key[r] = i < n ? (unsigned long long)__double_as_longlong(v[i]) : ~0ull;
-  }
-  uint32_t *ctl = hist + NW * 256;  // [0] digit, [1] new rank
+  for (int i = 1; i < NT / 64; ++i) { sa += red[i]; sb += red[NT / 64 + i]; }
+  *ta = sa; *tb = sb;
+}
+
+// Sum of the m smallest of n non-negative doubles, and the sum of all of them,
+// without sorting.  Thread t holds the IEEE bit patterns of elements t, t+NT, ...
+// in key[] (~0 for slots beyond n).  An MSB-first radix select (up to 8 rounds of
+// 8 bits; the patterns order like the values for x >= 0) finds the m-th smallest
+// value v*; then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.  Two barriers per
+// round: the histograms and the control words are double-buffered.
+// hist: 2*(NT/64)*256 + 16 uint32 of LDS (8-byte aligned) that no thread touches
+// any more when the call starts; red: >= 2*NT/64 doubles.
+#define KWY_SELECT_WORDS(NT) (2 * ((NT) / 64) * 256 + 16)
+template <int RMAX, int NT = KWY_THREADS>
+__device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RMAX], int n, int m,
+                                              uint32_t *hist, double *red, double *sum_small,
+                                              double *sum_all) {
+  constexpr int NW = NT / 64, HW = NW * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t *ctlb = hist + 2 * HW;  // 2 x {digit, new rank, population}, then one 64-bit key
+  for (int b = tid; b < HW; b += NT) hist[b] = 0;
+  __syncthreads();
   unsigned long long prefix = 0ull;
   int kk = m;  // 1-based rank of the wanted element among the still-matching keys
   for (int round = 0; round < 8; ++round) {
     const int shift = 56 - 8 * round;
-    for (int b = tid; b < NW * 256; b += NT) hist[b] = 0;
-    __syncthreads();
+    uint32_t *h = hist + (round & 1) * HW, *hn = hist + ((round + 1) & 1) * HW;
+    uint32_t *ctl = ctlb + (round & 1) * 4;
+    for (int b = tid; b < HW; b += NT) hn[b] = 0;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       int i = tid + NT * r;
       bool match = i < n && (round == 0 || (key[r] >> (shift + 8)) == (prefix >> (shift + 8)));
-      if (match) atomicAdd(&hist[wv * 256 + (int)((key[r] >> shift) & 255ull)], 1u);
+      if (match) atomicAdd(&h[wv * 256 + (int)((key[r] >> shift) & 255ull)], 1u);
     }
     __syncthreads();
     if (wv == 0) {
@@ -188,7 +208,7 @@ __device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uin
       for (int q = 0; q < 4; ++q) {
         uint32_t a = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) a += hist[w * 256 + 4 * lane + q];
+        for (int w = 0; w < NW; ++w) a += h[w * 256 + 4 * lane + q];
         c[q] = a;
         tot += a;
       }
@@ -212,11 +232,9 @@ __device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uin
     __syncthreads();
     prefix |= (unsigned long long)ctl[0] << shift;
     kk = (int)ctl[1];
-    const bool single = ctl[2] == 1u;
-    __syncthreads();
-    if (single && round < 7) {
+    if (ctl[2] == 1u && round < 7) {
       // exactly one key carries this prefix: it IS the wanted element, skip the remaining rounds
-      unsigned long long *k64 = (unsigned long long *)(ctl + 4);
+      unsigned long long *k64 = (unsigned long long *)(ctlb + 8);
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) {
         int i = tid + NT * r;
@@ -239,14 +257,14 @@ __device__ inline void kwy_block_smallest_sum(const double *v, int n, int m, uin
       if (key[r] < prefix) s_less += x;
     }
   }
-  const double t_less = kwy_block_sum<NT>(s_less, red);
-  const double t_all = kwy_block_sum<NT>(s_all, red);
+  double t_less, t_all;
+  kwy_block_sum2<NT>(s_less, s_all, red, &t_less, &t_all);
   *sum_small = t_less + (double)kk * vstar;
   *sum_all = t_all;
 }
 
 // ------------------------------------------------------------------- LDS FFTs
-struct kwy_c { double x, y; };  // complex double (16 B, LDS b128 accesses)
+struct __attribute__((aligned(16))) kwy_c { double x, y; };  // complex double (16 B, LDS b128 accesses)
 
 __device__ __forceinline__ kwy_c cadd(kwy_c a, kwy_c b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ kwy_c csub(kwy_c a, kwy_c b) { return {a.x - b.x, a.y - b.y}; }
@@ -366,6 +384,159 @@ __device__ inline kwy_c *kwy_irfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_
     b[k] = {er - oi, ei + orr};
   }
   return kwy_fft_lds<true, NT>(b, a, log2H, twH);
+}
+
+// ------------------------------------------------- in-place radix-8 LDS FFT
+// One buffer instead of the ping-pong pair above: every pass loads its operands
+// into registers, all threads meet at a barrier, and the results go back to the
+// same array (Stockham ordering, so the output is in natural order).  8 points
+// per thread and pass: an H = 2048 point transform is 8*8*8*4 = 4 LDS round trips.
+template <bool INV>
+__device__ __forceinline__ kwy_c kwy_rot90(kwy_c a) {  // a * (-i) forward, a * (+i) inverse
+  return INV ? kwy_c{-a.y, a.x} : kwy_c{a.y, -a.x};
+}
+
+template <bool INV>
+__device__ __forceinline__ void kwy_dft8(kwy_c (&a)[8]) {
+  const double h = 0.70710678118654752440;
+  kwy_c t0 = cadd(a[0], a[4]), t1 = csub(a[0], a[4]);
+  kwy_c t2 = cadd(a[2], a[6]), t3 = kwy_rot90<INV>(csub(a[2], a[6]));
+  kwy_c t4 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]);
+  kwy_c t6 = cadd(a[3], a[7]), t7 = csub(a[3], a[7]);
+  kwy_c u0 = cadd(t0, t2), u1 = csub(t0, t2), u2 = cadd(t4, t6), u3 = kwy_rot90<INV>(csub(t4, t6));
+  // c1 = t5 * w8, c3 = t7 * w8^3 with w8 = exp(-+ i pi/4)
+  kwy_c c1 = INV ? kwy_c{h * (t5.x - t5.y), h * (t5.x + t5.y)} : kwy_c{h * (t5.x + t5.y), h * (t5.y - t5.x)};
+  kwy_c c3 = INV ? kwy_c{h * (-t7.x - t7.y), h * (t7.x - t7.y)} : kwy_c{h * (t7.y - t7.x), h * (-t7.x - t7.y)};
+  kwy_c v0 = cadd(t1, t3), v1 = csub(t1, t3), v2 = cadd(c1, c3), v3 = kwy_rot90<INV>(csub(c1, c3));
+  a[0] = cadd(u0, u2); a[4] = csub(u0, u2); a[2] = cadd(u1, u3); a[6] = csub(u1, u3);
+  a[1] = cadd(v0, v2); a[5] = csub(v0, v2); a[3] = cadd(v1, v3); a[7] = csub(v1, v3);
+}
+
+// Radix-8 pass with sub-transform stride S = 2^LOG2S over H points, in place.
+// The first pass (S = 1) would store each thread's 8 results 128 B apart -- an
+// 8-way conflict on ds_write_b128 -- so it stores to i ^ ((i >> 3) & 7) instead,
+// and the second pass (S = 8) reads through the same permutation.
+// tw: exp(-2 pi i k / H) for k < H/8 at least (the factors of one radix-8 pass are tw[ps], ps < H/8,
+// and its 2nd .. 7th powers, which are formed by multiplication); it may live in LDS.
+template <int LOG2H, int LOG2S, int NT, bool INV>
+__device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict__ tw) {
+  constexpr int H = 1 << LOG2H, Q = H / 8, S = 1 << LOG2S;
+  constexpr int IT = (Q + NT - 1) / NT;
+  constexpr bool LAST = (LOG2S + 3 == LOG2H);
+  static_assert(Q >= 64, "transform too short for the radix-8 kernel");
+  kwy_c a[IT][8];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = threadIdx.x + it * NT;
+    if (j < Q) {
+      const int swz = (LOG2S == 3) ? ((j >> 3) & 7) : 0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) a[it][m] = z[(j + m * Q) ^ swz];
+      kwy_dft8<INV>(a[it]);
+      if (!LAST) {
+        const int ps = (j >> LOG2S) << LOG2S;
+        kwy_c w1 = tw[ps];
+        if (INV) w1.y = -w1.y;
+        const kwy_c w2 = cmul(w1, w1), w4 = cmul(w2, w2);
+        const kwy_c w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
+        const kwy_c w7 = cmul(w4, w3);
+        a[it][1] = cmul(w1, a[it][1]); a[it][2] = cmul(w2, a[it][2]); a[it][3] = cmul(w3, a[it][3]);
+        a[it][4] = cmul(w4, a[it][4]); a[it][5] = cmul(w5, a[it][5]); a[it][6] = cmul(w6, a[it][6]);
+        a[it][7] = cmul(w7, a[it][7]);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = threadIdx.x + it * NT;
+    if (j < Q) {
+      const int q = j & (S - 1), p = j >> LOG2S;
+      const int o = q + ((8 * p) << LOG2S);
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        if (LOG2S == 0) z[8 * j + (m ^ (j & 7))] = a[it][m];
+        else z[o + (m << LOG2S)] = a[it][m];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// closing radix-4 (TAIL = 2) or radix-2 (TAIL = 1) pass: sub-transform stride H/4 resp. H/2, no twiddles
+template <int LOG2H, int TAIL, int NT, bool INV>
+__device__ __forceinline__ void kwy_fft_tail(kwy_c *z) {
+  constexpr int H = 1 << LOG2H, R = 1 << TAIL, Q = H / R;
+  constexpr int IT = (Q + NT - 1) / NT;
+  kwy_c a[IT][R];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int j = threadIdx.x + it * NT;
+    if (j < Q) {
+#pragma unroll
+      for (int m = 0; m < R; ++m) a[it][m] = z[j + m * Q];
+      if constexpr (TAIL == 2) {
+        kwy_c apc = cadd(a[it][0], a[it][2]), amc = csub(a[it][0], a[it][2]);
+        kwy_c bpd = cadd(a[it][1], a[it][3]), jb = kwy_rot90<INV>(csub(a[it][1], a[it][3]));
+        a[it][0] = cadd(apc, bpd); a[it][1] = cadd(amc, jb);
+        a[it][2] = csub(apc, bpd); a[it][3] = csub(amc, jb);
+      } else {
+        kwy_c s0 = cadd(a[it][0], a[it][1]), s1 = csub(a[it][0], a[it][1]);
+        a[it][0] = s0; a[it][1] = s1;
+      }
+      // the closing pass writes exactly the locations it read: no barrier in between
+#pragma unroll
+      for (int m = 0; m < R; ++m) z[j + m * Q] = a[it][m];
+    }
+  }
+  __syncthreads();
+}
+
+// In-place complex FFT of H = 2^LOG2H (512 .. 4096) points in LDS.  The caller
+// has a barrier between filling z and this call; ends with a barrier.
+// tw: exp(-2 pi i k / H), k < H/8 (global or LDS).  Unnormalised in both directions.
+template <int LOG2H, int NT, bool INV>
+__device__ inline void kwy_fft_inplace(kwy_c *z, const kwy_c *__restrict__ tw) {
+  static_assert(LOG2H >= 9 && LOG2H <= 12, "unsupported in-place FFT length");
+  kwy_fft_pass8<LOG2H, 0, NT, INV>(z, tw);
+  kwy_fft_pass8<LOG2H, 3, NT, INV>(z, tw);
+  kwy_fft_pass8<LOG2H, 6, NT, INV>(z, tw);
+  if constexpr (LOG2H == 12) kwy_fft_pass8<LOG2H, 9, NT, INV>(z, tw);
+  if constexpr (LOG2H == 11) kwy_fft_tail<LOG2H, 2, NT, INV>(z);
+  if constexpr (LOG2H == 10) kwy_fft_tail<LOG2H, 1, NT, INV>(z);
+}
+
+// Bin k (0 <= k <= H) of the real FFT of the N = 2H reals whose packed
+// half-length transform sits in z; twN: exp(-2 pi i k / N).  Read-only on z.
+template <int LOG2H>
+__device__ __forceinline__ kwy_c kwy_rfft_bin_w(const kwy_c *z, int k, kwy_c w) {  // w = exp(-2 pi i k / N)
+  constexpr int H = 1 << LOG2H;
+  if (k == 0) return {z[0].x + z[0].y, 0.0};
+  if (k == H) return {z[0].x - z[0].y, 0.0};
+  const kwy_c A = z[k];
+  const kwy_c B = {z[H - k].x, -z[H - k].y};
+  const double er = 0.5 * (A.x + B.x), ei = 0.5 * (A.y + B.y);
+  const double dr = 0.5 * (A.x - B.x), di = 0.5 * (A.y - B.y);
+  const double orr = di, oi = -dr;
+  return {er + (orr * w.x - oi * w.y), ei + (orr * w.y + oi * w.x)};
+}
+template <int LOG2H>
+__device__ __forceinline__ kwy_c kwy_rfft_bin(const kwy_c *z, int k, const kwy_c *__restrict__ twN) {
+  return kwy_rfft_bin_w<LOG2H>(z, k, twN[k & ((2 << LOG2H) - 1)]);
+}
+// exp(-2 pi i (t + r*NT) / N) from base = exp(-2 pi i t / N) when NT = N/8: base times an 8th root of unity
+__device__ __forceinline__ kwy_c kwy_tw_octant(kwy_c b, int r) {
+  const double h = 0.70710678118654752440;
+  switch (r & 7) {
+    case 0: return b;
+    case 1: return {h * (b.x + b.y), h * (b.y - b.x)};
+    case 2: return {b.y, -b.x};
+    case 3: return {h * (b.y - b.x), h * (-b.x - b.y)};
+    case 4: return {-b.x, -b.y};
+    case 5: return {h * (-b.x - b.y), h * (b.x - b.y)};
+    case 6: return {-b.y, b.x};
+    default: return {h * (b.x - b.y), h * (b.x + b.y)};
+  }
 }
 
 __device__ __forceinline__ int kwy_matlab_round(double x) {
