@@ -29,10 +29,10 @@ enum { D4C_HANNING = 1, D4C_BLACKMAN = 2 };
 
 __device__ __forceinline__ double d4c_window(int type, int i, int half, double ratio, int fs, double cf0) {
   double position = (2.0 * (i - half) / ratio) / fs;
-  if (type == D4C_HANNING) return 0.5 * cos(KWY_PI * position * cf0) + 0.5;
+  if (type == D4C_HANNING) return 0.5 * kwy_cos_pi_range(KWY_PI * position * cf0) + 0.5;
   // Blackman: the second harmonic through the double-angle identity (one cos instead of two;
   // differs from cos(2x) by <= 2 ulp of the window value)
-  const double c1 = cos(KWY_PI * position * cf0);
+  const double c1 = kwy_cos_pi_range(KWY_PI * position * cf0);
   return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
 }
 
@@ -314,7 +314,9 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
   double *red = tot + NT;                    // 16
   double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
   uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);  // KWY_EBASE_WORDS
-  kwy_c *twL = (kwy_c *)(e + KWY_EBASE_WORDS);   // H/16 entries: exp(-2 pi i k / (N/2)), k < N/16
+  kwy_c *twL = (kwy_c *)(e + KWY_EBASE_WORDS);   // H/8 entries: exp(-2 pi i k / H), k < H/8
+  // Nuttall window of the band loop, <= 1023 doubles: for N = 4096 in the idle tail of the overlay
+  double *nutw = (LOG2N == 12) ? Bd + (2 * H + 2) : (double *)(twL + H / 8);
   uint32_t *hist = (uint32_t *)B;            // KWY_SELECT_WORDS(NT), band loop only
   // centroid phase only: bins 0..H/2 in Dv (H+2 doubles = H/2+1 complex), the rest behind B
   kwy_c *X1s = (kwy_c *)Dv;
@@ -337,10 +339,6 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
   // exp(-2 pi i k / N) of "my" spectrum bins k = tid + NT*r is this times an 8th root of unity
   const kwy_c twb = twN[tid];
   constexpr int OCT = 8 * NT / N;
-  // Nuttall window of the band loop (window_length <= 2*NT)
-  double nutr[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) nutr[r] = (tid + NT * r < p.window_length) ? nuttall[tid + NT * r] : 0.0;
   __syncthreads();
   const int wl4 = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0) * 2 + 1;
   const int c = (3 * wl4 + NT - 1) / NT;  // draws per thread, <= C
@@ -430,18 +428,35 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
 
   D4C_STAMP(10);
   // ---- coarse aperiodicity per band
+  for (int i = tid; i < p.window_length; i += NT) nutw[i] = nuttall[i];
+  __syncthreads();
   const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
   const int half_window_length = p.window_length / 2;
   for (int b = 0; b < p.nbands; ++b) {
     const int center = (int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs);
+    const double *Dc = Dv + (center - half_window_length);
+    if (p.window_length <= 2 * (H / 8) + 1) {
+      // only the first H/8 (+1) packed points are non-zero: the first pass needs no input buffer
+      kwy_c a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
+      if (tid < H / 8) {
+        // nutr[] holds nuttall[tid], nuttall[tid + NT]; elements 2 tid, 2 tid + 1 come from LDS-resident copies
+        a0.x = (2 * tid < p.window_length) ? Dc[2 * tid] * nutw[2 * tid] : 0.0;
+        a0.y = (2 * tid + 1 < p.window_length) ? Dc[2 * tid + 1] * nutw[2 * tid + 1] : 0.0;
+        if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * nutw[2 * (H / 8)];
+      }
+      if (b == 0) D4C_STAMP(11);
+      kwy_fft_pass8_first_sparse<LOG2N - 1, NT, false>(B, twL, a0, a1);
+      kwy_fft_inplace_rest<LOG2N - 1, NT, false>(B, twL);
+    } else {
 #pragma unroll
-    for (int r = 0; r < E; ++r) {
-      const int j = tid + NT * r;
-      Bd[j] = (r < 2 && j <= half_window_length * 2) ? Dv[center - half_window_length + j] * nutr[r < 2 ? r : 0] : 0.0;
+      for (int r = 0; r < E; ++r) {
+        const int j = tid + NT * r;
+        Bd[j] = (j < p.window_length) ? Dc[j] * nutw[j] : 0.0;
+      }
+      __syncthreads();
+      if (b == 0) D4C_STAMP(11);
+      kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
     }
-    __syncthreads();
-    if (b == 0) D4C_STAMP(11);
-    kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
     if (b == 0) D4C_STAMP(12);
     // CPU: power spectrum, sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
     unsigned long long key[RK];
@@ -498,7 +513,7 @@ static constexpr size_t d4c_body_lds() {
   constexpr int N = 1 << LOG2N, H = N / 2;
   // Dv | overlay (B, or P + S, or the select histograms) | tot | red | coarse | e
   return sizeof(double) * ((H + 2) + d4c_overlay_doubles(H) + D4C_NT + 16 + D4C_MAX_BANDS + 2) +
-         sizeof(uint32_t) * KWY_EBASE_WORDS + sizeof(kwy_c) * (H / 8);
+         sizeof(uint32_t) * KWY_EBASE_WORDS + sizeof(kwy_c) * (H / 8) + (LOG2N == 12 ? 0 : sizeof(double) * 1024);
 }
 
 // ------------------------------------------------------------------ host side

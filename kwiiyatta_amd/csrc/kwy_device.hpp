@@ -99,6 +99,35 @@ __device__ __forceinline__ kwy_rng kwy_rng_combine(const uint32_t *e, uint4 c) {
   return r;
 }
 
+// ------------------------------------------------------------------ cos on [-pi, pi]
+// The analysis windows evaluate cos() a few thousand times per frame with arguments that never
+// leave [-pi, pi] (up to rounding).  Two-constant Cody-Waite reduction by pi/2 and the fdlibm
+// kernel polynomials: < 1 ulp, a quarter of the instructions of the general-range routine.
+__device__ __forceinline__ double kwy_cos_pi_range(double x) {
+  const double ax = fabs(x);
+  const double kf = rint(ax * 6.36619772367581382433e-01);  // 0, 1 or 2 (3 if x is a hair beyond pi... )
+  const int k = (int)kf;
+  double y = ax - kf * 1.57079632673412561417e+00;
+  y = y - kf * 6.07710050650619224932e-11;
+  const double z = y * y;
+  // sin kernel
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sn = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
+  // cos kernel
+  const double rc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 +
+                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cs = w + (((1.0 - w) - hz) + z * rc);
+  // cos(ax) = cos(y + k pi/2)
+  const double v = (k & 1) ? sn : cs;
+  return ((k + 1) & 2) ? -v : v;
+}
+
 // ------------------------------------------------------------ block reductions
 __device__ __forceinline__ double kwy_wave_sum(double v) {
 #pragma unroll
@@ -198,7 +227,19 @@ __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RM
     for (int r = 0; r < RMAX; ++r) {
       int i = tid + NT * r;
       bool match = i < n && (round == 0 || (key[r] >> (shift + 8)) == (prefix >> (shift + 8)));
-      if (match) atomicAdd(&h[wv * 256 + (int)((key[r] >> shift) & 255ull)], 1u);
+      // spectra are smooth: most lanes of a wavefront carry the same leading digits, and 64
+      // atomics on one LDS word serialise.  The lanes that share the first matching lane's digit
+      // are counted with one atomic, the others go one by one.
+      const int d = (int)((key[r] >> shift) & 255ull);
+      const unsigned long long mm = __ballot(match);
+      if (mm != 0ull) {
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+        const int d0 = __builtin_amdgcn_readlane(d, leader);
+        const bool same = match && d == d0;
+        const unsigned long long ms = __ballot(same);
+        if (lane == leader) atomicAdd(&h[wv * 256 + d0], (uint32_t)__popcll(ms));
+        if (match && !same) atomicAdd(&h[wv * 256 + d], 1u);
+      }
     }
     __syncthreads();
     if (wv == 0) {
@@ -461,6 +502,47 @@ __device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict_
     }
   }
   __syncthreads();
+}
+
+// First radix-8 pass (S = 1) of a transform whose input is zero except for x[0 .. H/8]: thread j
+// supplies x[j] in a0, thread 0 also x[H/8] in a1.  The butterfly degenerates to a copy (every
+// output of thread j is x[j] times its twiddle), so nothing is read from LDS and no barrier is
+// needed before the stores -- as long as the buffer itself is free.  Ends with a barrier.
+template <int LOG2H, int NT, bool INV>
+__device__ __forceinline__ void kwy_fft_pass8_first_sparse(kwy_c *z, const kwy_c *__restrict__ tw, kwy_c a0, kwy_c a1) {
+  constexpr int H = 1 << LOG2H, Q = H / 8;
+  static_assert(Q <= NT, "one butterfly per thread");
+  const int j = threadIdx.x;
+  if (j < Q) {
+    kwy_c a[8];
+    if (j == 0) {
+      a[0] = a0; a[1] = a1;
+#pragma unroll
+      for (int m = 2; m < 8; ++m) a[m] = {0.0, 0.0};
+      kwy_dft8<INV>(a);
+    } else {
+      kwy_c w1 = tw[j];
+      if (INV) w1.y = -w1.y;
+      const kwy_c w2 = cmul(w1, w1), w4 = cmul(w2, w2);
+      const kwy_c w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
+      const kwy_c w7 = cmul(w4, w3);
+      a[0] = a0; a[1] = cmul(w1, a0); a[2] = cmul(w2, a0); a[3] = cmul(w3, a0);
+      a[4] = cmul(w4, a0); a[5] = cmul(w5, a0); a[6] = cmul(w6, a0); a[7] = cmul(w7, a0);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) z[8 * j + (m ^ (j & 7))] = a[m];
+  }
+  __syncthreads();
+}
+
+// the remaining passes after kwy_fft_pass8_first_sparse
+template <int LOG2H, int NT, bool INV>
+__device__ inline void kwy_fft_inplace_rest(kwy_c *z, const kwy_c *__restrict__ tw) {
+  kwy_fft_pass8<LOG2H, 3, NT, INV>(z, tw);
+  kwy_fft_pass8<LOG2H, 6, NT, INV>(z, tw);
+  if constexpr (LOG2H == 12) kwy_fft_pass8<LOG2H, 9, NT, INV>(z, tw);
+  if constexpr (LOG2H == 11) kwy_fft_tail<LOG2H, 2, NT, INV>(z);
+  if constexpr (LOG2H == 10) kwy_fft_tail<LOG2H, 1, NT, INV>(z);
 }
 
 // closing radix-4 (TAIL = 2) or radix-2 (TAIL = 1) pass: sub-transform stride H/4 resp. H/2, no twiddles
