@@ -41,6 +41,11 @@ def _preload_hip_runtime():
                 pass
 
 
+# The batch drivers give every utterance its own HIP stream; streams beyond the runtime's default of
+# 4 hardware queues would share a queue and run one after the other.  Only effective if the HIP
+# runtime has not started yet (it reads the variable once); an explicit setting wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')
+
 _preload_hip_runtime()
 lib = ctypes.CDLL(_SO)
 

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_rng_ebase(const uint64_t *__res
   const int64_t item = (int64_t)blockIdx.x * KWY_WAVES + wv;
   if (item >= n) return;
   const uint64_t base_draws = base_ptr ? *base_ptr : 0ull;
+  if (offsets[item] == ~0ull) return;  // item without draws
   uint64_t steps = 12ull * (base_draws + offsets[item]);
   uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
   kwy_wave_jump(s, steps, pow2);

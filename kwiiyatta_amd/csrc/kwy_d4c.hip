@@ -36,6 +36,18 @@ __device__ __forceinline__ double d4c_window(int type, int i, int half, double r
   return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
 }
 
+// interp1Q with the grid step given as its reciprocal (two divisions per output bin saved;
+// the position differs from (xi - x0) / shift by an ulp, the interpolant is continuous)
+__device__ __forceinline__ double d4c_interp1q_inv(double x0, double inv_shift, const double *y, int x_length,
+                                                   double xi) {
+  double r = (xi - x0) * inv_shift;
+  int base = (int)r;
+  double frac = r - base;
+  double y0 = y[base];
+  double dy = (base >= x_length - 1) ? 0.0 : y[base + 1] - y0;
+  return y0 + dy * frac;
+}
+
 __device__ __forceinline__ double d4c_interp1q(double x0, double shift, const double *y, int x_length,
                                                double xi) {
   double r = (xi - x0) / shift;
@@ -77,12 +89,12 @@ __device__ inline void d4c_linear_smoothing(const double *in, double *out, doubl
   __syncthreads();
   kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
-  const double dfi = (double)fs / N;
+  const double inv_dfi = (double)N / fs;
   for (int k = threadIdx.x; k <= H; k += NT) {
     double fa = (double)k / N * fs - width / 2.0;
-    double low = d4c_interp1q(origin, dfi, S, L, fa);
+    double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     fa += width;
-    double high = d4c_interp1q(origin, dfi, S, L, fa);
+    double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     out[k] = (high - low) / width;
   }
   __syncthreads();
@@ -97,6 +109,16 @@ __global__ void k_d4c_lt_counts(const double *__restrict__ f0, int64_t T, int fs
   if (f == 0.0) { counts[i] = 0; return; }
   double cf0 = f > 40.0 ? f : 40.0;
   counts[i] = (uint32_t)(kwy_matlab_round(1.5 * fs / cf0) * 2 + 1);
+}
+
+// draw offsets of the three windows of every gated frame (~0 = no work) from the frame offsets
+__global__ void k_d4c_window_offsets(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ counts,
+                                     int64_t T, uint64_t *__restrict__ offs3) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T) return;
+  const uint32_t wl = counts[i] / 3;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) offs3[3 * i + w] = wl ? offs[i] + (uint64_t)w * wl : ~0ull;
 }
 
 // per-frame draw counts for the general body (0 for ungated frames)
@@ -196,24 +218,48 @@ struct d4c_params {
 
 // One WORLD window of the frame: x around `pos`, times the window function, plus the
 // safeguard noise, DC removed with the window as weight.  Element i = tid + NT*r
-// stays in av[r] (0 beyond the window); Bd (N doubles of LDS, free on entry) only
-// carries the noise draws from the threads that drew them (thread t holds draws
-// [c*t, c*t+c) of the frame's 3*wl, window `which` uses [which*wl, (which+1)*wl))
-// to the threads that use them.  `normalise` scales to unit power (GetCentroid).
-template <int N, int C, int NT>
+// stays in av[r] (0 beyond the window).  The window's wl noise draws are a contiguous piece
+// of the serial stream; `eb` holds the generator's extended state sequence at the piece's
+// start, thread t jumps to draw c*t and produces c = ceil(wl/NT) draws, which travel through
+// Bd (N doubles of LDS, free on entry) to the threads that use them.  `normalise` scales to
+// unit power (GetCentroid).
+template <int N, int NT>
 __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
-                                                 double pos, int type, int which, int c,
-                                                 const uint32_t (&nzraw)[C], double *Bd, bool normalise,
-                                                 double *red, double (&av)[N / NT]) {
+                                                 double pos, int type, const uint32_t *__restrict__ eb,
+                                                 const uint4 *__restrict__ poly, uint32_t *e, uint4 *jtab,
+                                                 double *Bd, bool normalise, double *red,
+                                                 double (&av)[N / NT]) {
   constexpr int E = N / NT;
-  const int tid = threadIdx.x;
+  const int tid = kwy_tid_opaque();
+  // The window function is the same for the two centroid windows; left alone, the compiler
+  // evaluates it once and carries 2 x E doubles per thread across the FFTs (through scratch
+  // memory).  Re-evaluating it is far cheaper, so cf0 is made opaque here.
+  asm volatile("" : "+s"(cf0));
   const int half = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0);
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(pos * p.fs + 0.001);
+  // the samples are independent of the noise: get them on their way first
+  double xv[E];
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    int d = c * tid + j - which * wl;
-    if (j < c && d >= 0 && d < wl) Bd[d] = nzraw[j] / 268435456.0 - 6.0;
+  for (int r = 0; r < E; ++r) {
+    const int i = tid + NT * r;
+    xv[r] = (i < wl) ? x[min(p.x_length - 1, max(0, origin + i - half))] : 0.0;
+  }
+  for (int i = tid; i < KWY_EBASE_WORDS; i += NT) e[i] = eb[i];
+  __syncthreads();
+  kwy_rng_build_table<NT>(e, jtab);
+  __syncthreads();
+  {
+    const int c = (wl + NT - 1) / NT;  // <= E
+    kwy_rng rng = kwy_rng_combine_table(jtab, poly[(c - 1) * NT + tid]);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      if (j < c) {
+        const double nzv = kwy_rng_randn(rng);
+        const int d = c * tid + j;
+        if (d < wl) Bd[d] = nzv;
+      }
+    }
   }
   __syncthreads();
   double s1 = 0.0, s2 = 0.0;
@@ -223,8 +269,7 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, c
     double v = 0.0;
     if (i < wl) {
       const double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
-      int idx = min(p.x_length - 1, max(0, origin + i - half));
-      v = x[idx] * w;
+      v = xv[r] * w;
       v = v + Bd[i] * D4C_SAFE;
       Bd[i] = w;                       // the window value takes the place of the consumed draw
       s1 += v; s2 += w;
@@ -268,12 +313,12 @@ __device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot,
   __syncthreads();
   kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
-  const double dfi = (double)fs / N;
+  const double inv_dfi = (double)N / fs;
   for (int k = threadIdx.x; k <= H; k += NT) {
     double fa = (double)k / N * fs - width / 2.0;
-    double low = d4c_interp1q(origin, dfi, S, L, fa);
+    double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     fa += width;
-    double high = d4c_interp1q(origin, dfi, S, L, fa);
+    double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     io[k] = io[k] - (high - low) / width;
   }
   __syncthreads();
@@ -300,23 +345,29 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
     const double *__restrict__ nuttall, double *__restrict__ out, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int NT = D4C_NT;
-  constexpr int C = 3 * N / NT;            // draws per thread (3 windows, each shorter than N)
   constexpr int E = N / NT;                // window elements per thread
   constexpr int RK = (H + 1 + NT - 1) / NT;  // spectrum bins per thread
 #define D4C_STAMP(n) do { if (dbg && threadIdx.x == 0 && blockIdx.x == (unsigned)dbg[63]) dbg[n] = clock64(); } while (0)
+  // small arrays first: everything but the tail of the overlay then sits below 64 KB, within
+  // reach of the 16-bit offset field of the ds_ instructions (one address register per thread
+  // instead of one per array)
   extern __shared__ double smem[];
-  double *Dv = smem;                         // H+2
-  kwy_c *B = (kwy_c *)(Dv + (H + 2));        // H+1 complex
-  double *Bd = (double *)B;
-  double *P = Bd;                            // H+1 doubles (+1 pad)
-  double *S = Bd + (H + 2);                  // <= 2H+3 doubles: reaches past B, see d4c_body_lds()
-  double *tot = Bd + d4c_overlay_doubles(H);  // NT
+  double *tot = smem;                        // NT
   double *red = tot + NT;                    // 16
   double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
   uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);  // KWY_EBASE_WORDS
   kwy_c *twL = (kwy_c *)(e + KWY_EBASE_WORDS);   // H/8 entries: exp(-2 pi i k / H), k < H/8
+  double *nut_small = (double *)(twL + H / 8);   // 1024 doubles, only for N < 4096
+  double *Dv = nut_small + (LOG2N == 12 ? 0 : 1024);  // H+2
+  kwy_c *B = (kwy_c *)(Dv + (H + 2));        // H+1 complex
+  double *Bd = (double *)B;
+  double *P = Bd;                            // H+1 doubles (+1 pad)
+  double *S = Bd + (H + 2);                  // <= 2H+3 doubles: reaches past B, see d4c_body_lds()
+  // RNG jump table of the window phases (8 KB): the tail of the overlay for N = 4096 (X1s' second
+  // piece lives there too, but only between a window's two FFTs), else the Nuttall area
+  uint4 *jtab = (uint4 *)((LOG2N == 12) ? Bd + (2 * H + 2) : nut_small);
   // Nuttall window of the band loop, <= 1023 doubles: for N = 4096 in the idle tail of the overlay
-  double *nutw = (LOG2N == 12) ? Bd + (2 * H + 2) : (double *)(twL + H / 8);
+  double *nutw = (LOG2N == 12) ? Bd + (2 * H + 2) : nut_small;
   uint32_t *hist = (uint32_t *)B;            // KWY_SELECT_WORDS(NT), band loop only
   // centroid phase only: bins 0..H/2 in Dv (H+2 doubles = H/2+1 complex), the rest behind B
   kwy_c *X1s = (kwy_c *)Dv;
@@ -324,28 +375,22 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
 
   const int tid = threadIdx.x;
   const int64_t frame = blockIdx.x;
-  const double f0v = f0[frame];
+  const double f0v = kwy_uniform(f0[frame]);
   double *o = out + frame * p.K;
-  if (f0v == 0.0 || ap0[frame] <= p.threshold) {
+  if (f0v == 0.0 || kwy_uniform(ap0[frame]) <= p.threshold) {
     for (int k = tid; k < p.K; k += NT) o[k] = 1.0 - D4C_SAFE;
     return;
   }
-  const double cf0 = f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0;
-  const double pos = tpos[frame];
+  const double cf0 = kwy_uniform(f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0);
+  const double pos = kwy_uniform(tpos[frame]);
 
   D4C_STAMP(0);
-  for (int i = tid; i < KWY_EBASE_WORDS; i += NT) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
   for (int i = tid; i < H / 8; i += NT) twL[i] = twH[i];
   // exp(-2 pi i k / N) of "my" spectrum bins k = tid + NT*r is this times an 8th root of unity
   const kwy_c twb = twN[tid];
   constexpr int OCT = 8 * NT / N;
+  const uint32_t *eb = ebase + (size_t)frame * 3 * KWY_EBASE_WORDS;  // one extended state per window
   __syncthreads();
-  const int wl4 = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0) * 2 + 1;
-  const int c = (3 * wl4 + NT - 1) / NT;  // draws per thread, <= C
-  kwy_rng rng = kwy_rng_combine(e, poly[(c - 1) * NT + tid]);
-  uint32_t nzraw[C];
-#pragma unroll
-  for (int j = 0; j < C; ++j) nzraw[j] = (j < c) ? kwy_rng_randn_raw(rng) : 0u;
 
   D4C_STAMP(1);
   // ---- static centroid: two temporal centroids at pos -+ 0.25/f0, each Re(X2 conj X1) of the
@@ -353,8 +398,9 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
   double cen[RK];
   double av[E];
   for (int which = 0; which < 2; ++which) {
+    const int tid = kwy_tid_opaque();
     double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-    d4c_frame_window<N, C, NT>(x, p, cf0, cpos, D4C_BLACKMAN, which, c, nzraw, Bd, true, red, av);
+    d4c_frame_window<N, NT>(x, p, cf0, cpos, D4C_BLACKMAN, eb + which * KWY_EBASE_WORDS, poly, e, jtab, Bd, true, red, av);
 #pragma unroll
     for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];   // each thread overwrites the draws it consumed
     __syncthreads();
@@ -393,7 +439,7 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
 
   D4C_STAMP(6);
   // ---- smoothed power spectrum
-  d4c_frame_window<N, C, NT>(x, p, cf0, pos, D4C_HANNING, 2, c, nzraw, Bd, false, red, av);
+  d4c_frame_window<N, NT>(x, p, cf0, pos, D4C_HANNING, eb + 2 * KWY_EBASE_WORDS, poly, e, jtab, Bd, false, red, av);
 #pragma unroll
   for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];
   __syncthreads();
@@ -433,6 +479,7 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
   const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
   const int half_window_length = p.window_length / 2;
   for (int b = 0; b < p.nbands; ++b) {
+    const int tid = kwy_tid_opaque();
     const int center = (int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs);
     const double *Dc = Dv + (center - half_window_length);
     if (p.window_length <= 2 * (H / 8) + 1) {
@@ -544,7 +591,7 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly_multi(ctx, 3 * N / D4C_NT, D4C_NT, &poly));
+  KWY_TRY(kwy_get_poly_multi(ctx, N / D4C_NT, D4C_NT, &poly));
   size_t lds = d4c_body_lds<LOG2N>();
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -575,7 +622,8 @@ static int get_nuttall(kwy_ctx *ctx, int window_length, const double **out) {
 
 static size_t d4c_scratch_bytes(int64_t T) {
   return 2 * (kwy_pad(sizeof(uint32_t) * T) + kwy_pad(sizeof(uint64_t) * (T + 1))) +
-         kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * T) + kwy_pad(sizeof(double) * T);
+         kwy_pad(sizeof(uint64_t) * 3 * T) + kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * 3 * T) +
+         kwy_pad(sizeof(double) * T);
 }
 
 static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
@@ -603,9 +651,10 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   uint32_t *counts = kwy_arena<uint32_t>(ctx, T);
   uint64_t *offs_lt = kwy_arena<uint64_t>(ctx, T + 1);
   uint64_t *offs_b = kwy_arena<uint64_t>(ctx, T + 1);
-  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * T);
+  uint64_t *offs3 = kwy_arena<uint64_t>(ctx, 3 * T);
+  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * 3 * T);
   double *ap0 = kwy_arena<double>(ctx, T);
-  if (!counts || !offs_lt || !offs_b || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
+  if (!counts || !offs_lt || !offs_b || !offs3 || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
   const double *nuttall;
   KWY_TRY(get_nuttall(ctx, p.window_length, &nuttall));
   const unsigned gb = (unsigned)((T + 255) / 256);
@@ -625,7 +674,9 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
                      threshold, counts);
   KWY_HIP(hipGetLastError());
   KWY_TRY(kwy_launch_scan(ctx, counts, offs_b, T));
-  KWY_TRY(kwy_launch_ebase(ctx, offs_b, offs_lt + T, T, ebase));
+  hipLaunchKernelGGL(k_d4c_window_offsets, dim3(gb), dim3(256), 0, ctx->stream, offs_b, counts, T, offs3);
+  KWY_HIP(hipGetLastError());
+  KWY_TRY(kwy_launch_ebase(ctx, offs3, offs_lt + T, 3 * T, ebase));
   switch (l4) {
     case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
     case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);

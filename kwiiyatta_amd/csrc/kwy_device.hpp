@@ -99,6 +99,56 @@ __device__ __forceinline__ kwy_rng kwy_rng_combine(const uint32_t *e, uint4 c) {
   return r;
 }
 
+// threadIdx.x behind an optimisation barrier: address arithmetic derived from it is redone where it
+// is used instead of being computed once per kernel and carried (spilled) across every phase.
+__device__ __forceinline__ int kwy_tid_opaque() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
+// A value every lane holds identically, moved to scalar registers (so that everything
+// derived from it is scalar too and stays out of the vector register budget).
+__device__ __forceinline__ double kwy_uniform(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The same combination four coefficient bits at a time: for every nibble position g (32 of
+// them) and nibble value v the XOR of the <= 4 selected state vectors is tabulated once per
+// stream position (512 entries of 16 B, built by the whole workgroup from e[]), after which a
+// thread's jump is 32 table reads + XORs instead of 128 select-and-XOR steps.
+template <int NT>
+__device__ __forceinline__ void kwy_rng_build_table(const uint32_t *e, uint4 *tab) {
+  for (int id = threadIdx.x; id < 512; id += NT) {
+    const int g = id >> 4, v = id & 15;
+    const uint32_t *q = e + 4 * g;
+    uint32_t x = 0, y = 0, z = 0, w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t m = 0u - ((v >> b) & 1u);
+      x ^= q[b] & m; y ^= q[b + 1] & m; z ^= q[b + 2] & m; w ^= q[b + 3] & m;
+    }
+    tab[id] = make_uint4(x, y, z, w);
+  }
+}
+
+__device__ __forceinline__ kwy_rng kwy_rng_combine_table(const uint4 *tab, uint4 c) {
+  kwy_rng r = {0, 0, 0, 0};
+  const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const uint4 t = tab[(8 * k + n) * 16 + ((cw[k] >> (4 * n)) & 15u)];
+      r.x ^= t.x; r.y ^= t.y; r.z ^= t.z; r.w ^= t.w;
+    }
+  }
+  return r;
+}
+
 // ------------------------------------------------------------------ cos on [-pi, pi]
 // The analysis windows evaluate cos() a few thousand times per frame with arguments that never
 // leave [-pi, pi] (up to rounding).  Two-constant Cody-Waite reduction by pi/2 and the fdlibm
@@ -129,9 +179,53 @@ __device__ __forceinline__ double kwy_cos_pi_range(double x) {
 }
 
 // ------------------------------------------------------------ block reductions
+// Cross-lane moves through the DPP path of the vector ALU (a few cycles) rather than
+// ds_bpermute (__shfl_*: an LDS round trip per step, which is what the reductions and scans
+// between two barriers used to spend most of their time on).  CTRL: 0x100+n row_shl:n (lane i
+// reads lane i+n of its 16-lane row), 0x110+n row_shr:n, 0x142 row_bcast:15, 0x143 row_bcast:31.
+// Lanes without a source (row boundary, masked row) read 0.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t kwy_dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double kwy_dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double kwy_readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the wavefront; every lane gets the result
 __device__ __forceinline__ double kwy_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  v += kwy_dpp_f64<0x101>(v);
+  v += kwy_dpp_f64<0x102>(v);
+  v += kwy_dpp_f64<0x104>(v);
+  v += kwy_dpp_f64<0x108>(v);  // lane 0 of every row now holds its row's sum
+  return (kwy_readlane_f64(v, 0) + kwy_readlane_f64(v, 16)) + (kwy_readlane_f64(v, 32) + kwy_readlane_f64(v, 48));
+}
+
+// inclusive prefix sums over the wavefront
+__device__ __forceinline__ uint32_t kwy_wave_scan_u32(uint32_t v) {
+  v += kwy_dpp_u32<0x111>(v);
+  v += kwy_dpp_u32<0x112>(v);
+  v += kwy_dpp_u32<0x114>(v);
+  v += kwy_dpp_u32<0x118>(v);
+  v += kwy_dpp_u32<0x142, 0xa>(v);  // rows 1 and 3 += last lane of the row before
+  v += kwy_dpp_u32<0x143, 0xc>(v);  // rows 2 and 3 += lane 31
+  return v;
+}
+__device__ __forceinline__ double kwy_wave_scan_f64(double v) {
+  v += kwy_dpp_f64<0x111>(v);
+  v += kwy_dpp_f64<0x112>(v);
+  v += kwy_dpp_f64<0x114>(v);
+  v += kwy_dpp_f64<0x118>(v);
+  v += kwy_dpp_f64<0x142, 0xa>(v);
+  v += kwy_dpp_f64<0x143, 0xc>(v);
   return v;
 }
 
@@ -166,12 +260,7 @@ __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
     double acc = 0.0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) { acc += tot[PER * t + q]; a[q] = acc; }
-    double inc = acc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      double u = __shfl_up(inc, o);
-      if (t >= o) inc += u;
-    }
+    const double inc = kwy_wave_scan_f64(acc);
     const double excl = inc - acc;  // sum of the lanes before this one
     tot[PER * t] = excl;
 #pragma unroll
@@ -203,63 +292,51 @@ __device__ __forceinline__ void kwy_block_sum2(double a, double b, double *red, 
 // in key[] (~0 for slots beyond n).  An MSB-first radix select (up to 8 rounds of
 // 8 bits; the patterns order like the values for x >= 0) finds the m-th smallest
 // value v*; then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.  Two barriers per
-// round: the histograms and the control words are double-buffered.
-// hist: 2*(NT/64)*256 + 16 uint32 of LDS (8-byte aligned) that no thread touches
+// round: the 256-bin histogram and the control words are double-buffered.
+// hist: KWY_SELECT_WORDS uint32 of LDS (8-byte aligned) that no thread touches
 // any more when the call starts; red: >= 2*NT/64 doubles.
-#define KWY_SELECT_WORDS(NT) (2 * ((NT) / 64) * 256 + 16)
+#define KWY_SELECT_WORDS(NT) (2 * 256 + 16)
 template <int RMAX, int NT = KWY_THREADS>
 __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RMAX], int n, int m,
                                               uint32_t *hist, double *red, double *sum_small,
                                               double *sum_all) {
-  constexpr int NW = NT / 64, HW = NW * 256;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  uint32_t *ctlb = hist + 2 * HW;  // 2 x {digit, new rank, population}, then one 64-bit key
-  for (int b = tid; b < HW; b += NT) hist[b] = 0;
+  uint32_t *ctlb = hist + 2 * 256;  // 2 x {digit, new rank, population}, then one 64-bit key
+  if (tid < 256) hist[tid] = 0;
   __syncthreads();
   unsigned long long prefix = 0ull;
   int kk = m;  // 1-based rank of the wanted element among the still-matching keys
+  bool alive[RMAX];  // key still carries the prefix found so far
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) alive[r] = tid + NT * r < n;
   for (int round = 0; round < 8; ++round) {
     const int shift = 56 - 8 * round;
-    uint32_t *h = hist + (round & 1) * HW, *hn = hist + ((round + 1) & 1) * HW;
+    uint32_t *h = hist + (round & 1) * 256, *hn = hist + ((round + 1) & 1) * 256;
     uint32_t *ctl = ctlb + (round & 1) * 4;
-    for (int b = tid; b < HW; b += NT) hn[b] = 0;
+    if (tid < 256) hn[tid] = 0;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
-      int i = tid + NT * r;
-      bool match = i < n && (round == 0 || (key[r] >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (NT * r + (tid & ~63) >= n) continue;  // nothing in this slot for the whole wavefront
       // spectra are smooth: most lanes of a wavefront carry the same leading digits, and 64
-      // atomics on one LDS word serialise.  The lanes that share the first matching lane's digit
+      // atomics on one LDS word serialise.  The lanes that share the first live lane's digit
       // are counted with one atomic, the others go one by one.
       const int d = (int)((key[r] >> shift) & 255ull);
-      const unsigned long long mm = __ballot(match);
+      const unsigned long long mm = __ballot(alive[r]);
       if (mm != 0ull) {
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
         const int d0 = __builtin_amdgcn_readlane(d, leader);
-        const bool same = match && d == d0;
+        const bool same = alive[r] && d == d0;
         const unsigned long long ms = __ballot(same);
-        if (lane == leader) atomicAdd(&h[wv * 256 + d0], (uint32_t)__popcll(ms));
-        if (match && !same) atomicAdd(&h[wv * 256 + d], 1u);
+        if (lane == leader) atomicAdd(&h[d0], (uint32_t)__popcll(ms));
+        if (alive[r] && !same) atomicAdd(&h[d], 1u);
       }
     }
     __syncthreads();
     if (wv == 0) {
-      uint32_t c[4];
-      uint32_t tot = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint32_t a = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) a += h[w * 256 + 4 * lane + q];
-        c[q] = a;
-        tot += a;
-      }
-      uint32_t inc = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        uint32_t u = __shfl_up(inc, o);
-        if (lane >= o) inc += u;
-      }
-      uint32_t before = inc - tot;
+      const uint4 c4 = ((const uint4 *)h)[lane];
+      const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+      const uint32_t tot = c[0] + c[1] + c[2] + c[3];
+      uint32_t before = kwy_wave_scan_u32(tot) - tot;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if ((uint32_t)kk > before && (uint32_t)kk <= before + c[q]) {
@@ -271,16 +348,17 @@ __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RM
       }
     }
     __syncthreads();
-    prefix |= (unsigned long long)ctl[0] << shift;
+    const int chosen = (int)ctl[0];
+    prefix |= (unsigned long long)chosen << shift;
     kk = (int)ctl[1];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) alive[r] = alive[r] && (int)((key[r] >> shift) & 255ull) == chosen;
     if (ctl[2] == 1u && round < 7) {
       // exactly one key carries this prefix: it IS the wanted element, skip the remaining rounds
       unsigned long long *k64 = (unsigned long long *)(ctlb + 8);
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        int i = tid + NT * r;
-        if (i < n && (key[r] >> shift) == (prefix >> shift)) *k64 = key[r];
-      }
+      for (int r = 0; r < RMAX; ++r)
+        if (alive[r]) *k64 = key[r];
       __syncthreads();
       prefix = *k64;
       kk = 1;
@@ -466,9 +544,10 @@ __device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict_
   constexpr bool LAST = (LOG2S + 3 == LOG2H);
   static_assert(Q >= 64, "transform too short for the radix-8 kernel");
   kwy_c a[IT][8];
+  const int tid = kwy_tid_opaque();
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const int j = threadIdx.x + it * NT;
+    const int j = tid + it * NT;
     if (j < Q) {
       const int swz = (LOG2S == 3) ? ((j >> 3) & 7) : 0;
 #pragma unroll
@@ -490,7 +569,7 @@ __device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict_
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const int j = threadIdx.x + it * NT;
+    const int j = tid + it * NT;
     if (j < Q) {
       const int q = j & (S - 1), p = j >> LOG2S;
       const int o = q + ((8 * p) << LOG2S);
@@ -512,7 +591,7 @@ template <int LOG2H, int NT, bool INV>
 __device__ __forceinline__ void kwy_fft_pass8_first_sparse(kwy_c *z, const kwy_c *__restrict__ tw, kwy_c a0, kwy_c a1) {
   constexpr int H = 1 << LOG2H, Q = H / 8;
   static_assert(Q <= NT, "one butterfly per thread");
-  const int j = threadIdx.x;
+  const int j = kwy_tid_opaque();
   if (j < Q) {
     kwy_c a[8];
     if (j == 0) {
@@ -551,9 +630,10 @@ __device__ __forceinline__ void kwy_fft_tail(kwy_c *z) {
   constexpr int H = 1 << LOG2H, R = 1 << TAIL, Q = H / R;
   constexpr int IT = (Q + NT - 1) / NT;
   kwy_c a[IT][R];
+  const int tid = kwy_tid_opaque();
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const int j = threadIdx.x + it * NT;
+    const int j = tid + it * NT;
     if (j < Q) {
 #pragma unroll
       for (int m = 0; m < R; ++m) a[it][m] = z[j + m * Q];
