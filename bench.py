@@ -181,6 +181,19 @@ def main():
                     a = kernel_ms.setdefault(nme, [0.0, 0])
                     a[0] += ms
                     a[1] += n
+        # the same kernels with the GPU to themselves: one pair, one stream, after the timed region
+        # (per-launch durations inside the timed region include the time a kernel shares the CUs with
+        # the other streams' kernels)
+        alone_ms = {}
+        pipes[0].run(); pipes[0].sync()
+        for nme in names:
+            pipes[0].ctx.profile_read(nme)
+        for _ in range(2):
+            pipes[0].run(); pipes[0].sync()
+        for nme in names:
+            ms, n = pipes[0].ctx.profile_read(nme)
+            if n:
+                alone_ms[nme] = ms / n
         # Frames one launch of a per-frame kernel processes (pair: source and target utterances alternate).
         fpl = float(T) if args.workload == 'utterance' else (pipes[0].src.T + pipes[0].tgt.T) / 2.0
         hop = FS * FRAME_PERIOD / 1000.0
@@ -208,9 +221,14 @@ def main():
                     'frac': (achieved / 8000.0) if achieved else None, 'traffic': traffic,
                     'avg_launch_ms': tot_ms / launches if launches else None, 'launches': launches,
                     'algorithmic_bytes_per_launch': bytes_per_launch,
-                    'note': 'kernel is f64-FFT/LDS bound, not HBM bound; the HBM fraction is reported as asked '
-                            '(DESIGN.md section 5).  traffic = FETCH_SIZE+WRITE_SIZE of profiles/r1_pmc_traffic.json '
-                            'scaled to the frames of one launch; avg_launch_ms is measured while other streams run'}
+                    'alone_avg_launch_ms': alone_ms.get(dom),
+                    'alone_achieved': (bytes_per_launch / (alone_ms[dom] * 1e-3) / 1e9) if dom in alone_ms else None,
+                    'note': 'kernel is bound by f64 FFT arithmetic and barrier latency in LDS, not by HBM; the HBM '
+                            'fraction is reported as asked (DESIGN.md section 5).  traffic = FETCH_SIZE+WRITE_SIZE of '
+                            'profiles/r1_pmc_traffic.json scaled to the frames of one launch.  avg_launch_ms is '
+                            'measured inside the timed region, where a launch shares the CUs with the kernels of '
+                            'the other streams; alone_* is the same kernel measured after the timed region with '
+                            'one stream running'}
         # whole-path algorithmic bytes per source frame
         path_bytes = 36664 if args.workload == 'utterance' else 81000
         out = {
@@ -228,6 +246,7 @@ def main():
             'real_time_factor': value / 200.0,
             'hbm_fraction_whole_path': value / world * path_bytes / 8e12,
             'kernel_ms_per_launch': {k: v[0] / v[1] for k, v in sorted(kernel_ms.items())},
+            'kernel_ms_per_launch_alone': {k: v for k, v in sorted(alone_ms.items())},
             'roofline': roofline,
             'cpu_baseline': None,
         }

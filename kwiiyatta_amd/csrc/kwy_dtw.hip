@@ -127,6 +127,10 @@ __device__ __forceinline__ uint64_t dtw_row_words_end(const uint64_t *__restrict
 // processed by wave k % DTW_WAVES; strip k+1 trails strip k by one 64-step block, synchronised
 // through a progress word in LDS (the boundary row written by strip k is read by strip k+1).
 #define DTW_WAVES 4
+// Steps between two looks at the previous strip's progress.  Strip k+1 trails strip k by the 63
+// steps of the row skew plus one chunk; with 4 wavefronts a wavefront's next strip is ready when it
+// finishes the current one only if 4 x (63 + chunk) stays below the strip length (~300 steps).
+#define DTW_CHUNK 16
 template <bool BND_LDS>
 __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y, const int32_t *__restrict__ lo,
                                               const int32_t *__restrict__ hi,
@@ -140,7 +144,16 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
   extern __shared__ unsigned char bt[];  // DTW_BT_BYTES [+ boundary rows]
   const long long t_start = dbg ? clock64() : 0;
   __shared__ int s_i, s_j, s_n;
-  __shared__ volatile long long s_prog[DTW_WAVES];  // (strip << 32) | (last finished column + 1)
+  // (strip << 32) | (last finished column + 1).  Plain LDS words written/read with relaxed
+  // workgroup-scope atomics: a volatile (generic) access would be a flat_ instruction with a
+  // vmcnt(0) wait behind it, i.e. every progress update would also wait for the distance
+  // prefetches in flight.  Ordering against the boundary-row accesses needs no wait either: the
+  // LDS executes one wavefront's instructions in issue order.
+  __shared__ long long s_prog[DTW_WAVES];
+#define DTW_PROG_LOAD(b) __hip_atomic_load(&s_prog[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define DTW_PROG_STORE(b, v) __hip_atomic_store(&s_prog[b], (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define DTW_RELEASE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); else __threadfence(); } while (0)
+#define DTW_ACQUIRE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); else __threadfence(); } while (0)
   __shared__ double s_last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (*status != 0) { if (threadIdx.x == 0) { *path_len = 0; *out_dist = NAN; } return; }
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
   const int rowlen = len_y + 2;  // boundary rows are indexed by j + 1 (entry 0 is column -1)
   double *const lds_rows = (double *)(bt + DTW_BT_BYTES);
 #define BROW(buf, ix) (BND_LDS ? lds_rows[(buf) * rowlen + (ix)] : bnd_global[(size_t)(buf) * rowlen + (ix)])
-  if (threadIdx.x < DTW_WAVES) s_prog[threadIdx.x] = -1;
+  if (threadIdx.x < DTW_WAVES) DTW_PROG_STORE(threadIdx.x, -1);
   __syncthreads();
   const int nstrips = (len_x + 63) / 64;
   for (int k = wv; k < nstrips; k += DTW_WAVES) {
@@ -172,23 +185,31 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     // lane 0's diagonal input at the first step: D[i0-1][jmin-1]
     double up0_prev = INF;
     if (k == 0) { if (jmin == 0) up0_prev = 0.0; }  // D[-1][-1] = 0: the origin of the recurrence
-    double curd[8], nxtd[8];
+    // distances of this lane's row, 8 steps per block, fetched two blocks ahead: the loads of
+    // block b+2 are still behind the predecessor-word stores of blocks b and b+1 in the memory
+    // queue, so that waiting for block b+1's data never waits for the youngest requests
+    double curd[8], nxtd[8], nx2d[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) curd[u] = drow[min(max(u - shift, 0), rwc)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) nxtd[u] = drow[min(max(8 + u - shift, 0), rwc)];
     bool first_chunk = true;
-    for (int c0 = 0; c0 < nsteps; c0 += 64) {
+    for (int c0 = 0; c0 < nsteps; c0 += DTW_CHUNK) {
       // wait until the previous strip's last row has produced the columns this chunk reads
       if (k > 0) {
-        const int need = min(jmin + c0 + 63, phi);  // last column we may read (valid ones only)
+        const int need = min(jmin + c0 + DTW_CHUNK - 1, phi);  // last column we may read (valid ones only)
+        const long long tw0 = dbg ? clock64() : 0;
         while (true) {
-          const long long pv = s_prog[pbuf];
+          const long long pv = DTW_PROG_LOAD(pbuf);
           const int ps = (int)(pv >> 32), pc = (int)(pv & 0xffffffffll) - 1;
           if (ps > k - 1 || (ps == k - 1 && pc >= need)) break;
           __builtin_amdgcn_s_sleep(2);
         }
-        if (BND_LDS) __threadfence_block(); else __threadfence();
+        DTW_ACQUIRE();
+        if (dbg && lane == 0) { atomicAdd((unsigned long long *)&dbg[8 + wv], (unsigned long long)(clock64() - tw0)); }
       }
-      // the boundary values lane 0 needs in the next 64 steps: one read per lane
+      if (dbg && lane == 0) atomicAdd((unsigned long long *)&dbg[12 + wv], 1ull);
+      // the boundary values lane 0 needs in the next DTW_CHUNK steps: one read per lane
       const int jb = jmin + c0 + lane;
       double bchunk = INF;
       if (k > 0 && jb >= plo && jb <= phi) bchunk = BROW(pbuf, jb + 1);
@@ -197,9 +218,9 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
         up0_prev = (jd >= plo && jd <= phi) ? BROW(pbuf, jd + 1) : INF;
         first_chunk = false;
       }
-      for (int s0 = c0; s0 < min(c0 + 64, nsteps); s0 += 8) {
+      for (int s0 = c0; s0 < min(c0 + DTW_CHUNK, nsteps); s0 += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nxtd[u] = drow[min(max(s0 + 8 + u - shift, 0), rwc)];
+        for (int u = 0; u < 8; ++u) nx2d[u] = drow[min(max(s0 + 16 + u - shift, 0), rwc)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int s = s0 + u;
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
           const int pos = s - shift;
           const bool act = pos >= 0 && pos <= rw;
           double up = dtw_wave_shr1(v1), dg = dtw_wave_shr1(v2);
-          const double bup = dtw_readlane(bchunk, (s - c0) & 63);
+          const double bup = dtw_readlane(bchunk, (s - c0) & (DTW_CHUNK - 1));
           if (lane == 0) { up = bup; dg = up0_prev; }
           up0_prev = bup;
           double cur = INF;
@@ -227,17 +248,17 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
           v1 = cur;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) curd[u] = nxtd[u];
+        for (int u = 0; u < 8; ++u) { curd[u] = nxtd[u]; nxtd[u] = nx2d[u]; }
         // publish how far this strip's last row has got (after its boundary writes)
-        if (BND_LDS) __threadfence_block(); else __threadfence();
+        DTW_RELEASE();
         if (i == ilast) {
           const int jdone = min(jmin + (s0 + 7) - lane, rh);
-          s_prog[nbuf] = ((long long)k << 32) | (long long)(unsigned int)(jdone + 1 > 0 ? jdone + 1 : 0);
+          DTW_PROG_STORE(nbuf, ((long long)k << 32) | (long long)(unsigned int)(jdone + 1 > 0 ? jdone + 1 : 0));
         }
       }
     }
-    if (BND_LDS) __threadfence_block(); else __threadfence();
-    if (i == ilast) s_prog[nbuf] = ((long long)k << 32) | 0x7fffffffll;
+    DTW_RELEASE();
+    if (i == ilast) DTW_PROG_STORE(nbuf, ((long long)k << 32) | 0x7fffffffll);
   }
 #undef BROW
   __syncthreads();
