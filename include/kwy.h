@@ -165,6 +165,17 @@ int kwy_gmm_mlpg(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
 int kwy_gmm_mlpg_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
                      const double *weights, const double *means, const double *covs, int diff,
                      double *y);
+/* The part of MLPG(gmm, windows, diff).__init__ that depends on the GMM only
+ * (nnmnkwii computes it in the constructor, kwiiyatta/converter/gmm.py:32 builds one MLPG per
+ * convert call): per mixture the Cholesky factor of Sxx, A = Syx Sxx^-1, b = mu_y - A mu_x, the
+ * conditional variances and the log-density constants.  model: kwy_gmm_model_doubles(d, M)
+ * doubles of device memory, filled once and reused by kwy_gmm_mlpg_model_dev for every utterance.
+ * kwy_gmm_prepare_dev synchronises the stream (it reports a non-positive-definite Sxx). */
+int64_t kwy_gmm_model_doubles(int d, int M);
+int kwy_gmm_prepare_dev(kwy_ctx *ctx, const double *weights, const double *means, const double *covs,
+                        int d, int M, int diff, double *model);
+int kwy_gmm_mlpg_model_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *model,
+                           double *y);
 
 /* ---- converter fit: EM building blocks --------------------------------------------------------
  * sklearn.mixture.GaussianMixture(covariance_type='full').fit as used at

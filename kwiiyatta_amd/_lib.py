@@ -104,6 +104,9 @@ SIGNATURES = {
     'kwy_gmm_em_scratch_bytes': (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_mlpg_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'kwy_gmm_model_doubles': (c_i64, [c_int, c_int]),
+    'kwy_gmm_prepare_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'kwy_gmm_mlpg_model_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
 }
 
 MISSING = []

@@ -248,76 +248,118 @@ __global__ void k_mlpg_build(const double *__restrict__ E, const double *__restr
 }
 
 // ---- MLPG: banded Cholesky + forward/backward sweeps, one lane per static dimension ------------------
-// The recurrence is serial in t, so the wavefront streams the band through LDS in tiles of
-// ML_SOLVE_TILE frames: all 64 lanes load/store a tile coalesced, lanes c < d walk it.
-#define ML_SOLVE_TILE 64
-__global__ __launch_bounds__(64) void k_mlpg_solve(double *__restrict__ band, double *__restrict__ rhs, ml_dims dm,
-                                                  double *__restrict__ y, int *__restrict__ status) {
-  extern __shared__ double sm[];  // band tile [ML_SOLVE_TILE][d][3] followed by rhs tile [ML_SOLVE_TILE][d]
-  const int lane = threadIdx.x, d = dm.d;
+// The recurrence is serial in t and only d (24) systems wide: wavefront 0 walks the frames, one
+// lane per dimension, on a tile of frames held in LDS, while wavefronts 1..3 stream the band
+// through two LDS buffers around it -- write the finished tile back, fetch the next one -- so the
+// walk never waits for HBM.  (One wavefront doing both spent 90 % of its time on the copies.)
+#define ML_SOLVE_NT 256
+__device__ __forceinline__ void ml_tile_copy(double *__restrict__ dst, const double *__restrict__ src, int n,
+                                             int first, int nthreads) {
+#pragma unroll 8
+  for (int e = first; e < n; e += nthreads) dst[e] = src[e];
+}
+
+__global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__ band, double *__restrict__ rhs,
+                                                           ml_dims dm, int tile, double *__restrict__ y,
+                                                           int *__restrict__ status) {
+  extern __shared__ double sm[];  // 2 x { band tile [tile][d][3], rhs tile [tile][d] }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = dm.d;
   const int64_t T = dm.T;
   const int c = lane;
-  double *sb = sm, *sr = sm + ML_SOLVE_TILE * d * 3;
-  // L[t][0] diag, L[t][1] = L[t][t-1], L[t][2] = L[t][t-2]; z = L^-1 b
-  double l1_0 = 0, l1_1 = 0, z1 = 0;  // row t-1: diag, sub1; z[t-1]
-  double l2_0 = 0, z2 = 0;            // row t-2: diag; z[t-2]
-  for (int64_t t0 = 0; t0 < T; t0 += ML_SOLVE_TILE) {
-    const int nt = (int)min((int64_t)ML_SOLVE_TILE, T - t0);
-    for (int e = lane; e < nt * d * 3; e += 64) sb[e] = band[t0 * d * 3 + e];
-    for (int e = lane; e < nt * d; e += 64) sr[e] = rhs[t0 * d + e];
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    if (c < d) {
+  const int bufsz = tile * d * 4;
+  const int64_t ntiles = (T + tile - 1) / tile;
+  auto SB = [&](int64_t k) { return sm + (k & 1) * bufsz; };
+  auto SR = [&](int64_t k) { return sm + (k & 1) * bufsz + tile * d * 3; };
+  auto NT_OF = [&](int64_t k) { return (int)min((int64_t)tile, T - k * tile); };
+
+  // ---------------- forward: L L' = A, z = L^-1 b ----------------
+  // stored per row: 1/L[t][t], L[t][t-1], L[t][t-2]
+  double r1 = 0, l1_1 = 0, z1 = 0;  // row t-1: 1/diag, sub1; z[t-1]
+  double r2 = 0, z2 = 0;            // row t-2: 1/diag; z[t-2]
+  ml_tile_copy(SB(0), band, NT_OF(0) * d * 3, tid, ML_SOLVE_NT);
+  ml_tile_copy(SR(0), rhs, NT_OF(0) * d, tid, ML_SOLVE_NT);
+  __syncthreads();
+  for (int64_t k = 0; k < ntiles; ++k) {
+    const int nt = NT_OF(k);
+    const int64_t t0 = k * tile;
+    if (wv > 0) {
+      const int h = tid - 64;
+      if (k > 0) {  // tile k-1 is finished: back to memory, its buffer is then free for tile k+1
+        ml_tile_copy(band + (k - 1) * tile * d * 3, SB(k - 1), tile * d * 3, h, ML_SOLVE_NT - 64);
+        ml_tile_copy(rhs + (k - 1) * tile * d, SR(k - 1), tile * d, h, ML_SOLVE_NT - 64);
+      }
+      if (k + 1 < ntiles) {
+        ml_tile_copy(SB(k + 1), band + (k + 1) * tile * d * 3, NT_OF(k + 1) * d * 3, h, ML_SOLVE_NT - 64);
+        ml_tile_copy(SR(k + 1), rhs + (k + 1) * tile * d, NT_OF(k + 1) * d, h, ML_SOLVE_NT - 64);
+      }
+    } else if (c < d) {
+      double *sb = SB(k), *sr = SR(k);
+      // Row t needs 1/L[t-1][t-1] and 1/L[t-2][t-2] twice and 1/L[t][t] once: the reciprocal of
+      // the diagonal is formed once per row (and stored instead of the diagonal for the backward
+      // sweep), which leaves one division and one square root on the serial chain instead of three
+      // divisions and a square root.  Each quotient then rounds twice instead of once
+      // (~1e-16 relative per row against the CPU's divisions).
+#pragma unroll 4
       for (int tt = 0; tt < nt; ++tt) {
         const int64_t t = t0 + tt;
         double *q = sb + (tt * d + c) * 3;
         double p0 = q[0], p1 = q[1], p2 = q[2];
         double L2 = 0.0, L1 = 0.0;
-        if (t >= 2) L2 = p2 / l2_0;
+        if (t >= 2) L2 = p2 * r2;
         if (t >= 1) {
           double v = p1;
           if (t >= 2) v -= L2 * l1_1;  // L[t][t-2] * L[t-1][t-2]
-          L1 = v / l1_0;
+          L1 = v * r1;
         }
         double v = p0;
         if (t >= 2) v -= L2 * L2;
         if (t >= 1) v -= L1 * L1;
         if (!(v > 0.0)) { atomicExch(status, 2); v = 1.0; }
-        const double L0 = sqrt(v);
+        const double r0 = 1.0 / sqrt(v);
         double zz = sr[tt * d + c];
         if (t >= 1) zz -= L1 * z1;
         if (t >= 2) zz -= L2 * z2;
-        zz = zz / L0;
-        q[0] = L0; q[1] = L1; q[2] = L2;
+        zz = zz * r0;
+        q[0] = r0; q[1] = L1; q[2] = L2;
         sr[tt * d + c] = zz;
-        l2_0 = l1_0; z2 = z1;
-        l1_0 = L0; l1_1 = L1; z1 = zz;
+        r2 = r1; z2 = z1;
+        r1 = r0; l1_1 = L1; z1 = zz;
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (int e = lane; e < nt * d * 3; e += 64) band[t0 * d * 3 + e] = sb[e];
-    for (int e = lane; e < nt * d; e += 64) rhs[t0 * d + e] = sr[e];
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
-  __threadfence();
+  {  // the last tile
+    const int64_t k = ntiles - 1;
+    ml_tile_copy(band + k * tile * d * 3, SB(k), NT_OF(k) * d * 3, tid, ML_SOLVE_NT);
+    ml_tile_copy(rhs + k * tile * d, SR(k), NT_OF(k) * d, tid, ML_SOLVE_NT);
+  }
+  __threadfence();  // the tiles are read back below: past this CU's L1
+  __syncthreads();
+
+  // ---------------- backward: y = L^-T z ----------------
   double y1 = 0, y2 = 0, n1_1 = 0, n2_2 = 0, n1_2 = 0;  // y[t+1], y[t+2]; L[t+1][1], L[t+2][2]
-  const int64_t ntiles = (T + ML_SOLVE_TILE - 1) / ML_SOLVE_TILE;
-  for (int64_t ti = ntiles - 1; ti >= 0; --ti) {
-    const int64_t t0 = ti * ML_SOLVE_TILE;
-    const int nt = (int)min((int64_t)ML_SOLVE_TILE, T - t0);
-    for (int e = lane; e < nt * d * 3; e += 64) sb[e] = band[t0 * d * 3 + e];
-    for (int e = lane; e < nt * d; e += 64) sr[e] = rhs[t0 * d + e];
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    if (c < d) {
+  // the last tile is still in its buffer
+  for (int64_t k = ntiles - 1; k >= 0; --k) {
+    const int nt = NT_OF(k);
+    const int64_t t0 = k * tile;
+    if (wv > 0) {
+      const int h = tid - 64;
+      if (k + 1 < ntiles) ml_tile_copy(y + (k + 1) * tile * d, SR(k + 1), NT_OF(k + 1) * d, h, ML_SOLVE_NT - 64);
+      if (k > 0) {
+        ml_tile_copy(SB(k - 1), band + (k - 1) * tile * d * 3, tile * d * 3, h, ML_SOLVE_NT - 64);
+        ml_tile_copy(SR(k - 1), rhs + (k - 1) * tile * d, tile * d, h, ML_SOLVE_NT - 64);
+      }
+    } else if (c < d) {
+      const double *sb = SB(k);
+      double *sr = SR(k);
+#pragma unroll 4
       for (int tt = nt - 1; tt >= 0; --tt) {
         const int64_t t = t0 + tt;
         const double *q = sb + (tt * d + c) * 3;
         double v = sr[tt * d + c];
         if (t + 1 < T) v -= n1_1 * y1;
         if (t + 2 < T) v -= n2_2 * y2;
-        v = v / q[0];
+        v = v * q[0];  // q[0] holds 1/L[t][t]
         n2_2 = n1_2;  // L[t+1][2] becomes L[(t-1)+2][2]
         y2 = y1;
         n1_1 = q[1]; n1_2 = q[2];
@@ -325,11 +367,9 @@ __global__ __launch_bounds__(64) void k_mlpg_solve(double *__restrict__ band, do
         sr[tt * d + c] = v;
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (int e = lane; e < nt * d; e += 64) y[t0 * d + e] = sr[e];
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
+  ml_tile_copy(y, SR(0), NT_OF(0) * d, tid, ML_SOLVE_NT);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -340,11 +380,13 @@ static size_t ml_scratch_bytes(int64_t T, int d, int M) {
          kwy_pad(sizeof(double) * T * d) + kwy_pad(64);
 }
 
+// `prepared`: a model made by kwy_gmm_prepare_dev (then weights/means/covs are unused), or null
 static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,
-                     const double *means, const double *covs, int diff, double *y, int **status_out) {
+                     const double *means, const double *covs, int diff, double *y, int **status_out,
+                     const double *prepared = nullptr) {
   const int D = 3 * d;
   ml_dims dm = {d, D, M, T};
-  double *model = kwy_arena<double>(ctx, ml_model_stride(D) * M);
+  double *model = prepared ? const_cast<double *>(prepared) : kwy_arena<double>(ctx, ml_model_stride(D) * M);
   double *X = kwy_arena<double>(ctx, (size_t)T * D);
   double *E = kwy_arena<double>(ctx, (size_t)T * D);
   double *Dv = kwy_arena<double>(ctx, (size_t)T * D);
@@ -364,17 +406,23 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024) { ctx->err = "gmm_mlpg: feature dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
+  // frames per LDS tile of the solve: two buffers of tile x d x 4 doubles within 128 KB
+  int solve_tile = 64;
+  while (solve_tile > 4 && (size_t)2 * solve_tile * d * 4 * sizeof(double) > 128 * 1024) solve_tile /= 2;
+  const size_t lds_solve = (size_t)2 * solve_tile * d * 4 * sizeof(double);
+  if (lds_solve > 160 * 1024) { ctx->err = "gmm_mlpg: static dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_mlpg_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(sizeof(double) * ML_SOLVE_TILE * d * 4)));
-  hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
-                     diff, model, status);
+                              (int)lds_solve));
+  if (!prepared)
+    hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
+                       diff, model, status);
   const unsigned ge = (unsigned)((T * d + 255) / 256);
   hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, x, dm, X);
   KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)((T + ML_TILE - 1) / ML_TILE), M), dim3(KWY_THREADS), lds_logp,
                      ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
   hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band, rhs);
-  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(64), sizeof(double) * ML_SOLVE_TILE * d * 4, ctx->stream, band, rhs, dm, y, status));
+  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(ML_SOLVE_NT), lds_solve, ctx->stream, band, rhs, dm, solve_tile, y, status));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -397,6 +445,46 @@ extern "C" int kwy_gmm_mlpg_dev(kwy_ctx *ctx, const double *x, int64_t T, int d,
   KWY_TRY(kwy_arena_begin(ctx, ml_scratch_bytes(T, d, M)));
   int *status;
   return mlpg_core(ctx, x, T, d, M, weights, means, covs, diff, y, &status);
+}
+
+extern "C" int64_t kwy_gmm_model_doubles(int d, int M) {
+  if (d <= 0 || d > 64 || M <= 0) return 0;
+  return (int64_t)ml_model_stride(3 * d) * M;
+}
+
+extern "C" int kwy_gmm_prepare_dev(kwy_ctx *ctx, const double *weights, const double *means, const double *covs,
+                                   int d, int M, int diff, double *model) {
+  if (!ctx) return KWY_EINVAL;
+  if (!weights || !means || !covs || !model || d <= 0 || d > 64 || M <= 0) {
+    ctx->err = "gmm_prepare: bad argument";
+    return KWY_EINVAL;
+  }
+  KWY_HIP(hipSetDevice(ctx->device));
+  const int D = 3 * d;
+  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(64)));
+  int *status = kwy_arena<int>(ctx, 16);
+  if (!status) { ctx->err = "gmm_prepare: scratch arena too small"; return KWY_ENOMEM; }
+  KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
+  size_t lds_prep = sizeof(double) * 3 * D * D;
+  if (lds_prep > 160 * 1024) { ctx->err = "gmm_prepare: feature dimension too large"; return KWY_EINVAL; }
+  KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+  KWY_PROF(ctx, "k_gmm_prep", hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
+                     diff, model, status));
+  KWY_HIP(hipGetLastError());
+  int hstatus = 0;
+  KWY_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  if (hstatus != 0) { ctx->err = "gmm_prepare: source covariance is not positive definite"; return KWY_ENUMERIC; }
+  return KWY_OK;
+}
+
+extern "C" int kwy_gmm_mlpg_model_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *model,
+                                      double *y) {
+  KWY_TRY(ml_check(ctx, x, T, d, M, model, model, model, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, ml_scratch_bytes(T, d, M)));
+  int *status;
+  return mlpg_core(ctx, x, T, d, M, nullptr, nullptr, nullptr, 0, y, &status, model);
 }
 
 extern "C" int kwy_gmm_mlpg(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,

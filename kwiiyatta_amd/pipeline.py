@@ -49,6 +49,21 @@ class DeviceGMM:
         self.weights = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float64)).to(device)
         self.means = torch.from_numpy(np.ascontiguousarray(means, dtype=np.float64)).to(device)
         self.covs = torch.from_numpy(np.ascontiguousarray(covs, dtype=np.float64)).to(device)
+        self.device = torch.device(device)
+        self._model = {}
+
+    def model(self, diff=False):
+        """The per-mixture matrices MLPG needs (Cholesky factor of Sxx, A = Syx Sxx^-1, conditional
+        variances ...), computed on the GPU once per GMM instead of once per converted utterance."""
+        diff = bool(diff)
+        if diff not in self._model:
+            d = self.D2 // 6
+            buf = torch.empty(lib.kwy_gmm_model_doubles(d, self.M), dtype=torch.float64, device=self.device)
+            ctx = _lib.Context(self.device.index or 0, stream=torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(ctx, lib.kwy_gmm_prepare_dev(ctx.handle, _p(self.weights), _p(self.means), _p(self.covs),
+                                                    d, self.M, int(diff), _p(buf)))
+            self._model[diff] = buf
+        return self._model[diff]
 
 
 class _Side:
@@ -89,6 +104,7 @@ class PairPipeline:
         self.alpha = sptk.mcepalpha(self.fs)
         self.gmm = gmm
         assert gmm.D2 == 6 * order
+        self.gmm_model = gmm.model(diff=False)
         f64 = dict(dtype=torch.float64, device=self.dev)
         with torch.cuda.stream(self.stream):
             self.src = _Side(*source, self.fs, self.K, order, self.dev)
@@ -145,8 +161,8 @@ class PairPipeline:
                 self._chk(lib.kwy_gather_rows_dev(h, _p(src_arr), self.src.Tp, w, _p(self.idx), Tt, _p(dst)))
             self.mc_x.copy_(self.mc_al[:, 1:])
             g = self.gmm
-            self._chk(lib.kwy_gmm_mlpg_dev(h, _p(self.mc_x), Tt, order, g.M, _p(g.weights), _p(g.means),
-                                           _p(g.covs), 0, _p(self.mc_y)))
+            self._chk(lib.kwy_gmm_mlpg_model_dev(h, _p(self.mc_x), Tt, order, g.M, _p(self.gmm_model),
+                                                 _p(self.mc_y)))
             self.mc_conv[:, 0].copy_(self.mc_al[:, 0])
             self.mc_conv[:, 1:].copy_(self.mc_y)
             self._chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), Tt, order, self.alpha, fft, _p(self.sp_conv)))
