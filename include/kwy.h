@@ -177,6 +177,34 @@ int kwy_gmm_prepare_dev(kwy_ctx *ctx, const double *weights, const double *means
 int kwy_gmm_mlpg_model_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *model,
                            double *y);
 
+/* ---- cross-rate aperiodicity codec ------------------------------------------------------
+ * pyworld.code_aperiodicity(ap, fs) / pyworld.decode_aperiodicity(coded, fs, fft_size)
+ *                                        kwiiyatta/vocoder/world.py:98-145
+ * ap: T x (fft_size/2+1); coded: T x kwy_aperiodicity_bands(fs) on the coding side.  The
+ * decoder takes the number of coded columns explicitly (the reference truncates or extends the
+ * coded array when it changes the sampling rate, world.py:121-143). */
+int kwy_aperiodicity_bands(int fs);
+int kwy_code_aperiodicity(kwy_ctx *ctx, const double *ap, int64_t T, int fs, int fft_size, double *coded);
+int kwy_code_aperiodicity_dev(kwy_ctx *ctx, const double *ap, int64_t T, int fs, int fft_size, double *coded);
+int kwy_decode_aperiodicity(kwy_ctx *ctx, const double *coded, int64_t T, int fs, int fft_size, int bands,
+                            double *ap);
+int kwy_decode_aperiodicity_dev(kwy_ctx *ctx, const double *coded, int64_t T, int fs, int fft_size, int bands,
+                                double *ap);
+
+/* ---- MLSA differential-spectrum filter ---------------------------------------------------
+ * pysptk.mc2b(mc, alpha)                                     kwiiyatta/filter/mlsa.py:28
+ * pysptk.synthesis.Synthesizer(MLSADF(order, alpha, pd), hopsize).synthesis(x, b)     :24-29
+ * mc, b: T x (order+1).  Frame i filters samples [i hopsize, (i+1) hopsize) with coefficients
+ * interpolated linearly from frame i-1's to frame i's (frame 0 from its own); the input is
+ * scaled by exp(b[0]); frames that reach the end of x are left unprocessed (output 0 there;
+ * upstream leaves them uninitialised).  pd: Pade order, 4 (pysptk default) or 5.  x, y: n samples. */
+int kwy_mc2b(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, double *b);
+int kwy_mc2b_dev(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, double *b);
+int kwy_mlsa_synthesis(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int order,
+                       double alpha, int pd, int hopsize, double *y);
+int kwy_mlsa_synthesis_dev(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int order,
+                           double alpha, int pd, int hopsize, double *y);
+
 /* ---- converter fit: EM building blocks --------------------------------------------------------
  * sklearn.mixture.GaussianMixture(covariance_type='full').fit as used at
  *                                                    kwiiyatta/converter/gmm.py:14-26

@@ -105,6 +105,15 @@ SIGNATURES = {
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_mlpg_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_model_doubles': (c_i64, [c_int, c_int]),
+    'kwy_aperiodicity_bands': (c_int, [c_int]),
+    'kwy_code_aperiodicity': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    'kwy_code_aperiodicity_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    'kwy_decode_aperiodicity': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
+    'kwy_decode_aperiodicity_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
+    'kwy_mc2b': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
+    'kwy_mc2b_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
+    'kwy_mlsa_synthesis': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),
+    'kwy_mlsa_synthesis_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),
     'kwy_gmm_prepare_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_gmm_mlpg_model_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
 }

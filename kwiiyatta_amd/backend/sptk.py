@@ -1,5 +1,6 @@
-"""pysptk-shaped front-end of the HIP mel-cepstrum kernels
-(reference call sites /root/reference/kwiiyatta/vocoder/mcep.py:26,65,71)."""
+"""pysptk-shaped front-end of the HIP mel-cepstrum and MLSA kernels
+(reference call sites /root/reference/kwiiyatta/vocoder/mcep.py:26,65,71 and
+/root/reference/kwiiyatta/filter/mlsa.py:24-29)."""
 import functools
 
 import numpy as np
@@ -48,3 +49,43 @@ def mcepalpha(fs, start=0.0, stop=1.0, step=0.001, num_points=1000):
     warp = warp / warp[:, -1:]
     dist = np.sqrt(np.mean((mel[None, :] - warp) ** 2, axis=1))
     return float(alphas[np.argmin(dist)])
+
+
+def mc2b(mc, alpha=0.35, ctx=None):
+    """pysptk.mc2b: mel-cepstrum -> MLSA filter coefficients, row-wise."""
+    m, lead = _rows(mc)
+    ctx = ctx or _lib.default_context()
+    b = np.empty_like(m)
+    _lib.check(ctx, lib.kwy_mc2b(ctx.handle, ptr(m), m.shape[0], m.shape[1] - 1, float(alpha), ptr(b)))
+    return b.reshape(lead + (m.shape[1],))
+
+
+class MLSADF:
+    """pysptk.synthesis.MLSADF: holds the filter description (the state lives on the GPU for the
+    duration of one Synthesizer.synthesis call)."""
+
+    def __init__(self, order=25, alpha=0.35, pd=4):
+        if pd not in (4, 5):
+            raise ValueError('4 or 5 pade approximations are supported')
+        self.order, self.alpha, self.pd = int(order), float(alpha), int(pd)
+
+
+class Synthesizer:
+    """pysptk.synthesis.Synthesizer for an MLSADF: synthesis(source, b) filters `source` with the
+    frame-wise coefficients b (T, order+1), interpolating inside each hop."""
+
+    def __init__(self, filt, hopsize, ctx=None):
+        if not isinstance(filt, MLSADF):
+            raise NotImplementedError('only MLSADF, the filter the reference uses, is implemented')
+        self.filt, self.hopsize, self.ctx = filt, int(hopsize), ctx
+
+    def synthesis(self, source, b):
+        x = _lib.as_f64(np.asarray(source, dtype=np.float64))
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if b.ndim != 2 or b.shape[1] != self.filt.order + 1:
+            raise ValueError('order of the filter coefficients does not match the filter')
+        ctx = self.ctx or _lib.default_context()
+        y = np.empty_like(x)
+        _lib.check(ctx, lib.kwy_mlsa_synthesis(ctx.handle, ptr(x), len(x), ptr(b), b.shape[0], self.filt.order,
+                                               self.filt.alpha, self.filt.pd, self.hopsize, ptr(y)))
+        return y

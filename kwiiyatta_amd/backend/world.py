@@ -72,14 +72,33 @@ def synthesize(f0, spectrogram, aperiodicity, fs, frame_period=default_frame_per
     return y
 
 
-def code_aperiodicity(aperiodicity, fs):
-    raise NotImplementedError('WORLD aperiodicity band coding (cross-sampling-rate resampling, '
-                              'SURVEY.md 8(f)-3) is not implemented in kwiiyatta_amd yet')
+def get_num_aperiodicities(fs):
+    return lib.kwy_aperiodicity_bands(int(fs))
 
 
-def decode_aperiodicity(coded_aperiodicity, fs, fft_size):
-    raise NotImplementedError('WORLD aperiodicity band decoding (cross-sampling-rate resampling, '
-                              'SURVEY.md 8(f)-3) is not implemented in kwiiyatta_amd yet')
+def code_aperiodicity(aperiodicity, fs, ctx=None):
+    """(T, K) aperiodicity -> (T, bands) dB values at 3 kHz, 6 kHz, ...  (pyworld.code_aperiodicity)"""
+    ap = _lib.as_f64(aperiodicity)
+    if ap.ndim != 2:
+        raise ValueError('aperiodicity must be 2-dimensional')
+    ctx = ctx or _lib.default_context()
+    nb = get_num_aperiodicities(fs)
+    coded = np.empty((ap.shape[0], nb))
+    _lib.check(ctx, lib.kwy_code_aperiodicity(ctx.handle, ptr(ap), ap.shape[0], int(fs),
+                                              (ap.shape[1] - 1) * 2, ptr(coded)))
+    return coded
+
+
+def decode_aperiodicity(coded_aperiodicity, fs, fft_size, ctx=None):
+    """(T, bands) -> (T, fft_size/2+1)  (pyworld.decode_aperiodicity)"""
+    coded = _lib.as_f64(coded_aperiodicity)
+    if coded.ndim != 2:
+        raise ValueError('coded_aperiodicity must be 2-dimensional')
+    ctx = ctx or _lib.default_context()
+    ap = np.empty((coded.shape[0], fft_size // 2 + 1))
+    _lib.check(ctx, lib.kwy_decode_aperiodicity(ctx.handle, ptr(coded), coded.shape[0], int(fs), int(fft_size),
+                                                coded.shape[1], ptr(ap)))
+    return ap
 
 
 def dio(x, fs, f0_floor=default_f0_floor, f0_ceil=default_f0_ceil, channels_in_octave=2.0,

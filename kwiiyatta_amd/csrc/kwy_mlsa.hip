@@ -1,0 +1,210 @@
+// kwy_mlsa.hip -- MLSA differential-spectrum filter on gfx950.
+//
+// Replaces the pysptk calls of kwiiyatta/filter/mlsa.py:24-29:
+//     b = pysptk.mc2b(mc, alpha)
+//     Synthesizer(MLSADF(order, alpha), hopsize).synthesis(wav, b)
+// (SPTK mlsadf: Pade approximant of order pd of exp F(z); per-sample linear interpolation of
+// the filter coefficients inside a frame; input scaled by exp(b[0]).)
+//
+// The filter is a time-varying IIR: serial in the sample index.  One wavefront filters one
+// signal; what parallelism there is inside a sample is spread over lanes:
+//   * lane k (k <= order) owns coefficient k: interpolation b[k] += slope[k]
+//   * lane s (s < pd) owns Pade section s+1 of mlsadf2: its all-pass chain state d[0..m+1]
+//     (in LDS, two copies alternating per sample, which replaces SPTK's shift loop) and runs
+//     mlsafir() on it -- the pd sections of one sample are independent, each consumes the
+//     previous sample's output of the section before it (DPP shift)
+//   * the short mlsadf1 cascade and the Pade sums are uniform and computed by every lane
+// The waveform is staged through LDS one frame at a time.  Operation order per sample follows
+// SPTK exactly; only exp() differs from the CPU's libm in the last bit.
+#include <math.h>
+
+#include "kwy_internal.hpp"
+
+#define MLSA_MAX_ORDER 62
+#define MLSA_MAX_HOP 2048
+
+__constant__ double c_pade[21] = {1.0,
+                                  1.0, 0.0,
+                                  1.0, 0.0, 0.0,
+                                  1.0, 0.0, 0.0, 0.0,
+                                  1.0, 0.4999273, 0.1067005, 0.01170221, 0.0005656279,
+                                  1.0, 0.4999391, 0.1107098, 0.01369984, 0.0009564853, 0.00003041721};
+
+// b[m] = c[m]; b[i] = c[i] - a b[i+1]   (pysptk.mc2b, one thread per frame)
+__global__ void k_mc2b(const double *__restrict__ mc, int64_t T, int m, double a, double *__restrict__ b) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const double *c = mc + t * (m + 1);
+  double *o = b + t * (m + 1);
+  double nxt = c[m];
+  o[m] = nxt;
+  for (int i = m - 1; i >= 0; --i) { nxt = c[i] - a * nxt; o[i] = nxt; }
+}
+
+__global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x, int64_t n,
+                                                   const double *__restrict__ b, int64_t T, int m, double a,
+                                                   int pd, int hop, double *__restrict__ y) {
+  extern __shared__ double sm[];
+  // sd[2][pd][m+3] section states (two copies), sb[m+1] current coefficients, sx[hop] in, sy[hop] out
+  const int ds = m + 3;
+  double *sd = sm;
+  double *sb = sd + 2 * 8 * ds;  // room for pd <= 5 (8 rows reserved)
+  double *sx = sb + 64;
+  double *sy = sx + hop;
+  const int lane = threadIdx.x;
+  const double aa = 1 - a * a;
+  const double *ppade = &c_pade[pd * (pd + 1) / 2];
+  for (int i = lane; i < 2 * 8 * ds; i += 64) sd[i] = 0.0;
+  // frame f is processed iff (f+1) hop < n; what lies behind the last processed frame stays zero
+  int64_t nproc = (n - 1) / hop;
+  if (nproc > T) nproc = T;
+  for (int64_t j = nproc * hop + lane; j < n; j += 64) y[j] = 0.0;
+  // mlsadf1 state (uniform): d1[1..pd], pt1[0..pd]
+  double d1[6] = {0, 0, 0, 0, 0, 0}, pt1[6] = {0, 0, 0, 0, 0, 0};
+  double pt0 = 0.0;   // pt[0] of mlsadf2: the section input of the previous sample
+  double po = 0.0;    // this lane's section output of the previous sample
+  double prevb = (lane <= m) ? b[lane] : 0.0;  // coefficient `lane` of the previous frame (frame 0: its own)
+  int par = 0;
+  __syncthreads();
+  for (int64_t f = 0; f < nproc; ++f) {
+    const int64_t s0 = f * hop;
+    const double curb = (lane <= m) ? b[f * (m + 1) + lane] : 0.0;
+    const double slope = (curb - prevb) / hop;
+    double cur = prevb;
+    for (int j = lane; j < hop; j += 64) sx[j] = x[s0 + j];
+    __syncthreads();
+    for (int j = 0; j < hop; ++j) {
+      if (lane <= m) sb[lane] = cur;
+      __syncthreads();
+      const double b0 = sb[0], b1 = sb[1];
+      double xv = sx[j] * exp(b0);
+      // ---- mlsadf1 (uniform)
+      double out = 0.0;
+#pragma unroll
+      for (int i = 5; i >= 1; --i) {
+        if (i <= pd) {
+          d1[i] = aa * pt1[i - 1] + a * d1[i];
+          pt1[i] = d1[i] * b1;
+          const double v = pt1[i] * ppade[i];
+          xv += (1 & i) ? v : -v;
+          out += v;
+        }
+      }
+      pt1[0] = xv;
+      out += xv;
+      const double x2 = out;
+      // ---- mlsadf2: section lane+1 runs mlsafir on its chain
+      double in = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(po), 0x138, 0xf, 0xf, false),
+                                   __builtin_amdgcn_update_dpp(0, __double2loint(po), 0x138, 0xf, 0xf, false));
+      if (lane == 0) in = pt0;
+      double yo = 0.0;
+      if (lane < pd) {
+        const double *dold = sd + (par * 8 + lane) * ds;
+        double *dnew = sd + ((par ^ 1) * 8 + lane) * ds;
+        // SPTK: d[0] = x; d[1] = aa d[0] + a d[1]; d[i] += a (d[i+1] - d[i-1]) (i = 2..m), y += d[i] b[i];
+        //       then d[i] = d[i-1] (i = m+1..2).  dnew holds the shifted result directly.
+        double u_prev = aa * in + a * dold[1];  // new d[1]
+        dnew[0] = in;
+        dnew[1] = u_prev;
+        double di = dold[2];
+#pragma unroll 4
+        for (int i = 2; i <= m; ++i) {
+          const double dn = dold[i + 1];
+          const double u = di + a * (dn - u_prev);
+          yo += u * sb[i];
+          dnew[i + 1] = u;
+          u_prev = u;
+          di = dn;
+        }
+        dnew[2] = dnew[1];  // the shift copies d[1] into d[2] as well
+      }
+      // ---- Pade sums (uniform): sections pd .. 1
+      double xx = x2, out2 = 0.0;
+#pragma unroll
+      for (int i = 5; i >= 1; --i) {
+        if (i <= pd) {
+          const double pti = kwy_readlane_f64(yo, i - 1);
+          const double v = pti * ppade[i];
+          xx += (1 & i) ? v : -v;
+          out2 += v;
+        }
+      }
+      pt0 = xx;
+      out2 += xx;
+      po = yo;
+      if (lane == 0) sy[j] = out2;
+      cur += slope;
+      par ^= 1;
+      __syncthreads();
+    }
+    for (int j = lane; j < hop; j += 64) y[s0 + j] = sy[j];
+    prevb = curb;
+    __syncthreads();
+  }
+}
+
+static int mlsa_check(kwy_ctx *ctx, const void *x, int64_t n, const void *b, int64_t T, int m, double a, int pd,
+                      int hop, const void *y) {
+  if (!ctx) return KWY_EINVAL;
+  if (!x || !b || !y || n <= 0 || T <= 0 || m < 2 || m > MLSA_MAX_ORDER || !(fabs(a) < 1.0) || pd < 4 || pd > 5 ||
+      hop < 1 || hop > MLSA_MAX_HOP) {
+    ctx->err = "mlsa_synthesis: bad argument (order 2..62, pd 4 or 5, hopsize 1..2048)";
+    return KWY_EINVAL;
+  }
+  return KWY_OK;
+}
+
+static int mlsa_core(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int m, double a,
+                     int pd, int hop, double *y) {
+  const size_t lds = sizeof(double) * (2 * 8 * (m + 3) + 64 + 2 * hop);
+  KWY_HIP(hipFuncSetAttribute((const void *)k_mlsa_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  KWY_PROF(ctx, "k_mlsa_filter", hipLaunchKernelGGL(k_mlsa_filter, dim3(1), dim3(64), lds, ctx->stream, x, n, b, T, m, a, pd, hop, y));
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+extern "C" int kwy_mc2b_dev(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, double *b) {
+  if (!ctx) return KWY_EINVAL;
+  if (!mc || !b || T <= 0 || order < 1) { ctx->err = "mc2b: bad argument"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_mc2b, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, mc, T, order, alpha, b);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+extern "C" int kwy_mc2b(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, double *b) {
+  if (!ctx) return KWY_EINVAL;
+  if (!mc || !b || T <= 0 || order < 1) { ctx->err = "mc2b: bad argument"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  const size_t bm = kwy_pad(sizeof(double) * T * (order + 1));
+  KWY_TRY(kwy_arena_begin(ctx, 2 * bm));
+  double *dmc = kwy_arena<double>(ctx, (size_t)T * (order + 1)), *db = kwy_arena<double>(ctx, (size_t)T * (order + 1));
+  KWY_HIP(hipMemcpyAsync(dmc, mc, sizeof(double) * T * (order + 1), hipMemcpyHostToDevice, ctx->stream));
+  KWY_TRY(kwy_mc2b_dev(ctx, dmc, T, order, alpha, db));
+  KWY_HIP(hipMemcpyAsync(b, db, sizeof(double) * T * (order + 1), hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}
+
+extern "C" int kwy_mlsa_synthesis_dev(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T,
+                                      int order, double alpha, int pd, int hopsize, double *y) {
+  KWY_TRY(mlsa_check(ctx, x, n, b, T, order, alpha, pd, hopsize, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  return mlsa_core(ctx, x, n, b, T, order, alpha, pd, hopsize, y);
+}
+
+extern "C" int kwy_mlsa_synthesis(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int order,
+                                  double alpha, int pd, int hopsize, double *y) {
+  KWY_TRY(mlsa_check(ctx, x, n, b, T, order, alpha, pd, hopsize, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  const size_t bx = kwy_pad(sizeof(double) * n), bm = kwy_pad(sizeof(double) * T * (order + 1));
+  KWY_TRY(kwy_arena_begin(ctx, 2 * bx + bm));
+  double *dx = kwy_arena<double>(ctx, n), *dy = kwy_arena<double>(ctx, n);
+  double *db = kwy_arena<double>(ctx, (size_t)T * (order + 1));
+  KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(db, b, sizeof(double) * T * (order + 1), hipMemcpyHostToDevice, ctx->stream));
+  KWY_TRY(mlsa_core(ctx, dx, n, db, T, order, alpha, pd, hopsize, dy));
+  KWY_HIP(hipMemcpyAsync(y, dy, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  return KWY_OK;
+}

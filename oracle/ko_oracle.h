@@ -45,7 +45,17 @@ int ko_synthesize(const double *f0, int64_t f0_length, const double *spectrogram
                   const double *aperiodicity, int fft_size, double frame_period_ms,
                   int fs, int64_t y_length, double *y);
 
-/* SPTK (ko_sptk.c) */
+int ko_code_aperiodicity(const double *aperiodicity, int64_t f0_length, int fs, int fft_size,
+                         double *coded);
+int ko_decode_aperiodicity(const double *coded, int64_t f0_length, int fs, int fft_size, int nb,
+                           double *aperiodicity);
+
+/* SPTK (ko_sptk.c, ko_mlsa.c) */
+void ko_mc2b(const double *mc, int64_t T, int m, double a, double *b);
+int ko_mlsadf_delay_length(int m, int pd);
+double ko_mlsadf(double x, const double *b, int m, double a, int pd, double *d);
+int ko_mlsa_synthesis(const double *x, int64_t n, const double *b, int64_t T, int m, double a, int pd,
+                      int hop, double *y);
 void ko_freqt(const double *c1, int m1, double *c2, int m2, double a);
 int ko_sp2mc(const double *sp, int64_t T, int K, int order, double alpha, double *mc);
 int ko_mc2sp(const double *mc, int64_t T, int order, double alpha, int fftlen, double *sp);

@@ -551,6 +551,52 @@ int ko_d4c(const double *x, int64_t x_length_, int fs, const double *t,
   return 0;
 }
 
+/* ---- codec.cpp: aperiodicity band codec ------------------------------------
+ * pyworld.code_aperiodicity / decode_aperiodicity, used by the reference only when
+ * features move between sampling rates or spectrum lengths
+ * (kwiiyatta/vocoder/world.py:98-145).  WORLD codec.cpp as shipped with pyworld 0.2.8:
+ * the dB aperiodicity is sampled at 3 kHz, 6 kHz, ... (interp1Q on the bin grid) and
+ * rebuilt by linear interpolation over {0: -60 dB, 3k.., fs/2: -1e-12 dB}; a frame whose
+ * mean coded value exceeds -0.5 dB is "unvoiced" and decodes to 1 - 1e-12. */
+int ko_code_aperiodicity(const double *aperiodicity, int64_t f0_length, int fs, int fft_size,
+                         double *coded) {
+  const int nb = ko_d4c_num_bands(fs), K = fft_size / 2 + 1;
+  if (nb <= 0) return 0;
+  double *axis = dalloc(nb), *logap = dalloc(K);
+  for (int i = 0; i < nb; ++i) axis[i] = kFrequencyInterval * (i + 1.0);
+  for (int64_t i = 0; i < f0_length; ++i) {
+    for (int j = 0; j < K; ++j) logap[j] = 20 * log10(aperiodicity[i * K + j]);
+    interp1Q(0, (double)fs / fft_size, logap, K, axis, nb, coded + i * nb);
+  }
+  free(axis); free(logap);
+  return 0;
+}
+
+int ko_decode_aperiodicity(const double *coded, int64_t f0_length, int fs, int fft_size,
+                           int nb, double *aperiodicity) {
+  /* nb = number of coded columns = GetNumberOfAperiodicities(fs) in WORLD */
+  const int K = fft_size / 2 + 1;
+  for (int64_t i = 0; i < f0_length * K; ++i) aperiodicity[i] = 1.0 - kMySafeGuardMinimum;
+  if (nb <= 0) return 0;
+  double *faxis = dalloc(K), *caxis = dalloc(nb + 2), *cap = dalloc(nb + 2);
+  for (int i = 0; i < K; ++i) faxis[i] = (double)fs / fft_size * i;
+  for (int i = 0; i <= nb; ++i) caxis[i] = i * kFrequencyInterval;
+  caxis[nb + 1] = fs / 2.0;
+  cap[0] = -60.0;
+  cap[nb + 1] = -kMySafeGuardMinimum;
+  for (int64_t i = 0; i < f0_length; ++i) {
+    double tmp = 0.0;
+    for (int j = 0; j < nb; ++j) { tmp += coded[i * nb + j]; cap[j + 1] = coded[i * nb + j]; }
+    tmp /= nb;
+    if (tmp > -0.5) continue;
+    double *ap = aperiodicity + i * K;
+    interp1(caxis, cap, nb + 2, faxis, K, ap);
+    for (int j = 0; j < K; ++j) ap[j] = pow(10.0, ap[j] / 20.0);
+  }
+  free(faxis); free(caxis); free(cap);
+  return 0;
+}
+
 /* ---- Synthesis ------------------------------------------------------------ */
 static inline double GetSafeAperiodicity(double x) {
   return dmax(0.001, dmin(0.999999999999, x));

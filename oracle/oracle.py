@@ -98,6 +98,13 @@ def lib():
                                   c_double_p, c_double_p, c_double_p, ctypes.c_int,
                                   ctypes.c_int, c_int_p, c_int_p, c_double_p, c_double_p,
                                   c_int32_p]
+        L.ko_d4c_num_bands.argtypes = [ctypes.c_int]
+        L.ko_code_aperiodicity.argtypes = [c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_double_p]
+        L.ko_decode_aperiodicity.argtypes = [c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, c_double_p]
+        L.ko_mc2b.argtypes = [c_double_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, c_double_p]
+        L.ko_mlsa_synthesis.argtypes = [c_double_p, ctypes.c_int64, c_double_p, ctypes.c_int64, ctypes.c_int,
+                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, c_double_p]
         _lib = L
     return _lib
 
@@ -178,6 +185,23 @@ def d4c(x, f0, temporal_positions, fs, threshold=0.85, fft_size=None):
     return out
 
 
+def code_aperiodicity(aperiodicity, fs):
+    """pyworld.code_aperiodicity: (T, K) -> (T, number of 3 kHz bands)"""
+    ap = _chk(aperiodicity)
+    nb = lib().ko_d4c_num_bands(int(fs))
+    out = np.zeros((ap.shape[0], nb))
+    lib().ko_code_aperiodicity(_dp(ap), ap.shape[0], int(fs), 2 * (ap.shape[1] - 1), _dp(out))
+    return out
+
+
+def decode_aperiodicity(coded_aperiodicity, fs, fft_size):
+    """pyworld.decode_aperiodicity: (T, bands) -> (T, fft_size/2+1)"""
+    c = _chk(coded_aperiodicity)
+    out = np.zeros((c.shape[0], fft_size // 2 + 1))
+    lib().ko_decode_aperiodicity(_dp(c), c.shape[0], int(fs), int(fft_size), c.shape[1], _dp(out))
+    return out
+
+
 def synth_timebase(f0, fs, frame_period, y_length, fft_size):
     f0 = _chk(f0)
     idx = np.zeros(y_length, dtype=np.int32)
@@ -222,6 +246,27 @@ def mc2sp(mc, alpha, fftlen):
     sp = np.zeros((mc2.shape[0], fftlen // 2 + 1))
     lib().ko_mc2sp(_dp(mc2), mc2.shape[0], mc2.shape[1] - 1, alpha, int(fftlen), _dp(sp))
     return sp[0] if one else sp
+
+
+def mc2b(mc, alpha):
+    """pysptk.mc2b (rows of a 2-D array independently)"""
+    mc = np.ascontiguousarray(mc, dtype=np.float64)
+    m2 = np.atleast_2d(mc)
+    out = np.zeros_like(m2)
+    lib().ko_mc2b(_dp(m2), m2.shape[0], m2.shape[1] - 1, float(alpha), _dp(out))
+    return out.reshape(mc.shape)
+
+
+def mlsa_synthesis(source, b, alpha, hopsize, pd=4):
+    """pysptk.synthesis.Synthesizer(MLSADF(order, alpha, pd), hopsize).synthesis(source, b)"""
+    x = np.ascontiguousarray(source, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    y = np.zeros_like(x)
+    rc = lib().ko_mlsa_synthesis(_dp(x), len(x), _dp(b), b.shape[0], b.shape[1] - 1, float(alpha), int(pd),
+                                 int(hopsize), _dp(y))
+    if rc != 0:
+        raise ValueError('mlsa_synthesis: bad argument')
+    return y
 
 
 def mcepalpha(fs, start=0.0, stop=1.0, step=0.001, num_points=1000):

@@ -72,6 +72,13 @@ def _install_oracle_backend(monkeypatch):
     monkeypatch.setattr(world, 'synthesize', synthesize)
     monkeypatch.setattr(sptk, 'sp2mc', lambda sp, order, alpha, ctx=None: ko.sp2mc(sp, order, alpha))
     monkeypatch.setattr(sptk, 'mc2sp', lambda mc, alpha, fftlen, ctx=None: ko.mc2sp(mc, alpha, fftlen))
+    monkeypatch.setattr(world, 'code_aperiodicity', lambda ap, fs, ctx=None: ko.code_aperiodicity(ap, fs))
+    monkeypatch.setattr(world, 'decode_aperiodicity',
+                        lambda c, fs, fft_size, ctx=None: ko.decode_aperiodicity(c, fs, fft_size))
+    monkeypatch.setattr(sptk, 'mc2b', lambda mc, alpha=0.35, ctx=None: ko.mc2b(mc, alpha))
+    monkeypatch.setattr(sptk.Synthesizer, 'synthesis',
+                        lambda self, source, b: ko.mlsa_synthesis(source, b, self.filt.alpha, self.hopsize,
+                                                                  self.filt.pd))
     monkeypatch.setattr(dtw, 'fastdtw', lambda x, y, radius=1, dist=2, ctx=None: ko.fastdtw(x, y, radius, dist))
     monkeypatch.setattr(mlpg, 'MLPG', OracleMLPG)
     from kwiiyatta_amd.converter import gmm as gmm_mod
