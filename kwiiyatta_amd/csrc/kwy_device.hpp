@@ -505,6 +505,21 @@ __device__ inline kwy_c *kwy_irfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_
   return kwy_fft_lds<true, NT>(b, a, log2H, twH);
 }
 
+// exp(-2 pi i (t + r*NT) / N) from base = exp(-2 pi i t / N) when NT = N/8: base times an 8th root of unity
+__device__ __forceinline__ kwy_c kwy_tw_octant(kwy_c b, int r) {
+  const double h = 0.70710678118654752440;
+  switch (r & 7) {
+    case 0: return b;
+    case 1: return {h * (b.x + b.y), h * (b.y - b.x)};
+    case 2: return {b.y, -b.x};
+    case 3: return {h * (b.y - b.x), h * (-b.x - b.y)};
+    case 4: return {-b.x, -b.y};
+    case 5: return {h * (-b.x - b.y), h * (b.x - b.y)};
+    case 6: return {-b.y, b.x};
+    default: return {h * (b.x - b.y), h * (b.x + b.y)};
+  }
+}
+
 // ------------------------------------------------- in-place radix-8 LDS FFT
 // One buffer instead of the ping-pong pair above: every pass loads its operands
 // into registers, all threads meet at a barrier, and the results go back to the
@@ -542,16 +557,18 @@ __device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict_
   constexpr int H = 1 << LOG2H, Q = H / 8, S = 1 << LOG2S;
   constexpr int IT = (Q + NT - 1) / NT;
   constexpr bool LAST = (LOG2S + 3 == LOG2H);
-  static_assert(Q >= 64, "transform too short for the radix-8 kernel");
+  static_assert(Q >= 8, "transform too short for the radix-8 kernel");
   kwy_c a[IT][8];
   const int tid = kwy_tid_opaque();
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int j = tid + it * NT;
     if (j < Q) {
-      const int swz = (LOG2S == 3) ? ((j >> 3) & 7) : 0;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) a[it][m] = z[(j + m * Q) ^ swz];
+      for (int m = 0; m < 8; ++m) {
+        const int idx = j + m * Q;
+        a[it][m] = z[(LOG2S == 3) ? (idx ^ ((idx >> 3) & 7)) : idx];
+      }
       kwy_dft8<INV>(a[it]);
       if (!LAST) {
         const int ps = (j >> LOG2S) << LOG2S;
@@ -659,13 +676,81 @@ __device__ __forceinline__ void kwy_fft_tail(kwy_c *z) {
 // tw: exp(-2 pi i k / H), k < H/8 (global or LDS).  Unnormalised in both directions.
 template <int LOG2H, int NT, bool INV>
 __device__ inline void kwy_fft_inplace(kwy_c *z, const kwy_c *__restrict__ tw) {
-  static_assert(LOG2H >= 9 && LOG2H <= 12, "unsupported in-place FFT length");
+  static_assert(LOG2H >= 8 && LOG2H <= 12, "unsupported in-place FFT length");
   kwy_fft_pass8<LOG2H, 0, NT, INV>(z, tw);
   kwy_fft_pass8<LOG2H, 3, NT, INV>(z, tw);
-  kwy_fft_pass8<LOG2H, 6, NT, INV>(z, tw);
+  if constexpr (LOG2H >= 9) kwy_fft_pass8<LOG2H, 6, NT, INV>(z, tw);
   if constexpr (LOG2H == 12) kwy_fft_pass8<LOG2H, 9, NT, INV>(z, tw);
-  if constexpr (LOG2H == 11) kwy_fft_tail<LOG2H, 2, NT, INV>(z);
-  if constexpr (LOG2H == 10) kwy_fft_tail<LOG2H, 1, NT, INV>(z);
+  if constexpr (LOG2H % 3 != 0) kwy_fft_tail<LOG2H, LOG2H % 3, NT, INV>(z);
+}
+
+// Real transforms around it, in place in a buffer of H+1 complex.
+// kwy_rfft_inplace: z holds N = 2H reals (viewed as H packed complex); on return z[0..H] are the
+// bins X[0..H].  Each thread combines "its" pairs (k, H-k) -- both results come from the same two
+// packed values -- so no barrier separates the loads from the stores.  twb = exp(-2 pi i tid / N):
+// for NT >= N/8 the pair twiddles are twb times 8th roots of unity, else they are read from twN[].
+// Ends with a barrier.
+template <int LOG2H, int NT>
+__device__ inline void kwy_rfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw, kwy_c twb,
+                                   const kwy_c *__restrict__ twN = nullptr) {
+  constexpr int H = 1 << LOG2H, N = 2 * H;
+  constexpr int OCT = 8 * NT / N;  // 0: the workgroup is narrower than N/8, pair twiddles come from twN[]
+  kwy_fft_inplace<LOG2H, NT, false>(z, tw);
+  const int tid = kwy_tid_opaque();
+#pragma unroll
+  for (int r = 0; r * NT <= H / 2; ++r) {
+    const int k = tid + NT * r;
+    if (k > H / 2) continue;
+    if (k == 0) {
+      const kwy_c z0 = z[0];
+      z[0] = {z0.x + z0.y, 0.0};
+      z[H] = {z0.x - z0.y, 0.0};
+    } else {
+      const kwy_c w = (OCT >= 1) ? kwy_tw_octant(twb, OCT * r) : twN[k];
+      const kwy_c A = z[k], Bc = z[H - k];
+      // X[k] = E + O w,  X[H-k] = conj(E - O w)  with E = (A + conj B)/2, O = (A - conj B)/(2i)
+      const double er = 0.5 * (A.x + Bc.x), ei = 0.5 * (A.y - Bc.y);
+      const double dr = 0.5 * (A.x - Bc.x), di = 0.5 * (A.y + Bc.y);
+      const double orr = di, oi = -dr;
+      const double pr = orr * w.x - oi * w.y, pi = orr * w.y + oi * w.x;
+      z[k] = {er + pr, ei + pi};
+      if (k != H - k) z[H - k] = {er - pr, -(ei - pi)};
+    }
+  }
+  __syncthreads();
+}
+
+// kwy_irfft_inplace: z[0..H] holds X; on return the first N doubles of z are the signal times N
+// (unnormalised, like kwy_irfft_lds).  Ends with a barrier.
+template <int LOG2H, int NT>
+__device__ inline void kwy_irfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw, kwy_c twb,
+                                   const kwy_c *__restrict__ twN = nullptr) {
+  constexpr int H = 1 << LOG2H, N = 2 * H;
+  constexpr int OCT = 8 * NT / N;  // 0: the workgroup is narrower than N/8, pair twiddles come from twN[]
+  const int tid = kwy_tid_opaque();
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r * NT <= H / 2; ++r) {
+    const int k = tid + NT * r;
+    if (k > H / 2) continue;
+    if (k == 0) {
+      // b[0] from a[0], a[H] (imaginary parts ignored, as kwy_irfft_lds does)
+      const double ar = z[0].x, br = z[H].x;
+      z[0] = {ar + br, ar - br};
+    } else {
+      const kwy_c w = (OCT >= 1) ? kwy_tw_octant(twb, OCT * r) : twN[k];  // exp(-2 pi i k / N); the inverse conjugates it
+      const kwy_c A = z[k], Bc = z[H - k];
+      // b[k]: (a, conj b) = (A, conj Bc);  b[H-k]: (Bc, conj A), twiddle -conj(w)
+      const double er = A.x + Bc.x, ei = A.y - Bc.y;
+      const double dr = A.x - Bc.x, di = A.y + Bc.y;
+      const double wr = w.x, wi = -w.y;
+      const double orr = dr * wr - di * wi, oi = dr * wi + di * wr;
+      z[k] = {er - oi, ei + orr};
+      if (k != H - k) z[H - k] = {er + oi, -(ei - orr)};
+    }
+  }
+  __syncthreads();
+  kwy_fft_inplace<LOG2H, NT, true>(z, tw);
 }
 
 // Bin k (0 <= k <= H) of the real FFT of the N = 2H reals whose packed
@@ -685,20 +770,6 @@ __device__ __forceinline__ kwy_c kwy_rfft_bin_w(const kwy_c *z, int k, kwy_c w) 
 template <int LOG2H>
 __device__ __forceinline__ kwy_c kwy_rfft_bin(const kwy_c *z, int k, const kwy_c *__restrict__ twN) {
   return kwy_rfft_bin_w<LOG2H>(z, k, twN[k & ((2 << LOG2H) - 1)]);
-}
-// exp(-2 pi i (t + r*NT) / N) from base = exp(-2 pi i t / N) when NT = N/8: base times an 8th root of unity
-__device__ __forceinline__ kwy_c kwy_tw_octant(kwy_c b, int r) {
-  const double h = 0.70710678118654752440;
-  switch (r & 7) {
-    case 0: return b;
-    case 1: return {h * (b.x + b.y), h * (b.y - b.x)};
-    case 2: return {b.y, -b.x};
-    case 3: return {h * (b.y - b.x), h * (-b.x - b.y)};
-    case 4: return {-b.x, -b.y};
-    case 5: return {h * (-b.x - b.y), h * (b.x - b.y)};
-    case 6: return {-b.y, b.x};
-    default: return {h * (b.x - b.y), h * (b.x + b.y)};
-  }
 }
 
 __device__ __forceinline__ int kwy_matlab_round(double x) {

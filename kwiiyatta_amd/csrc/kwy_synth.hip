@@ -460,44 +460,60 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_ebase(const int32_t *__rest
   }
 }
 
-// Minimum-phase spectrum (common.cpp GetMinimumPhaseSpectrum).  bufL holds the
-// half log-spectrum L[0..H] as reals; bufS is scratch.  Returns the buffer
-// holding M[0..H].  (The ~1e-17 imaginary rounding residue of the real
-// cepstrum that the CPU code carries along is dropped.)
+// Minimum-phase spectrum (common.cpp GetMinimumPhaseSpectrum), in place: buf holds the half
+// log-spectrum L[0..H] as reals on entry and M[0..H] on return.  (The ~1e-17 imaginary rounding
+// residue of the real cepstrum that the CPU code carries along is dropped.)
 template <int LOG2N>
-__device__ inline kwy_c *syn_min_phase(kwy_c *bufL, kwy_c *bufS, const kwy_c *__restrict__ twH,
-                                       const kwy_c *__restrict__ twN) {
+__device__ inline void syn_min_phase(kwy_c *buf, const kwy_c *__restrict__ twl, kwy_c twb,
+                                     const kwy_c *__restrict__ twN) {
   constexpr int N = 1 << LOG2N, H = N / 2;
-  double *L = (double *)bufL;
+  constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
+  double *L = (double *)buf;
+  const int tid = kwy_tid_opaque();
   __syncthreads();
-  for (int i = H + 1 + threadIdx.x; i < N; i += KWY_THREADS) L[i] = L[N - i];
-  kwy_c *C = kwy_rfft_lds(bufL, bufS, LOG2N - 1, twH, twN);
-  kwy_c *F = (C == bufL) ? bufS : bufL;
-  double *r = (double *)F;
-  for (int n = threadIdx.x; n < N; n += KWY_THREADS) {
+  for (int i = H + 1 + tid; i < N; i += KWY_THREADS) L[i] = L[N - i];
+  __syncthreads();
+  kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+  // causal cepstrum: c[0], 2 c[1..H-1], c[H], zeros -- packed reals over the complex bins they came from
+  double cv[RK];
+#pragma unroll
+  for (int r = 0; r < RK; ++r) {
+    const int n = tid + KWY_THREADS * r;
     double v = 0.0;
     if (n <= H) {
-      v = C[n].x;
+      v = buf[n].x;
       if (n >= 1 && n < H) v *= 2.0;
     }
-    r[n] = v;
-  }
-  kwy_c *R = kwy_rfft_lds(F, C, LOG2N - 1, twH, twN);
-  for (int k = threadIdx.x; k <= H; k += KWY_THREADS) {
-    double tmp = exp(R[k].x / N);
-    double ph = R[k].y / N;
-    R[k] = {tmp * cos(ph), tmp * sin(ph)};
+    cv[r] = v;
   }
   __syncthreads();
-  return R;
+#pragma unroll
+  for (int r = 0; r < RK; ++r) {
+    const int n = tid + KWY_THREADS * r;
+    if (n <= H) L[n] = cv[r];
+  }
+  for (int n = H + 1 + tid; n < N; n += KWY_THREADS) L[n] = 0.0;
+  __syncthreads();
+  kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+  for (int k = tid; k <= H; k += KWY_THREADS) {
+    const kwy_c R = buf[k];
+    const double tmp = exp(R.x / N);
+    const double ph = R.y / N;
+    buf[k] = {tmp * cos(ph), tmp * sin(ph)};
+  }
+  __syncthreads();
 }
 
 __device__ __forceinline__ double syn_safe_ap(double x) {
   return fmax(0.001, fmin(0.999999999999, x));
 }
 
+// One pulse per workgroup iteration.  LDS: one FFT buffer (in-place transforms), the
+// interpolated envelope / aperiodic ratio rows, a small twiddle table -- 35 KB at 48 kHz, four
+// workgroups per CU.  The noise spectrum waits in registers (bins tid + 256 r) while the
+// buffer computes the aperiodic minimum-phase response.
 template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse(
+__global__ __launch_bounds__(KWY_THREADS, 3) void k_syn_pulse(
     const double *__restrict__ sp, const double *__restrict__ ap, syn_params p,
     const int32_t *__restrict__ pidx, const double *__restrict__ pshift,
     const unsigned char *__restrict__ vuv8, const int *__restrict__ npulse, int cap,
@@ -506,18 +522,22 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse(
     const double *__restrict__ dc_remover, double *__restrict__ y) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   constexpr int C = N / KWY_THREADS;  // draws / output samples per thread
+  constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
+  constexpr int TWL = (H / 8 > 1) ? H / 8 : 1;
   extern __shared__ double smem[];
-  kwy_c *bufA = (kwy_c *)smem;
-  kwy_c *bufB = bufA + (H + 1);
-  kwy_c *Nz = bufB + (H + 1);              // noise spectrum
-  double *env = (double *)(Nz + (H + 1));  // K
+  double *red = smem;                      // 8
+  uint32_t *e = (uint32_t *)(red + 8);     // KWY_EBASE_WORDS
+  kwy_c *twl = (kwy_c *)(e + KWY_EBASE_WORDS);  // exp(-2 pi i k / H), k < H/8
+  kwy_c *buf = twl + TWL;                  // H+1 complex
+  double *env = (double *)(buf + (H + 1)); // K
   double *ratio = env + K + 1;             // K
-  double *red = ratio + K + 1;             // 8
-  uint32_t *e = (uint32_t *)(red + 8);
 
   const int tid = threadIdx.x;
+  for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
+  const kwy_c twb = twN[tid];
   const int P = min(npulse[0], cap);
   for (int pp = blockIdx.x; pp < P; pp += gridDim.x) {
+    const int tid = kwy_tid_opaque();  // keeps address arithmetic local to the pulse (no spills across the FFTs)
     const int idx = pidx[pp];
     const int nxt = pidx[min(P - 1, pp + 1)];
     const int noise_size = nxt - idx;
@@ -557,20 +577,19 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse(
 #pragma unroll
     for (int m = 0; m < C; ++m) per[m] = 0.0;
     if (current_vuv > 0.5 && !(ratio[0] > 0.999)) {
-      double *L = (double *)bufA;
+      double *L = (double *)buf;
       for (int k = tid; k <= H; k += KWY_THREADS)
         L[k] = log(env[k] * (1.0 - ratio[k]) + SYN_SAFE) / 2.0;
-      kwy_c *M = syn_min_phase<LOG2N>(bufA, bufB, twH, twN);
-      kwy_c *O = (M == bufA) ? bufB : bufA;
+      syn_min_phase<LOG2N>(buf, twl, twb, twN);
       const double coefficient = 2.0 * KWY_PI * shift * p.fs / N;
       for (int k = tid; k <= H; k += KWY_THREADS) {
-        double re = M[k].x, im = M[k].y;
-        double re2 = cos(coefficient * k);
-        double im2 = sqrt(1.0 - re2 * re2);
-        M[k] = {re * re2 + im * im2, im * re2 - re * im2};
+        const double re = buf[k].x, im = buf[k].y;
+        const double re2 = cos(coefficient * k);
+        const double im2 = sqrt(1.0 - re2 * re2);
+        buf[k] = {re * re2 + im * im2, im * re2 - re * im2};
       }
-      kwy_c *W = kwy_irfft_lds(M, O, LOG2N - 1, twH, twN);
-      const double *w = (const double *)W;
+      kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+      const double *w = (const double *)buf;
       double part = 0.0;
       for (int i = tid; i < H; i += KWY_THREADS) part += w[i];
       const double dc_component = kwy_block_sum(part, red);
@@ -585,8 +604,18 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse(
 
     // ---- aperiodic response
     {
-      kwy_rng rng = kwy_rng_combine(e, poly[tid]);
-      double *A = (double *)bufA;
+      const int tid = kwy_tid_opaque();
+      // jump table of this pulse's stream position (8 KB), built in the currently idle FFT buffer
+      // when that is large enough
+      kwy_rng rng;
+      if constexpr (sizeof(kwy_c) * (H + 1) >= 8192) {
+        kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)buf);
+        __syncthreads();
+        rng = kwy_rng_combine_table((const uint4 *)buf, poly[tid]);
+      } else {
+        rng = kwy_rng_combine(e, poly[tid]);
+      }
+      double *A = (double *)buf;
       double nv[C];
       double sum = 0.0;
 #pragma unroll
@@ -602,23 +631,32 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse(
         int d = C * tid + j;
         A[d] = (d < ns_used) ? nv[j] - average : 0.0;
       }
-      kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
-      for (int k = tid; k <= H; k += KWY_THREADS) Nz[k] = X[k];
       __syncthreads();
-      double *L = (double *)bufA;
+      kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+      kwy_c nz[RK];
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const int k = tid + KWY_THREADS * r;
+        nz[r] = k <= H ? buf[k] : kwy_c{0.0, 0.0};
+      }
+      __syncthreads();
+      double *L = (double *)buf;
       if (current_vuv != 0.0) {
         for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k] * ratio[k]) / 2.0;
       } else {
         for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k]) / 2.0;
       }
-      kwy_c *M = syn_min_phase<LOG2N>(bufA, bufB, twH, twN);
-      kwy_c *O = (M == bufA) ? bufB : bufA;
-      for (int k = tid; k <= H; k += KWY_THREADS) {
-        kwy_c a = M[k], b = Nz[k];
-        M[k] = {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+      syn_min_phase<LOG2N>(buf, twl, twb, twN);
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const int k = tid + KWY_THREADS * r;
+        if (k <= H) {
+          const kwy_c a = buf[k], b = nz[r];
+          buf[k] = {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+        }
       }
-      kwy_c *W = kwy_irfft_lds(M, O, LOG2N - 1, twH, twN);
-      const double *w = (const double *)W;
+      kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+      const double *w = (const double *)buf;
       const double sqrt_noise_size = sqrt((double)noise_size);
       const int64_t offset = (int64_t)idx - H + 1;
 #pragma unroll
@@ -669,7 +707,7 @@ static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const 
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
-  size_t lds = sizeof(kwy_c) * 3 * (H + 1) + sizeof(double) * (2 * (K + 1) + 8) +
+  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (2 * (K + 1) + 8) +
                sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
