@@ -164,7 +164,14 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
   __syncthreads();
   // this thread draws the c noise values [c*tid, c*tid + c) of the frame (c adapts to the window)
   const int c = (wl + KWY_THREADS - 1) / KWY_THREADS;
-  kwy_rng rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
+  kwy_rng rng;
+  if constexpr (sizeof(kwy_c) * (H + 1) >= 8192) {  // table-driven jump, table in the still idle first buffer
+    kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)bufA);
+    __syncthreads();
+    rng = kwy_rng_combine_table((const uint4 *)bufA, poly[(c - 1) * KWY_THREADS + tid]);
+  } else {
+    rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
+  }
   double *A = (double *)bufA;
   double *NZ = (double *)bufB;  // noise, then the window values
 #pragma unroll
