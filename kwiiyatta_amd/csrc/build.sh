@@ -9,7 +9,7 @@ PIDS=()
 for f in $SRCS; do
   o=obj/${f%.hip}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ kwy_device.hpp -nt "$o" ] || [ kwy_internal.hpp -nt "$o" ] || [ ../../include/kwy.h -nt "$o" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -c "$f" -o "$o" &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 -c "$f" -o "$o" &
     PIDS+=($!)
   fi
 done

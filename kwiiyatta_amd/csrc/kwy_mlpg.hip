@@ -133,43 +133,107 @@ __global__ void k_delta(const double *__restrict__ x, ml_dims dm, double *__rest
 }
 
 // ---- log p(x_t | m) up to the shared constant -------------------------------------------
+// || Z_m (x_t - mu_m) ||^2 for a tile of 64 frames and one mixture is a 64 x D times D x D
+// (lower-triangular) product: the one MFMA-shaped piece of the conversion path.  One workgroup
+// keeps Z_m (zero above the diagonal, rows padded) in LDS and walks over frame tiles; wavefront w
+// owns frames 16w..16w+15 and, per 16-column block of Z, runs v_mfma_f64_16x16x4_f64 over the
+// k-steps that reach the block's diagonal (58 instead of 90 MFMAs per wavefront and tile for D = 72).
+// Lane map of that instruction: A[row l&15][k l>>4], B[k l>>4][col l&15], D[row (l>>4)+4r][col l&15].
+typedef double ml_v4f64 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ static inline int ml_kp(int D) { return (D + 3) & ~3; }
+__host__ __device__ static inline int ml_np(int D) { return (D + 15) & ~15; }
+
 __global__ __launch_bounds__(KWY_THREADS) void k_gmm_logp(const double *__restrict__ X, ml_dims dm,
                                                          const double *__restrict__ model,
                                                          double *__restrict__ logp) {
   extern __shared__ double smem[];
-  const int D = dm.D, DP = D + 1;
-  double *Z = smem;               // D x D
-  double *dt = Z + D * D;         // ML_TILE x DP
-  double *qp = dt + ML_TILE * DP; // 4 x ML_TILE
-  const int tid = threadIdx.x, m = blockIdx.y;
-  const int64_t t0 = (int64_t)blockIdx.x * ML_TILE;
+  const int D = dm.D, Kp = ml_kp(D), NP = ml_np(D), ZS = Kp + 1;
+  double *Zs = smem;             // NP x ZS
+  double *dts = Zs + NP * ZS;    // ML_TILE x ZS
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.y;
   const double *mod = model + (size_t)m * ml_model_stride(D);
   const double *mZ = mod, *mux = mod + 2 * D * D;
-  for (int e = tid; e < D * D; e += KWY_THREADS) Z[e] = mZ[e];
-  for (int e = tid; e < ML_TILE * D; e += KWY_THREADS) {
-    int tl = e / D, i = e % D;
-    int64_t t = t0 + tl;
-    dt[tl * DP + i] = t < dm.T ? X[t * D + i] - mux[i] : 0.0;
+  const double cst = mod[2 * D * D + 3 * D];
+  for (int jb = 4 * wv; jb < NP; jb += 4 * KWY_WAVES) {  // four rows per wavefront and step, loads batched
+    double z0[4], z1[4];
+    const int i0 = lane, i1 = lane + 64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = jb + r;
+      z0[r] = (j < D && i0 <= j) ? mZ[j * D + i0] : 0.0;
+      z1[r] = (j < D && i1 <= j) ? mZ[j * D + i1] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = jb + r;
+      if (j < NP) {
+        if (i0 < Kp) Zs[j * ZS + i0] = z0[r];
+        if (i1 < Kp) Zs[j * ZS + i1] = z1[r];
+        for (int i = lane + 128; i < Kp; i += 64) Zs[j * ZS + i] = (j < D && i <= j) ? mZ[j * D + i] : 0.0;
+      }
+    }
   }
-  __syncthreads();
-  const int tl = tid & 63, jg = tid >> 6;
-  const int per = (D + 3) / 4;
-  const int j0 = jg * per, j1 = min(D, j0 + per);
-  double q = 0.0;
-  const double *drow = dt + tl * DP;
-  for (int j = j0; j < j1; ++j) {
-    double y = 0.0;
-    const double *zr = Z + j * D;
-    for (int i = 0; i <= j; ++i) y += drow[i] * zr[i];
-    q += y * y;
-  }
-  qp[jg * ML_TILE + tl] = q;
-  __syncthreads();
-  if (tid < ML_TILE) {
-    int64_t t = t0 + tid;
-    if (t < dm.T) {
-      double qq = ((qp[tid] + qp[ML_TILE + tid]) + qp[2 * ML_TILE + tid]) + qp[3 * ML_TILE + tid];
-      logp[t * dm.M + m] = mod[2 * D * D + 3 * D] - 0.5 * qq;
+  const int ar = lane & 15, ak = lane >> 4;
+  const int64_t ntiles = (dm.T + ML_TILE - 1) / ML_TILE;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t t0 = tile * ML_TILE;
+    __syncthreads();  // the previous tile has been consumed (and Zs is complete)
+    // every wavefront stages the 16 frames it multiplies itself
+    {
+      // all loads of the wavefront's 16 rows in flight before the first store (two columns per lane)
+      const int i0 = lane, i1 = lane + 64;
+      const double mu0 = i0 < D ? mux[i0] : 0.0, mu1 = i1 < D ? mux[i1] : 0.0;
+      double v0[16], v1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t t = t0 + 16 * wv + r;
+        v0[r] = (t < dm.T && i0 < D) ? X[t * D + i0] : mu0;
+        v1[r] = (t < dm.T && i1 < D) ? X[t * D + i1] : mu1;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double *row = dts + (16 * wv + r) * ZS;
+        if (i0 < Kp) row[i0] = v0[r] - mu0;
+        if (i1 < Kp) row[i1] = v1[r] - mu1;
+      }
+      for (int i = lane + 128; i < Kp; i += 64)   // wider features: the remaining columns, plainly
+        for (int r = 0; r < 16; ++r) {
+          const int64_t t = t0 + 16 * wv + r;
+          dts[(16 * wv + r) * ZS + i] = (t < dm.T && i < D) ? X[t * D + i] - mux[i] : 0.0;
+        }
+    }
+    __syncthreads();
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    const double *arow = dts + (16 * wv + ar) * ZS + ak;
+    for (int nt = 0; nt < NP / 16; ++nt) {
+      ml_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+      const int ksteps = min(Kp / 4, 4 * (nt + 1));
+      const double *brow = Zs + (16 * nt + ar) * ZS + ak;
+      // (built with -mllvm -amdgpu-mfma-vgpr-form=1: the accumulator stays in VGPRs across the loop
+      // instead of being copied to and from AGPRs around every MFMA)
+#pragma unroll 4
+      for (int ks = 0; ks < ksteps; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * ks], brow[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] += acc[r] * acc[r];
+    }
+    // sum over the 16 columns held by the lanes of one row group: lane 15 of the group ends up with the total
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = q[r];
+      v += kwy_dpp_f64<0x111>(v);
+      v += kwy_dpp_f64<0x112>(v);
+      v += kwy_dpp_f64<0x114>(v);
+      v += kwy_dpp_f64<0x118>(v);
+      q[r] = v;
+    }
+    if (ar == 15) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t t = t0 + 16 * wv + ak + 4 * r;
+        if (t < dm.T) logp[t * dm.M + m] = cst - 0.5 * q[r];
+      }
     }
   }
 }
@@ -380,6 +444,14 @@ static size_t ml_scratch_bytes(int64_t T, int d, int M) {
          kwy_pad(sizeof(double) * T * d) + kwy_pad(64);
 }
 
+// frame-tile walkers per mixture: enough workgroups for every CU (one fits per CU), not more than tiles
+static int ml_logp_splits(int64_t T, int M) {
+  const int64_t ntiles = (T + ML_TILE - 1) / ML_TILE;
+  int64_t s = (256 + M - 1) / M;
+  if (s > ntiles) s = ntiles;
+  return (int)(s < 1 ? 1 : s);
+}
+
 // `prepared`: a model made by kwy_gmm_prepare_dev (then weights/means/covs are unused), or null
 static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,
                      const double *means, const double *covs, int diff, double *y, int **status_out,
@@ -402,7 +474,7 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   *status_out = status;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
   size_t lds_prep = sizeof(double) * 3 * D * D;
-  size_t lds_logp = sizeof(double) * (D * D + ML_TILE * (D + 1) + 4 * ML_TILE);
+  size_t lds_logp = sizeof(double) * (size_t)(ml_np(D) + ML_TILE) * (ml_kp(D) + 1);
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024) { ctx->err = "gmm_mlpg: feature dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
@@ -418,7 +490,7 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
                        diff, model, status);
   const unsigned ge = (unsigned)((T * d + 255) / 256);
   hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, x, dm, X);
-  KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)((T + ML_TILE - 1) / ML_TILE), M), dim3(KWY_THREADS), lds_logp,
+  KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)ml_logp_splits(T, M), M), dim3(KWY_THREADS), lds_logp,
                      ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
   hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band, rhs);
