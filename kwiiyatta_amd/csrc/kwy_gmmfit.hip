@@ -23,7 +23,6 @@
 #define FIT_NT 512            // threads of the log-prob workgroup
 #define FIT_TILE 64           // frames per log-prob workgroup
 #define FIT_SUM_ROWS 64       // rows per LDS tile in k_fit_sums
-#define FIT_COV_ROWS 32       // rows per LDS tile in k_fit_cov
 #define FIT_COV_SPLIT 8       // row splits per mixture in k_fit_cov
 
 __host__ __device__ static inline size_t fit_tri(int D) { return (size_t)D * (D + 1) / 2; }
@@ -80,47 +79,97 @@ __global__ __launch_bounds__(KWY_THREADS) void k_fit_prec(const double *__restri
 }
 
 // weighted log prob wlp[t][m] = cst[m] - 0.5 * || Z_m (x_t - mu_m) ||^2
-__global__ __launch_bounds__(FIT_NT) void k_fit_logprob(const double *__restrict__ X, int64_t n, int D, int M,
-                                                       const double *__restrict__ means,
-                                                       const double *__restrict__ Zp,
-                                                       const double *__restrict__ cst,
-                                                       double *__restrict__ wlp) {
+// The n x D by D x D (lower-triangular) product runs on v_mfma_f64_16x16x4_f64.  A workgroup owns one
+// mixture: its packed triangular Z stays in LDS (83.5 KB for D = 144) while the workgroup walks over
+// frame tiles; wavefront w stages and multiplies frames 16w..16w+15 of a tile on its own (no block
+// barrier inside the walk), fetching the next tile's rows into registers while the MFMAs of the
+// current one run.  Per 16-column block of Z only the k-steps up to the block's diagonal are issued
+// (180 instead of 324 MFMAs per wavefront and tile for D = 144).
+// Lane map: A[row l&15][k l>>4], B[k l>>4][col l&15], D[row (l>>4)+4r][col l&15].
+typedef double fit_v4f64 __attribute__((ext_vector_type(4)));
+#define FIT_LP_NT 256
+#define FIT_LP_COLS 3   // feature columns per lane when staging a row: D <= 192
+
+__global__ __launch_bounds__(FIT_LP_NT) void k_fit_logprob(const double *__restrict__ X, int64_t n, int D, int M,
+                                                          const double *__restrict__ means,
+                                                          const double *__restrict__ Zp,
+                                                          const double *__restrict__ cst,
+                                                          double *__restrict__ wlp) {
   extern __shared__ double sm[];
-  const int nt = (int)fit_tri(D), DP = D + 1;
-  double *Z = sm;                     // packed
-  double *dt = Z + nt;                // FIT_TILE x DP
-  double *qp = dt + FIT_TILE * DP;    // 8 x FIT_TILE
-  const int tid = threadIdx.x, m = blockIdx.x;
-  const int64_t t0 = (int64_t)blockIdx.y * FIT_TILE;
+  const int nt = (int)fit_tri(D), Kp = (D + 3) & ~3, NP = (D + 15) & ~15, ZS = Kp + 1;
+  double *Z = sm;                 // packed lower triangle
+  double *dts = Z + nt;           // FIT_TILE x ZS
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
   const double *zp = Zp + (size_t)m * nt, *mu = means + (size_t)m * D;
-  for (int e = tid; e < nt; e += FIT_NT) Z[e] = zp[e];
-  for (int e = tid; e < FIT_TILE * D; e += FIT_NT) {
-    int tl = e / D, i = e % D;
-    int64_t t = t0 + tl;
-    dt[tl * DP + i] = t < n ? X[t * D + i] - mu[i] : 0.0;
-  }
-  __syncthreads();
-  const int tl = tid & 63, jg = tid >> 6;  // 8 j-groups
-  const int per = (D + 7) / 8;
-  const int j0 = jg * per, j1 = min(D, j0 + per);
-  const double *drow = dt + tl * DP;
-  double q = 0.0;
-  for (int j = j0; j < j1; ++j) {
-    const double *zr = Z + tri(j, 0);
-    double y = 0.0;
-    for (int i = 0; i <= j; ++i) y += drow[i] * zr[i];
-    q += y * y;
-  }
-  qp[jg * FIT_TILE + tl] = q;
-  __syncthreads();
-  if (tid < FIT_TILE) {
-    int64_t t = t0 + tid;
-    if (t < n) {
-      double qq = 0.0;
+  for (int e = tid; e < nt; e += FIT_LP_NT) Z[e] = zp[e];
+  const double cm = cst[m];
+  double muv[FIT_LP_COLS];
 #pragma unroll
-      for (int g = 0; g < 8; ++g) qq += qp[g * FIT_TILE + tid];
-      wlp[t * M + m] = cst[m] - 0.5 * qq;
+  for (int c = 0; c < FIT_LP_COLS; ++c) muv[c] = (lane + 64 * c < D) ? mu[lane + 64 * c] : 0.0;
+  const int ar = lane & 15, ak = lane >> 4;
+  const int64_t ntiles = (n + FIT_TILE - 1) / FIT_TILE;
+  double *myrows = dts + (16 * wv) * ZS;
+  // rows of the first tile
+  double xv[16][FIT_LP_COLS];
+  auto fetch = [&](int64_t tile) {
+    const int64_t tb = tile * FIT_TILE + 16 * wv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int c = 0; c < FIT_LP_COLS; ++c) {
+        const int i = lane + 64 * c;
+        xv[r][c] = (tile < ntiles && tb + r < n && i < D) ? X[(tb + r) * D + i] : muv[c];
+      }
+  };
+  fetch(blockIdx.y);
+  __syncthreads();  // Z complete
+  for (int64_t tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int c = 0; c < FIT_LP_COLS; ++c) {
+        const int i = lane + 64 * c;
+        if (i < Kp) myrows[r * ZS + i] = xv[r][c] - muv[c];
+      }
+    __builtin_amdgcn_wave_barrier();
+    fetch(tile + gridDim.y);  // in flight during the MFMAs below
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
+    const double *arow = myrows + ar * ZS + ak;
+    for (int nb = 0; nb < NP / 16; ++nb) {
+      const int j = 16 * nb + ar;
+      const double *zrow = Z + tri(j < D ? j : 0, 0) + ak;
+      fit_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+      for (int ks = 0; ks < 4 * nb; ++ks)  // strictly below the diagonal block: no masking (j >= 16 nb > i)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * ks], j < D ? zrow[4 * ks] : 0.0, acc, 0, 0, 0);
+#pragma unroll
+      for (int dgn = 0; dgn < 4; ++dgn) {  // the diagonal block
+        const int ks = 4 * nb + dgn;
+        if (4 * ks < Kp) {
+          const int i = 4 * ks + ak;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * ks], (j < D && i <= j) ? zrow[4 * ks] : 0.0, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] += acc[r] * acc[r];
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = q[r];
+      v += kwy_dpp_f64<0x111>(v);
+      v += kwy_dpp_f64<0x112>(v);
+      v += kwy_dpp_f64<0x114>(v);
+      v += kwy_dpp_f64<0x118>(v);
+      q[r] = v;
+    }
+    if (ar == 15) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t t = tile * FIT_TILE + 16 * wv + ak + 4 * r;
+        if (t < n) wlp[t * M + m] = cm - 0.5 * q[r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -199,55 +248,90 @@ __global__ void k_fit_reduce(const double *__restrict__ part, int nchunks, int64
 }
 
 // local statistics: cpart[split][m] = sum over the split's rows of r (x - mu_m)(x - mu_m)'  (full D x D)
-// 256 threads as a 16 x 16 grid, each owning a TS x TS tile of the D x D result (D <= 16*TS).
-template <int TS>
+// A D x n by n x D product with the frame index as the MFMA's k: v_mfma_f64_16x16x4_f64 consumes four
+// frames per instruction, A = r_t d_t[i], B = d_t[j].  A workgroup owns (mixture, row split) and
+// walks over 64-frame tiles staged in LDS; wavefront w accumulates the 16-row blocks w, w+4, w+8 of
+// the result against all 16-column blocks (the full square: the symmetric half would need a
+// per-wavefront tile list, i.e. dynamically indexed accumulators).
+#define FIT_COV_NB 10      // 16-column blocks: D <= 160
+#define FIT_COV_RB 3       // 16-row blocks per wavefront: ceil(10 / 4)
 __global__ __launch_bounds__(KWY_THREADS) void k_fit_cov(const double *__restrict__ X,
                                                         const double *__restrict__ resp, int64_t n, int D,
                                                         int M, const double *__restrict__ means,
                                                         double *__restrict__ cpart) {
   extern __shared__ double sm[];
-  const int DP = 16 * TS;
-  double *ds = sm;                       // FIT_COV_ROWS x DP (zero padded)
-  double *rs = ds + FIT_COV_ROWS * DP;   // FIT_COV_ROWS
-  const int tid = threadIdx.x, m = blockIdx.x, split = blockIdx.y;
-  const int ti = tid >> 4, tj = tid & 15;
-  const int64_t rows = (n + FIT_COV_SPLIT - 1) / FIT_COV_SPLIT;
+  const int NP = (D + 15) & ~15, nb = NP / 16, ZS = NP + 1;
+  double *ds = sm;                 // FIT_TILE x ZS, zero padded columns
+  double *rs = ds + FIT_TILE * ZS; // FIT_TILE
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x, split = blockIdx.y;
+  const int ar = lane & 15, ak = lane >> 4;
+  const int64_t rows = (n + gridDim.y - 1) / gridDim.y;
   const int64_t r0 = split * rows, r1 = min(n, r0 + rows);
   const double *mu = means + (size_t)m * D;
-  double acc[TS][TS];
+  double muv[FIT_LP_COLS];
 #pragma unroll
-  for (int a = 0; a < TS; ++a)
+  for (int c = 0; c < FIT_LP_COLS; ++c) muv[c] = (lane + 64 * c < D) ? mu[lane + 64 * c] : 0.0;
+  fit_v4f64 acc[FIT_COV_RB][FIT_COV_NB];
 #pragma unroll
-    for (int b = 0; b < TS; ++b) acc[a][b] = 0.0;
-  for (int64_t b0 = r0; b0 < r1; b0 += FIT_COV_ROWS) {
-    const int nr = (int)min((int64_t)FIT_COV_ROWS, r1 - b0);
+  for (int a = 0; a < FIT_COV_RB; ++a)
+#pragma unroll
+    for (int b = 0; b < FIT_COV_NB; ++b) acc[a][b] = fit_v4f64{0.0, 0.0, 0.0, 0.0};
+  // this wavefront stages rows 16w..16w+15 of every tile: fetched one tile ahead into registers
+  double xv[16][FIT_LP_COLS], rv = 0.0;
+  auto fetch = [&](int64_t b0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int c = 0; c < FIT_LP_COLS; ++c) {
+        const int i = lane + 64 * c;
+        const int64_t t = b0 + 16 * wv + r;
+        xv[r][c] = (t < r1 && i < D) ? X[t * D + i] : muv[c];
+      }
+    const int64_t t = b0 + 16 * wv + lane;
+    rv = (lane < 16 && t < r1) ? resp[t * M + m] : 0.0;
+  };
+  fetch(r0);
+  for (int64_t b0 = r0; b0 < r1; b0 += FIT_TILE) {
+    __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int c = 0; c < FIT_LP_COLS; ++c) {
+        const int i = lane + 64 * c;
+        if (i < NP) ds[(16 * wv + r) * ZS + i] = xv[r][c] - muv[c];
+      }
+    if (lane < 16) rs[16 * wv + lane] = rv;
     __syncthreads();
-    for (int e = tid; e < FIT_COV_ROWS * DP; e += KWY_THREADS) {
-      int r = e / DP, i = e % DP;
-      ds[e] = (r < nr && i < D) ? X[(b0 + r) * D + i] - mu[i] : 0.0;
-    }
-    for (int r = tid; r < FIT_COV_ROWS; r += KWY_THREADS) rs[r] = r < nr ? resp[(b0 + r) * M + m] : 0.0;
-    __syncthreads();
-    for (int r = 0; r < nr; ++r) {
-      const double rr = rs[r];
-      const double *dr = ds + r * DP;
-      double av[TS], bv[TS];
+    fetch(b0 + FIT_TILE);
+#pragma unroll 2
+    for (int ks = 0; ks < FIT_TILE / 4; ++ks) {
+      const double *drow = ds + (4 * ks + ak) * ZS + ar;
+      const double rr = rs[4 * ks + ak];
+      double bv[FIT_COV_NB], av[FIT_COV_RB];
 #pragma unroll
-      for (int a = 0; a < TS; ++a) { av[a] = rr * dr[ti * TS + a]; bv[a] = dr[tj * TS + a]; }
+      for (int b = 0; b < FIT_COV_NB; ++b) bv[b] = b < nb ? drow[16 * b] : 0.0;
 #pragma unroll
-      for (int a = 0; a < TS; ++a)
+      for (int a = 0; a < FIT_COV_RB; ++a) av[a] = (wv + 4 * a < nb) ? rr * drow[16 * (wv + 4 * a)] : 0.0;
 #pragma unroll
-        for (int b = 0; b < TS; ++b) acc[a][b] += av[a] * bv[b];
+      for (int a = 0; a < FIT_COV_RB; ++a) {
+        if (wv + 4 * a < nb) {
+#pragma unroll
+          for (int b = 0; b < FIT_COV_NB; ++b)
+            if (b < nb) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+      }
     }
   }
   double *out = cpart + ((size_t)split * M + m) * D * D;
 #pragma unroll
-  for (int a = 0; a < TS; ++a)
+  for (int a = 0; a < FIT_COV_RB; ++a)
 #pragma unroll
-    for (int b = 0; b < TS; ++b) {
-      int i = ti * TS + a, j = tj * TS + b;
-      if (i < D && j < D) out[(size_t)i * D + j] = acc[a][b];
-    }
+    for (int b = 0; b < FIT_COV_NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * (wv + 4 * a) + ak + 4 * r, j = 16 * b + ar;
+        if (wv + 4 * a < nb && b < nb && i < D && j < D) out[(size_t)i * D + j] = acc[a][b][r];
+      }
 }
 
 // means = sx / nk   (nk already holds sum r + 10 eps)
@@ -278,10 +362,18 @@ __global__ void k_fit_finalize(const double *__restrict__ stats, const double *_
   covs[e] = v;
 }
 
+// frame-tile walkers per mixture: one workgroup fits per CU
+static unsigned fit_lp_splits(int64_t n, int M) {
+  const int64_t ntiles = (n + FIT_TILE - 1) / FIT_TILE;
+  int64_t s = (256 + M - 1) / M;
+  if (s > ntiles) s = ntiles;
+  return (unsigned)(s < 1 ? 1 : s);
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------
 static int fit_check(kwy_ctx *ctx, int64_t n, int D, int M) {
   if (!ctx) return KWY_EINVAL;
-  if (n <= 0 || D <= 0 || D > 160 || M <= 0 || M > 256) {
+  if (n <= 0 || D <= 0 || D > 160 || D > 64 * FIT_LP_COLS || M <= 0 || M > 256) {
     ctx->err = "gmm_em: need 0 < D <= 160 and 0 < M <= 256";
     return KWY_EINVAL;
   }
@@ -314,13 +406,13 @@ extern "C" int kwy_gmm_em_estep_dev(kwy_ctx *ctx, const double *X, int64_t n, in
   if (!Zp || !zcol || !cst) { ctx->err = "gmm_em_estep: scratch"; return KWY_ENOMEM; }
   KWY_HIP(hipMemsetAsync(status_out, 0, sizeof(int), ctx->stream));
   const size_t lds_prec = sizeof(double) * nt;
-  const size_t lds_lp = sizeof(double) * (nt + (size_t)FIT_TILE * (D + 1) + 8 * FIT_TILE);
+  const size_t lds_lp = sizeof(double) * (nt + (size_t)FIT_TILE * (((D + 3) & ~3) + 1));
   if (lds_lp > 160 * 1024) { ctx->err = "gmm_em_estep: feature dimension too large for LDS"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_fit_prec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prec));
   KWY_HIP(hipFuncSetAttribute((const void *)k_fit_logprob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lp));
   hipLaunchKernelGGL(k_fit_prec, dim3(M), dim3(KWY_THREADS), lds_prec, ctx->stream, weights, covs, D, Zp, zcol, cst,
                      status_out);
-  KWY_PROF(ctx, "k_fit_logprob", hipLaunchKernelGGL(k_fit_logprob, dim3(M, (unsigned)((n + FIT_TILE - 1) / FIT_TILE)), dim3(FIT_NT), lds_lp,
+  KWY_PROF(ctx, "k_fit_logprob", hipLaunchKernelGGL(k_fit_logprob, dim3(M, fit_lp_splits(n, M)), dim3(FIT_LP_NT), lds_lp,
                      ctx->stream, X, n, D, M, means, Zp, cst, resp));
   hipLaunchKernelGGL(k_fit_resp, dim3((unsigned)((n + KWY_THREADS - 1) / KWY_THREADS)), dim3(KWY_THREADS), 0,
                      ctx->stream, resp, n, M, loglik_parts);
@@ -376,26 +468,10 @@ extern "C" int kwy_gmm_em_cov_dev(kwy_ctx *ctx, const double *X, int64_t n, int 
   KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)FIT_COV_SPLIT * len)));
   double *cpart = kwy_arena<double>(ctx, (size_t)FIT_COV_SPLIT * len);
   if (!cpart) { ctx->err = "gmm_em_cov: scratch"; return KWY_ENOMEM; }
-  const int TS = (D + 15) / 16;
-  const size_t lds = sizeof(double) * ((size_t)FIT_COV_ROWS * 16 * TS + FIT_COV_ROWS);
-#define LAUNCH_COV(ts)                                                                                              \
-  do {                                                                                                              \
-    KWY_HIP(hipFuncSetAttribute((const void *)k_fit_cov<ts>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<ts>, dim3(M, FIT_COV_SPLIT), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, means, cpart)); \
-  } while (0)
-  switch (TS) {
-    case 1: LAUNCH_COV(1); break;
-    case 2: LAUNCH_COV(2); break;
-    case 3: LAUNCH_COV(3); break;
-    case 4: LAUNCH_COV(4); break;
-    case 5: LAUNCH_COV(5); break;
-    case 6: LAUNCH_COV(6); break;
-    case 7: LAUNCH_COV(7); break;
-    case 8: LAUNCH_COV(8); break;
-    case 9: LAUNCH_COV(9); break;
-    default: LAUNCH_COV(10); break;
-  }
-#undef LAUNCH_COV
+  const int NP = (D + 15) & ~15;
+  const size_t lds = sizeof(double) * ((size_t)FIT_TILE * (NP + 1) + FIT_TILE);
+  KWY_HIP(hipFuncSetAttribute((const void *)k_fit_cov, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov, dim3(M, FIT_COV_SPLIT), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, means, cpart));
   hipLaunchKernelGGL(k_fit_reduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, cpart,
                      FIT_COV_SPLIT, len, sxx);
   KWY_HIP(hipGetLastError());
