@@ -51,10 +51,14 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   constexpr int K = H + 1;
   constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;  // draws owned per thread
 
+  // LDS: one FFT buffer (in-place radix-8 transforms; it also serves as the smoothing scratch and
+  // the log-spectrum), the power spectrum, a small twiddle table: 29 KB at fft 2048
+  constexpr int TWL = (H / 8 > 1) ? H / 8 : 1;
   extern __shared__ double smem[];
   kwy_c *bufA = (kwy_c *)smem;           // H+1 complex
-  kwy_c *bufB = bufA + (H + 1);          // H+1 complex
-  double *red = (double *)(bufB + (H + 1));  // 8
+  double *P = (double *)(bufA + (H + 1));  // K (+1 pad)
+  kwy_c *twl = (kwy_c *)(P + K + 1);     // exp(-2 pi i k / H), k < H/8
+  double *red = (double *)(twl + TWL);   // 8
   double *tot = red + 8;                 // KWY_THREADS
   uint32_t *e = (uint32_t *)(tot + KWY_THREADS);  // KWY_EBASE_WORDS
 
@@ -67,32 +71,46 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(pos * fs + 0.001);
 
+  for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
+  const kwy_c twb = twN[tid];
   // ---- noise: this thread owns draws [C*tid, C*tid + C) of the frame's stream
   for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
   __syncthreads();
-  kwy_rng rng = kwy_rng_combine(e, poly[tid]);
+  // the frame consumes wl + K draws; a thread owns c = ceil((wl + K) / 256) <= C consecutive ones
+  const int c = (wl + K + KWY_THREADS - 1) / KWY_THREADS;
+  kwy_rng rng;
+  if constexpr (sizeof(double) * (K + 1) >= 8192) {  // table-driven jump, table in the not yet used P array
+    kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)P);
+    __syncthreads();
+    rng = kwy_rng_combine_table((const uint4 *)P, poly[(c - 1) * KWY_THREADS + tid]);
+  } else {
+    rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
+  }
   double nz[C];
 #pragma unroll
-  for (int j = 0; j < C; ++j) nz[j] = kwy_rng_randn(rng);
+  for (int j = 0; j < C; ++j) nz[j] = (j < c) ? kwy_rng_randn(rng) : 0.0;
 
-  // ---- F0-adaptive window (thread owns samples i = C*tid + j < wl)
+  // ---- F0-adaptive window (thread owns samples i = c*tid + j < wl)
   double wv[C];
   double sumsq = 0.0;
 #pragma unroll
   for (int j = 0; j < C; ++j) {
-    int i = C * tid + j;
-    double position = (i - half) / 1.5 / fs;
-    double w = 0.5 * cos(KWY_PI * position * cf0) + 0.5;
+    int i = c * tid + j;
+    double w = 0.0;
+    if (j < c && i < wl) {
+      double position = (i - half) / 1.5 / fs;
+      w = 0.5 * kwy_cos_pi_range(KWY_PI * position * cf0) + 0.5;   // |argument| <= pi inside the window
+      sumsq += w * w;
+    }
     wv[j] = w;
-    if (i < wl) sumsq += w * w;
   }
   const double average = sqrt(kwy_block_sum(sumsq, red));
   double *A = (double *)bufA;
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int j = 0; j < C; ++j) {
-    int i = C * tid + j;
-    if (i < wl) {
+    int i = c * tid + j;
+    if (j < c && i < wl) {
       double wn = wv[j] / average;
       wv[j] = wn;
       int idx = min(x_length - 1, max(0, origin + i - half));
@@ -108,18 +126,17 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   const double coef = t1 / t2;
 #pragma unroll
   for (int j = 0; j < C; ++j) {
-    int i = C * tid + j;
-    if (i < wl) A[i] -= wv[j] * coef;
+    int i = c * tid + j;
+    if (j < c && i < wl) A[i] -= wv[j] * coef;
   }
   for (int i = wl + tid; i < N; i += KWY_THREADS) A[i] = 0.0;
 
   // ---- power spectrum
-  kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
-  kwy_c *Yc = (X == bufA) ? bufB : bufA;
-  double *P = (double *)Yc;  // K doubles
-  double *S = (double *)X;   // scratch after P is formed (N+2 doubles)
+  __syncthreads();
+  kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(bufA, twl, twb, twN);
+  double *S = (double *)bufA;   // scratch after P is formed (N+2 doubles)
   for (int k = tid; k <= H; k += KWY_THREADS) {
-    kwy_c v = X[k];
+    kwy_c v = bufA[k];
     P[k] = v.x * v.x + v.y * v.y;
   }
   __syncthreads();
@@ -166,8 +183,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   // ---- infinitesimal noise: draw wl + k belongs to bin k
 #pragma unroll
   for (int j = 0; j < C; ++j) {
-    int k = C * tid + j - wl;
-    if (k >= 0 && k <= H) P[k] = P[k] + fabs(nz[j]) * CT_EPS;
+    int k = c * tid + j - wl;
+    if (j < c && k >= 0 && k <= H) P[k] = P[k] + fabs(nz[j]) * CT_EPS;
   }
   __syncthreads();
 
@@ -179,8 +196,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
     if (k >= 1 && k < H) Lg[N - k] = v;
   }
   __syncthreads();
-  kwy_c *Cx = kwy_rfft_lds(X, Yc, LOG2N - 1, twH, twN);
-  kwy_c *Co = (Cx == bufA) ? bufB : bufA;
+  kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(bufA, twl, twb, twN);
+  kwy_c *Cx = bufA;
 
   // ---- smoothing + recovery lifter
   for (int k = tid; k <= H; k += KWY_THREADS) {
@@ -195,8 +212,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
     }
     Cx[k] = {Cx[k].x * sl * cl / N, 0.0};
   }
-  kwy_c *W = kwy_irfft_lds(Cx, Co, LOG2N - 1, twH, twN);
-  const double *wr = (const double *)W;
+  kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(bufA, twl, twb, twN);
+  const double *wr = (const double *)bufA;
   double *o = out + frame * K;
   if (out_div == 1.0) {
     for (int k = tid; k <= H; k += KWY_THREADS) o[k] = exp(wr[k]);
@@ -215,8 +232,8 @@ static int launch_ct(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly(ctx, 12ull * C, &poly));
-  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * (8 + KWY_THREADS) +
+  KWY_TRY(kwy_get_poly_multi(ctx, C, KWY_THREADS, &poly));
+  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (K + 1 + 8 + KWY_THREADS) +
                sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_cheaptrick<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -42,6 +42,17 @@ __device__ __forceinline__ double kwy_rng_randn(kwy_rng &r) {
   return kwy_rng_randn_raw(r) / 268435456.0 - 6.0;
 }
 
+// XOR over the wavefront, result in every lane: row-local DPP shifts, then the four row totals
+// through scalar registers (no LDS round trips).
+__device__ __forceinline__ uint32_t kwy_wave_xor_u32(uint32_t v) {
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // lane 15 of a row: the row's XOR
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 15) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 31) ^
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 47) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Wavefront-cooperative jump: all 64 lanes hold the same state s[4]; on return
 // every lane holds T^steps s.  pow2: [64][128] columns of T^(2^k) (uint4 each).
 __device__ inline void kwy_wave_jump(uint32_t (&s)[4], uint64_t steps, const uint4 *__restrict__ pow2) {
@@ -58,12 +69,8 @@ __device__ inline void kwy_wave_jump(uint32_t (&s)[4], uint64_t steps, const uin
     m = 0u - ((whi >> (lane & 31)) & 1u);
     c = pow2[k * 128 + 64 + lane];
     o0 ^= c.x & m; o1 ^= c.y & m; o2 ^= c.z & m; o3 ^= c.w & m;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      o0 ^= __shfl_xor(o0, d); o1 ^= __shfl_xor(o1, d);
-      o2 ^= __shfl_xor(o2, d); o3 ^= __shfl_xor(o3, d);
-    }
-    s[0] = o0; s[1] = o1; s[2] = o2; s[3] = o3;
+    s[0] = kwy_wave_xor_u32(o0); s[1] = kwy_wave_xor_u32(o1);
+    s[2] = kwy_wave_xor_u32(o2); s[3] = kwy_wave_xor_u32(o3);
   }
 }
 
