@@ -89,13 +89,13 @@ __device__ inline void d4c_linear_smoothing(const double *in, double *out, doubl
   __syncthreads();
   kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
-  const double inv_dfi = (double)N / fs;
+  const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
   for (int k = threadIdx.x; k <= H; k += NT) {
     double fa = (double)k / N * fs - width / 2.0;
     double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     fa += width;
     double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
-    out[k] = (high - low) / width;
+    out[k] = (high - low) * inv_width;
   }
   __syncthreads();
 }
@@ -320,65 +320,108 @@ __device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot,
   __syncthreads();
   kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
-  const double inv_dfi = (double)N / fs;
+  const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
   for (int k = threadIdx.x; k <= H; k += NT) {
     double fa = (double)k / N * fs - width / 2.0;
     double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     fa += width;
     double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
-    io[k] = io[k] - (high - low) / width;
+    io[k] = io[k] - (high - low) * inv_width;
   }
   __syncthreads();
 }
 
-// General body.  One 512-thread workgroup per frame; the frame lives in ~61 KB of
-// LDS so that two frames share a CU:
-//   Dv  (H+2 doubles)   centroid sum, later the static group delay
-//   B   (H+1 complex)   the one FFT buffer (in-place radix-8 transforms); afterwards the
-//                       power spectrum P = B[0..H] as doubles, the smoothing scratch S
-//                       behind it, and during the band loop the select histograms
-// The spectra themselves never go back to LDS: each thread pulls "its" bins
-// k = tid + NT*r out of the packed half-length transform into registers.
-#define D4C_NT 512
-// doubles of the region shared by B (2H+2), P + S (H+2 + 2H+4) and the select histograms
-__host__ __device__ constexpr int d4c_overlay_doubles(int H) {
-  return (3 * H + 6) > (KWY_SELECT_WORDS(D4C_NT) / 2) ? (3 * H + 6) : (KWY_SELECT_WORDS(D4C_NT) / 2);
+// WORLD LinearSmoothing with the result left in registers: outv[r] = smoothed[tid + NT*r]
+template <int NT, int RK>
+__device__ inline void d4c_linear_smoothing_regs(const double *in, double (&outv)[RK], double *S, double *tot,
+                                                 double width, int fs, int N) {
+  const int H = N / 2;
+  int boundary = (int)(width * N / fs) + 1;
+  if (boundary > H / 2) boundary = H / 2;
+  const int L = H + boundary * 2 + 1;
+  for (int i = threadIdx.x; i < L; i += NT) {
+    double m;
+    if (i < boundary) m = in[boundary - i];
+    else if (i < H + boundary) m = in[i - boundary];
+    else m = in[H - (i - (H + boundary))];
+    S[i] = m * fs / N;
+  }
+  __syncthreads();
+  kwy_block_cumsum<NT>(S, L, tot);
+  const double origin = -(boundary - 0.5) * fs / N;
+  const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
+#pragma unroll
+  for (int r = 0; r < RK; ++r) {
+    const int k = threadIdx.x + NT * r;
+    outv[r] = 0.0;
+    if (k <= H) {
+      double fa = (double)k / N * fs - width / 2.0;
+      double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+      fa += width;
+      double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+      outv[r] = (high - low) * inv_width;
+    }
+  }
+  __syncthreads();
 }
+
+// a per-thread constant behind an optimisation barrier: what is derived from it (the nine bin
+// twiddles, a few multiplications each) is recomputed at every use instead of living in -- at this
+// register budget, being spilled from -- 36 registers for the whole kernel
+__device__ __forceinline__ kwy_c d4c_opaque(kwy_c v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y));
+  return v;
+}
+
+// General body.  One 256-thread workgroup per frame, and the frame's working set squeezed into
+// 51 KB of LDS so that THREE frames share a CU (the kernel is bound by barrier latency and f64 issue,
+// not by bandwidth: a third resident frame is worth more than wider workgroups):
+//   A0 (H+2 doubles)   RNG jump table during the window phases; then the power spectrum P; then the
+//                      static group delay Dv
+//   B  (H+1 complex)   the one FFT buffer (in-place radix-8 transforms); also the smoothing scratch S
+//                      and, in the band loop, the select histogram
+// What would not fit stays in registers: the centroid sum across the power-spectrum phase, X1 across the
+// second FFT of a centroid, the smoothed power spectrum, the Nuttall window, the FFT pass factors.
+// The spectra themselves never go back to LDS: each thread pulls "its" bins k = tid + NT*r out of the
+// packed half-length transform into registers.
+#define D4C_NT 256
 template <int LOG2N>
-__global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
+static constexpr size_t d4c_body_lds() {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  // tot | red | coarse | e | [jtab when it does not fit A0] | A0 | B (+2 doubles of smoothing overflow)
+  return sizeof(double) * (D4C_NT + 16 + D4C_MAX_BANDS + 2) + sizeof(uint32_t) * KWY_EBASE_WORDS +
+         (LOG2N == 12 ? 0 : 8192) + sizeof(double) * ((H + 2) + (2 * H + 2) + 2) +
+         // the select scratch lives in B; short transforms need room for it
+         ((sizeof(uint32_t) * KWY_SELECT_WORDS(D4C_NT) > sizeof(double) * (2 * H + 4))
+              ? sizeof(uint32_t) * KWY_SELECT_WORDS(D4C_NT) - sizeof(double) * (2 * H + 4) : 0);
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(D4C_NT, 3) void k_d4c_body(
     const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
     const double *__restrict__ ap0, d4c_params p, const uint32_t *__restrict__ ebase,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     const double *__restrict__ nuttall, double *__restrict__ out, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int NT = D4C_NT;
-  constexpr int E = N / NT;                // window elements per thread
+  constexpr int E = N / NT;                  // window elements per thread
   constexpr int RK = (H + 1 + NT - 1) / NT;  // spectrum bins per thread
+  constexpr int HEX = 16 * NT / N;           // 16th-root index step of the bin twiddles
+  static_assert(HEX >= 1, "workgroup narrower than N/16");
 #define D4C_STAMP(n) do { if (dbg && threadIdx.x == 0 && blockIdx.x == (unsigned)dbg[63]) dbg[n] = clock64(); } while (0)
-  // small arrays first: everything but the tail of the overlay then sits below 64 KB, within
-  // reach of the 16-bit offset field of the ds_ instructions (one address register per thread
-  // instead of one per array)
   extern __shared__ double smem[];
   double *tot = smem;                        // NT
   double *red = tot + NT;                    // 16
   double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
   uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);  // KWY_EBASE_WORDS
-  kwy_c *twL = (kwy_c *)(e + KWY_EBASE_WORDS);   // H/8 entries: exp(-2 pi i k / H), k < H/8
-  double *nut_small = (double *)(twL + H / 8);   // 1024 doubles, only for N < 4096
-  double *Dv = nut_small + (LOG2N == 12 ? 0 : 1024);  // H+2
-  kwy_c *B = (kwy_c *)(Dv + (H + 2));        // H+1 complex
+  double *jt_own = (double *)(e + KWY_EBASE_WORDS);        // 1024 doubles unless the table fits A0
+  double *A0 = jt_own + (LOG2N == 12 ? 0 : 1024);          // H+2
+  kwy_c *B = (kwy_c *)(A0 + (H + 2));        // H+1 complex (+2 doubles)
   double *Bd = (double *)B;
-  double *P = Bd;                            // H+1 doubles (+1 pad)
-  double *S = Bd + (H + 2);                  // <= 2H+3 doubles: reaches past B, see d4c_body_lds()
-  // RNG jump table of the window phases (8 KB): the tail of the overlay for N = 4096 (X1s' second
-  // piece lives there too, but only between a window's two FFTs), else the Nuttall area
-  uint4 *jtab = (uint4 *)((LOG2N == 12) ? Bd + (2 * H + 2) : nut_small);
-  // Nuttall window of the band loop, <= 1023 doubles: for N = 4096 in the idle tail of the overlay
-  double *nutw = (LOG2N == 12) ? Bd + (2 * H + 2) : nut_small;
+  double *P = A0, *Dv = A0;
+  double *S = Bd;                            // <= 2H+3 doubles
+  uint4 *jtab = (uint4 *)((LOG2N == 12) ? A0 : jt_own);
   uint32_t *hist = (uint32_t *)B;            // KWY_SELECT_WORDS(NT), band loop only
-  // centroid phase only: bins 0..H/2 in Dv (H+2 doubles = H/2+1 complex), the rest behind B
-  kwy_c *X1s = (kwy_c *)Dv;
-  constexpr int XGAP = (H + 1);              // complex elements of B between the two pieces
 
   const int tid = threadIdx.x;
   const int64_t frame = blockIdx.x;
@@ -392,124 +435,134 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
   const double pos = kwy_uniform(tpos[frame]);
 
   D4C_STAMP(0);
-  for (int i = tid; i < H / 8; i += NT) twL[i] = twH[i];
-  // exp(-2 pi i k / N) of "my" spectrum bins k = tid + NT*r is this times an 8th root of unity
+  kwy_c tw4[4];   // this thread's factor of every radix-8 pass
+  kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
+  // exp(-2 pi i k / N) of "my" spectrum bins k = tid + NT*r is this times a 16th root of unity
   const kwy_c twb = twN[tid];
-  constexpr int OCT = 8 * NT / N;
   const uint32_t *eb = ebase + (size_t)frame * 3 * KWY_EBASE_WORDS;  // one extended state per window
-  __syncthreads();
 
   D4C_STAMP(1);
   // ---- static centroid: two temporal centroids at pos -+ 0.25/f0, each Re(X2 conj X1) of the
   //      normalised window (X1) and the window times its sample index (X2)
   double cen[RK];
-  double av[E];
-  for (int which = 0; which < 2; ++which) {
-    const int tid = kwy_tid_opaque();
-    double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-    d4c_frame_window<N, NT>(x, p, cf0, cpos, D4C_BLACKMAN, eb + which * KWY_EBASE_WORDS, poly, e, jtab, Bd, true, red, av);
+  {
+    double av[E];
+    for (int which = 0; which < 2; ++which) {
+      const int tid = kwy_tid_opaque();
+      double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
+      d4c_frame_window<N, NT>(x, p, cf0, cpos, D4C_BLACKMAN, eb + which * KWY_EBASE_WORDS, poly, e, jtab, Bd, true, red, av);
 #pragma unroll
-    for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];   // each thread overwrites the draws it consumed
-    __syncthreads();
-    D4C_STAMP(2 + which * 2);
-    kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
-    // X1 of "my" bins waits in the LDS that is idle until the centroid is complete (Dv and the
-    // tail of the overlay): written and read back by the same thread, no barrier involved
+      for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];   // each thread overwrites the draws it consumed
+      __syncthreads();
+      D4C_STAMP(2 + which * 2);
+      kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
+      kwy_c X1[RK];
 #pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + NT * r;
-      if (k <= H) X1s[k < H / 2 + 1 ? k : k + XGAP] = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r] * (tid + NT * r + 1.0);
-    __syncthreads();
-    kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + NT * r;
-      if (k <= H) {
-        const kwy_c X2 = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
-        const kwy_c X1 = X1s[k < H / 2 + 1 ? k : k + XGAP];
-        const double v = X2.x * X1.x + X1.y * X2.y;
-        cen[r] = which == 0 ? v : cen[r] + v;
+      for (int r = 0; r < RK; ++r) {
+        const int k = tid + NT * r;
+        X1[r] = k <= H ? kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r)) : kwy_c{0.0, 0.0};
       }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r] * (tid + NT * r + 1.0);
+      __syncthreads();
+      kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const int k = tid + NT * r;
+        if (k <= H) {
+          const kwy_c X2 = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
+          const double v = X2.x * X1[r].x + X1[r].y * X2.y;
+          cen[r] = which == 0 ? v : cen[r] + v;
+        }
+      }
+      __syncthreads();
+      D4C_STAMP(3 + which * 2);
     }
+
+    D4C_STAMP(6);
+    // ---- smoothed power spectrum (the centroid sum waits in registers)
+    d4c_frame_window<N, NT>(x, p, cf0, pos, D4C_HANNING, eb + 2 * KWY_EBASE_WORDS, poly, e, jtab, Bd, false, red, av);
+#pragma unroll
+    for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];
     __syncthreads();
-    D4C_STAMP(3 + which * 2);
   }
+  D4C_STAMP(7);
+  kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
+  D4C_STAMP(8);
+  double pv[RK];
+#pragma unroll
+  for (int r = 0; r < RK; ++r) {
+    const int k = tid + NT * r;
+    pv[r] = 0.0;
+    if (k <= H) {
+      const kwy_c v = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
+      pv[r] = v.x * v.x + v.y * v.y;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RK; ++r)
+    if (tid + NT * r <= H) P[tid + NT * r] = pv[r];
+  __syncthreads();
+  d4c_dc_correction<NT>(P, S, cf0, p.fs, N);
+  d4c_linear_smoothing_regs<NT, RK>(P, pv, S, tot, cf0, p.fs, N);   // P is dead from here on
+
+  D4C_STAMP(9);
+  // ---- static group delay: the centroid sum moves into A0
 #pragma unroll
   for (int r = 0; r < RK; ++r)
     if (tid + NT * r <= H) Dv[tid + NT * r] = cen[r];
   __syncthreads();
-  d4c_dc_correction<NT>(Dv, Bd, cf0, p.fs, N);
-
-  D4C_STAMP(6);
-  // ---- smoothed power spectrum
-  d4c_frame_window<N, NT>(x, p, cf0, pos, D4C_HANNING, eb + 2 * KWY_EBASE_WORDS, poly, e, jtab, Bd, false, red, av);
+  d4c_dc_correction<NT>(Dv, S, cf0, p.fs, N);
 #pragma unroll
-  for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];
-  __syncthreads();
-  D4C_STAMP(7);
-  kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
-  D4C_STAMP(8);
-  {
-    double pv[RK];
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + NT * r;
-      if (k <= H) {
-        const kwy_c v = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
-        pv[r] = v.x * v.x + v.y * v.y;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RK; ++r)
-      if (tid + NT * r <= H) P[tid + NT * r] = pv[r];
-    __syncthreads();
-  }
-  d4c_dc_correction<NT>(P, S, cf0, p.fs, N);
-  d4c_linear_smoothing<NT>(P, P, S, tot, cf0, p.fs, N);
-
-  D4C_STAMP(9);
-  // ---- static group delay
-  for (int k = tid; k <= H; k += NT) Dv[k] = Dv[k] / P[k];
+  for (int r = 0; r < RK; ++r)
+    if (tid + NT * r <= H) Dv[tid + NT * r] = Dv[tid + NT * r] / pv[r];
   __syncthreads();
   d4c_linear_smoothing<NT>(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N);
   d4c_subtract_smoothed<NT>(Dv, S, tot, cf0, p.fs, N);
 
   D4C_STAMP(10);
   // ---- coarse aperiodicity per band
-  for (int i = tid; i < p.window_length; i += NT) nutw[i] = nuttall[i];
-  __syncthreads();
   const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
   const int half_window_length = p.window_length / 2;
+  const bool sparse = p.window_length <= 2 * (H / 8) + 1;
+  // the Nuttall window stays in registers: elements 2 tid, 2 tid + 1 (and the last one) for the
+  // copy-only first pass, elements tid + NT r otherwise
+  double ns0 = 0.0, ns1 = 0.0, ns2 = 0.0, nutr[4] = {0.0, 0.0, 0.0, 0.0};
+  if (sparse) {
+    if (2 * tid < p.window_length) ns0 = nuttall[2 * tid];
+    if (2 * tid + 1 < p.window_length) ns1 = nuttall[2 * tid + 1];
+    if (2 * (H / 8) < p.window_length) ns2 = nuttall[2 * (H / 8)];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (tid + NT * r < p.window_length) nutr[r] = nuttall[tid + NT * r];
+  }
   for (int b = 0; b < p.nbands; ++b) {
     const int tid = kwy_tid_opaque();
     const int center = (int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs);
     const double *Dc = Dv + (center - half_window_length);
-    if (p.window_length <= 2 * (H / 8) + 1) {
+    if (sparse) {
       // only the first H/8 (+1) packed points are non-zero: the first pass needs no input buffer
       kwy_c a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
       if (tid < H / 8) {
-        // nutr[] holds nuttall[tid], nuttall[tid + NT]; elements 2 tid, 2 tid + 1 come from LDS-resident copies
-        a0.x = (2 * tid < p.window_length) ? Dc[2 * tid] * nutw[2 * tid] : 0.0;
-        a0.y = (2 * tid + 1 < p.window_length) ? Dc[2 * tid + 1] * nutw[2 * tid + 1] : 0.0;
-        if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * nutw[2 * (H / 8)];
+        a0.x = (2 * tid < p.window_length) ? Dc[2 * tid] * ns0 : 0.0;
+        a0.y = (2 * tid + 1 < p.window_length) ? Dc[2 * tid + 1] * ns1 : 0.0;
+        if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * ns2;
       }
       if (b == 0) D4C_STAMP(11);
-      kwy_fft_pass8_first_sparse<LOG2N - 1, NT, false>(B, twL, a0, a1);
-      kwy_fft_inplace_rest<LOG2N - 1, NT, false>(B, twL);
+      kwy_fft_pass8_first_sparse_core<LOG2N - 1, NT, false>(B, kwy_tw_reg{tw4[0]}, a0, a1);
+      kwy_fft_inplace_rest_w<LOG2N - 1, NT, false>(B, tw4);
     } else {
 #pragma unroll
       for (int r = 0; r < E; ++r) {
         const int j = tid + NT * r;
-        Bd[j] = (j < p.window_length) ? Dc[j] * nutw[j] : 0.0;
+        Bd[j] = (r < 4 && j < p.window_length) ? Dc[j] * nutr[r < 4 ? r : 0] : 0.0;
       }
       __syncthreads();
       if (b == 0) D4C_STAMP(11);
-      kwy_fft_inplace<LOG2N - 1, NT, false>(B, twL);
+      kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
     }
     if (b == 0) D4C_STAMP(12);
     // CPU: power spectrum, sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
@@ -519,7 +572,7 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
       const int k = tid + NT * r;
       key[r] = ~0ull;
       if (k <= H) {
-        const kwy_c cc = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_octant(twb, OCT * r));
+        const kwy_c cc = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
         key[r] = (unsigned long long)__double_as_longlong(cc.x * cc.x + cc.y * cc.y);
       }
     }
@@ -560,14 +613,6 @@ __global__ __launch_bounds__(D4C_NT, 4) void k_d4c_body(
   }
   D4C_STAMP(15);
 #undef D4C_STAMP
-}
-
-template <int LOG2N>
-static constexpr size_t d4c_body_lds() {
-  constexpr int N = 1 << LOG2N, H = N / 2;
-  // Dv | overlay (B, or P + S, or the select histograms) | tot | red | coarse | e
-  return sizeof(double) * ((H + 2) + d4c_overlay_doubles(H) + D4C_NT + 16 + D4C_MAX_BANDS + 2) +
-         sizeof(uint32_t) * KWY_EBASE_WORDS + sizeof(kwy_c) * (H / 8) + (LOG2N == 12 ? 0 : sizeof(double) * 1024);
 }
 
 // ------------------------------------------------------------------ host side

@@ -559,8 +559,23 @@ __device__ __forceinline__ void kwy_dft8(kwy_c (&a)[8]) {
 // and the second pass (S = 8) reads through the same permutation.
 // tw: exp(-2 pi i k / H) for k < H/8 at least (the factors of one radix-8 pass are tw[ps], ps < H/8,
 // and its 2nd .. 7th powers, which are formed by multiplication); it may live in LDS.
-template <int LOG2H, int LOG2S, int NT, bool INV>
-__device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict__ tw) {
+struct kwy_tw_table {   // pass factor from a table exp(-2 pi i k / H) (global or LDS)
+  const kwy_c *tw;
+  __device__ __forceinline__ kwy_c operator()(int ps) const { return tw[ps]; }
+};
+struct kwy_tw_reg {     // pass factor held by the thread itself (one butterfly per thread and pass)
+  kwy_c w;
+  // behind an optimisation barrier: its 2nd..7th powers are formed again in every pass instead of
+  // being computed once per kernel and carried (spilled) across all transforms
+  __device__ __forceinline__ kwy_c operator()(int) const {
+    kwy_c v = w;
+    asm volatile("" : "+v"(v.x), "+v"(v.y));
+    return v;
+  }
+};
+
+template <int LOG2H, int LOG2S, int NT, bool INV, class TW>
+__device__ __forceinline__ void kwy_fft_pass8_core(kwy_c *z, TW tw) {
   constexpr int H = 1 << LOG2H, Q = H / 8, S = 1 << LOG2S;
   constexpr int IT = (Q + NT - 1) / NT;
   constexpr bool LAST = (LOG2S + 3 == LOG2H);
@@ -579,7 +594,7 @@ __device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict_
       kwy_dft8<INV>(a[it]);
       if (!LAST) {
         const int ps = (j >> LOG2S) << LOG2S;
-        kwy_c w1 = tw[ps];
+        kwy_c w1 = tw(ps);
         if (INV) w1.y = -w1.y;
         const kwy_c w2 = cmul(w1, w1), w4 = cmul(w2, w2);
         const kwy_c w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
@@ -607,12 +622,17 @@ __device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict_
   __syncthreads();
 }
 
+template <int LOG2H, int LOG2S, int NT, bool INV>
+__device__ __forceinline__ void kwy_fft_pass8(kwy_c *z, const kwy_c *__restrict__ tw) {
+  kwy_fft_pass8_core<LOG2H, LOG2S, NT, INV>(z, kwy_tw_table{tw});
+}
+
 // First radix-8 pass (S = 1) of a transform whose input is zero except for x[0 .. H/8]: thread j
 // supplies x[j] in a0, thread 0 also x[H/8] in a1.  The butterfly degenerates to a copy (every
 // output of thread j is x[j] times its twiddle), so nothing is read from LDS and no barrier is
 // needed before the stores -- as long as the buffer itself is free.  Ends with a barrier.
-template <int LOG2H, int NT, bool INV>
-__device__ __forceinline__ void kwy_fft_pass8_first_sparse(kwy_c *z, const kwy_c *__restrict__ tw, kwy_c a0, kwy_c a1) {
+template <int LOG2H, int NT, bool INV, class TW>
+__device__ __forceinline__ void kwy_fft_pass8_first_sparse_core(kwy_c *z, TW tw, kwy_c a0, kwy_c a1) {
   constexpr int H = 1 << LOG2H, Q = H / 8;
   static_assert(Q <= NT, "one butterfly per thread");
   const int j = kwy_tid_opaque();
@@ -624,7 +644,7 @@ __device__ __forceinline__ void kwy_fft_pass8_first_sparse(kwy_c *z, const kwy_c
       for (int m = 2; m < 8; ++m) a[m] = {0.0, 0.0};
       kwy_dft8<INV>(a);
     } else {
-      kwy_c w1 = tw[j];
+      kwy_c w1 = tw(j);
       if (INV) w1.y = -w1.y;
       const kwy_c w2 = cmul(w1, w1), w4 = cmul(w2, w2);
       const kwy_c w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2);
@@ -636,6 +656,11 @@ __device__ __forceinline__ void kwy_fft_pass8_first_sparse(kwy_c *z, const kwy_c
     for (int m = 0; m < 8; ++m) z[8 * j + (m ^ (j & 7))] = a[m];
   }
   __syncthreads();
+}
+
+template <int LOG2H, int NT, bool INV>
+__device__ __forceinline__ void kwy_fft_pass8_first_sparse(kwy_c *z, const kwy_c *__restrict__ tw, kwy_c a0, kwy_c a1) {
+  kwy_fft_pass8_first_sparse_core<LOG2H, NT, INV>(z, kwy_tw_table{tw}, a0, a1);
 }
 
 // the remaining passes after kwy_fft_pass8_first_sparse
@@ -689,6 +714,52 @@ __device__ inline void kwy_fft_inplace(kwy_c *z, const kwy_c *__restrict__ tw) {
   if constexpr (LOG2H >= 9) kwy_fft_pass8<LOG2H, 6, NT, INV>(z, tw);
   if constexpr (LOG2H == 12) kwy_fft_pass8<LOG2H, 9, NT, INV>(z, tw);
   if constexpr (LOG2H % 3 != 0) kwy_fft_tail<LOG2H, LOG2H % 3, NT, INV>(z);
+}
+
+// The same transform with the pass factors held by the threads: when a pass has one butterfly
+// per thread (H/8 <= NT), the factor of pass p is the thread constant
+// w[p] = exp(-2 pi i ((tid >> 3p) << 3p) / H)  -- no table at all (kwy_fft_thread_twiddles).
+template <int LOG2H, int NT>
+__device__ __forceinline__ void kwy_fft_thread_twiddles(const kwy_c *__restrict__ twH, kwy_c (&w)[4]) {
+  static_assert((1 << LOG2H) / 8 <= NT, "one butterfly per thread and pass");
+  const int j = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ps = (j >> (3 * p)) << (3 * p);
+    w[p] = (3 * p + 3 < LOG2H + 0 && ps < (1 << LOG2H) / 8) ? twH[ps] : kwy_c{1.0, 0.0};
+  }
+}
+template <int LOG2H, int NT, bool INV>
+__device__ inline void kwy_fft_inplace_rest_w(kwy_c *z, const kwy_c (&w)[4]) {
+  kwy_fft_pass8_core<LOG2H, 3, NT, INV>(z, kwy_tw_reg{w[1]});
+  if constexpr (LOG2H >= 9) kwy_fft_pass8_core<LOG2H, 6, NT, INV>(z, kwy_tw_reg{w[2]});
+  if constexpr (LOG2H == 12) kwy_fft_pass8_core<LOG2H, 9, NT, INV>(z, kwy_tw_reg{w[3]});
+  if constexpr (LOG2H % 3 != 0) kwy_fft_tail<LOG2H, LOG2H % 3, NT, INV>(z);
+}
+template <int LOG2H, int NT, bool INV>
+__device__ inline void kwy_fft_inplace_w(kwy_c *z, const kwy_c (&w)[4]) {
+  static_assert(LOG2H >= 8 && LOG2H <= 12, "unsupported in-place FFT length");
+  kwy_fft_pass8_core<LOG2H, 0, NT, INV>(z, kwy_tw_reg{w[0]});
+  kwy_fft_inplace_rest_w<LOG2H, NT, INV>(z, w);
+}
+
+// exp(-2 pi i (t + r*NT) / N) from base = exp(-2 pi i t / N): base times a 16th root of unity,
+// idx16 = r * 16 NT / N.  Even indices go through the exact 8th-root form.
+__device__ __forceinline__ kwy_c kwy_tw_hex(kwy_c b, int idx16) {
+  if (!(idx16 & 1)) return kwy_tw_octant(b, idx16 >> 1);
+  const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;  // cos, sin of pi/8
+  double wr, wi;  // exp(-i pi idx16 / 8)
+  switch (idx16 & 15) {
+    case 1: wr = c1; wi = -s1; break;
+    case 3: wr = s1; wi = -c1; break;
+    case 5: wr = -s1; wi = -c1; break;
+    case 7: wr = -c1; wi = -s1; break;
+    case 9: wr = -c1; wi = s1; break;
+    case 11: wr = -s1; wi = c1; break;
+    case 13: wr = s1; wi = c1; break;
+    default: wr = c1; wi = s1; break;
+  }
+  return {b.x * wr - b.y * wi, b.x * wi + b.y * wr};
 }
 
 // Real transforms around it, in place in a buffer of H+1 complex.
