@@ -134,6 +134,7 @@ __global__ void k_d4c_body_counts(const double *__restrict__ f0, const double *_
 }
 
 // ------------------------------------------------------------------ LoveTrain
+// One FFT buffer (in-place transform, pass factors in registers): 33 KB of LDS, four frames per CU.
 template <int LOG2N>
 __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
     const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
@@ -142,11 +143,13 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
     double *__restrict__ ap0) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int C = N / KWY_THREADS;
+  constexpr int HEX = 16 * KWY_THREADS / N;
+  constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
   extern __shared__ double smem[];
-  kwy_c *bufA = (kwy_c *)smem;
-  kwy_c *bufB = bufA + (H + 1);
-  double *red = (double *)(bufB + (H + 1));
-  uint32_t *e = (uint32_t *)(red + 8);
+  double *red = smem;                                 // 8
+  uint32_t *e = (uint32_t *)(red + 8);                // KWY_EBASE_WORDS
+  kwy_c *B = (kwy_c *)(e + KWY_EBASE_WORDS);          // H+1 complex (at least 8 KB: the RNG jump table)
+  double *Bd = (double *)B;
 
   const int tid = threadIdx.x;
   const int64_t frame = blockIdx.x;
@@ -159,58 +162,68 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
   const int half = kwy_matlab_round(3.0 * fs / cf0 / 2.0);
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(tpos[frame] * fs + 0.001);
+  kwy_c tw4[4];
+  kwy_fft_thread_twiddles<LOG2N - 1, KWY_THREADS>(twH, tw4);
+  const kwy_c twb = twN[tid];
 
   for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
   __syncthreads();
   // this thread draws the c noise values [c*tid, c*tid + c) of the frame (c adapts to the window)
   const int c = (wl + KWY_THREADS - 1) / KWY_THREADS;
-  kwy_rng rng;
-  if constexpr (sizeof(kwy_c) * (H + 1) >= 8192) {  // table-driven jump, table in the still idle first buffer
-    kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)bufA);
-    __syncthreads();
-    rng = kwy_rng_combine_table((const uint4 *)bufA, poly[(c - 1) * KWY_THREADS + tid]);
-  } else {
-    rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
-  }
-  double *A = (double *)bufA;
-  double *NZ = (double *)bufB;  // noise, then the window values
+  kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)B);
+  __syncthreads();
+  kwy_rng rng = kwy_rng_combine_table((const uint4 *)B, poly[(c - 1) * KWY_THREADS + tid]);
+  __syncthreads();  // the table is consumed: the buffer takes the draws
 #pragma unroll
   for (int j = 0; j < C; ++j) {
     if (j < c) {
       int d = c * tid + j;
       double nzv = kwy_rng_randn(rng);
-      if (d < wl) NZ[d] = nzv;
+      if (d < wl) Bd[d] = nzv;
     }
   }
   __syncthreads();
+  // sample i = tid + 256 r: the draw in Bd[i] is replaced by the window value, the sample waits in a register
+  double vv[C];
   double s1 = 0.0, s2 = 0.0;
-  for (int i = tid; i < N; i += KWY_THREADS) {
+#pragma unroll
+  for (int r = 0; r < C; ++r) {
+    const int i = tid + KWY_THREADS * r;
     double v = 0.0;
     if (i < wl) {
       double w = d4c_window(D4C_BLACKMAN, i, half, 3.0, fs, cf0);
       int idx = min(x_length - 1, max(0, origin + i - half));
       v = x[idx] * w;
-      v = v + NZ[i] * D4C_SAFE;
-      NZ[i] = w;
+      v = v + Bd[i] * D4C_SAFE;
+      Bd[i] = w;
       s1 += v; s2 += w;
     }
-    A[i] = v;
+    vv[r] = v;
   }
   const double t1 = kwy_block_sum(s1, red);
   const double t2 = kwy_block_sum(s2, red);
   const double coef = t1 / t2;
-  for (int i = tid; i < wl; i += KWY_THREADS) A[i] -= NZ[i] * coef;
-  kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
+#pragma unroll
+  for (int r = 0; r < C; ++r) {
+    const int i = tid + KWY_THREADS * r;
+    Bd[i] = (i < wl) ? vv[r] - Bd[i] * coef : 0.0;
+  }
+  __syncthreads();
+  kwy_fft_inplace_w<LOG2N - 1, KWY_THREADS, false>(B, tw4);
 
   const int boundary0 = (int)ceil(100.0 * N / fs);
   const int boundary1 = (int)ceil(4000.0 * N / fs);
   const int boundary2 = (int)ceil(7900.0 * N / fs);
   double c1 = 0.0, c2 = 0.0;
-  for (int k = boundary0 + 1 + tid; k <= boundary2 && k <= H; k += KWY_THREADS) {
-    kwy_c v = X[k];
-    double p = v.x * v.x + v.y * v.y;
-    c2 += p;
-    if (k <= boundary1) c1 += p;
+#pragma unroll
+  for (int r = 0; r < RK; ++r) {
+    const int k = tid + KWY_THREADS * r;
+    if (k > boundary0 && k <= boundary2 && k <= H) {
+      const kwy_c v = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(twb, HEX * r));
+      double pw = v.x * v.x + v.y * v.y;
+      c2 += pw;
+      if (k <= boundary1) c1 += pw;
+    }
   }
   const double n1 = kwy_block_sum(c1, red);
   const double n2 = kwy_block_sum(c2, red);
@@ -625,7 +638,7 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   KWY_TRY(kwy_get_poly_multi(ctx, N / KWY_THREADS, KWY_THREADS, &poly));
-  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
+  size_t lds = sizeof(kwy_c) * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_d4c_lovetrain", hipLaunchKernelGGL(k_d4c_lovetrain<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream,
