@@ -229,6 +229,18 @@ def main():
                             'measured inside the timed region, where a launch shares the CUs with the kernels of '
                             'the other streams; alone_* is the same kernel measured after the timed region with '
                             'one stream running'}
+        # the kernel with the largest SUMMED duration of all (what a rocprofv3 --stats table puts first)
+        top = max(kernel_ms, key=lambda k: kernel_ms[k][0]) if kernel_ms else None
+        by_sum = None
+        if top is not None:
+            by_sum = {'kernel': top, 'avg_launch_ms': kernel_ms[top][0] / kernel_ms[top][1],
+                      'launches': kernel_ms[top][1], 'alone_avg_launch_ms': alone_ms.get(top),
+                      'share_of_tracked_kernel_time': kernel_ms[top][0] / sum(v[0] for v in kernel_ms.values()),
+                      'note': ('one workgroup per launch: a serial recurrence (FastDTW DP + back-trace, critical path '
+                               'Tx+Ty steps) that holds 1 of 256 CUs and overlaps with the other streams; it bounds the '
+                               'latency of one pair, not the throughput, and has no HBM or MFMA roofline')
+                              if top in ('k_dtw_dp', 'k_mlpg_solve', 'k_syn_phase', 'k_align_project') else
+                              'whole-chip kernel'}
         # whole-path algorithmic bytes per source frame
         path_bytes = 36664 if args.workload == 'utterance' else 81000
         out = {
@@ -248,6 +260,7 @@ def main():
             'kernel_ms_per_launch': {k: v[0] / v[1] for k, v in sorted(kernel_ms.items())},
             'kernel_ms_per_launch_alone': {k: v for k, v in sorted(alone_ms.items())},
             'roofline': roofline,
+            'largest_summed_kernel': by_sum,
             'cpu_baseline': None,
         }
         if not args.no_cpu_baseline and world == 1:

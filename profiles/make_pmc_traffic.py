@@ -25,10 +25,10 @@ def per_launch(path, counter):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
-        for k in KERNELS:
-            if k + '<' in r['Kernel_Name'] or r['Kernel_Name'].startswith(k):
-                tot[k] += float(r['Counter_Value'])
-                n[k] += 1
+        base = r['Kernel_Name'].split('(')[0].split('<')[0].replace('void ', '').strip()
+        if base in KERNELS:     # exact kernel name (k_d4c_body, not k_d4c_body_counts)
+            tot[base] += float(r['Counter_Value'])
+            n[base] += 1
     return {k: tot[k] / n[k] for k in KERNELS if n[k]}
 
 
