@@ -46,15 +46,18 @@ __global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x
                                                    int pd, int hop, double *__restrict__ y) {
   extern __shared__ double sm[];
   // sd[2][pd][m+3] section states (two copies), sb[m+1] current coefficients, sx[hop] in, sy[hop] out
-  const int ds = m + 3;
+  const int mp = 1 + ((m - 1 + 7) / 8) * 8;   // chain length padded to whole blocks of 8 links
+  const int ds = mp + 3;
   double *sd = sm;
   double *sb = sd + 2 * 8 * ds;  // room for pd <= 5 (8 rows reserved)
-  double *sx = sb + 64;
+  double *sx = sb + 72;
   double *sy = sx + hop;
   const int lane = threadIdx.x;
   const double aa = 1 - a * a;
   const double *ppade = &c_pade[pd * (pd + 1) / 2];
   for (int i = lane; i < 2 * 8 * ds; i += 64) sd[i] = 0.0;
+  for (int i = lane; i < 72; i += 64) sb[i] = 0.0;
+  if (lane + 64 < 72) sb[lane + 64] = 0.0;
   // frame f is processed iff (f+1) hop < n; what lies behind the last processed frame stays zero
   int64_t nproc = (n - 1) / hop;
   if (nproc > T) nproc = T;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x
     __syncthreads();
     for (int j = 0; j < hop; ++j) {
       if (lane <= m) sb[lane] = cur;
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();   // one wavefront: the LDS executes its accesses in issue order
       const double b0 = sb[0], b1 = sb[1];
       double xv = sx[j] * exp(b0);
       // ---- mlsadf1 (uniform)
@@ -99,24 +102,32 @@ __global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x
       if (lane == 0) in = pt0;
       double yo = 0.0;
       if (lane < pd) {
-        const double *dold = sd + (par * 8 + lane) * ds;
-        double *dnew = sd + ((par ^ 1) * 8 + lane) * ds;
+        const double *__restrict__ dold = sd + (par * 8 + lane) * ds;
+        double *__restrict__ dnew = sd + ((par ^ 1) * 8 + lane) * ds;
         // SPTK: d[0] = x; d[1] = aa d[0] + a d[1]; d[i] += a (d[i+1] - d[i-1]) (i = 2..m), y += d[i] b[i];
-        //       then d[i] = d[i-1] (i = m+1..2).  dnew holds the shifted result directly.
+        //       then d[i] = d[i-1] (i = m+1..2).  dnew holds the shifted result directly.  The chain
+        //       u[i] = d[i] + a (d[i+1] - u[i-1]) is serial; the operands are fetched eight at a time
+        //       so that their LDS latency is paid once per block, not once per link.
         double u_prev = aa * in + a * dold[1];  // new d[1]
         dnew[0] = in;
         dnew[1] = u_prev;
+        dnew[2] = u_prev;                       // the shift copies d[1] into d[2] as well
         double di = dold[2];
-#pragma unroll 4
-        for (int i = 2; i <= m; ++i) {
-          const double dn = dold[i + 1];
-          const double u = di + a * (dn - u_prev);
-          yo += u * sb[i];
-          dnew[i + 1] = u;
-          u_prev = u;
-          di = dn;
+        for (int i0 = 2; i0 <= m; i0 += 8) {   // the chain is padded to whole blocks (b = 0 there): no guards
+          double dn[8], bb[8], uu[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { dn[q] = dold[i0 + q + 1]; bb[q] = sb[i0 + q]; }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const double u = di + a * (dn[q] - u_prev);
+            yo += u * bb[q];
+            uu[q] = u;
+            u_prev = u;
+            di = dn[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) dnew[i0 + q + 1] = uu[q];
         }
-        dnew[2] = dnew[1];  // the shift copies d[1] into d[2] as well
       }
       // ---- Pade sums (uniform): sections pd .. 1
       double xx = x2, out2 = 0.0;
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x
       if (lane == 0) sy[j] = out2;
       cur += slope;
       par ^= 1;
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
     }
     for (int j = lane; j < hop; j += 64) y[s0 + j] = sy[j];
     prevb = curb;
@@ -156,7 +167,7 @@ static int mlsa_check(kwy_ctx *ctx, const void *x, int64_t n, const void *b, int
 
 static int mlsa_core(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int m, double a,
                      int pd, int hop, double *y) {
-  const size_t lds = sizeof(double) * (2 * 8 * (m + 3) + 64 + 2 * hop);
+  const size_t lds = sizeof(double) * (2 * 8 * (1 + ((m - 1 + 7) / 8) * 8 + 3) + 72 + 2 * hop);
   KWY_HIP(hipFuncSetAttribute((const void *)k_mlsa_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_mlsa_filter", hipLaunchKernelGGL(k_mlsa_filter, dim3(1), dim3(64), lds, ctx->stream, x, n, b, T, m, a, pd, hop, y));
   KWY_HIP(hipGetLastError());
