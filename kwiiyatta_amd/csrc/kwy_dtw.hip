@@ -178,13 +178,13 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     const int pbuf = (k + DTW_WAVES - 1) % DTW_WAVES, nbuf = k % DTW_WAVES;
     const double *drow = dist + DTW_PAD + (valid ? off[i] : 0);
     uint32_t *pwrow = predw + (valid ? dtw_word_base(off, i) : 0);
-    double v1 = INF, v2 = INF;  // this lane's values at the two previous steps
+    double v1 = INF;      // this lane's value at the previous step
+    double up_prev = INF; // the `up` input of the previous step = this step's diagonal input
     const int nsteps = (jmax - jmin + 1) + 63;
     const int shift = lane + rl - jmin;  // this lane's row index at step s is s - shift
     uint32_t pw = 0u;                    // predecessor codes of the current 16-cell word
     // lane 0's diagonal input at the first step: D[i0-1][jmin-1]
-    double up0_prev = INF;
-    if (k == 0) { if (jmin == 0) up0_prev = 0.0; }  // D[-1][-1] = 0: the origin of the recurrence
+    if (k == 0 && lane == 0 && jmin == 0) up_prev = 0.0;  // D[-1][-1] = 0: the origin of the recurrence
     // distances of this lane's row, 8 steps per block, fetched two blocks ahead: the loads of
     // block b+2 are still behind the predecessor-word stores of blocks b and b+1 in the memory
     // queue, so that waiting for block b+1's data never waits for the youngest requests
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
       if (k > 0 && jb >= plo && jb <= phi) bchunk = BROW(pbuf, jb + 1);
       if (first_chunk && k > 0) {
         const int jd = jmin - 1;
-        up0_prev = (jd >= plo && jd <= phi) ? BROW(pbuf, jd + 1) : INF;
+        const double dv = (jd >= plo && jd <= phi) ? BROW(pbuf, jd + 1) : INF;
+        if (lane == 0) up_prev = dv;
         first_chunk = false;
       }
       for (int s0 = c0; s0 < min(c0 + DTW_CHUNK, nsteps); s0 += 8) {
@@ -227,24 +228,27 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
           const int j = jmin + s - lane;
           const int pos = s - shift;
           const bool act = pos >= 0 && pos <= rw;
-          double up = dtw_wave_shr1(v1), dg = dtw_wave_shr1(v2);
+          // up = D[i-1][j]: the neighbouring lane's value of the previous step (lane 0: the boundary row).
+          // The diagonal D[i-1][j-1] is what `up` was one step ago -- no second shift.
+          double up = dtw_wave_shr1(v1);
           const double bup = dtw_readlane(bchunk, (s - c0) & (DTW_CHUNK - 1));
-          if (lane == 0) { up = bup; dg = up0_prev; }
-          up0_prev = bup;
-          double cur = INF;
-          if (act) {
-            const double dt = curd[u];
-            const double c0v = up + dt, c1v = v1 + dt, c2v = dg + dt;
-            double best = c0v; uint32_t pb = 0u;
-            if (c1v < best) { best = c1v; pb = 1u; }
-            if (c2v < best) { best = c2v; pb = 2u; }
-            cur = best;
-            pw |= pb << (2 * (s & 15));
-            if ((s & 15) == 15 || pos == rw) { pwrow[(s >> 4) - (shift >> 4)] = pw; pw = 0u; }
-            if (i == ilast) BROW(nbuf, j + 1) = cur;
-            if (i == len_x - 1 && j == len_y - 1) s_last = cur;
+          if (lane == 0) up = bup;
+          const double dg = up_prev;
+          up_prev = up;
+          // predicated rather than branched: inactive lanes compute on a clamped distance and drop the result
+          const double dt = curd[u];
+          const double c0v = up + dt, c1v = v1 + dt, c2v = dg + dt;
+          double best = c0v; uint32_t pb = 0u;
+          if (c1v < best) { best = c1v; pb = 1u; }
+          if (c2v < best) { best = c2v; pb = 2u; }
+          const double cur = act ? best : INF;
+          pw |= act ? (pb << (2 * (s & 15))) : 0u;
+          const bool rowend = act && pos == rw;
+          if ((s & 15) == 15 || __ballot(rowend) != 0ull) {   // wave-uniform: a word boundary or some row ends
+            if (act && ((s & 15) == 15 || rowend)) { pwrow[(s >> 4) - (shift >> 4)] = pw; pw = 0u; }
+            if (rowend && i == len_x - 1 && j == len_y - 1) s_last = cur;
           }
-          v2 = v1;
+          if (act && i == ilast) BROW(nbuf, j + 1) = cur;
           v1 = cur;
         }
 #pragma unroll

@@ -57,12 +57,24 @@ def main():
     conv = ko.gmm_mlpg(conv_in, weights, means, covs, diff=False)
     conv_diff = ko.gmm_mlpg(conv_in, weights, means, covs, diff=True)
 
+    # MLSA differential filter: the first 0.4 s of the recording through a slowly varying filter
+    T_ml, hop = 80, fs // 200
+    walk = np.cumsum(rng.standard_normal((T_ml, 24)) * 0.02, axis=0) / np.arange(1, 25)
+    mlsa_mc = np.hstack([np.zeros((T_ml, 1)), walk])
+    mlsa_b = ko.mc2b(mlsa_mc, alpha)
+    mlsa_x = np.ascontiguousarray(x[:T_ml * hop])
+    mlsa_y = ko.mlsa_synthesis(mlsa_x, mlsa_b, alpha, hop)
+    # aperiodicity codec
+    ap_coded = ko.code_aperiodicity(np.ascontiguousarray(ap[FRAMES]), fs)
+    ap_decoded = ko.decode_aperiodicity(ap_coded, fs, 512)
+
     out = os.path.join(HERE, 'golden.npz')
     np.savez_compressed(
         out, fs=fs, x=x, t=t, f0_dio=f0_dio, f0=f0, frames=FRAMES, sp_rows=sp[FRAMES], ap_rows=ap[FRAMES],
         sp_sum=sp.sum(axis=1), ap_mean=ap.mean(axis=1), y=y, alpha=alpha, mc=mc, sp_back=sp_back,
         feat_x=feat_x, feat_y=feat_y, dtw_dist=dist, dtw_path=np.asarray(path, dtype=np.int32),
-        gmm_weights=weights, gmm_means=means, gmm_covs=covs, conv_in=conv_in, conv=conv, conv_diff=conv_diff)
+        gmm_weights=weights, gmm_means=means, gmm_covs=covs, conv_in=conv_in, conv=conv, conv_diff=conv_diff,
+        mlsa_mc=mlsa_mc, mlsa_b=mlsa_b, mlsa_y=mlsa_y, mlsa_hop=hop, ap_coded=ap_coded, ap_decoded=ap_decoded)
     print(out, os.path.getsize(out), 'bytes; frames', len(f0), 'path', len(path), 'dist', dist)
 
 

@@ -60,6 +60,18 @@ def test_oracle_mcep_dtw_mlpg_vectors():
         assert np.abs(got - G[key]).max() <= 1e-9
 
 
+def test_oracle_mlsa_codec_vectors():
+    from oracle import oracle as ko
+    hop = int(G['mlsa_hop'])
+    b = ko.mc2b(G['mlsa_mc'], float(G['alpha']))
+    assert np.abs(b - G['mlsa_b']).max() <= 1e-15
+    y = ko.mlsa_synthesis(np.ascontiguousarray(G['x'][:len(G['mlsa_y'])]), G['mlsa_b'], float(G['alpha']), hop)
+    assert np.abs(y - G['mlsa_y']).max() <= 1e-12 * np.abs(G['mlsa_y']).max()
+    coded = ko.code_aperiodicity(np.ascontiguousarray(G['ap_rows']), FS)
+    assert np.abs(coded - G['ap_coded']).max() <= 1e-9
+    assert np.abs(ko.decode_aperiodicity(G['ap_coded'], FS, 512) - G['ap_decoded']).max() <= 1e-12
+
+
 # ----------------------------------------------------------------------------- GPU: libkwy.so
 @pytest.mark.gpu
 def test_hip_world_vectors():
@@ -99,3 +111,15 @@ def test_hip_mcep_dtw_mlpg_vectors():
     for diff, key in ((False, 'conv'), (True, 'conv_diff')):
         got = mlpg.MLPG(Gmm, windows=mlpg.DELTA_WINDOWS, diff=diff).transform(X)
         assert np.abs(got - G[key]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_mlsa_codec_vectors():
+    from kwiiyatta_amd.backend import sptk, world as kw
+    hop, alpha = int(G['mlsa_hop']), float(G['alpha'])
+    assert np.abs(sptk.mc2b(G['mlsa_mc'], alpha) - G['mlsa_b']).max() <= 1e-15
+    x = np.ascontiguousarray(G['x'][:len(G['mlsa_y'])])
+    y = sptk.Synthesizer(sptk.MLSADF(order=24, alpha=alpha), hopsize=hop).synthesis(x, G['mlsa_b'])
+    assert np.abs(y - G['mlsa_y']).max() <= 1e-11 * np.abs(G['mlsa_y']).max()
+    assert np.abs(kw.code_aperiodicity(np.ascontiguousarray(G['ap_rows']), FS) - G['ap_coded']).max() <= 1e-9
+    assert np.abs(kw.decode_aperiodicity(G['ap_coded'], FS, 512) - G['ap_decoded']).max() <= 1e-12
