@@ -266,82 +266,108 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
   }
 #undef BROW
   __syncthreads();
-  if (wv != 0) return;
   const long long t_dp = dbg ? clock64() : 0;
   double last_val = s_last;
-  if (lane == 0) *out_dist = last_val;
+  if (threadIdx.x == 0) *out_dist = last_val;
   __threadfence();  // predecessor codes written above are read back below through global memory
 
   // ---- back-trace, staged through LDS in groups of rows (codes AND row descriptors), with the
-  //      produced cells buffered in LDS too: the serial walk of lane 0 touches no global memory
-  uint32_t *btw = (uint32_t *)bt;
+  //      produced cells buffered in LDS too: the serial walk of lane 0 touches no global memory.
+  //      Two staging buffers: while wavefront 0 walks group g, wavefronts 1..3 fetch group g+1
+  //      (which rows it covers does not depend on where the path runs).
   const uint64_t bt_words = DTW_BT_BYTES / 4;
-  __shared__ int g_lo[DTW_BT_ROWS], g_hi[DTW_BT_ROWS];
-  __shared__ unsigned int g_wb[DTW_BT_ROWS];
-  __shared__ int g_sh[DTW_BT_ROWS];
+  __shared__ int g_lo[2][DTW_BT_ROWS], g_hi[2][DTW_BT_ROWS];
+  __shared__ unsigned int g_wb[2][DTW_BT_ROWS];
+  __shared__ int g_sh[2][DTW_BT_ROWS];
   __shared__ int g_rev[2 * DTW_BT_OUT];
-  int ci = len_x - 1, cj = len_y - 1, n = 0;
+  // group of rows ending at `top`: smallest r0 such that the words of rows r0..top fit the budget
+  auto group_start = [&](int top) {
+    const uint64_t wend = dtw_row_words_end(off, lo, hi, top);
+    int lo_r = max(0, top - DTW_BT_ROWS + 1), hi_r = top;
+    while (lo_r < hi_r) {  // the predicate is monotone in r
+      const int mid = (lo_r + hi_r) >> 1;
+      if (wend - dtw_word_base(off, mid) <= bt_words) hi_r = mid; else lo_r = mid + 1;
+    }
+    return lo_r;
+  };
+  auto stage = [&](int top, int r0g, int buf, int first, int nthr) {
+    uint32_t *btwb = (uint32_t *)(bt + (size_t)buf * DTW_BT_BYTES);
+    const uint64_t wbase = dtw_word_base(off, r0g);
+    const uint64_t nw = dtw_row_words_end(off, lo, hi, top) - wbase;
+    if (nw <= bt_words)
+      for (uint64_t b = first; b < nw; b += nthr) btwb[b] = predw[wbase + b];
+    for (int r = r0g + first; r <= top; r += nthr) {
+      g_lo[buf][r - r0g] = lo[r];
+      g_hi[buf][r - r0g] = hi[r];
+      g_wb[buf][r - r0g] = (unsigned int)(dtw_word_base(off, r) - wbase);
+      g_sh[buf][r - r0g] = dtw_row_shift(lo, r);
+    }
+  };
+  int ci = len_x - 1, cj = len_y - 1, n = 0, buf = 0;
+  int r0 = group_start(ci);
+  stage(ci, r0, 0, threadIdx.x, 64 * DTW_WAVES);
+  __syncthreads();
   while (ci >= 0) {
-    // rows [r0, ci]: at most DTW_BT_ROWS rows whose code words fit in the LDS budget
-    const uint64_t wend = dtw_row_words_end(off, lo, hi, ci);
-    int r0 = ci;
-    {  // smallest r in [ci - DTW_BT_ROWS + 1, ci] whose words still fit (the predicate is monotone in r)
-      int lo_r = max(0, ci - DTW_BT_ROWS + 1), hi_r = ci;
-      while (lo_r < hi_r) {
-        const int mid = (lo_r + hi_r) >> 1;
-        if (wend - dtw_word_base(off, mid) <= bt_words) hi_r = mid; else lo_r = mid + 1;
-      }
-      r0 = lo_r;
-    }
-    const uint64_t wbase = dtw_word_base(off, r0);
-    const uint64_t nw = wend - wbase;
-    const bool staged = nw <= bt_words;
-    if (staged)
-      for (uint64_t b = lane; b < nw; b += 64) btw[b] = predw[wbase + b];
-    for (int r = r0 + lane; r <= ci; r += 64) {
-      g_lo[r - r0] = lo[r];
-      g_hi[r - r0] = hi[r];
-      g_wb[r - r0] = (unsigned int)(dtw_word_base(off, r) - wbase);
-      g_sh[r - r0] = dtw_row_shift(lo, r);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    bool group_done = false;
-    while (!group_done) {
-      if (lane == 0) {
-        int i = ci, j = cj, m = 0;
-        int crow = -1, l = 0, h = -1, sh = 0;
-        unsigned int wb = 0, cw = 0xffffffffu;
-        uint32_t word = 0u;
-        while (i >= r0 && m < DTW_BT_OUT) {
-          g_rev[2 * m] = i; g_rev[2 * m + 1] = j; ++m;
-          if (i == 0 && j == 0) { i = -1; break; }
-          if (i != crow) { crow = i; l = g_lo[i - r0]; h = g_hi[i - r0]; wb = g_wb[i - r0]; sh = g_sh[i - r0]; cw = 0xffffffffu; }
-          unsigned int pb = 0;
-          if (j >= l && j <= h) {
-            const int st = sh + (j - l);  // the step at which this cell was computed
-            const unsigned int w = wb + (unsigned int)((st >> 4) - (sh >> 4));
-            if (w != cw) {
-              cw = w;
-              if (staged) word = btw[w]; else word = predw[wbase + w];
+    const int top = ci;
+    const int next_top = r0 - 1;
+    const int next_r0 = next_top >= 0 ? group_start(next_top) : 0;
+    if (wv != 0) {
+      if (next_top >= 0) stage(next_top, next_r0, buf ^ 1, threadIdx.x - 64, 64 * (DTW_WAVES - 1));
+    } else {
+      const uint32_t *btw = (const uint32_t *)(bt + (size_t)buf * DTW_BT_BYTES);
+      const uint64_t wbase = dtw_word_base(off, r0);
+      const bool staged = dtw_row_words_end(off, lo, hi, top) - wbase <= bt_words;
+      bool group_done = false;
+      while (!group_done) {
+        if (lane == 0) {
+          int i = ci, j = cj, m = 0;
+          int crow = -1, l = 0, h = -1, sh = 0;
+          unsigned int wb = 0, cw = 0xffffffffu;
+          uint32_t word = 0u;
+          while (i >= r0 && m < DTW_BT_OUT) {
+            g_rev[2 * m] = i; g_rev[2 * m + 1] = j; ++m;
+            if (i == 0 && j == 0) { i = -1; break; }
+            if (i != crow) { crow = i; l = g_lo[buf][i - r0]; h = g_hi[buf][i - r0]; wb = g_wb[buf][i - r0]; sh = g_sh[buf][i - r0]; cw = 0xffffffffu; }
+            unsigned int pb = 0;
+            if (j >= l && j <= h) {
+              const int st = sh + (j - l);  // the step at which this cell was computed
+              const unsigned int w = wb + (unsigned int)((st >> 4) - (sh >> 4));
+              if (w != cw) {
+                cw = w;
+                if (staged) word = btw[w]; else word = predw[wbase + w];
+              }
+              pb = (word >> (2 * (st & 15))) & 3u;
             }
-            pb = (word >> (2 * (st & 15))) & 3u;
+            if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
+            if (j < 0) { i = -1; break; }
           }
-          if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
-          if (j < 0) { i = -1; break; }
+          s_i = i; s_j = j; s_n = m;
         }
-        s_i = i; s_j = j; s_n = m;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int made = s_n;
+        for (int e = lane; e < 2 * made; e += 64) rev[2 * n + e] = g_rev[e];
+        n += made;
+        ci = s_i; cj = s_j;
+        group_done = ci < r0;
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
-      __threadfence_block();
-      const int made = s_n;
-      for (int e = lane; e < 2 * made; e += 64) rev[2 * n + e] = g_rev[e];
-      n += made;
-      ci = s_i; cj = s_j;
-      group_done = ci < r0;
-      __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();   // the walk is through with this buffer, the next one is filled
+    ci = s_i; cj = s_j;   // (wavefront 0's last values; the others only need ci)
+    if (ci >= 0 && ci != next_top) {
+      // cannot happen for a path that leaves a group through its lowest row; kept as a guard:
+      // restage synchronously for wherever the walk stopped
+      r0 = group_start(ci);
+      __syncthreads();
+      stage(ci, r0, buf ^ 1, threadIdx.x, 64 * DTW_WAVES);
+      __syncthreads();
+    } else {
+      r0 = next_r0;
+    }
+    buf ^= 1;
   }
+  if (wv != 0) return;
   __threadfence();
   for (int k = lane; k < n; k += 64) {
     path[2 * k] = rev[2 * (n - 1 - k)];
@@ -419,8 +445,10 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   *status_out = status;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
   const size_t bnd_bytes = sizeof(double) * DTW_WAVES * (Ty + 2);
-  const bool bnd_lds = DTW_BT_BYTES + bnd_bytes <= 150 * 1024;
-  const size_t dp_lds = DTW_BT_BYTES + (bnd_lds ? bnd_bytes : 0);
+  // two back-trace staging buffers; the boundary rows of the DP phase share the second one and what follows it
+  const bool bnd_lds = DTW_BT_BYTES + bnd_bytes <= 130 * 1024;  // + 25 KB of static LDS in the kernel
+  size_t dp_lds = DTW_BT_BYTES + (bnd_lds ? bnd_bytes : 0);
+  if (dp_lds < 2 * (size_t)DTW_BT_BYTES) dp_lds = 2 * (size_t)DTW_BT_BYTES;
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
 
