@@ -1,0 +1,18 @@
+import sys, numpy as np, torch
+sys.path.insert(0,'.')
+from kwiiyatta_amd import _lib, pipeline as pl
+from kwiiyatta_amd._lib import lib, c_vp
+from kwiiyatta_amd.synthetic import make_utterance
+u = make_utterance(seed=1234, fs=48000, seconds=10.0)
+p = pl.UtterancePipeline(0, 48000, u)
+dbg = torch.zeros(64, dtype=torch.int64, device='cuda')
+f0 = u[1]
+frame = int(np.where(f0>0)[0][200]); dbg[63] = frame
+lib.kwy_ctx_debug_buffer(p.ctx.handle, c_vp(dbg.data_ptr()))
+p.run(); p.sync(); p.run(); p.sync()
+d = dbg.cpu().numpy()
+names = ['start','rng','win0','fft+cen0','win1','fft+cen1','dccorr','win2','fft2','pow+smooth','gd smooth x2','band0 fill','band0 fft','band0 select','bands end','output']
+print('frame', frame, 'f0', f0[frame])
+for i in range(1,16):
+    print(names[i].ljust(16), d[i]-d[i-1])
+print('total', d[15]-d[0])
