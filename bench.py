@@ -98,6 +98,11 @@ def main():
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
     ap_.add_argument('--components', type=int, default=64)
     ap_.add_argument('--no-cpu-baseline', action='store_true')
+    ap_.add_argument('--gmm-prepare-per-pair', action='store_true',
+                     help='redo the GMM-only precomputation of MLPG for every pair (the reference builds an MLPG '
+                          'object per convert() call) instead of once per converter')
+    ap_.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo lets '
+                                                        'several ranks share one GPU when rehearsing the launch)')
     args = ap_.parse_args()
 
     import torch
@@ -105,11 +110,16 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    rdev = dev if args.backend == 'nccl' else torch.device('cpu')   # where the timing reductions live
 
     from kwiiyatta_amd import pipeline as pl
     from kwiiyatta_amd.parallel import shard_indices
@@ -125,7 +135,7 @@ def main():
     for i in range(len(mine)):
         src, tgt = base[i % nbase]
         if args.workload == 'pair':
-            pipes.append(pl.PairPipeline(local_rank, FS, src, tgt, dgmm))
+            pipes.append(pl.PairPipeline(local_rank, FS, src, tgt, dgmm, prepare_gmm_per_run=args.gmm_prepare_per_pair))
         else:
             pipes.append(pl.UtterancePipeline(local_rank, FS, src))
     torch.cuda.synchronize()
@@ -155,13 +165,13 @@ def main():
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        tt = torch.tensor([el], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
     frames_rank = sum(p.frames for p in pipes) * args.steps
     if world > 1:
-        ft = torch.tensor([frames_rank], dtype=torch.float64, device=dev)
+        ft = torch.tensor([frames_rank], dtype=torch.float64, device=rdev)
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
         frames_total = float(ft.item())
     else:
@@ -254,6 +264,9 @@ def main():
                             'config2: 48 kHz 10 s utterances (T=2001, K=1025): CheapTrick + D4C + WORLD synthesis',
                 'pairs_per_gpu' if args.workload == 'pair' else 'utterances_per_gpu': args.batch,
                 'source_frames_per_pair': T, 'streams_per_gpu': args.batch,
+                'gmm_model_prepared': ('per pair' if args.gmm_prepare_per_pair else
+                                       'once per converter (the per-mixture matrices depend on the GMM only)')
+                if args.workload == 'pair' else None,
                 'parallelism': f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective'},
             'real_time_factor': value / 200.0,
             'hbm_fraction_whole_path': value / world * path_bytes / 8e12,

@@ -92,8 +92,11 @@ class _Side:
 
 class PairPipeline:
     def __init__(self, device_index, fs, source, target, gmm, order=24, radius=32, frame_period=5.0,
-                 stream=None):
-        """source / target: (x, f0, timeaxis) numpy triples; gmm: DeviceGMM over 2*3*order dims."""
+                 stream=None, prepare_gmm_per_run=False):
+        """source / target: (x, f0, timeaxis) numpy triples; gmm: DeviceGMM over 2*3*order dims.
+        prepare_gmm_per_run: redo the GMM-only part of MLPG (nnmnkwii's MLPG.__init__) in every run(),
+        as the reference does per convert() call, instead of once per converter."""
+        self.prepare_gmm_per_run = bool(prepare_gmm_per_run)
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
@@ -161,8 +164,12 @@ class PairPipeline:
                 self._chk(lib.kwy_gather_rows_dev(h, _p(src_arr), self.src.Tp, w, _p(self.idx), Tt, _p(dst)))
             self.mc_x.copy_(self.mc_al[:, 1:])
             g = self.gmm
-            self._chk(lib.kwy_gmm_mlpg_model_dev(h, _p(self.mc_x), Tt, order, g.M, _p(self.gmm_model),
-                                                 _p(self.mc_y)))
+            if self.prepare_gmm_per_run:
+                self._chk(lib.kwy_gmm_mlpg_dev(h, _p(self.mc_x), Tt, order, g.M, _p(g.weights), _p(g.means),
+                                               _p(g.covs), 0, _p(self.mc_y)))
+            else:
+                self._chk(lib.kwy_gmm_mlpg_model_dev(h, _p(self.mc_x), Tt, order, g.M, _p(self.gmm_model),
+                                                     _p(self.mc_y)))
             self.mc_conv[:, 0].copy_(self.mc_al[:, 0])
             self.mc_conv[:, 1:].copy_(self.mc_y)
             self._chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), Tt, order, self.alpha, fft, _p(self.sp_conv)))
