@@ -41,68 +41,131 @@ static void freqt_matrix(int ncols, int m2, double a, std::vector<double> &F) {
 }
 
 // ---- sp2mc -----------------------------------------------------------------------
-// F: [ncut][MC_STRIDE] with MC_STRIDE = 64 doubles per cepstral index
+// F: [ncut][MC_STRIDE] with MC_STRIDE = 64 doubles per cepstral index.
+// A workgroup converts MC_FR frames: the cepstra are formed one after the other in the one FFT
+// buffer (in-place inverse transform) and parked in LDS, then the freqt matrix -- 360 KB, read from
+// L2 -- is walked ONCE for all of them.
 #define MC_STRIDE 64
+#define MC_FR 4
 template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS) void k_sp2mc(const double *__restrict__ sp, int order,
+__global__ __launch_bounds__(KWY_THREADS) void k_sp2mc(const double *__restrict__ sp, int64_t T, int order,
                                                       const double *__restrict__ F, int ncut,
                                                       const kwy_c *__restrict__ twH,
                                                       const kwy_c *__restrict__ twN,
                                                       double *__restrict__ mc) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
+  constexpr int TWL = (H / 8 > 1) ? H / 8 : 1;
   extern __shared__ double smem[];
-  kwy_c *bufA = (kwy_c *)smem;
-  kwy_c *bufB = bufA + (H + 1);
-  double *part = (double *)(bufB + (H + 1));  // 4 x 64 partial sums
+  kwy_c *buf = (kwy_c *)smem;                 // H+1 complex
+  kwy_c *twl = buf + (H + 1);                 // exp(-2 pi i k / H), k < H/8
+  double *part = (double *)(twl + TWL);       // MC_FR x 4 x 64 partial sums
+  double *cep = part + MC_FR * 256;           // MC_FR x ncut
   const int tid = threadIdx.x;
-  const int64_t frame = blockIdx.x;
-  const double *p = sp + frame * K;
-  for (int k = tid; k <= H; k += KWY_THREADS) bufA[k] = {log(p[k]), 0.0};
-  kwy_c *W = kwy_irfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
-  const double *c = (const double *)W;  // N * cepstrum (unnormalised c2r)
-  // mc[j] = sum_n F[n][j] * c[n]; thread (j = tid & 63, part = tid >> 6) strides n by 4
-  const int j = tid & 63, q = tid >> 6;
-  double acc = 0.0;
-  if (j <= order) {
-    for (int n = q; n < ncut; n += 4) {
+  const int64_t f0 = (int64_t)blockIdx.x * MC_FR;
+  for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
+  const kwy_c twb = twN[tid & (N - 1)];
+  for (int fr = 0; fr < MC_FR; ++fr) {
+    const int64_t frame = f0 + fr;
+    if (frame >= T) break;   // uniform
+    const double *p = sp + frame * K;
+    __syncthreads();
+    for (int k = tid; k <= H; k += KWY_THREADS) buf[k] = {log(p[k]), 0.0};
+    kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+    const double *c = (const double *)buf;  // N * cepstrum (unnormalised c2r)
+    for (int n = tid; n < ncut; n += KWY_THREADS) {
       double cn = c[n] / N;
       if (n == 0) cn /= 2.0;
-      acc += F[(size_t)n * MC_STRIDE + j] * cn;
+      cep[fr * ncut + n] = cn;
     }
   }
-  part[q * 64 + j] = acc;
   __syncthreads();
-  if (tid <= order) mc[frame * (order + 1) + tid] = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];
+  // mc[j] = sum_n F[n][j] * c[n]; thread (j = tid & 63, part = tid >> 6) strides n by 4
+  const int j = tid & 63, q = tid >> 6;
+  double acc[MC_FR];
+#pragma unroll
+  for (int fr = 0; fr < MC_FR; ++fr) acc[fr] = 0.0;
+  if (j <= order) {
+#pragma unroll 8
+    for (int n = q; n < ncut; n += 4) {   // unrolled: eight matrix loads in flight, not one L2 round trip per step
+      const double f = F[(size_t)n * MC_STRIDE + j];
+#pragma unroll
+      for (int fr = 0; fr < MC_FR; ++fr) acc[fr] += f * cep[fr * ncut + n];
+    }
+  }
+#pragma unroll
+  for (int fr = 0; fr < MC_FR; ++fr) part[fr * 256 + q * 64 + j] = acc[fr];
+  __syncthreads();
+  for (int e = tid; e < MC_FR * 64; e += KWY_THREADS) {
+    const int fr = e >> 6, jj = e & 63;
+    const double *pp = part + fr * 256;
+    if (jj <= order && f0 + fr < T)
+      mc[(f0 + fr) * (order + 1) + jj] = ((pp[jj] + pp[64 + jj]) + pp[128 + jj]) + pp[192 + jj];
+  }
 }
 
 // ---- mc2sp -----------------------------------------------------------------------
-// F2T: [order+1][H+1]: cepstrum index n <- mel-cepstral coefficient m
+// F2T: [order+1][H+1]: cepstrum index n <- mel-cepstral coefficient m.  MC_FR frames per workgroup share
+// one walk over F2T (the cepstra stay in registers, bins tid + 256 r), then take turns in the FFT buffer.
 template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict__ mc, int order,
+__global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict__ mc, int64_t T, int order,
                                                       const double *__restrict__ F2T,
                                                       const kwy_c *__restrict__ twH,
                                                       const kwy_c *__restrict__ twN,
                                                       double *__restrict__ sp) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
+  constexpr int TWL = (H / 8 > 1) ? H / 8 : 1;
+  constexpr int RK = (K + KWY_THREADS - 1) / KWY_THREADS;
   extern __shared__ double smem[];
-  kwy_c *bufA = (kwy_c *)smem;
-  kwy_c *bufB = bufA + (H + 1);
-  double *m = (double *)(bufB + (H + 1));  // order+1
+  kwy_c *buf = (kwy_c *)smem;                 // H+1 complex
+  kwy_c *twl = buf + (H + 1);
+  double *m = (double *)(twl + TWL);          // MC_FR x (order+1)
   const int tid = threadIdx.x;
-  const int64_t frame = blockIdx.x;
-  if (tid <= order) m[tid] = mc[frame * (order + 1) + tid];
-  __syncthreads();
-  double *sym = (double *)bufA;
-  for (int n = tid; n <= H; n += KWY_THREADS) {
-    double acc = 0.0;
-    for (int i = 0; i <= order; ++i) acc += F2T[(size_t)i * K + n] * m[i];
-    if (n == 0) acc *= 2.0;
-    sym[n] = acc;
-    if (n >= 1 && n < H) sym[N - n] = acc;
+  const int64_t f0 = (int64_t)blockIdx.x * MC_FR;
+  for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
+  const kwy_c twb = twN[tid & (N - 1)];
+  for (int e = tid; e < MC_FR * (order + 1); e += KWY_THREADS) {
+    const int fr = e / (order + 1), i = e - fr * (order + 1);
+    m[e] = (f0 + fr < T) ? mc[(f0 + fr) * (order + 1) + i] : 0.0;
   }
-  kwy_c *X = kwy_rfft_lds(bufA, bufB, LOG2N - 1, twH, twN);
-  double *o = sp + frame * K;
-  for (int k = tid; k <= H; k += KWY_THREADS) o[k] = exp(X[k].x);
+  __syncthreads();
+  double acc[MC_FR][RK];
+#pragma unroll
+  for (int fr = 0; fr < MC_FR; ++fr)
+#pragma unroll
+    for (int r = 0; r < RK; ++r) acc[fr][r] = 0.0;
+#pragma unroll 4
+  for (int i = 0; i <= order; ++i) {
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+      const int n = tid + KWY_THREADS * r;
+      if (n <= H) {
+        const double f = F2T[(size_t)i * K + n];
+#pragma unroll
+        for (int fr = 0; fr < MC_FR; ++fr) acc[fr][r] += f * m[fr * (order + 1) + i];
+      }
+    }
+  }
+  double *sym = (double *)buf;
+#pragma unroll
+  for (int fr = 0; fr < MC_FR; ++fr) {
+    const int64_t frame = f0 + fr;
+    if (frame >= T) break;   // uniform
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+      const int n = tid + KWY_THREADS * r;
+      if (n <= H) {
+        double v = acc[fr][r];
+        if (n == 0) v *= 2.0;
+        sym[n] = v;
+        if (n >= 1 && n < H) sym[N - n] = v;
+      }
+    }
+    __syncthreads();
+    kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+    double *o = sp + frame * K;
+    for (int k = tid; k <= H; k += KWY_THREADS) o[k] = exp(buf[k].x);
+  }
 }
 
 // ---- host side ----------------------------------------------------------------------
@@ -160,9 +223,10 @@ static int launch_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int order, co
   const kwy_c *twH, *twN;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 256;
+  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (size_t)MC_FR * (256 + ncut);
+  if (lds > 160 * 1024) { ctx->err = "sp2mc: transform too long for the LDS"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_sp2mc<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_sp2mc", hipLaunchKernelGGL(k_sp2mc<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, sp, order, F,
+  KWY_PROF(ctx, "k_sp2mc", hipLaunchKernelGGL(k_sp2mc<LOG2N>, dim3((unsigned)((T + MC_FR - 1) / MC_FR)), dim3(KWY_THREADS), lds, ctx->stream, sp, T, order, F,
                      ncut, twH, twN, mc));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
@@ -174,9 +238,9 @@ static int launch_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, co
   const kwy_c *twH, *twN;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  size_t lds = sizeof(kwy_c) * 2 * (H + 1) + sizeof(double) * 64;
+  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (size_t)MC_FR * (order + 1);
   KWY_HIP(hipFuncSetAttribute((const void *)k_mc2sp<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_mc2sp", hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, mc, order, F2T,
+  KWY_PROF(ctx, "k_mc2sp", hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)((T + MC_FR - 1) / MC_FR)), dim3(KWY_THREADS), lds, ctx->stream, mc, T, order, F2T,
                      twH, twN, sp));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
