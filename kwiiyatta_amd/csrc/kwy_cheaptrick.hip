@@ -175,7 +175,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
       double low = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
       fa += width;
       double high = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
-      P[k] = (high - low) / width;
+      // the serial CPU cumulative sum is monotone, so its differences are >= 0; the block-parallel one can
+      // come out an ulp of the running total below zero in bins that carry no energy at all
+      P[k] = fmax((high - low) / width, 0.0);
     }
     __syncthreads();
   }

@@ -372,7 +372,7 @@ __device__ inline void d4c_linear_smoothing_regs(const double *in, double (&outv
       double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
       fa += width;
       double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
-      outv[r] = (high - low) * inv_width;
+      outv[r] = fmax((high - low) * inv_width, 0.0);   // a smoothed POWER spectrum (see kwy_cheaptrick.hip)
     }
   }
   __syncthreads();

@@ -476,7 +476,10 @@ static double d4c_lovetrain_sub(const double *x, int fs, int x_length,
                                 int fft_size, int boundary0, int boundary1,
                                 int boundary2, ko_rng *rng, double *waveform,
                                 double *spec) {
-  double *power_spectrum = dalloc(fft_size);
+  /* WORLD allocates fft_size doubles and fills bins 0..fft_size/2 only, but for fs < 15.8 kHz the
+   * 7.9 kHz boundary lies above fft_size/2 and the cumulative sum runs into uninitialised memory
+   * (undefined upstream).  Defined here: the bins above Nyquist are zero. */
+  double *power_spectrum = (double *)calloc(fft_size ? fft_size : 1, sizeof(double));
   int window_length = matlab_round(1.5 * fs / current_f0) * 2 + 1;
   d4c_windowed_waveform(x, x_length, fs, current_f0, current_position, kBlackman,
                         3.0, rng, waveform);

@@ -111,6 +111,23 @@ def test_frame_periods(ko, kw, frame_period):
     assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-9
 
 
+@pytest.mark.parametrize('fs,up,down', [(8000, 1, 2), (12000, 3, 4)])
+def test_low_sampling_rates(ko, kw, fs, up, down):
+    """Rates below the reference's fixtures: other FFT sizes in every kernel (D4C 1024, CheapTrick 512),
+    no / one aperiodicity band, and LoveTrain's 7.9 kHz boundary above Nyquist (undefined upstream,
+    zero-extended in the oracle)."""
+    import scipy.signal as ss
+    _, x16 = load(CLB_WAV)
+    x = np.ascontiguousarray(ss.resample_poly(x16, up, down))
+    f0, t = f0_track(ko, x, fs)
+    check_spectrum(kw.cheaptrick(x, f0, t, fs), ko.cheaptrick(x, f0, t, fs))
+    got, ref = kw.d4c(x, f0, t, fs), ko.d4c(x, f0, t, fs)
+    assert np.array_equal(got[:, 0] < 0.99, ref[:, 0] < 0.99)
+    assert np.abs(got - ref).max() <= 1e-4
+    sp, ap = ko.cheaptrick(x, f0, t, fs), ref
+    assert np.sqrt(np.mean((kw.synthesize(f0, sp, ap, fs) - ko.synthesize(f0, sp, ap, fs)) ** 2)) <= 1e-9
+
+
 def test_options(ko, kw):
     """q1 / fft_size / threshold keyword paths (reference call sites
     tests/kwiiyatta/test_vocoder.py:429-430, view/qt/kwiieiya.py:84)."""
