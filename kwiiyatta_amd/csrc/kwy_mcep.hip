@@ -104,7 +104,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_sp2mc(const double *__restrict_
 }
 
 // ---- mc2sp -----------------------------------------------------------------------
-// F2T: [order+1][H+1]: cepstrum index n <- mel-cepstral coefficient m.  MC_FR frames per workgroup share
+#define MC2_FR 2
+// F2T: [order+1][H+1]: cepstrum index n <- mel-cepstral coefficient m.  MC2_FR frames per workgroup share
 // one walk over F2T (the cepstra stay in registers, bins tid + 256 r), then take turns in the FFT buffer.
 template <int LOG2N>
 __global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict__ mc, int64_t T, int order,
@@ -118,19 +119,19 @@ __global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict_
   extern __shared__ double smem[];
   kwy_c *buf = (kwy_c *)smem;                 // H+1 complex
   kwy_c *twl = buf + (H + 1);
-  double *m = (double *)(twl + TWL);          // MC_FR x (order+1)
+  double *m = (double *)(twl + TWL);          // MC2_FR x (order+1)
   const int tid = threadIdx.x;
-  const int64_t f0 = (int64_t)blockIdx.x * MC_FR;
+  const int64_t f0 = (int64_t)blockIdx.x * MC2_FR;
   for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
   const kwy_c twb = twN[tid & (N - 1)];
-  for (int e = tid; e < MC_FR * (order + 1); e += KWY_THREADS) {
+  for (int e = tid; e < MC2_FR * (order + 1); e += KWY_THREADS) {
     const int fr = e / (order + 1), i = e - fr * (order + 1);
     m[e] = (f0 + fr < T) ? mc[(f0 + fr) * (order + 1) + i] : 0.0;
   }
   __syncthreads();
-  double acc[MC_FR][RK];
+  double acc[MC2_FR][RK];
 #pragma unroll
-  for (int fr = 0; fr < MC_FR; ++fr)
+  for (int fr = 0; fr < MC2_FR; ++fr)
 #pragma unroll
     for (int r = 0; r < RK; ++r) acc[fr][r] = 0.0;
 #pragma unroll 4
@@ -141,13 +142,13 @@ __global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict_
       if (n <= H) {
         const double f = F2T[(size_t)i * K + n];
 #pragma unroll
-        for (int fr = 0; fr < MC_FR; ++fr) acc[fr][r] += f * m[fr * (order + 1) + i];
+        for (int fr = 0; fr < MC2_FR; ++fr) acc[fr][r] += f * m[fr * (order + 1) + i];
       }
     }
   }
   double *sym = (double *)buf;
 #pragma unroll
-  for (int fr = 0; fr < MC_FR; ++fr) {
+  for (int fr = 0; fr < MC2_FR; ++fr) {
     const int64_t frame = f0 + fr;
     if (frame >= T) break;   // uniform
     __syncthreads();
@@ -238,9 +239,9 @@ static int launch_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, co
   const kwy_c *twH, *twN;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (size_t)MC_FR * (order + 1);
+  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (size_t)MC2_FR * (order + 1);
   KWY_HIP(hipFuncSetAttribute((const void *)k_mc2sp<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_mc2sp", hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)((T + MC_FR - 1) / MC_FR)), dim3(KWY_THREADS), lds, ctx->stream, mc, T, order, F2T,
+  KWY_PROF(ctx, "k_mc2sp", hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)((T + MC2_FR - 1) / MC2_FR)), dim3(KWY_THREADS), lds, ctx->stream, mc, T, order, F2T,
                      twH, twN, sp));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
