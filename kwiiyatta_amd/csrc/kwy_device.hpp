@@ -398,120 +398,6 @@ __device__ __forceinline__ kwy_c cmul(kwy_c a, kwy_c b) {
   return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
 
-// One Stockham radix-4 pass over H points: x -> y, sub-transform stride s.
-// tw: H-entry table exp(-2 pi i k / H).  INV conjugates the twiddles.
-template <bool INV, int NT = KWY_THREADS>
-__device__ __forceinline__ void kwy_fft_r4(const kwy_c *__restrict__ x, kwy_c *__restrict__ y,
-                                           int H, int s, int log2s,
-                                           const kwy_c *__restrict__ tw) {
-  const int Q = H >> 2;
-  for (int j = threadIdx.x; j < Q; j += NT) {
-    const int q = j & (s - 1);
-    const int p = j >> log2s;
-    kwy_c a = x[j], b = x[j + Q], c = x[j + 2 * Q], d = x[j + 3 * Q];
-    kwy_c apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
-    kwy_c jb = INV ? kwy_c{bmd.y, -bmd.x} : kwy_c{-bmd.y, bmd.x};  // = +-i*(b-d), sign folded below
-    // forward: y1 = amc - i*bmd, y3 = amc + i*bmd ; inverse: swapped
-    kwy_c y0 = cadd(apc, bpd);
-    kwy_c y1 = csub(amc, jb);
-    kwy_c y2 = csub(apc, bpd);
-    kwy_c y3 = cadd(amc, jb);
-    const int ps = p << log2s;
-    kwy_c w1 = tw[ps], w2 = tw[2 * ps], w3 = tw[3 * ps];
-    if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
-    const int o = q + ((4 * p) << log2s);
-    y[o] = y0;
-    y[o + s] = cmul(w1, y1);
-    y[o + 2 * s] = cmul(w2, y2);
-    y[o + 3 * s] = cmul(w3, y3);
-  }
-}
-
-// final radix-2 pass (sub-transform size 2, no twiddle), s = H/2
-template <int NT = KWY_THREADS>
-__device__ __forceinline__ void kwy_fft_r2(const kwy_c *__restrict__ x, kwy_c *__restrict__ y, int H) {
-  const int s = H >> 1;
-  for (int q = threadIdx.x; q < s; q += NT) {
-    kwy_c a = x[q], b = x[q + s];
-    y[q] = cadd(a, b);
-    y[q + s] = csub(a, b);
-  }
-}
-
-// Complex FFT of H = 2^log2H points held in LDS buffer a; b is a scratch buffer
-// of the same size.  Returns the buffer that holds the (natural order) result.
-// Unnormalised in both directions.  Ends with a barrier.
-template <bool INV, int NT = KWY_THREADS>
-__device__ inline kwy_c *kwy_fft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ tw) {
-  const int H = 1 << log2H;
-  kwy_c *src = a, *dst = b;
-  int log2s = 0;
-  __syncthreads();
-  for (int rem = log2H; rem >= 2; rem -= 2) {
-    kwy_fft_r4<INV, NT>(src, dst, H, 1 << log2s, log2s, tw);
-    __syncthreads();
-    kwy_c *t = src; src = dst; dst = t;
-    log2s += 2;
-  }
-  if (log2H & 1) {
-    kwy_fft_r2<NT>(src, dst, H);
-    __syncthreads();
-    kwy_c *t = src; src = dst; dst = t;
-  }
-  return src;
-}
-
-// Real FFT of N = 2H reals.  `a` holds the N reals (viewed as H packed complex),
-// `b` is scratch; both need room for H+1 complex.  twH: H-entry table for the
-// H-point transform, twN: table exp(-2 pi i k / N) for k < H.
-// Returns the buffer holding X[0..H] (H+1 complex bins).
-template <int NT = KWY_THREADS>
-__device__ inline kwy_c *kwy_rfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ twH,
-                                      const kwy_c *__restrict__ twN) {
-  const int H = 1 << log2H;
-  kwy_c *z = kwy_fft_lds<false, NT>(a, b, log2H, twH);
-  kwy_c *o = (z == a) ? b : a;
-  for (int k = threadIdx.x; k <= H; k += NT) {
-    kwy_c r;
-    if (k == 0) {
-      r = {z[0].x + z[0].y, 0.0};
-    } else if (k == H) {
-      r = {z[0].x - z[0].y, 0.0};
-    } else {
-      kwy_c A = z[k];
-      kwy_c B = {z[H - k].x, -z[H - k].y};
-      double er = 0.5 * (A.x + B.x), ei = 0.5 * (A.y + B.y);
-      double dr = 0.5 * (A.x - B.x), di = 0.5 * (A.y - B.y);
-      double orr = di, oi = -dr;
-      kwy_c w = twN[k];
-      r = {er + (orr * w.x - oi * w.y), ei + (orr * w.y + oi * w.x)};
-    }
-    o[k] = r;
-  }
-  __syncthreads();
-  return o;
-}
-
-// Inverse of the above (unnormalised c2r: result = N * true inverse).
-// `a` holds X[0..H]; returns the buffer whose first N doubles are the signal.
-template <int NT = KWY_THREADS>
-__device__ inline kwy_c *kwy_irfft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ twH,
-                                       const kwy_c *__restrict__ twN) {
-  const int H = 1 << log2H;
-  __syncthreads();
-  for (int k = threadIdx.x; k < H; k += NT) {
-    double ar = a[k].x, ai = (k == 0) ? 0.0 : a[k].y;
-    double br = a[H - k].x, bi = (k == 0) ? 0.0 : -a[H - k].y;
-    double er = ar + br, ei = ai + bi;
-    double dr = ar - br, di = ai - bi;
-    kwy_c w = twN[k];
-    double wr = w.x, wi = -w.y;
-    double orr = dr * wr - di * wi, oi = dr * wi + di * wr;
-    b[k] = {er - oi, ei + orr};
-  }
-  return kwy_fft_lds<true, NT>(b, a, log2H, twH);
-}
-
 // exp(-2 pi i (t + r*NT) / N) from base = exp(-2 pi i t / N) when NT = N/8: base times an 8th root of unity
 __device__ __forceinline__ kwy_c kwy_tw_octant(kwy_c b, int r) {
   const double h = 0.70710678118654752440;
@@ -663,6 +549,9 @@ __device__ __forceinline__ void kwy_fft_pass8_first_sparse(kwy_c *z, const kwy_c
   kwy_fft_pass8_first_sparse_core<LOG2H, NT, INV>(z, kwy_tw_table{tw}, a0, a1);
 }
 
+template <int LOG2H, int TAIL, int NT, bool INV>
+__device__ __forceinline__ void kwy_fft_tail(kwy_c *z);
+
 // the remaining passes after kwy_fft_pass8_first_sparse
 template <int LOG2H, int NT, bool INV>
 __device__ inline void kwy_fft_inplace_rest(kwy_c *z, const kwy_c *__restrict__ tw) {
@@ -799,7 +688,7 @@ __device__ inline void kwy_rfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw, 
 }
 
 // kwy_irfft_inplace: z[0..H] holds X; on return the first N doubles of z are the signal times N
-// (unnormalised, like kwy_irfft_lds).  Ends with a barrier.
+// (unnormalised: N times the true inverse).  Ends with a barrier.
 template <int LOG2H, int NT>
 __device__ inline void kwy_irfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw, kwy_c twb,
                                    const kwy_c *__restrict__ twN = nullptr) {
@@ -812,7 +701,7 @@ __device__ inline void kwy_irfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw,
     const int k = tid + NT * r;
     if (k > H / 2) continue;
     if (k == 0) {
-      // b[0] from a[0], a[H] (imaginary parts ignored, as kwy_irfft_lds does)
+      // b[0] from a[0], a[H] (imaginary parts of the DC and Nyquist bins ignored)
       const double ar = z[0].x, br = z[H].x;
       z[0] = {ar + br, ar - br};
     } else {

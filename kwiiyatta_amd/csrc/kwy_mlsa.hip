@@ -41,29 +41,36 @@ __global__ void k_mc2b(const double *__restrict__ mc, int64_t T, int m, double a
   for (int i = m - 1; i >= 0; --i) { nxt = c[i] - a * nxt; o[i] = nxt; }
 }
 
+// NB = number of 8-link blocks of the all-pass chain (links i = 2 .. 8 NB + 1 >= m; the coefficients
+// of the links behind m are zero).  The chain state lives in registers: the loops over links are
+// unrolled, SPTK's shift d[i] = d[i-1] becomes the register the new value is written to.
+template <int NB, int PD>
 __global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x, int64_t n,
                                                    const double *__restrict__ b, int64_t T, int m, double a,
-                                                   int pd, int hop, double *__restrict__ y) {
+                                                   int hop, double *__restrict__ y) {
+  constexpr int pd = PD;
+  constexpr int ML = 8 * NB;
   extern __shared__ double sm[];
-  // sd[2][pd][m+3] section states (two copies), sb[m+1] current coefficients, sx[hop] in, sy[hop] out
-  const int mp = 1 + ((m - 1 + 7) / 8) * 8;   // chain length padded to whole blocks of 8 links
-  const int ds = mp + 3;
-  double *sd = sm;
-  double *sb = sd + 2 * 8 * ds;  // room for pd <= 5 (8 rows reserved)
-  double *sx = sb + 72;
+  // sb[2][72] interpolated coefficients of this and the next sample, sx[hop] in, sy[hop] out
+  double *sb = sm;
+  double *sx = sb + 2 * 72;
   double *sy = sx + hop;
   const int lane = threadIdx.x;
   const double aa = 1 - a * a;
   const double *ppade = &c_pade[pd * (pd + 1) / 2];
-  for (int i = lane; i < 2 * 8 * ds; i += 64) sd[i] = 0.0;
-  for (int i = lane; i < 72; i += 64) sb[i] = 0.0;
-  if (lane + 64 < 72) sb[lane + 64] = 0.0;
+  for (int i = lane; i < 2 * 72; i += 64) sb[i] = 0.0;
   // frame f is processed iff (f+1) hop < n; what lies behind the last processed frame stays zero
   int64_t nproc = (n - 1) / hop;
   if (nproc > T) nproc = T;
   for (int64_t j = nproc * hop + lane; j < n; j += 64) y[j] = 0.0;
   // mlsadf1 state (uniform): d1[1..pd], pt1[0..pd]
-  double d1[6] = {0, 0, 0, 0, 0, 0}, pt1[6] = {0, 0, 0, 0, 0, 0};
+  double d1[PD + 1], pt1[PD + 1];
+#pragma unroll
+  for (int i = 0; i <= PD; ++i) d1[i] = pt1[i] = 0.0;
+  // mlsadf2: lane s < pd owns Pade section s+1 and its chain d[0..m+1]
+  double d[ML + 3];
+#pragma unroll
+  for (int i = 0; i < ML + 3; ++i) d[i] = 0.0;
   double pt0 = 0.0;   // pt[0] of mlsadf2: the section input of the previous sample
   double po = 0.0;    // this lane's section output of the previous sample
   double prevb = (lane <= m) ? b[lane] : 0.0;  // coefficient `lane` of the previous frame (frame 0: its own)
@@ -75,23 +82,25 @@ __global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x
     const double slope = (curb - prevb) / hop;
     double cur = prevb;
     for (int j = lane; j < hop; j += 64) sx[j] = x[s0 + j];
+    if (lane <= m) sb[par * 72 + lane] = cur;
     __syncthreads();
     for (int j = 0; j < hop; ++j) {
-      if (lane <= m) sb[lane] = cur;
-      __builtin_amdgcn_wave_barrier();   // one wavefront: the LDS executes its accesses in issue order
-      const double b0 = sb[0], b1 = sb[1];
+      // one wavefront: the LDS executes its accesses in issue order, no barrier between the
+      // store of a coefficient and its broadcast load
+      const double *__restrict__ bc = sb + par * 72;
+      const double b0 = bc[0], b1 = bc[1];
+      cur += slope;
+      if (lane <= m) sb[(par ^ 1) * 72 + lane] = cur;   // the coefficients of the next sample
       double xv = sx[j] * exp(b0);
       // ---- mlsadf1 (uniform)
       double out = 0.0;
 #pragma unroll
-      for (int i = 5; i >= 1; --i) {
-        if (i <= pd) {
-          d1[i] = aa * pt1[i - 1] + a * d1[i];
-          pt1[i] = d1[i] * b1;
-          const double v = pt1[i] * ppade[i];
-          xv += (1 & i) ? v : -v;
-          out += v;
-        }
+      for (int i = PD; i >= 1; --i) {
+        d1[i] = aa * pt1[i - 1] + a * d1[i];
+        pt1[i] = d1[i] * b1;
+        const double v = pt1[i] * ppade[i];
+        xv += (1 & i) ? v : -v;
+        out += v;
       }
       pt1[0] = xv;
       out += xv;
@@ -100,51 +109,52 @@ __global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x
       double in = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(po), 0x138, 0xf, 0xf, false),
                                    __builtin_amdgcn_update_dpp(0, __double2loint(po), 0x138, 0xf, 0xf, false));
       if (lane == 0) in = pt0;
+      if (lane >= pd) in = 0.0;   // idle lanes keep an all-zero chain
+      // SPTK: d[0] = x; d[1] = aa d[0] + a d[1]; d[i] += a (d[i+1] - d[i-1]) (i = 2..m), y += d[i] b[i];
+      //       then d[i] = d[i-1] (i = m+1..2): the new d[i] is written to d[i+1] straight away.
       double yo = 0.0;
-      if (lane < pd) {
-        const double *__restrict__ dold = sd + (par * 8 + lane) * ds;
-        double *__restrict__ dnew = sd + ((par ^ 1) * 8 + lane) * ds;
-        // SPTK: d[0] = x; d[1] = aa d[0] + a d[1]; d[i] += a (d[i+1] - d[i-1]) (i = 2..m), y += d[i] b[i];
-        //       then d[i] = d[i-1] (i = m+1..2).  dnew holds the shifted result directly.  The chain
-        //       u[i] = d[i] + a (d[i+1] - u[i-1]) is serial; the operands are fetched eight at a time
-        //       so that their LDS latency is paid once per block, not once per link.
-        double u_prev = aa * in + a * dold[1];  // new d[1]
-        dnew[0] = in;
-        dnew[1] = u_prev;
-        dnew[2] = u_prev;                       // the shift copies d[1] into d[2] as well
-        double di = dold[2];
-        for (int i0 = 2; i0 <= m; i0 += 8) {   // the chain is padded to whole blocks (b = 0 there): no guards
-          double dn[8], bb[8], uu[8];
+      double u_prev = aa * in + a * d[1];  // new d[1]
+      double di = d[2];
+      d[0] = in;
+      d[1] = u_prev;
+      d[2] = u_prev;                        // the shift copies d[1] into d[2] as well
+      // coefficients of block k+1 are fetched (LDS broadcast loads) while the links of block k run
+      double bb[8], bn[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) { dn[q] = dold[i0 + q + 1]; bb[q] = sb[i0 + q]; }
+      for (int q = 0; q < 8; ++q) bb[q] = bc[2 + q];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const double u = di + a * (dn[q] - u_prev);
-            yo += u * bb[q];
-            uu[q] = u;
-            u_prev = u;
-            di = dn[q];
-          }
+      for (int k = 0; k < NB; ++k) {
+        if (k + 1 < NB) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) dnew[i0 + q + 1] = uu[q];
+          for (int q = 0; q < 8; ++q) bn[q] = bc[2 + 8 * (k + 1) + q];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = 2 + 8 * k + q;
+          const double dn = d[i + 1];
+          const double u = di + a * (dn - u_prev);
+          yo += u * bb[q];
+          d[i + 1] = u;
+          u_prev = u;
+          di = dn;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bb[q] = bn[q];
       }
       // ---- Pade sums (uniform): sections pd .. 1
       double xx = x2, out2 = 0.0;
 #pragma unroll
-      for (int i = 5; i >= 1; --i) {
-        if (i <= pd) {
-          const double pti = kwy_readlane_f64(yo, i - 1);
-          const double v = pti * ppade[i];
-          xx += (1 & i) ? v : -v;
-          out2 += v;
-        }
+      for (int i = PD; i >= 1; --i) {
+        const double pti = kwy_readlane_f64(yo, i - 1);
+        const double v = pti * ppade[i];
+        xx += (1 & i) ? v : -v;
+        out2 += v;
       }
       pt0 = xx;
       out2 += xx;
       po = yo;
       if (lane == 0) sy[j] = out2;
-      cur += slope;
       par ^= 1;
       __builtin_amdgcn_wave_barrier();
     }
@@ -165,13 +175,30 @@ static int mlsa_check(kwy_ctx *ctx, const void *x, int64_t n, const void *b, int
   return KWY_OK;
 }
 
-static int mlsa_core(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int m, double a,
-                     int pd, int hop, double *y) {
-  const size_t lds = sizeof(double) * (2 * 8 * (1 + ((m - 1 + 7) / 8) * 8 + 3) + 72 + 2 * hop);
-  KWY_HIP(hipFuncSetAttribute((const void *)k_mlsa_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_mlsa_filter", hipLaunchKernelGGL(k_mlsa_filter, dim3(1), dim3(64), lds, ctx->stream, x, n, b, T, m, a, pd, hop, y));
+template <int NB>
+static int mlsa_launch(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int m, double a,
+                       int pd, int hop, double *y) {
+  const size_t lds = sizeof(double) * (2 * 72 + 2 * hop);
+  void (*kern)(const double *, int64_t, const double *, int64_t, int, double, int, double *) =
+      (pd == 4) ? k_mlsa_filter<NB, 4> : k_mlsa_filter<NB, 5>;
+  KWY_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  KWY_PROF(ctx, "k_mlsa_filter", hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds, ctx->stream, x, n, b, T, m, a, hop, y));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
+}
+
+static int mlsa_core(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int m, double a,
+                     int pd, int hop, double *y) {
+  switch ((m - 1 + 7) / 8) {   // links 2..m in blocks of 8
+    case 1: return mlsa_launch<1>(ctx, x, n, b, T, m, a, pd, hop, y);
+    case 2: return mlsa_launch<2>(ctx, x, n, b, T, m, a, pd, hop, y);
+    case 3: return mlsa_launch<3>(ctx, x, n, b, T, m, a, pd, hop, y);
+    case 4: return mlsa_launch<4>(ctx, x, n, b, T, m, a, pd, hop, y);
+    case 5: return mlsa_launch<5>(ctx, x, n, b, T, m, a, pd, hop, y);
+    case 6: return mlsa_launch<6>(ctx, x, n, b, T, m, a, pd, hop, y);
+    case 7: return mlsa_launch<7>(ctx, x, n, b, T, m, a, pd, hop, y);
+    default: return mlsa_launch<8>(ctx, x, n, b, T, m, a, pd, hop, y);
+  }
 }
 
 extern "C" int kwy_mc2b_dev(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, double *b) {

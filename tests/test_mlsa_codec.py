@@ -68,7 +68,9 @@ def test_oracle_codec_round_trip_and_vuv():
 
 # ----------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize('fs,order,pd', [(16000, 24, 4), (48000, 48, 4), (16000, 24, 5)])
+@pytest.mark.parametrize('fs,order,pd', [(16000, 24, 4), (48000, 48, 4), (16000, 24, 5), (16000, 2, 4), (16000, 9, 5),
+                                         (16000, 10, 4), (22050, 33, 5), (44100, 41, 4), (48000, 57, 5),
+                                         (48000, 62, 4)])
 def test_hip_mlsa_matches_oracle(fs, order, pd):
     from oracle import oracle as ko
     from kwiiyatta_amd.backend import sptk

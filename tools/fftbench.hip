@@ -6,6 +6,71 @@
 #include <vector>
 #include "../kwiiyatta_amd/csrc/kwy_device.hpp"
 
+// Baseline for the comparison: the two-buffer radix-4 Stockham transform the
+// kernels used before kwy_fft_inplace replaced it.
+// One Stockham radix-4 pass over H points: x -> y, sub-transform stride s.
+// tw: H-entry table exp(-2 pi i k / H).  INV conjugates the twiddles.
+template <bool INV, int NT = KWY_THREADS>
+__device__ __forceinline__ void kwy_fft_r4(const kwy_c *__restrict__ x, kwy_c *__restrict__ y,
+                                           int H, int s, int log2s,
+                                           const kwy_c *__restrict__ tw) {
+  const int Q = H >> 2;
+  for (int j = threadIdx.x; j < Q; j += NT) {
+    const int q = j & (s - 1);
+    const int p = j >> log2s;
+    kwy_c a = x[j], b = x[j + Q], c = x[j + 2 * Q], d = x[j + 3 * Q];
+    kwy_c apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+    kwy_c jb = INV ? kwy_c{bmd.y, -bmd.x} : kwy_c{-bmd.y, bmd.x};  // = +-i*(b-d), sign folded below
+    // forward: y1 = amc - i*bmd, y3 = amc + i*bmd ; inverse: swapped
+    kwy_c y0 = cadd(apc, bpd);
+    kwy_c y1 = csub(amc, jb);
+    kwy_c y2 = csub(apc, bpd);
+    kwy_c y3 = cadd(amc, jb);
+    const int ps = p << log2s;
+    kwy_c w1 = tw[ps], w2 = tw[2 * ps], w3 = tw[3 * ps];
+    if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+    const int o = q + ((4 * p) << log2s);
+    y[o] = y0;
+    y[o + s] = cmul(w1, y1);
+    y[o + 2 * s] = cmul(w2, y2);
+    y[o + 3 * s] = cmul(w3, y3);
+  }
+}
+
+// final radix-2 pass (sub-transform size 2, no twiddle), s = H/2
+template <int NT = KWY_THREADS>
+__device__ __forceinline__ void kwy_fft_r2(const kwy_c *__restrict__ x, kwy_c *__restrict__ y, int H) {
+  const int s = H >> 1;
+  for (int q = threadIdx.x; q < s; q += NT) {
+    kwy_c a = x[q], b = x[q + s];
+    y[q] = cadd(a, b);
+    y[q + s] = csub(a, b);
+  }
+}
+
+// Complex FFT of H = 2^log2H points held in LDS buffer a; b is a scratch buffer
+// of the same size.  Returns the buffer that holds the (natural order) result.
+// Unnormalised in both directions.  Ends with a barrier.
+template <bool INV, int NT = KWY_THREADS>
+__device__ inline kwy_c *kwy_fft_lds(kwy_c *a, kwy_c *b, int log2H, const kwy_c *__restrict__ tw) {
+  const int H = 1 << log2H;
+  kwy_c *src = a, *dst = b;
+  int log2s = 0;
+  __syncthreads();
+  for (int rem = log2H; rem >= 2; rem -= 2) {
+    kwy_fft_r4<INV, NT>(src, dst, H, 1 << log2s, log2s, tw);
+    __syncthreads();
+    kwy_c *t = src; src = dst; dst = t;
+    log2s += 2;
+  }
+  if (log2H & 1) {
+    kwy_fft_r2<NT>(src, dst, H);
+    __syncthreads();
+    kwy_c *t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <int LOG2H, int NT, int VAR>
