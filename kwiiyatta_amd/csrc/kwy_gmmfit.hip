@@ -18,12 +18,11 @@
 // rate of gfx950 equals its f64 vector rate).
 #include <math.h>
 
+#include <type_traits>
+
 #include "kwy_internal.hpp"
 
-#define FIT_NT 512            // threads of the log-prob workgroup
-#define FIT_TILE 64           // frames per log-prob workgroup
 #define FIT_SUM_ROWS 64       // rows per LDS tile in k_fit_sums
-#define FIT_COV_SPLIT 8       // row splits per mixture in k_fit_cov
 
 __host__ __device__ static inline size_t fit_tri(int D) { return (size_t)D * (D + 1) / 2; }
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // j <= i
@@ -78,98 +77,117 @@ __global__ __launch_bounds__(KWY_THREADS) void k_fit_prec(const double *__restri
   }
 }
 
-// weighted log prob wlp[t][m] = cst[m] - 0.5 * || Z_m (x_t - mu_m) ||^2
-// The n x D by D x D (lower-triangular) product runs on v_mfma_f64_16x16x4_f64.  A workgroup owns one
-// mixture: its packed triangular Z stays in LDS (83.5 KB for D = 144) while the workgroup walks over
-// frame tiles; wavefront w stages and multiplies frames 16w..16w+15 of a tile on its own (no block
-// barrier inside the walk), fetching the next tile's rows into registers while the MFMAs of the
-// current one run.  Per 16-column block of Z only the k-steps up to the block's diagonal are issued
-// (180 instead of 324 MFMAs per wavefront and tile for D = 144).
+// weighted log prob wlp[t][m] = cst[m] - 0.5 * || Z_m x_t - Z_m mu_m ||^2   (sklearn's form:
+// np.dot(X, prec_chol) - np.dot(mu, prec_chol))
+// The n x D by D x D (lower-triangular) product runs on v_mfma_f64_16x16x4_f64 (2048 flop per
+// instruction on two 512-byte operands: fed from LDS alone it is LDS-bound, so the frame operand
+// stays in registers).  A workgroup of eight wavefronts owns one mixture: Z is expanded once into
+// MFMA-fragment order in LDS (one conflict-free 512-byte read per B operand, the entries above the
+// diagonal stored as zeros: no masking in the loop; 92 KB for D = 144).  A wavefront takes 32 frames at
+// a time: it loads their D columns straight from global memory into the A registers of two 16-frame
+// sub-tiles (2 x 36 doubles per lane), and every B fragment it reads feeds two MFMAs.  Per 16-column
+// block of Z only the k-steps up to the block's diagonal are issued (180 instead of 324 fragments for
+// D = 144).  The second wavefront of each SIMD computes while the first one waits for its rows.
 // Lane map: A[row l&15][k l>>4], B[k l>>4][col l&15], D[row (l>>4)+4r][col l&15].
 typedef double fit_v4f64 __attribute__((ext_vector_type(4)));
-#define FIT_LP_NT 256
-#define FIT_LP_COLS 3   // feature columns per lane when staging a row: D <= 192
+#define FIT_LP_NT 512
+#define FIT_LP_COLS 3   // feature columns per lane when staging a row (k_fit_cov): D <= 192
 
+template <int NBLK>
 __global__ __launch_bounds__(FIT_LP_NT) void k_fit_logprob(const double *__restrict__ X, int64_t n, int D, int M,
-                                                          const double *__restrict__ means,
+                                                          int nsplit, const double *__restrict__ means,
                                                           const double *__restrict__ Zp,
                                                           const double *__restrict__ cst,
                                                           double *__restrict__ wlp) {
+  constexpr int KS = 4 * NBLK, NFRAG = 2 * NBLK * (NBLK + 1);
   extern __shared__ double sm[];
-  const int nt = (int)fit_tri(D), Kp = (D + 3) & ~3, NP = (D + 15) & ~15, ZS = Kp + 1;
-  double *Z = sm;                 // packed lower triangle
-  double *dts = Z + nt;           // FIT_TILE x ZS
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
-  const double *zp = Zp + (size_t)m * nt, *mu = means + (size_t)m * D;
-  for (int e = tid; e < nt; e += FIT_LP_NT) Z[e] = zp[e];
-  const double cm = cst[m];
-  double muv[FIT_LP_COLS];
-#pragma unroll
-  for (int c = 0; c < FIT_LP_COLS; ++c) muv[c] = (lane + 64 * c < D) ? mu[lane + 64 * c] : 0.0;
+  double *zf = sm;                  // NFRAG x 64: fragment (nb, ks), ks < 4 nb + 4, at 2 nb (nb + 1) + ks
+  double *cs = zf + NFRAG * 64;     // 16 NBLK: Z mu
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ar = lane & 15, ak = lane >> 4;
-  const int64_t ntiles = (n + FIT_TILE - 1) / FIT_TILE;
-  double *myrows = dts + (16 * wv) * ZS;
-  // rows of the first tile
-  double xv[16][FIT_LP_COLS];
-  auto fetch = [&](int64_t tile) {
-    const int64_t tb = tile * FIT_TILE + 16 * wv;
+  int m, split;
+  if ((nsplit & 7) == 0) {   // consecutive workgroups of one XCD (ids k, k+8, ...) = mixtures of one split
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    m = q % M;
+    split = xcd + 8 * (q / M);
+  } else {
+    m = blockIdx.x % M;
+    split = blockIdx.x / M;
+  }
+  const int nt = (int)fit_tri(D);
+  const double *zp = Zp + (size_t)m * nt, *mu = means + (size_t)m * D;
+  for (int idx = tid; idx < NFRAG * 64; idx += FIT_LP_NT) {
+    const int f = idx >> 6, l = idx & 63;
+    int nb = 0;
+    while (2 * (nb + 1) * (nb + 2) <= f) ++nb;
+    const int ks = f - 2 * nb * (nb + 1);
+    const int j = 16 * nb + (l & 15), i = 4 * ks + (l >> 4);
+    zf[idx] = (j < D && i <= j) ? zp[tri(j, i)] : 0.0;
+  }
+  for (int j = tid; j < 16 * NBLK; j += FIT_LP_NT) {
+    double c = 0.0;
+    if (j < D)
+      for (int i = 0; i <= j; ++i) c += zp[tri(j, i)] * mu[i];
+    cs[j] = c;
+  }
+  const double cm = cst[m];
+  __syncthreads();
+  const int64_t ntiles = (n + 255) / 256;
+  const int64_t per = (ntiles + nsplit - 1) / nsplit;
+  const int64_t tile0 = split * per, tile1 = min(ntiles, tile0 + per);
+  for (int64_t tile = tile0; tile < tile1; ++tile) {
+    const int64_t t0 = tile * 256 + 32 * wv;
+    if (t0 >= n) break;
+    // columns beyond D (last block only) meet zero fragments: clamping them keeps the loads in bounds
+    const double *xa = X + min(t0 + ar, n - 1) * D, *xb = X + min(t0 + 16 + ar, n - 1) * D;
+    double a0[KS], a1[KS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int ks = 0; ks < KS - 4; ++ks) {
+      a0[ks] = xa[4 * ks + ak];
+      a1[ks] = xb[4 * ks + ak];
+    }
 #pragma unroll
-      for (int c = 0; c < FIT_LP_COLS; ++c) {
-        const int i = lane + 64 * c;
-        xv[r][c] = (tile < ntiles && tb + r < n && i < D) ? X[(tb + r) * D + i] : muv[c];
+    for (int ks = KS - 4; ks < KS; ++ks) {
+      const int c = min(4 * ks + ak, D - 1);
+      a0[ks] = xa[c];
+      a1[ks] = xb[c];
+    }
+    double q0[4] = {0.0, 0.0, 0.0, 0.0}, q1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      fit_v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      const double *frag = zf + (2 * nb * (nb + 1)) * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < 4 * nb + 4; ++ks) {
+        const double b = frag[ks * 64];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], b, acc1, 0, 0, 0);
       }
-  };
-  fetch(blockIdx.y);
-  __syncthreads();  // Z complete
-  for (int64_t tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {
+      const double c = cs[16 * nb + ar];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int c = 0; c < FIT_LP_COLS; ++c) {
-        const int i = lane + 64 * c;
-        if (i < Kp) myrows[r * ZS + i] = xv[r][c] - muv[c];
+      for (int r = 0; r < 4; ++r) {
+        const double y0 = acc0[r] - c, y1 = acc1[r] - c;
+        q0[r] += y0 * y0;
+        q1[r] += y1 * y1;
       }
-    __builtin_amdgcn_wave_barrier();
-    fetch(tile + gridDim.y);  // in flight during the MFMAs below
-    double q[4] = {0.0, 0.0, 0.0, 0.0};
-    const double *arow = myrows + ar * ZS + ak;
-    for (int nb = 0; nb < NP / 16; ++nb) {
-      const int j = 16 * nb + ar;
-      const double *zrow = Z + tri(j < D ? j : 0, 0) + ak;
-      fit_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-      for (int ks = 0; ks < 4 * nb; ++ks)  // strictly below the diagonal block: no masking (j >= 16 nb > i)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * ks], j < D ? zrow[4 * ks] : 0.0, acc, 0, 0, 0);
-#pragma unroll
-      for (int dgn = 0; dgn < 4; ++dgn) {  // the diagonal block
-        const int ks = 4 * nb + dgn;
-        if (4 * ks < Kp) {
-          const int i = 4 * ks + ak;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * ks], (j < D && i <= j) ? zrow[4 * ks] : 0.0, acc, 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) q[r] += acc[r] * acc[r];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      double v = q[r];
-      v += kwy_dpp_f64<0x111>(v);
-      v += kwy_dpp_f64<0x112>(v);
-      v += kwy_dpp_f64<0x114>(v);
-      v += kwy_dpp_f64<0x118>(v);
-      q[r] = v;
+      double v = q0[r], w = q1[r];
+      v += kwy_dpp_f64<0x111>(v); w += kwy_dpp_f64<0x111>(w);
+      v += kwy_dpp_f64<0x112>(v); w += kwy_dpp_f64<0x112>(w);
+      v += kwy_dpp_f64<0x114>(v); w += kwy_dpp_f64<0x114>(w);
+      v += kwy_dpp_f64<0x118>(v); w += kwy_dpp_f64<0x118>(w);
+      q0[r] = v; q1[r] = w;
     }
     if (ar == 15) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t t = tile * FIT_TILE + 16 * wv + ak + 4 * r;
-        if (t < n) wlp[t * M + m] = cm - 0.5 * q[r];
+        const int64_t t = t0 + ak + 4 * r;
+        if (t < n) wlp[t * M + m] = cm - 0.5 * q0[r];
+        if (t + 16 < n) wlp[(t + 16) * M + m] = cm - 0.5 * q1[r];
       }
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -247,91 +265,171 @@ __global__ void k_fit_reduce(const double *__restrict__ part, int nchunks, int64
   out[e] = s;
 }
 
-// local statistics: cpart[split][m] = sum over the split's rows of r (x - mu_m)(x - mu_m)'  (full D x D)
+// local statistics: cpart[split][m] = sum over the split's rows of r (x - mu_m)(x - mu_m)'
 // A D x n by n x D product with the frame index as the MFMA's k: v_mfma_f64_16x16x4_f64 consumes four
-// frames per instruction, A = r_t d_t[i], B = d_t[j].  A workgroup owns (mixture, row split) and
-// walks over 64-frame tiles staged in LDS; wavefront w accumulates the 16-row blocks w, w+4, w+8 of
-// the result against all 16-column blocks (the full square: the symmetric half would need a
-// per-wavefront tile list, i.e. dynamically indexed accumulators).
-#define FIT_COV_NB 10      // 16-column blocks: D <= 160
-#define FIT_COV_RB 3       // 16-row blocks per wavefront: ceil(10 / 4)
-__global__ __launch_bounds__(KWY_THREADS) void k_fit_cov(const double *__restrict__ X,
-                                                        const double *__restrict__ resp, int64_t n, int D,
-                                                        int M, const double *__restrict__ means,
-                                                        double *__restrict__ cpart) {
+// frames per instruction, A = r_t d_t[i], B = d_t[j] -- the same lane layout, so one LDS read serves a
+// block index both as row and as column operand.  A workgroup owns (mixture, row split) and walks over
+// 32-frame tiles of d = x - mu, double-buffered in LDS (one barrier per tile, the next tile's rows are
+// in flight in registers meanwhile).  Only the 16x16 blocks (I, J <= I) of the lower triangle are
+// computed; they are dealt to the four wavefronts in row-major order (45 blocks -> 12/11/11/11 for
+// D = 144), so a wavefront holds at most 12 accumulator blocks (96 registers): two workgroups per CU,
+// every register an architectural VGPR.  Workgroups are numbered so that the 64 that run together on
+// one XCD (2 per CU) are the mixtures of one row split and share its frames in that XCD's L2.
+#define FIT_COV_TILE 32
+constexpr int fit_blk_row(int e) { int I = 0; while ((I + 1) * (I + 2) / 2 <= e) ++I; return I; }
+constexpr int fit_blk_col(int e) { return e - fit_blk_row(e) * (fit_blk_row(e) + 1) / 2; }
+constexpr int fit_blk_lo(int nblk, int w) { return (nblk * (nblk + 1) / 2) * w / 4; }
+// does wavefront w of an nblk-block problem touch block index b (as row or column operand)?
+constexpr bool fit_blk_uses(int nblk, int w, int b, bool as_row) {
+  for (int e = fit_blk_lo(nblk, w); e < fit_blk_lo(nblk, w + 1); ++e)
+    if ((as_row ? fit_blk_row(e) : fit_blk_col(e)) == b) return true;
+  return false;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void fit_static_for(F &&f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    fit_static_for<I0 + 1, I1>(f);
+  }
+}
+
+template <int NBLK, int W, int CMAX>
+__device__ __forceinline__ void fit_cov_tile(const double *__restrict__ tile, const double *__restrict__ rt, int ZS,
+                                             int ar, int ak, fit_v4f64 (&acc)[CMAX]) {
+  constexpr int E0 = fit_blk_lo(NBLK, W), E1 = fit_blk_lo(NBLK, W + 1);
+#pragma unroll 2
+  for (int ks = 0; ks < FIT_COV_TILE / 4; ++ks) {
+    const double *drow = tile + (4 * ks + ak) * ZS + ar;
+    const double rr = rt[4 * ks + ak];
+    double dv[NBLK], av[NBLK];
+    fit_static_for<0, NBLK>([&](auto bc) {
+      constexpr int b = decltype(bc)::value;
+      constexpr bool as_row = fit_blk_uses(NBLK, W, b, true), as_col = fit_blk_uses(NBLK, W, b, false);
+      if constexpr (as_row || as_col) dv[b] = drow[16 * b];
+      if constexpr (as_row) av[b] = rr * dv[b];
+    });
+    fit_static_for<E0, E1>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      constexpr int I = fit_blk_row(e), J = fit_blk_col(e);
+      acc[e - E0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], dv[J], acc[e - E0], 0, 0, 0);
+    });
+  }
+}
+
+template <int NBLK, int W, int CMAX>
+__device__ __forceinline__ void fit_cov_store(double *__restrict__ out, int D, int ar, int ak,
+                                              const fit_v4f64 (&acc)[CMAX]) {
+  constexpr int E0 = fit_blk_lo(NBLK, W), E1 = fit_blk_lo(NBLK, W + 1);
+  fit_static_for<E0, E1>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    constexpr int I = fit_blk_row(e), J = fit_blk_col(e);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * I + ak + 4 * r, j = 16 * J + ar;
+      if (i < D && j < D) out[(size_t)i * D + j] = acc[e - E0][r];
+    }
+  });
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__restrict__ X, const double *__restrict__ resp,
+                                                           int64_t n, int D, int M, int nsplit,
+                                                           const double *__restrict__ means,
+                                                           double *__restrict__ cpart) {
+  constexpr int NP = 16 * NBLK, ZS = NP + 1, CMAX = (NBLK * (NBLK + 1) / 2 + 3) / 4;
+  constexpr int ROWS = FIT_COV_TILE / 4;   // rows of a tile staged by one wavefront
   extern __shared__ double sm[];
-  const int NP = (D + 15) & ~15, nb = NP / 16, ZS = NP + 1;
-  double *ds = sm;                 // FIT_TILE x ZS, zero padded columns
-  double *rs = ds + FIT_TILE * ZS; // FIT_TILE
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x, split = blockIdx.y;
+  double *ds = sm;                              // 2 x FIT_COV_TILE x ZS
+  double *rs = ds + 2 * FIT_COV_TILE * ZS;      // 2 x FIT_COV_TILE
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ar = lane & 15, ak = lane >> 4;
-  const int64_t rows = (n + gridDim.y - 1) / gridDim.y;
+  // workgroup -> (mixture, split): consecutive workgroups of one XCD (ids k, k+8, ...) = mixtures of one split
+  int m, split;
+  if ((nsplit & 7) == 0) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    m = q % M;
+    split = xcd + 8 * (q / M);
+  } else {
+    m = blockIdx.x % M;
+    split = blockIdx.x / M;
+  }
+  const int64_t rows = (n + nsplit - 1) / nsplit;
   const int64_t r0 = split * rows, r1 = min(n, r0 + rows);
   const double *mu = means + (size_t)m * D;
   double muv[FIT_LP_COLS];
 #pragma unroll
   for (int c = 0; c < FIT_LP_COLS; ++c) muv[c] = (lane + 64 * c < D) ? mu[lane + 64 * c] : 0.0;
-  fit_v4f64 acc[FIT_COV_RB][FIT_COV_NB];
+  fit_v4f64 acc[CMAX];
 #pragma unroll
-  for (int a = 0; a < FIT_COV_RB; ++a)
-#pragma unroll
-    for (int b = 0; b < FIT_COV_NB; ++b) acc[a][b] = fit_v4f64{0.0, 0.0, 0.0, 0.0};
-  // this wavefront stages rows 16w..16w+15 of every tile: fetched one tile ahead into registers
-  double xv[16][FIT_LP_COLS], rv = 0.0;
+  for (int a = 0; a < CMAX; ++a) acc[a] = fit_v4f64{0.0, 0.0, 0.0, 0.0};
+  // this wavefront stages rows ROWS*w .. ROWS*w+ROWS-1 of every tile: fetched one tile ahead into registers
+  double xv[ROWS][FIT_LP_COLS], rv = 0.0;
   auto fetch = [&](int64_t b0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int c = 0; c < FIT_LP_COLS; ++c) {
         const int i = lane + 64 * c;
-        const int64_t t = b0 + 16 * wv + r;
+        const int64_t t = b0 + ROWS * wv + r;
         xv[r][c] = (t < r1 && i < D) ? X[t * D + i] : muv[c];
       }
-    const int64_t t = b0 + 16 * wv + lane;
-    rv = (lane < 16 && t < r1) ? resp[t * M + m] : 0.0;
+    const int64_t t = b0 + tid;
+    rv = (tid < FIT_COV_TILE && t < r1) ? resp[t * M + m] : 0.0;
   };
-  fetch(r0);
-  for (int64_t b0 = r0; b0 < r1; b0 += FIT_TILE) {
-    __syncthreads();  // the previous tile has been consumed
+  auto stage = [&](int buf) {
+    double *dt = ds + buf * FIT_COV_TILE * ZS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
       for (int c = 0; c < FIT_LP_COLS; ++c) {
         const int i = lane + 64 * c;
-        if (i < NP) ds[(16 * wv + r) * ZS + i] = xv[r][c] - muv[c];
+        if (i < NP) dt[(ROWS * wv + r) * ZS + i] = xv[r][c] - muv[c];
       }
-    if (lane < 16) rs[16 * wv + lane] = rv;
+    if (tid < FIT_COV_TILE) rs[buf * FIT_COV_TILE + tid] = rv;
+  };
+  if (r0 < r1) {
+    fetch(r0);
+    stage(0);
     __syncthreads();
-    fetch(b0 + FIT_TILE);
-#pragma unroll 2
-    for (int ks = 0; ks < FIT_TILE / 4; ++ks) {
-      const double *drow = ds + (4 * ks + ak) * ZS + ar;
-      const double rr = rs[4 * ks + ak];
-      double bv[FIT_COV_NB], av[FIT_COV_RB];
-#pragma unroll
-      for (int b = 0; b < FIT_COV_NB; ++b) bv[b] = b < nb ? drow[16 * b] : 0.0;
-#pragma unroll
-      for (int a = 0; a < FIT_COV_RB; ++a) av[a] = (wv + 4 * a < nb) ? rr * drow[16 * (wv + 4 * a)] : 0.0;
-#pragma unroll
-      for (int a = 0; a < FIT_COV_RB; ++a) {
-        if (wv + 4 * a < nb) {
-#pragma unroll
-          for (int b = 0; b < FIT_COV_NB; ++b)
-            if (b < nb) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
+    int buf = 0;
+    for (int64_t b0 = r0; b0 < r1; b0 += FIT_COV_TILE) {
+      fetch(b0 + FIT_COV_TILE);   // in flight during the MFMAs below
+      const double *tile = ds + buf * FIT_COV_TILE * ZS, *rt = rs + buf * FIT_COV_TILE;
+      switch (wv) {
+        case 0: fit_cov_tile<NBLK, 0, CMAX>(tile, rt, ZS, ar, ak, acc); break;
+        case 1: fit_cov_tile<NBLK, 1, CMAX>(tile, rt, ZS, ar, ak, acc); break;
+        case 2: fit_cov_tile<NBLK, 2, CMAX>(tile, rt, ZS, ar, ak, acc); break;
+        default: fit_cov_tile<NBLK, 3, CMAX>(tile, rt, ZS, ar, ak, acc); break;
       }
+      stage(buf ^ 1);             // last read two tiles ago, before the previous barrier
+      __syncthreads();
+      buf ^= 1;
     }
   }
+  // lower-triangle blocks only (diagonal blocks in full); k_fit_reduce_sym mirrors them
   double *out = cpart + ((size_t)split * M + m) * D * D;
-#pragma unroll
-  for (int a = 0; a < FIT_COV_RB; ++a)
-#pragma unroll
-    for (int b = 0; b < FIT_COV_NB; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * (wv + 4 * a) + ak + 4 * r, j = 16 * b + ar;
-        if (wv + 4 * a < nb && b < nb && i < D && j < D) out[(size_t)i * D + j] = acc[a][b][r];
-      }
+  switch (wv) {
+    case 0: fit_cov_store<NBLK, 0, CMAX>(out, D, ar, ak, acc); break;
+    case 1: fit_cov_store<NBLK, 1, CMAX>(out, D, ar, ak, acc); break;
+    case 2: fit_cov_store<NBLK, 2, CMAX>(out, D, ar, ak, acc); break;
+    default: fit_cov_store<NBLK, 3, CMAX>(out, D, ar, ak, acc); break;
+  }
+}
+
+// sxx[m][i][j] = sum over splits of cpart[split][m][max(i,j)][min(i,j)]
+__global__ void k_fit_reduce_sym(const double *__restrict__ cpart, int nsplit, int D, int M, double *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t len = (int64_t)M * D * D;
+  if (e >= len) return;
+  const int64_t m = e / ((int64_t)D * D);
+  const int rem = (int)(e % ((int64_t)D * D));
+  const int i = rem / D, j = rem % D;
+  const int64_t src = m * D * D + (int64_t)max(i, j) * D + min(i, j);
+  double s = 0.0;
+  for (int c = 0; c < nsplit; ++c) s += cpart[(size_t)c * len + src];
+  out[e] = s;
 }
 
 // means = sx / nk   (nk already holds sum r + 10 eps)
@@ -362,13 +460,27 @@ __global__ void k_fit_finalize(const double *__restrict__ stats, const double *_
   covs[e] = v;
 }
 
-// frame-tile walkers per mixture: one workgroup fits per CU
-static unsigned fit_lp_splits(int64_t n, int M) {
-  const int64_t ntiles = (n + FIT_TILE - 1) / FIT_TILE;
-  int64_t s = (256 + M - 1) / M;
+// frame splits per mixture in k_fit_logprob: one workgroup fits per CU (256 on the chip); two rounds,
+// a multiple of 8 (the XCD-aware numbering), at least one 256-frame tile per workgroup
+static int fit_lp_splits(int64_t n, int M) {
+  const int64_t ntiles = (n + 255) / 256;
+  int64_t s = (512 + M - 1) / M;
+  s = (s + 7) & ~(int64_t)7;
   if (s > ntiles) s = ntiles;
-  return (unsigned)(s < 1 ? 1 : s);
+  if (s > 64) s = 64;
+  return (int)(s < 1 ? 1 : s);
 }
+
+template <int NBLK>
+static int fit_lp_launch(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, int nsplit, const double *means,
+                         const double *Zp, const double *cst, double *wlp) {
+  const size_t lds = sizeof(double) * ((size_t)2 * NBLK * (NBLK + 1) * 64 + 16 * NBLK);
+  KWY_HIP(hipFuncSetAttribute((const void *)k_fit_logprob<NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  KWY_PROF(ctx, "k_fit_logprob", hipLaunchKernelGGL(k_fit_logprob<NBLK>, dim3((unsigned)(M * nsplit)), dim3(FIT_LP_NT), lds, ctx->stream, X, n, D, M, nsplit, means, Zp, cst, wlp));
+  return KWY_OK;
+}
+
+static int fit_cov_splits(int64_t n, int M);
 
 // ---- C ABI ------------------------------------------------------------------------------------------
 static int fit_check(kwy_ctx *ctx, int64_t n, int D, int M) {
@@ -385,7 +497,7 @@ extern "C" int kwy_gmm_em_scratch_bytes(int64_t n, int D, int M, int64_t *bytes)
   const int64_t nchunks = (n + 4095) / 4096;
   *bytes = (int64_t)(kwy_pad(sizeof(double) * fit_tri(D) * M) + kwy_pad(sizeof(double) * (size_t)M * D * D) +
                      kwy_pad(sizeof(double) * M) + kwy_pad(sizeof(double) * (size_t)nchunks * M * (D + 1)) +
-                     kwy_pad(sizeof(double) * (size_t)FIT_COV_SPLIT * M * D * D) + kwy_pad(64) + 4096);
+                     kwy_pad(sizeof(double) * (size_t)fit_cov_splits(n, M) * M * D * D) + kwy_pad(64) + 4096);
   return KWY_OK;
 }
 
@@ -406,14 +518,22 @@ extern "C" int kwy_gmm_em_estep_dev(kwy_ctx *ctx, const double *X, int64_t n, in
   if (!Zp || !zcol || !cst) { ctx->err = "gmm_em_estep: scratch"; return KWY_ENOMEM; }
   KWY_HIP(hipMemsetAsync(status_out, 0, sizeof(int), ctx->stream));
   const size_t lds_prec = sizeof(double) * nt;
-  const size_t lds_lp = sizeof(double) * (nt + (size_t)FIT_TILE * (((D + 3) & ~3) + 1));
-  if (lds_lp > 160 * 1024) { ctx->err = "gmm_em_estep: feature dimension too large for LDS"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_fit_prec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prec));
-  KWY_HIP(hipFuncSetAttribute((const void *)k_fit_logprob, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lp));
   hipLaunchKernelGGL(k_fit_prec, dim3(M), dim3(KWY_THREADS), lds_prec, ctx->stream, weights, covs, D, Zp, zcol, cst,
                      status_out);
-  KWY_PROF(ctx, "k_fit_logprob", hipLaunchKernelGGL(k_fit_logprob, dim3(M, fit_lp_splits(n, M)), dim3(FIT_LP_NT), lds_lp,
-                     ctx->stream, X, n, D, M, means, Zp, cst, resp));
+  const int nsplit = fit_lp_splits(n, M);
+  switch ((D + 15) / 16) {
+    case 1: KWY_TRY(fit_lp_launch<1>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 2: KWY_TRY(fit_lp_launch<2>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 3: KWY_TRY(fit_lp_launch<3>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 4: KWY_TRY(fit_lp_launch<4>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 5: KWY_TRY(fit_lp_launch<5>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 6: KWY_TRY(fit_lp_launch<6>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 7: KWY_TRY(fit_lp_launch<7>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 8: KWY_TRY(fit_lp_launch<8>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    case 9: KWY_TRY(fit_lp_launch<9>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+    default: KWY_TRY(fit_lp_launch<10>(ctx, X, n, D, M, nsplit, means, Zp, cst, resp)); break;
+  }
   hipLaunchKernelGGL(k_fit_resp, dim3((unsigned)((n + KWY_THREADS - 1) / KWY_THREADS)), dim3(KWY_THREADS), 0,
                      ctx->stream, resp, n, M, loglik_parts);
   KWY_HIP(hipGetLastError());
@@ -458,6 +578,26 @@ extern "C" int kwy_gmm_em_means_dev(kwy_ctx *ctx, const double *stats, int D, in
   return KWY_OK;
 }
 
+// row splits per mixture in k_fit_cov: about two rounds of the 512 workgroups the chip holds, a multiple
+// of 8 (the XCD-aware numbering), at least 512 frames per workgroup
+static int fit_cov_splits(int64_t n, int M) {
+  int64_t s = (1024 + M - 1) / M;
+  s = (s + 7) & ~(int64_t)7;
+  const int64_t most = (n + 511) / 512;
+  if (s > most) s = most;
+  if (s > 64) s = 64;
+  return (int)(s < 1 ? 1 : s);
+}
+
+template <int NBLK>
+static int fit_cov_launch(kwy_ctx *ctx, const double *X, const double *resp, int64_t n, int D, int M,
+                          const double *means, double *cpart, int nsplit) {
+  const size_t lds = sizeof(double) * (2 * (size_t)FIT_COV_TILE * (16 * NBLK + 1) + 2 * FIT_COV_TILE);
+  KWY_HIP(hipFuncSetAttribute((const void *)k_fit_cov<NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<NBLK>, dim3((unsigned)(M * nsplit)), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, nsplit, means, cpart));
+  return KWY_OK;
+}
+
 // sxx[m] = sum_t r[t][m] (x_t - mu_m)(x_t - mu_m)'    (local shard; full D x D per mixture)
 extern "C" int kwy_gmm_em_cov_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
                                   const double *means, double *sxx) {
@@ -465,15 +605,24 @@ extern "C" int kwy_gmm_em_cov_dev(kwy_ctx *ctx, const double *X, int64_t n, int 
   if (!X || !resp || !means || !sxx) { ctx->err = "gmm_em_cov: null pointer"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
   const int64_t len = (int64_t)M * D * D;
-  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)FIT_COV_SPLIT * len)));
-  double *cpart = kwy_arena<double>(ctx, (size_t)FIT_COV_SPLIT * len);
+  const int nsplit = fit_cov_splits(n, M);
+  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)nsplit * len)));
+  double *cpart = kwy_arena<double>(ctx, (size_t)nsplit * len);
   if (!cpart) { ctx->err = "gmm_em_cov: scratch"; return KWY_ENOMEM; }
-  const int NP = (D + 15) & ~15;
-  const size_t lds = sizeof(double) * ((size_t)FIT_TILE * (NP + 1) + FIT_TILE);
-  KWY_HIP(hipFuncSetAttribute((const void *)k_fit_cov, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov, dim3(M, FIT_COV_SPLIT), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, means, cpart));
-  hipLaunchKernelGGL(k_fit_reduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, cpart,
-                     FIT_COV_SPLIT, len, sxx);
+  switch ((D + 15) / 16) {
+    case 1: KWY_TRY(fit_cov_launch<1>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 2: KWY_TRY(fit_cov_launch<2>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 3: KWY_TRY(fit_cov_launch<3>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 4: KWY_TRY(fit_cov_launch<4>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 5: KWY_TRY(fit_cov_launch<5>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 6: KWY_TRY(fit_cov_launch<6>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 7: KWY_TRY(fit_cov_launch<7>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 8: KWY_TRY(fit_cov_launch<8>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 9: KWY_TRY(fit_cov_launch<9>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    default: KWY_TRY(fit_cov_launch<10>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+  }
+  hipLaunchKernelGGL(k_fit_reduce_sym, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, cpart, nsplit, D,
+                     M, sxx);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

@@ -107,7 +107,8 @@ def test_em_two_ranks_gloo():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,D,M', [(3000, 12, 4), (5000, 144, 8), (2000, 30, 64)])
+@pytest.mark.parametrize('n,D,M', [(3000, 12, 4), (5000, 144, 8), (2000, 30, 64), (2500, 150, 5), (1500, 160, 3),
+                                   (100, 20, 3), (20000, 144, 64), (777, 97, 7)])
 def test_hip_statistics_match_numpy(n, D, M):
     """E-step, sums, covariance statistics and finalisation of the HIP kernels vs numpy."""
     from kwiiyatta_amd.converter.gmm_fit import HipStats
