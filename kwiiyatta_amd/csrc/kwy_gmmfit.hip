@@ -22,57 +22,69 @@
 
 #include "kwy_internal.hpp"
 
-#define FIT_SUM_ROWS 64       // rows per LDS tile in k_fit_sums
 
 __host__ __device__ static inline size_t fit_tri(int D) { return (size_t)D * (D + 1) / 2; }
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // j <= i
 
 // per mixture: Zp[m] = packed lower-triangular inverse of chol(cov_m), cst[m] = log w - 0.5 D log 2pi - sum log L_ii
+// One workgroup per mixture, the packed triangle in LDS, thread i owns row i (D <= 160 < 256 threads).
+// Cholesky, left-looking: column j of L is a dot product per row, the pivot of column j+1 travels with
+// the row that owns it (one barrier per column).  Inverse, row by row in place: row i of Z = L^-1 needs
+// row i of L and the rows of Z above it, and takes the place of row i of L.
 __global__ __launch_bounds__(KWY_THREADS) void k_fit_prec(const double *__restrict__ weights,
                                                          const double *__restrict__ covs, int D,
-                                                         double *__restrict__ Zp, double *__restrict__ zcol,
-                                                         double *__restrict__ cst, int *__restrict__ status) {
-  extern __shared__ double L[];  // packed lower triangle
-  const int tid = threadIdx.x, m = blockIdx.x;
+                                                         double *__restrict__ Zp, double *__restrict__ cst,
+                                                         int *__restrict__ status) {
+  extern __shared__ double L[];  // packed lower triangle, then pivs[D]
+  const int tid = threadIdx.x, m = blockIdx.x, i = tid;
   const double *C = covs + (size_t)m * D * D;
   const int nt = (int)fit_tri(D);
-  for (int i = tid; i < D; i += KWY_THREADS)
-    for (int j = 0; j <= i; ++j) L[tri(i, j)] = C[(size_t)i * D + j];
+  double *pivs = L + nt;
+  for (int r = 0; r < D; ++r)
+    for (int c = tid; c <= r; c += KWY_THREADS) L[tri(r, c)] = C[(size_t)r * D + c];
+  __syncthreads();
+  double ri = i < D ? L[tri(i, i)] : 0.0;   // C[i][i] - sum_k L[i][k]^2 over the columns done so far
+  if (tid == 0) pivs[0] = ri;
   __syncthreads();
   for (int j = 0; j < D; ++j) {
-    const double piv = L[tri(j, j)];
-    if (!(piv > 0.0)) { if (tid == 0) atomicExch(status, 1); return; }
+    const double piv = pivs[j];
+    if (!(piv > 0.0)) { if (tid == 0) atomicExch(status, 1); return; }   // uniform: every thread reads pivs[j]
     const double dj = sqrt(piv);
-    __syncthreads();
-    if (tid == 0) L[tri(j, j)] = dj;
-    for (int i = j + 1 + tid; i < D; i += KWY_THREADS) L[tri(i, j)] = L[tri(i, j)] / dj;
-    __syncthreads();
-    const int rem = D - j - 1;
-    for (int e = tid; e < rem * rem; e += KWY_THREADS) {
-      int i = j + 1 + e / rem, k = j + 1 + e % rem;
-      if (k <= i) L[tri(i, k)] -= L[tri(i, j)] * L[tri(k, j)];
+    if (i > j && i < D) {
+      const double *li = L + tri(i, 0), *lj = L + tri(j, 0);
+      double sacc = li[j];
+#pragma unroll 8
+      for (int k = 0; k < j; ++k) sacc -= li[k] * lj[k];
+      const double v = sacc / dj;
+      L[tri(i, j)] = v;
+      ri -= v * v;
+      if (i == j + 1) pivs[j + 1] = ri;
+    } else if (i == j) {
+      L[tri(j, j)] = dj;
     }
     __syncthreads();
   }
-  // Z = L^-1, column c by thread c (its column lives in global scratch zcol[m][c][.])
-  double *zc_all = zcol + (size_t)m * D * D;
-  for (int c = tid; c < D; c += KWY_THREADS) {
-    double *zc = zc_all + (size_t)c * D;
-    for (int i = c; i < D; ++i) {
-      double v = (i == c) ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) v -= L[tri(i, k)] * zc[k];
-      zc[i] = v / L[tri(i, i)];
+  for (int r = 0; r < D; ++r) {
+    const double *lr = L + tri(r, 0);
+    const double lrr = lr[r];
+    double z = 0.0;
+    if (i < r) {
+      double sacc = 0.0;
+#pragma unroll 8
+      for (int k = i; k < r; ++k) sacc += lr[k] * L[tri(k, i)];
+      z = -sacc / lrr;
+    } else if (i == r) {
+      z = 1.0 / lrr;
     }
+    __syncthreads();   // row r of L has been read by everyone
+    if (i <= r) L[tri(r, i)] = z;
+    __syncthreads();
   }
-  __syncthreads();
   double *zp = Zp + (size_t)m * nt;
-  for (int e = tid; e < D * D; e += KWY_THREADS) {
-    int i = e / D, c = e % D;
-    if (c <= i) zp[tri(i, c)] = zc_all[(size_t)c * D + i];
-  }
+  for (int e = tid; e < nt; e += KWY_THREADS) zp[e] = L[e];
   if (tid == 0) {
     double ld = 0.0;
-    for (int i = 0; i < D; ++i) ld -= log(L[tri(i, i)]);
+    for (int r = 0; r < D; ++r) ld += log(L[tri(r, r)]);   // Z_rr = 1 / L_rr
     cst[m] = -0.5 * (D * log(2.0 * KWY_PI)) + ld + log(weights[m]);
   }
 }
@@ -192,68 +204,111 @@ __global__ __launch_bounds__(FIT_LP_NT) void k_fit_logprob(const double *__restr
 }
 
 // per frame: log-sum-exp over the mixtures; wlp is overwritten by the responsibilities;
-// per-block sums of the frame log-likelihoods go to ll_part[blockIdx.x]
+// per-block sums of the frame log-likelihoods go to ll_part[blockIdx.x].
+// Sixteen lanes (one DPP row) share a frame, lane c of the row holds mixtures c, c+16, ...: a
+// wavefront's loads cover four whole rows of wlp, and max and sum are rotations within the row.
+template <class OP>
+__device__ __forceinline__ double fit_row_allreduce(double v, OP op) {
+  v = op(v, kwy_dpp_f64<0x121>(v));   // row_ror:1
+  v = op(v, kwy_dpp_f64<0x122>(v));
+  v = op(v, kwy_dpp_f64<0x124>(v));
+  v = op(v, kwy_dpp_f64<0x128>(v));
+  return v;
+}
+#define FIT_RESP_Q 16   // mixtures per lane: M <= 256
+
 __global__ __launch_bounds__(KWY_THREADS) void k_fit_resp(double *__restrict__ wlp, int64_t n, int M,
                                                          double *__restrict__ ll_part) {
   __shared__ double red[8];
-  const int64_t t = (int64_t)blockIdx.x * KWY_THREADS + threadIdx.x;
-  double lse = 0.0;
-  if (t < n) {
-    double *w = wlp + t * M;
+  const int c = threadIdx.x & 15, f = threadIdx.x >> 4;
+  double lsum = 0.0;
+  for (int pass = 0; pass < KWY_THREADS / 16; ++pass) {
+    const int64_t t = (int64_t)blockIdx.x * KWY_THREADS + 16 * pass + f;
+    const bool live = t < n;
+    double *w = wlp + (live ? t : 0) * M;
+    double v[FIT_RESP_Q];
     double mx = -INFINITY;
-    for (int m = 0; m < M; ++m) mx = fmax(mx, w[m]);
-    double s = 0.0;
-    for (int m = 0; m < M; ++m) s += exp(w[m] - mx);
-    lse = mx + log(s);
-    for (int m = 0; m < M; ++m) w[m] = exp(w[m] - lse);
+#pragma unroll
+    for (int q = 0; q < FIT_RESP_Q; ++q) {
+      const int m = c + 16 * q;
+      v[q] = (live && m < M) ? w[m] : -INFINITY;
+      mx = fmax(mx, v[q]);
+    }
+    mx = fit_row_allreduce(mx, [](double a, double b) { return fmax(a, b); });
+    double sm = 0.0;
+#pragma unroll
+    for (int q = 0; q < FIT_RESP_Q; ++q)
+      if (16 * q < M) sm += exp(v[q] - mx);
+    sm = fit_row_allreduce(sm, [](double a, double b) { return a + b; });
+    const double lse = mx + log(sm);
+#pragma unroll
+    for (int q = 0; q < FIT_RESP_Q; ++q) {
+      const int m = c + 16 * q;
+      if (live && m < M) w[m] = exp(v[q] - lse);
+    }
+    if (live && c == 0) lsum += lse;
   }
-  const double tot = kwy_block_sum(lse, red);
+  const double tot = kwy_block_sum(lsum, red);
   if (threadIdx.x == 0) ll_part[blockIdx.x] = tot;
 }
 
-// local statistics: part[chunk][m][0] = sum_t r, part[chunk][m][1+i] = sum_t r x_i over the chunk's rows
+// local statistics: part[chunk][m][0] = sum_t r, part[chunk][m][1+i] = sum_t r x_i over the chunk's rows.
+// resp' X on v_mfma_f64_16x16x4_f64 with the frame index as k: A[mixture][frame] and B[frame][feature]
+// are both rows of 16 consecutive doubles per frame, loaded straight from global memory FIT_SUM_PF
+// steps ahead.  Wavefront w of workgroup (chunk, g) owns mixtures 16 (4 g + w) .. +15 and all NBLK
+// feature blocks; the four wavefronts read the same rows of X (L1).
+#define FIT_SUM_PF 4
+template <int NBLK>
 __global__ __launch_bounds__(KWY_THREADS) void k_fit_sums(const double *__restrict__ X,
                                                          const double *__restrict__ resp, int64_t n, int D,
                                                          int M, int rows_per_chunk, double *__restrict__ part) {
-  extern __shared__ double sm[];
-  double *xs = sm;                        // FIT_SUM_ROWS x D
-  double *rs = xs + FIT_SUM_ROWS * D;     // FIT_SUM_ROWS x M
-  const int tid = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t r1 = min(n, r0 + rows_per_chunk);
-  // thread -> (mixture m = tid % Mp, slice g = tid / Mp of the D+1 outputs), Mp = M rounded up to 2^k
-  int Mp = 1;
-  while (Mp < M) Mp <<= 1;
-  const int groups = KWY_THREADS / Mp;
-  const int m = tid % Mp, g = tid / Mp;
-  const bool live = m < M;
-  const int per = (D + 1 + groups - 1) / groups;  // outputs per thread (index 0 = nk, 1+i = sx_i)
-  double acc[40];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ar = lane & 15, ak = lane >> 4;
+  const int rb = 4 * blockIdx.y + wv;
+  if (16 * rb >= M) return;       // no barrier in this kernel
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+  const int mrow = min(16 * rb + ar, M - 1);
+  const bool mok = 16 * rb + ar < M;
+  const int clast = min(16 * (NBLK - 1) + ar, D - 1);
+  fit_v4f64 acc[NBLK];
 #pragma unroll
-  for (int q = 0; q < 40; ++q) acc[q] = 0.0;
-  for (int64_t b = r0; b < r1; b += FIT_SUM_ROWS) {
-    const int nr = (int)min((int64_t)FIT_SUM_ROWS, r1 - b);
-    __syncthreads();
-    for (int e = tid; e < nr * D; e += KWY_THREADS) xs[e] = X[b * D + e];
-    for (int e = tid; e < nr * M; e += KWY_THREADS) rs[e] = resp[b * M + e];
-    __syncthreads();
-    for (int r = 0; r < nr; ++r) {
-      const double rr = live ? rs[r * M + m] : 0.0;
-      const double *xr = xs + r * D;
+  for (int b = 0; b < NBLK; ++b) acc[b] = fit_v4f64{0.0, 0.0, 0.0, 0.0};
+  double sumr = 0.0;
+  const int64_t nks = (r1 - r0 + 3) / 4;
+  double xs[FIT_SUM_PF][NBLK], as[FIT_SUM_PF];
+  auto load = [&](double *xq, double &aq, int64_t ks) {
+    const int64_t t = r0 + 4 * ks + ak;
+    const int64_t tc = min(t, r1 - 1);
+    const double *px = X + tc * D;
 #pragma unroll
-      for (int q = 0; q < 40; ++q) {
-        const int o = g * per + q;
-        if (q < per && o <= D) acc[q] += (o == 0) ? rr : rr * xr[o - 1];
-      }
+    for (int b = 0; b < NBLK; ++b) xq[b] = px[b == NBLK - 1 ? clast : 16 * b + ar];
+    aq = (t < r1 && mok) ? resp[tc * M + mrow] : 0.0;
+  };
+#pragma unroll
+  for (int p = 0; p < FIT_SUM_PF; ++p) load(xs[p], as[p], p);
+  for (int64_t ks = 0; ks < nks; ks += FIT_SUM_PF) {
+#pragma unroll
+    for (int p = 0; p < FIT_SUM_PF; ++p) {
+      double x[NBLK];
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) x[b] = xs[p][b];
+      const double a = as[p];     // zero behind the chunk's last frame
+      load(xs[p], as[p], ks + p + FIT_SUM_PF);
+      sumr += a;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x[b], acc[b], 0, 0, 0);
     }
   }
-  if (!live) return;
-  double *out = part + ((size_t)blockIdx.x * M + m) * (D + 1);
+  sumr += __shfl_xor(sumr, 16);
+  sumr += __shfl_xor(sumr, 32);
+  double *out = part + (size_t)blockIdx.x * M * (D + 1);
+  if (ak == 0 && mok) out[(size_t)(16 * rb + ar) * (D + 1)] = sumr;
 #pragma unroll
-  for (int q = 0; q < 40; ++q) {
-    const int o = g * per + q;
-    if (q < per && o <= D) out[o] = acc[q];
-  }
+  for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = 16 * rb + ak + 4 * r, i = 16 * b + ar;
+      if (m < M && i < D) out[(size_t)m * (D + 1) + 1 + i] = acc[b][r];
+    }
 }
 
 // out[e] = sum_c part[c][e]
@@ -482,6 +537,13 @@ static int fit_lp_launch(kwy_ctx *ctx, const double *X, int64_t n, int D, int M,
 
 static int fit_cov_splits(int64_t n, int M);
 
+// frames per workgroup of k_fit_sums: about 512 chunks, at least 512 frames each, a multiple of 4
+static int fit_sum_rows(int64_t n) {
+  int64_t r = (n + 511) / 512;
+  if (r < 512) r = 512;
+  return (int)((r + 3) & ~(int64_t)3);
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------
 static int fit_check(kwy_ctx *ctx, int64_t n, int D, int M) {
   if (!ctx) return KWY_EINVAL;
@@ -494,7 +556,7 @@ static int fit_check(kwy_ctx *ctx, int64_t n, int D, int M) {
 
 extern "C" int kwy_gmm_em_scratch_bytes(int64_t n, int D, int M, int64_t *bytes) {
   if (!bytes) return KWY_EINVAL;
-  const int64_t nchunks = (n + 4095) / 4096;
+  const int64_t nchunks = (n + fit_sum_rows(n) - 1) / fit_sum_rows(n);
   *bytes = (int64_t)(kwy_pad(sizeof(double) * fit_tri(D) * M) + kwy_pad(sizeof(double) * (size_t)M * D * D) +
                      kwy_pad(sizeof(double) * M) + kwy_pad(sizeof(double) * (size_t)nchunks * M * (D + 1)) +
                      kwy_pad(sizeof(double) * (size_t)fit_cov_splits(n, M) * M * D * D) + kwy_pad(64) + 4096);
@@ -510,16 +572,14 @@ extern "C" int kwy_gmm_em_estep_dev(kwy_ctx *ctx, const double *X, int64_t n, in
   if (!X || !weights || !means || !covs || !resp || !loglik_parts || !status_out) { ctx->err = "gmm_em_estep: null pointer"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
   const size_t nt = fit_tri(D);
-  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * nt * M) + kwy_pad(sizeof(double) * (size_t)M * D * D) +
-                                   kwy_pad(sizeof(double) * M)));
+  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * nt * M) + kwy_pad(sizeof(double) * M)));
   double *Zp = kwy_arena<double>(ctx, nt * M);
-  double *zcol = kwy_arena<double>(ctx, (size_t)M * D * D);
   double *cst = kwy_arena<double>(ctx, M);
-  if (!Zp || !zcol || !cst) { ctx->err = "gmm_em_estep: scratch"; return KWY_ENOMEM; }
+  if (!Zp || !cst) { ctx->err = "gmm_em_estep: scratch"; return KWY_ENOMEM; }
   KWY_HIP(hipMemsetAsync(status_out, 0, sizeof(int), ctx->stream));
-  const size_t lds_prec = sizeof(double) * nt;
+  const size_t lds_prec = sizeof(double) * (nt + D);
   KWY_HIP(hipFuncSetAttribute((const void *)k_fit_prec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prec));
-  hipLaunchKernelGGL(k_fit_prec, dim3(M), dim3(KWY_THREADS), lds_prec, ctx->stream, weights, covs, D, Zp, zcol, cst,
+  hipLaunchKernelGGL(k_fit_prec, dim3(M), dim3(KWY_THREADS), lds_prec, ctx->stream, weights, covs, D, Zp, cst,
                      status_out);
   const int nsplit = fit_lp_splits(n, M);
   switch ((D + 15) / 16) {
@@ -540,28 +600,36 @@ extern "C" int kwy_gmm_em_estep_dev(kwy_ctx *ctx, const double *X, int64_t n, in
   return KWY_OK;
 }
 
+template <int NBLK>
+static void fit_sums_launch(kwy_ctx *ctx, const double *X, const double *resp, int64_t n, int D, int M, int rows,
+                            int nchunks, double *part) {
+  KWY_PROF(ctx, "k_fit_sums", hipLaunchKernelGGL(k_fit_sums<NBLK>, dim3(nchunks, (M + 63) / 64), dim3(KWY_THREADS), 0, ctx->stream, X, resp, n, D, M, rows, part));
+}
+
 // stats[m][0] = sum_t r[t][m], stats[m][1+i] = sum_t r[t][m] x[t][i]   (local shard)
 extern "C" int kwy_gmm_em_sums_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
                                    double *stats) {
   KWY_TRY(fit_check(ctx, n, D, M));
   if (!X || !resp || !stats) { ctx->err = "gmm_em_sums: null pointer"; return KWY_EINVAL; }
-  {
-    int Mp = 1;
-    while (Mp < M) Mp <<= 1;
-    const int groups = 256 / Mp;
-    if ((D + 1 + groups - 1) / groups > 40) { ctx->err = "gmm_em_sums: D too large for this component count"; return KWY_EINVAL; }
-  }
   KWY_HIP(hipSetDevice(ctx->device));
-  const int rows_per_chunk = 4096;
+  const int rows_per_chunk = fit_sum_rows(n);
   const int nchunks = (int)((n + rows_per_chunk - 1) / rows_per_chunk);
   const int64_t len = (int64_t)M * (D + 1);
   KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)nchunks * len)));
   double *part = kwy_arena<double>(ctx, (size_t)nchunks * len);
   if (!part) { ctx->err = "gmm_em_sums: scratch"; return KWY_ENOMEM; }
-  const size_t lds = sizeof(double) * ((size_t)FIT_SUM_ROWS * D + (size_t)FIT_SUM_ROWS * M);
-  KWY_HIP(hipFuncSetAttribute((const void *)k_fit_sums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_fit_sums, dim3(nchunks), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, rows_per_chunk,
-                     part);
+  switch ((D + 15) / 16) {
+    case 1: fit_sums_launch<1>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 2: fit_sums_launch<2>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 3: fit_sums_launch<3>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 4: fit_sums_launch<4>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 5: fit_sums_launch<5>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 6: fit_sums_launch<6>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 7: fit_sums_launch<7>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 8: fit_sums_launch<8>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 9: fit_sums_launch<9>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    default: fit_sums_launch<10>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+  }
   hipLaunchKernelGGL(k_fit_reduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nchunks, len,
                      stats);
   KWY_HIP(hipGetLastError());
