@@ -67,12 +67,22 @@ def main():
     if rank == 0:
         lp, n1 = st.ctx.profile_read('k_fit_logprob')
         cv, n2 = st.ctx.profile_read('k_fit_cov')
-        flops = 2.0 * n_local * M * (D * (D + 1) / 2)          # E-step triangular products
+        flops = 2.0 * n_local * M * (D * (D + 1) / 2)          # triangular products: Z x per frame, lower half of sum r d d'
+        lp_ms, cv_ms = lp / max(n1, 1), cv / max(n2, 1)
+        peak = 78.6                                            # v_mfma_f64_16x16x4_f64: 64 cycles (tools/mfma_f64_bench.hip)
+        lp_tf = flops / (lp_ms * 1e-3) / 1e12 if n1 else None
+        cv_tf = flops / (cv_ms * 1e-3) / 1e12 if n2 else None
         print(json.dumps({'metric': 'EM iteration time, full-covariance GMM fit', 'value': el / args.iters * 1e3,
                           'unit': 'ms/iteration', 'n_gpus': world, 'frames_total': n_local * world, 'dim': D,
                           'components': M, 'higher_is_better': False, 'scaling': 'strong', 'dtype': 'f64',
-                          'k_fit_logprob_ms': lp / max(n1, 1), 'k_fit_cov_ms': cv / max(n2, 1),
-                          'logprob_tflops': flops / (lp / max(n1, 1) * 1e-3) / 1e12 if n1 else None,
+                          'k_fit_logprob_ms': lp_ms, 'k_fit_cov_ms': cv_ms,
+                          'logprob_tflops': lp_tf, 'cov_tflops': cv_tf,
+                          'roofline': {'bound': 'mfma', 'kernel': 'k_fit_logprob', 'achieved': lp_tf, 'peak': peak,
+                                       'unit': 'TFLOP/s', 'frac': lp_tf / peak if lp_tf else None, 'traffic': None,
+                                       'note': 'useful flops 2 n M D(D+1)/2 per kernel (the padded 16x16 blocks on the '
+                                               'diagonal add 10 % issued work); peak = 1024 SIMDs x 32 flop/cycle x '
+                                               '2.4 GHz, measured 75.4 with tools/mfma_f64_bench.hip; k_fit_cov: '
+                                               'cov_tflops / peak'},
                           'all_reduce_bytes_per_iteration': 8 * (M * (D + 1) + M * D * D + 1)}))
     if world > 1:
         dist.destroy_process_group()
