@@ -64,7 +64,16 @@ __global__ void k_dtw_window(const int32_t *__restrict__ cpath, const int64_t *_
   width[i] = (uint32_t)(h - l + 1);
 }
 
-// dist[off[i] + j - lo[i]] = || x_i - y_j ||_2   (sequential sum over the dimensions)
+// Band storage: row i holds width[i] distances at dist[DTW_PAD + off[i] + 16 i + 8 ...], with DTW_ROWPAD +inf
+// cells before and after them.  The DP fetches 8 consecutive cells per lane at a time from a clamped
+// start: a lane that is outside its row (wholly or partly) reads pad cells, so a cell outside the window
+// costs +inf by itself and the DP step needs no activity mask.
+#define DTW_ROWPAD 8
+__device__ __forceinline__ uint64_t dtw_row_base(const uint64_t *__restrict__ off, int i) {
+  return (uint64_t)DTW_PAD + off[i] + (uint64_t)(2 * DTW_ROWPAD) * (uint64_t)i + DTW_ROWPAD;
+}
+
+// dist[row_base(i) + j - lo[i]] = || x_i - y_j ||_2   (sequential sum over the dimensions)
 __global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(const double *__restrict__ x,
                                                          const double *__restrict__ y, int dim,
                                                          const int32_t *__restrict__ lo,
@@ -76,8 +85,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(const double *__restri
   if (off[i] + (uint64_t)(hi[i] - lo[i] + 1) > cap) { if (threadIdx.x == 0) atomicExch(status, 1); return; }
   for (int k = threadIdx.x; k < dim; k += KWY_THREADS) xs[k] = x[(int64_t)i * dim + k];
   __syncthreads();
-  double *row = dist + DTW_PAD + off[i];
+  double *row = dist + dtw_row_base(off, i);
   const int l = lo[i], h = hi[i];
+  if (threadIdx.x < DTW_ROWPAD) { row[-1 - (int)threadIdx.x] = INFINITY; row[h - l + 1 + threadIdx.x] = INFINITY; }
   for (int j = l + threadIdx.x; j <= h; j += KWY_THREADS) {
     const double *yr = y + (int64_t)j * dim;
     double s = 0.0;
@@ -87,11 +97,16 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(const double *__restri
 }
 
 // lane l <- lane l-1 across the whole wavefront (DPP wave_shr:1, no LDS round trip);
-// lane 0 keeps its own value.
-__device__ __forceinline__ double dtw_wave_shr1(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+// lane 0, which has no source, gets its own lane of `first`.
+__device__ __forceinline__ double dtw_wave_shr1(double v, double first) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// lane l <- lane l+1, lane 63 <- lane 0 (DPP wave_rol:1: every lane has a source)
+__device__ __forceinline__ double dtw_wave_rol1(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x134, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 
@@ -131,6 +146,8 @@ __device__ __forceinline__ uint64_t dtw_row_words_end(const uint64_t *__restrict
 // steps of the row skew plus one chunk; with 4 wavefronts a wavefront's next strip is ready when it
 // finishes the current one only if 4 x (63 + chunk) stays below the strip length (~300 steps).
 #define DTW_CHUNK 16
+#define DTW_RING 4           // chunks of distances held in registers (three of them in flight)
+typedef double dtw_d2 __attribute__((ext_vector_type(2), aligned(8)));
 template <bool BND_LDS>
 __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y, const int32_t *__restrict__ lo,
                                               const int32_t *__restrict__ hi,
@@ -154,7 +171,6 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
 #define DTW_PROG_STORE(b, v) __hip_atomic_store(&s_prog[b], (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define DTW_RELEASE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); else __threadfence(); } while (0)
 #define DTW_ACQUIRE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); else __threadfence(); } while (0)
-  __shared__ double s_last;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (*status != 0) { if (threadIdx.x == 0) { *path_len = 0; *out_dist = NAN; } return; }
   const double INF = INFINITY;
@@ -168,33 +184,53 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     const int i0 = k * 64;
     const int i = i0 + lane;
     const bool valid = i < len_x;
-    const int rl = valid ? lo[i] : 0, rh = valid ? hi[i] : -1;
-    const int rw = rh - rl;  // last valid index of the row
-    const int rwc = rw > 0 ? rw : 0;
+    const int rl = valid ? lo[i] : 0, rh = valid ? hi[i] : -1 - DTW_ROWPAD;
+    const int rw = rh - rl;  // last valid index of the row (no row: every fetch lands in the left pad)
     const int ilast = min(i0 + 63, len_x - 1);
+    const int L = ilast - i0;  // lane of the strip's last row
     const int jmin = lo[i0], jmax = hi[ilast];
     // the previous strip's last row: where its boundary values are valid
     const int plo = k > 0 ? lo[i0 - 1] : 0, phi = k > 0 ? hi[i0 - 1] : -1;
     const int pbuf = (k + DTW_WAVES - 1) % DTW_WAVES, nbuf = k % DTW_WAVES;
-    const double *drow = dist + DTW_PAD + (valid ? off[i] : 0);
+    // distances: a scalar base per strip (the first row's left pad) plus a 32-bit per-lane byte offset
+    const char *dbase = (const char *)(dist + dtw_row_base(off, i0) - DTW_ROWPAD);
+    const uint32_t boff = (uint32_t)((dtw_row_base(off, valid ? i : i0) - dtw_row_base(off, i0)) * 8ull);
     uint32_t *pwrow = predw + (valid ? dtw_word_base(off, i) : 0);
     double v1 = INF;      // this lane's value at the previous step
     double up_prev = INF; // the `up` input of the previous step = this step's diagonal input
     const int nsteps = (jmax - jmin + 1) + 63;
+    if (dbg && lane == 0 && k < 48) { dbg[64 + 4 * k] = clock64() - t_start; dbg[64 + 4 * k + 2] = nsteps; dbg[64 + 4 * k + 3] = jmin; }
     const int shift = lane + rl - jmin;  // this lane's row index at step s is s - shift
+    // the last row's range of steps and last column, as scalars: its boundary writes are guarded on the scalar unit
+    const int shL = __builtin_amdgcn_readlane(shift, L), rwL = __builtin_amdgcn_readlane(rw, L);
+    const int rhL = __builtin_amdgcn_readlane(rh, L);
     uint32_t pw = 0u;                    // predecessor codes of the current 16-cell word
     // lane 0's diagonal input at the first step: D[i0-1][jmin-1]
     if (k == 0 && lane == 0 && jmin == 0) up_prev = 0.0;  // D[-1][-1] = 0: the origin of the recurrence
-    // distances of this lane's row, 8 steps per block, fetched two blocks ahead: the loads of
-    // block b+2 are still behind the predecessor-word stores of blocks b and b+1 in the memory
-    // queue, so that waiting for block b+1's data never waits for the youngest requests
-    double curd[8], nxtd[8], nx2d[8];
+    // Distances of this lane's row: a ring of DTW_RING chunks of 16 steps in registers, each fetched
+    // DTW_RING - 1 chunks (48 steps) before it is used -- the band was written by another kernel on
+    // other XCDs and comes from memory (about 3500 cycles on an otherwise idle chip), and a step is
+    // only ~100 cycles.  Two 8-cell fetches per chunk, each from a clamped start (see DTW_ROWPAD).
+    double ring[DTW_RING][DTW_CHUNK];
+    auto fetch = [&](double (&b)[DTW_CHUNK], int cstart) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) curd[u] = drow[min(max(u - shift, 0), rwc)];
+      for (int half = 0; half < DTW_CHUNK / 8; ++half) {
+        const int start = min(max(cstart + 8 * half - shift, -DTW_ROWPAD), rw + 1);
+        const dtw_d2 *p = (const dtw_d2 *)(dbase + (boff + 8u * (uint32_t)(start + DTW_ROWPAD)));
 #pragma unroll
-    for (int u = 0; u < 8; ++u) nxtd[u] = drow[min(max(8 + u - shift, 0), rwc)];
+        for (int q = 0; q < 4; ++q) {
+          const dtw_d2 v = p[q];
+          b[8 * half + 2 * q] = v.x;
+          b[8 * half + 2 * q + 1] = v.y;
+        }
+      }
+    };
+#pragma unroll
+    for (int r = 0; r < DTW_RING - 1; ++r) fetch(ring[r], DTW_CHUNK * r);
     bool first_chunk = true;
-    for (int c0 = 0; c0 < nsteps; c0 += DTW_CHUNK) {
+    // one chunk of DTW_CHUNK steps on `cur`; `fill` (the buffer used one chunk ago) is refilled meanwhile
+    auto chunk = [&](int c0, const double (&cur)[DTW_CHUNK], double (&fill)[DTW_CHUNK]) {
+      fetch(fill, c0 + DTW_CHUNK * (DTW_RING - 1));
       // wait until the previous strip's last row has produced the columns this chunk reads
       if (k > 0) {
         const int need = min(jmin + c0 + DTW_CHUNK - 1, phi);  // last column we may read (valid ones only)
@@ -209,65 +245,89 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
         if (dbg && lane == 0) { atomicAdd((unsigned long long *)&dbg[8 + wv], (unsigned long long)(clock64() - tw0)); }
       }
       if (dbg && lane == 0) atomicAdd((unsigned long long *)&dbg[12 + wv], 1ull);
-      // the boundary values lane 0 needs in the next DTW_CHUNK steps: one read per lane
+      // the boundary values lane 0 needs in the next DTW_CHUNK steps: lane t holds the one of step c0 + t;
+      // the vector is rotated by one lane per step, so that lane 0 always holds the current one
       const int jb = jmin + c0 + lane;
-      double bchunk = INF;
-      if (k > 0 && jb >= plo && jb <= phi) bchunk = BROW(pbuf, jb + 1);
+      double brot = INF;
+      if (k > 0 && jb >= plo && jb <= phi) brot = BROW(pbuf, jb + 1);
       if (first_chunk && k > 0) {
         const int jd = jmin - 1;
         const double dv = (jd >= plo && jd <= phi) ? BROW(pbuf, jd + 1) : INF;
         if (lane == 0) up_prev = dv;
         first_chunk = false;
       }
-      for (int s0 = c0; s0 < min(c0 + DTW_CHUNK, nsteps); s0 += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) nx2d[u] = drow[min(max(s0 + 16 + u - shift, 0), rwc)];
+      for (int half = 0; half < DTW_CHUNK / 8; ++half) {
+        const int s0 = c0 + 8 * half;
+        double hist[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int s = s0 + u;
-          const int j = jmin + s - lane;
-          const int pos = s - shift;
-          const bool act = pos >= 0 && pos <= rw;
           // up = D[i-1][j]: the neighbouring lane's value of the previous step (lane 0: the boundary row).
           // The diagonal D[i-1][j-1] is what `up` was one step ago -- no second shift.
-          double up = dtw_wave_shr1(v1);
-          const double bup = dtw_readlane(bchunk, (s - c0) & (DTW_CHUNK - 1));
-          if (lane == 0) up = bup;
+          const double nbrot = dtw_wave_rol1(brot);
+          const double up = dtw_wave_shr1(v1, brot);   // brot dies here: the shift lands in its register
+          brot = nbrot;
           const double dg = up_prev;
           up_prev = up;
-          // predicated rather than branched: inactive lanes compute on a clamped distance and drop the result
-          const double dt = curd[u];
+          // a lane outside its row adds +inf: every candidate is +inf, the code stays 0
+          const double dt = cur[8 * half + u];
+          // fastdtw's min() keeps the first of equal candidates in the order (i-1,j), (i,j-1), (i-1,j-1):
+          // the value is the plain minimum (two v_min_f64 on the loop-carried chain instead of two
+          // compare-and-select pairs), the code is the first candidate equal to it (off the chain)
           const double c0v = up + dt, c1v = v1 + dt, c2v = dg + dt;
-          double best = c0v; uint32_t pb = 0u;
-          if (c1v < best) { best = c1v; pb = 1u; }
-          if (c2v < best) { best = c2v; pb = 2u; }
-          const double cur = act ? best : INF;
-          pw |= act ? (pb << (2 * (s & 15))) : 0u;
-          const bool rowend = act && pos == rw;
-          if ((s & 15) == 15 || __ballot(rowend) != 0ull) {   // wave-uniform: a word boundary or some row ends
-            if (act && ((s & 15) == 15 || rowend)) { pwrow[(s >> 4) - (shift >> 4)] = pw; pw = 0u; }
-            if (rowend && i == len_x - 1 && j == len_y - 1) s_last = cur;
-          }
-          if (act && i == ilast) BROW(nbuf, j + 1) = cur;
-          v1 = cur;
+          const double best = fmin(c0v, fmin(c1v, c2v));
+          const uint32_t pb = (best == c0v) ? 0u : ((best == c1v) ? 1u : 2u);
+          pw |= pb << (2 * (8 * half + u));   // c0 is a multiple of 16: the step's place in its word
+          hist[u] = best;
+          v1 = best;
         }
+        // the strip's last row goes to the boundary buffer (its lane only, the steps inside its row only)
+        if (s0 >= shL && s0 + 7 <= shL + rwL) {          // wave-uniform: the whole block lies inside the row
+          if (lane == L) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { curd[u] = nxtd[u]; nxtd[u] = nx2d[u]; }
+            for (int u = 0; u < 8; ++u) BROW(nbuf, jmin + s0 - L + 1 + u) = hist[u];
+          }
+        } else if (s0 + 7 >= shL && s0 <= shL + rwL) {   // the block straddles one of the row's ends
+          if (lane == L) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int s = s0 + u;
+              if (s >= shL && s <= shL + rwL) BROW(nbuf, jmin + s - L + 1) = hist[u];
+            }
+          }
+        }
         // publish how far this strip's last row has got (after its boundary writes)
         DTW_RELEASE();
-        if (i == ilast) {
-          const int jdone = min(jmin + (s0 + 7) - lane, rh);
+        if (lane == L) {
+          const int jdone = min(jmin + (s0 + 7) - L, rhL);
           DTW_PROG_STORE(nbuf, ((long long)k << 32) | (long long)(unsigned int)(jdone + 1 > 0 ? jdone + 1 : 0));
         }
       }
+      // one predecessor word per lane and chunk, if the lane's row has cells in it
+      if (valid && shift <= c0 + DTW_CHUNK - 1 && shift + rw >= c0) pwrow[(c0 >> 4) - (shift >> 4)] = pw;
+      pw = 0u;
+    };
+    // whole chunks (the steps behind nsteps see +inf only), the ring's phases unrolled
+    for (int c0 = 0; c0 < nsteps; c0 += DTW_RING * DTW_CHUNK) {
+      chunk(c0, ring[0], ring[3]);
+      if (c0 + DTW_CHUNK >= nsteps) break;
+      chunk(c0 + DTW_CHUNK, ring[1], ring[0]);
+      if (c0 + 2 * DTW_CHUNK >= nsteps) break;
+      chunk(c0 + 2 * DTW_CHUNK, ring[2], ring[1]);
+      if (c0 + 3 * DTW_CHUNK >= nsteps) break;
+      chunk(c0 + 3 * DTW_CHUNK, ring[3], ring[2]);
     }
     DTW_RELEASE();
-    if (i == ilast) DTW_PROG_STORE(nbuf, ((long long)k << 32) | 0x7fffffffll);
+    if (lane == L) DTW_PROG_STORE(nbuf, ((long long)k << 32) | 0x7fffffffll);
+    if (dbg && lane == 0 && k < 48) dbg[64 + 4 * k + 1] = clock64() - t_start;
   }
-#undef BROW
   __syncthreads();
+  if (!BND_LDS) __threadfence();
+  // D[len_x-1][len_y-1]: the last strip's last row is in its boundary buffer
+  const double last_val = BROW((nstrips - 1) % DTW_WAVES, len_y);
+#undef BROW
+  __syncthreads();   // every thread holds last_val: the back-trace staging may overwrite the boundary rows
   const long long t_dp = dbg ? clock64() : 0;
-  double last_val = s_last;
   if (threadIdx.x == 0) *out_dist = last_val;
   __threadfence();  // predecessor codes written above are read back below through global memory
 
@@ -401,7 +461,7 @@ static size_t dtw_scratch_bytes(int64_t Tx, int64_t Ty, int dim, int radius, boo
     tot += kwy_pad(sizeof(double) * (size_t)lx * dim) + kwy_pad(sizeof(double) * (size_t)ly * dim);
   }
   uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
-  tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_PAD)) + kwy_pad(4 * (cap / 16 + 2 * Tx + 64));
+  tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD)) + kwy_pad(4 * (cap / 16 + 2 * Tx + 64));
   tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1));
   tot += kwy_pad(sizeof(double) * 4 * (Ty + 2));
   tot += 3 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
@@ -427,7 +487,7 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     lv.push_back(c); xs.push_back(cx); ys.push_back(cy);
   }
   const uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
-  double *dist = kwy_arena<double>(ctx, cap + 2 * DTW_PAD);
+  double *dist = kwy_arena<double>(ctx, cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD);   // + the +inf cells of every row
   uint32_t *pred = kwy_arena<uint32_t>(ctx, cap / 16 + 2 * Tx + 64);
   int32_t *lo = kwy_arena<int32_t>(ctx, Tx), *hi = kwy_arena<int32_t>(ctx, Tx);
   uint32_t *width = kwy_arena<uint32_t>(ctx, Tx);

@@ -11,9 +11,12 @@ def series(T, dim, warp):
 x=series(2201,26,1.0); y=series(2401,26,1.3)
 ctx=_lib.default_context()
 dtw.fastdtw(x,y,radius=32)
-dbg=torch.zeros(64,dtype=torch.int64,device='cuda')
+dbg=torch.zeros(256,dtype=torch.int64,device='cuda')
 lib.kwy_ctx_debug_buffer(ctx.handle, c_vp(dbg.data_ptr()))
 dtw.fastdtw(x,y,radius=32)
 d=dbg.cpu().numpy()
 print('total dp cycles', d[0], 'total bt cycles', d[1], 'finest level dp', d[2], 'bt', d[3], 'path', d[4])
 print('spin cycles per wave', d[8:12], 'chunks per wave', d[12:16])
+print('finest level strips: k, start, end, steps, jmin')
+for k in range(48):
+    if d[64+4*k+1]: print(k, d[64+4*k], d[64+4*k+1], d[64+4*k+2], d[64+4*k+3])
