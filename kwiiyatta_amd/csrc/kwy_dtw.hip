@@ -9,11 +9,13 @@
 //   k_dtw_window   per-row column window from the coarser level's path
 //                  (monotone path => two binary searches per row, no atomics)
 //   k_dtw_dist     Euclidean frame distances for every cell of the band (parallel)
-//   k_dtw_dp       ONE wavefront: rows are processed in strips of 64, lane = row,
+//   k_dtw_dp       one workgroup: rows are processed in strips of 64, lane = row,
 //                  skewed so that lane l works on column j - l; the three
 //                  predecessors arrive by wave shuffles (DPP), the strip boundary
-//                  row goes through LDS; then the back-trace, strip by strip,
-//                  over predecessor codes staged in LDS.
+//                  row goes through LDS, four wavefronts pipeline the strips.  Every
+//                  cell also carries the column at which its best path entered the
+//                  strip, so that the back-trace first hops from strip to strip and
+//                  then walks all strips at once, one lane per strip.
 //
 // Tie-breaking follows fastdtw's pure-Python min(): (i-1,j), (i,j-1), (i-1,j-1).
 #include <math.h>
@@ -23,9 +25,6 @@
 #include "kwy_internal.hpp"
 
 #define DTW_PAD 128          // slack cells before/after the band storage
-#define DTW_BT_BYTES 49152   // LDS budget for staged predecessor codes
-#define DTW_BT_ROWS 512      // rows per back-trace group
-#define DTW_BT_OUT 1024      // path cells buffered in LDS between flushes
 
 __global__ void k_dtw_halve(const double *__restrict__ in, int n_out, int dim, double *__restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,6 +102,9 @@ __device__ __forceinline__ double dtw_wave_shr1(double v, double first) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int dtw_wave_shr1_i32(int v, int first) {
+  return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
 // lane l <- lane l+1, lane 63 <- lane 0 (DPP wave_rol:1: every lane has a source)
 __device__ __forceinline__ double dtw_wave_rol1(double v) {
   const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x134, 0xf, 0xf, false);
@@ -148,19 +150,21 @@ __device__ __forceinline__ uint64_t dtw_row_words_end(const uint64_t *__restrict
 #define DTW_CHUNK 16
 #define DTW_RING 4           // chunks of distances held in registers (three of them in flight)
 typedef double dtw_d2 __attribute__((ext_vector_type(2), aligned(8)));
+typedef int dtw_i4 __attribute__((ext_vector_type(4), aligned(4)));
 template <bool BND_LDS>
 __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y, const int32_t *__restrict__ lo,
                                               const int32_t *__restrict__ hi,
                                               const uint64_t *__restrict__ off, uint64_t cap,
-                                              const double *__restrict__ dist,
+                                              double *dist /* the strips' last rows get their cells' entry columns */,
                                               uint32_t *__restrict__ predw,
                                               double *__restrict__ bnd_global /* DTW_WAVES x (len_y+2) or null */,
                                               int32_t *__restrict__ path, int32_t *__restrict__ rev,
+                                              int32_t *__restrict__ sinfo /* 3 x strips */,
                                               int64_t *__restrict__ path_len, double *__restrict__ out_dist,
                                               const int *__restrict__ status, long long *__restrict__ dbg) {
-  extern __shared__ unsigned char bt[];  // DTW_BT_BYTES [+ boundary rows]
+  extern __shared__ unsigned char bt[];  // boundary rows (BND_LDS)
   const long long t_start = dbg ? clock64() : 0;
-  __shared__ int s_i, s_j, s_n;
+  __shared__ int s_n;
   // (strip << 32) | (last finished column + 1).  Plain LDS words written/read with relaxed
   // workgroup-scope atomics: a volatile (generic) access would be a flat_ instruction with a
   // vmcnt(0) wait behind it, i.e. every progress update would also wait for the distance
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
   if (*status != 0) { if (threadIdx.x == 0) { *path_len = 0; *out_dist = NAN; } return; }
   const double INF = INFINITY;
   const int rowlen = len_y + 2;  // boundary rows are indexed by j + 1 (entry 0 is column -1)
-  double *const lds_rows = (double *)(bt + DTW_BT_BYTES);
+  double *const lds_rows = (double *)bt;
 #define BROW(buf, ix) (BND_LDS ? lds_rows[(buf) * rowlen + (ix)] : bnd_global[(size_t)(buf) * rowlen + (ix)])
   if (threadIdx.x < DTW_WAVES) DTW_PROG_STORE(threadIdx.x, -1);
   __syncthreads();
@@ -193,11 +197,14 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     const int plo = k > 0 ? lo[i0 - 1] : 0, phi = k > 0 ? hi[i0 - 1] : -1;
     const int pbuf = (k + DTW_WAVES - 1) % DTW_WAVES, nbuf = k % DTW_WAVES;
     // distances: a scalar base per strip (the first row's left pad) plus a 32-bit per-lane byte offset
-    const char *dbase = (const char *)(dist + dtw_row_base(off, i0) - DTW_ROWPAD);
+    char *dbase = (char *)(dist + dtw_row_base(off, i0) - DTW_ROWPAD);
     const uint32_t boff = (uint32_t)((dtw_row_base(off, valid ? i : i0) - dtw_row_base(off, i0)) * 8ull);
     uint32_t *pwrow = predw + (valid ? dtw_word_base(off, i) : 0);
     double v1 = INF;      // this lane's value at the previous step
     double up_prev = INF; // the `up` input of the previous step = this step's diagonal input
+    // entry column of the best path into this strip, per cell (same selection as the value): lane 0's
+    // `up` / diagonal cells are boundary cells, which are their own entry columns
+    int o1 = 0, oup_prev = jmin - 1;
     const int nsteps = (jmax - jmin + 1) + 63;
     if (dbg && lane == 0 && k < 48) { dbg[64 + 4 * k] = clock64() - t_start; dbg[64 + 4 * k + 2] = nsteps; dbg[64 + 4 * k + 3] = jmin; }
     const int shift = lane + rl - jmin;  // this lane's row index at step s is s - shift
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
       for (int half = 0; half < DTW_CHUNK / 8; ++half) {
         const int s0 = c0 + 8 * half;
         double hist[8];
+        int ohist[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           // up = D[i-1][j]: the neighbouring lane's value of the previous step (lane 0: the boundary row).
@@ -276,23 +284,40 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
           // compare-and-select pairs), the code is the first candidate equal to it (off the chain)
           const double c0v = up + dt, c1v = v1 + dt, c2v = dg + dt;
           const double best = fmin(c0v, fmin(c1v, c2v));
-          const uint32_t pb = (best == c0v) ? 0u : ((best == c1v) ? 1u : 2u);
+          const bool e0 = best == c0v, e1 = best == c1v;
+          const uint32_t pb = e0 ? 0u : (e1 ? 1u : 2u);
           pw |= pb << (2 * (8 * half + u));   // c0 is a multiple of 16: the step's place in its word
+          const int oup = dtw_wave_shr1_i32(o1, jmin + s0 + u);
+          const int odg = oup_prev;
+          oup_prev = oup;
+          o1 = e0 ? oup : (e1 ? o1 : odg);
+          ohist[u] = o1;
           hist[u] = best;
           v1 = best;
+          // keep the compare masks of at most four steps alive (left alone, the scheduler collects the
+          // masks of all 16 steps in SGPRs and spills them)
+          if (u == 3 || u == 7) __builtin_amdgcn_sched_barrier(0);
         }
         // the strip's last row goes to the boundary buffer (its lane only, the steps inside its row only)
         if (s0 >= shL && s0 + 7 <= shL + rwL) {          // wave-uniform: the whole block lies inside the row
           if (lane == L) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) BROW(nbuf, jmin + s0 - L + 1 + u) = hist[u];
+            // the entry columns, as an int array laid over the start of the row's own distances (entry p
+            // sits inside cell p/2, which this lane fetched long ago)
+            dtw_i4 *op = (dtw_i4 *)(dbase + (boff + 8u * DTW_ROWPAD + 4u * (uint32_t)(s0 - shift)));
+            op[0] = dtw_i4{ohist[0], ohist[1], ohist[2], ohist[3]};
+            op[1] = dtw_i4{ohist[4], ohist[5], ohist[6], ohist[7]};
           }
         } else if (s0 + 7 >= shL && s0 <= shL + rwL) {   // the block straddles one of the row's ends
           if (lane == L) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const int s = s0 + u;
-              if (s >= shL && s <= shL + rwL) BROW(nbuf, jmin + s - L + 1) = hist[u];
+              if (s >= shL && s <= shL + rwL) {
+                BROW(nbuf, jmin + s - L + 1) = hist[u];
+                *(int32_t *)(dbase + (boff + 8u * DTW_ROWPAD + 4u * (uint32_t)(s - shift))) = ohist[u];
+              }
             }
           }
         }
@@ -329,116 +354,80 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
   __syncthreads();   // every thread holds last_val: the back-trace staging may overwrite the boundary rows
   const long long t_dp = dbg ? clock64() : 0;
   if (threadIdx.x == 0) *out_dist = last_val;
-  __threadfence();  // predecessor codes written above are read back below through global memory
-
-  // ---- back-trace, staged through LDS in groups of rows (codes AND row descriptors), with the
-  //      produced cells buffered in LDS too: the serial walk of lane 0 touches no global memory.
-  //      Two staging buffers: while wavefront 0 walks group g, wavefronts 1..3 fetch group g+1
-  //      (which rows it covers does not depend on where the path runs).
-  const uint64_t bt_words = DTW_BT_BYTES / 4;
-  __shared__ int g_lo[2][DTW_BT_ROWS], g_hi[2][DTW_BT_ROWS];
-  __shared__ unsigned int g_wb[2][DTW_BT_ROWS];
-  __shared__ int g_sh[2][DTW_BT_ROWS];
-  __shared__ int g_rev[2 * DTW_BT_OUT];
-  // group of rows ending at `top`: smallest r0 such that the words of rows r0..top fit the budget
-  auto group_start = [&](int top) {
-    const uint64_t wend = dtw_row_words_end(off, lo, hi, top);
-    int lo_r = max(0, top - DTW_BT_ROWS + 1), hi_r = top;
-    while (lo_r < hi_r) {  // the predicate is monotone in r
-      const int mid = (lo_r + hi_r) >> 1;
-      if (wend - dtw_word_base(off, mid) <= bt_words) hi_r = mid; else lo_r = mid + 1;
-    }
-    return lo_r;
-  };
-  auto stage = [&](int top, int r0g, int buf, int first, int nthr) {
-    uint32_t *btwb = (uint32_t *)(bt + (size_t)buf * DTW_BT_BYTES);
-    const uint64_t wbase = dtw_word_base(off, r0g);
-    const uint64_t nw = dtw_row_words_end(off, lo, hi, top) - wbase;
-    if (nw <= bt_words)
-      for (uint64_t b = first; b < nw; b += nthr) btwb[b] = predw[wbase + b];
-    for (int r = r0g + first; r <= top; r += nthr) {
-      g_lo[buf][r - r0g] = lo[r];
-      g_hi[buf][r - r0g] = hi[r];
-      g_wb[buf][r - r0g] = (unsigned int)(dtw_word_base(off, r) - wbase);
-      g_sh[buf][r - r0g] = dtw_row_shift(lo, r);
-    }
-  };
-  int ci = len_x - 1, cj = len_y - 1, n = 0, buf = 0;
-  int r0 = group_start(ci);
-  stage(ci, r0, 0, threadIdx.x, 64 * DTW_WAVES);
+  __threadfence();  // predecessor codes and entry columns written above are read back below through global memory
   __syncthreads();
-  while (ci >= 0) {
-    const int top = ci;
-    const int next_top = r0 - 1;
-    const int next_r0 = next_top >= 0 ? group_start(next_top) : 0;
-    if (wv != 0) {
-      if (next_top >= 0) stage(next_top, next_r0, buf ^ 1, threadIdx.x - 64, 64 * (DTW_WAVES - 1));
-    } else {
-      const uint32_t *btw = (const uint32_t *)(bt + (size_t)buf * DTW_BT_BYTES);
-      const uint64_t wbase = dtw_word_base(off, r0);
-      const bool staged = dtw_row_words_end(off, lo, hi, top) - wbase <= bt_words;
-      bool group_done = false;
-      while (!group_done) {
-        if (lane == 0) {
-          int i = ci, j = cj, m = 0;
-          int crow = -1, l = 0, h = -1, sh = 0;
-          unsigned int wb = 0, cw = 0xffffffffu;
-          uint32_t word = 0u;
-          while (i >= r0 && m < DTW_BT_OUT) {
-            g_rev[2 * m] = i; g_rev[2 * m + 1] = j; ++m;
-            if (i == 0 && j == 0) { i = -1; break; }
-            if (i != crow) { crow = i; l = g_lo[buf][i - r0]; h = g_hi[buf][i - r0]; wb = g_wb[buf][i - r0]; sh = g_sh[buf][i - r0]; cw = 0xffffffffu; }
-            unsigned int pb = 0;
-            if (j >= l && j <= h) {
-              const int st = sh + (j - l);  // the step at which this cell was computed
-              const unsigned int w = wb + (unsigned int)((st >> 4) - (sh >> 4));
-              if (w != cw) {
-                cw = w;
-                if (staged) word = btw[w]; else word = predw[wbase + w];
-              }
-              pb = (word >> (2 * (st & 15))) & 3u;
-            }
-            if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
-            if (j < 0) { i = -1; break; }
-          }
-          s_i = i; s_j = j; s_n = m;
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        const int made = s_n;
-        for (int e = lane; e < 2 * made; e += 64) rev[2 * n + e] = g_rev[e];
-        n += made;
-        ci = s_i; cj = s_j;
-        group_done = ci < r0;
-        __builtin_amdgcn_wave_barrier();
+
+  // ---- back-trace.  (1) one thread hops from strip to strip: the path leaves strip k through
+  //      (last row, exitc[k]) and the entry column stored there is where it leaves strip k-1.
+  //      (2) every strip is walked by its own lane, all at once, over the predecessor codes.
+  //      (3) the strips' cell counts are summed, (4) the segments are copied to their places.
+  int32_t *exitc = sinfo, *sbase = sinfo + nstrips, *cnt = sinfo + 2 * nstrips;
+  if (threadIdx.x == 0) {
+    int cj = len_y - 1, base = 0;
+    for (int k = nstrips - 1; k >= 0; --k) {
+      const int i0 = 64 * k, il = min(i0 + 63, len_x - 1);
+      exitc[k] = cj;
+      int e = 0;
+      if (k > 0) {
+        const int l = lo[il];
+        const int c = min(max(cj, l), hi[il]);
+        e = ((const int32_t *)(dist + dtw_row_base(off, il)))[c - l];
+        e = min(max(e, 0), cj);
       }
+      sbase[k] = base;
+      base += (il - i0 + 1) + (cj - e) + 1;   // rows + columns: more cells than the strip can hold
+      cj = e;
     }
-    __syncthreads();   // the walk is through with this buffer, the next one is filled
-    ci = s_i; cj = s_j;   // (wavefront 0's last values; the others only need ci)
-    if (ci >= 0 && ci != next_top) {
-      // cannot happen for a path that leaves a group through its lowest row; kept as a guard:
-      // restage synchronously for wherever the walk stopped
-      r0 = group_start(ci);
-      __syncthreads();
-      stage(ci, r0, buf ^ 1, threadIdx.x, 64 * DTW_WAVES);
-      __syncthreads();
-    } else {
-      r0 = next_r0;
-    }
-    buf ^= 1;
   }
-  if (wv != 0) return;
   __threadfence();
-  for (int k = lane; k < n; k += 64) {
-    path[2 * k] = rev[2 * (n - 1 - k)];
-    path[2 * k + 1] = rev[2 * (n - 1 - k) + 1];
+  __syncthreads();
+  for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
+    const int i0 = 64 * k, lo0 = lo[i0];
+    int i = min(i0 + 63, len_x - 1), j = exitc[k], m = 0;
+    int32_t *out = rev + 2 * (int64_t)sbase[k];
+    int crow = -1, l = 0, h = -1, sh = 0;
+    uint64_t wb = 0, cw = ~0ull;
+    uint32_t word = 0u;
+    while (i >= i0) {
+      out[2 * m] = i; out[2 * m + 1] = j; ++m;
+      if (i == 0 && j == 0) break;
+      if (i != crow) { crow = i; l = lo[i]; h = hi[i]; sh = (i - i0) + l - lo0; wb = dtw_word_base(off, i); cw = ~0ull; }
+      unsigned int pb = 0;
+      if (j >= l && j <= h) {
+        const int st = sh + (j - l);  // the step at which this cell was computed
+        const uint64_t w = wb + (uint64_t)((st >> 4) - (sh >> 4));
+        if (w != cw) { cw = w; word = predw[w]; }
+        pb = (word >> (2 * (st & 15))) & 3u;
+      }
+      if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
+      if (j < 0) break;
+    }
+    cnt[k] = m;
   }
-  if (lane == 0) *path_len = n;
-  if (dbg && lane == 0) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int k = 0; k < nstrips; ++k) { const int c = cnt[k]; exitc[k] = n; n += c; }   // exitc: now the output offset
+    s_n = n;
+    *path_len = n;
+  }
+  __threadfence();
+  __syncthreads();
+  for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
+    const int c = cnt[k];
+    const int32_t *in = rev + 2 * (int64_t)sbase[k];
+    int32_t *out = path + 2 * (int64_t)exitc[k];
+    for (int m = 0; m < c; ++m) {
+      out[2 * (c - 1 - m)] = in[2 * m];
+      out[2 * (c - 1 - m) + 1] = in[2 * m + 1];
+    }
+  }
+  if (dbg && threadIdx.x == 0) {
     const long long t_end = clock64();
     atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t_dp - t_start));
     atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(t_end - t_dp));
-    dbg[2] = t_dp - t_start; dbg[3] = t_end - t_dp; dbg[4] = n;
+    dbg[2] = t_dp - t_start; dbg[3] = t_end - t_dp; dbg[4] = s_n;
   }
 }
 
@@ -464,7 +453,8 @@ static size_t dtw_scratch_bytes(int64_t Tx, int64_t Ty, int dim, int radius, boo
   tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD)) + kwy_pad(4 * (cap / 16 + 2 * Tx + 64));
   tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1));
   tot += kwy_pad(sizeof(double) * 4 * (Ty + 2));
-  tot += 3 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
+  tot += 2 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + Tx / 64 + 8)) +
+         kwy_pad(sizeof(int32_t) * 3 * (Tx / 64 + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
   return tot + 16 * 256;
 }
 
@@ -495,20 +485,20 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   double *bnd = kwy_arena<double>(ctx, DTW_WAVES * (Ty + 2));
   int32_t *pathA = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
   int32_t *pathB = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
-  int32_t *rev = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
+  int32_t *rev = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + Tx / 64 + 8));   // the strips' segments, with slack per strip
+  int32_t *sinfo = kwy_arena<int32_t>(ctx, 3 * (Tx / 64 + 2));
   int64_t *lenA = kwy_arena<int64_t>(ctx, 8), *lenB = kwy_arena<int64_t>(ctx, 8);
   int *status = kwy_arena<int>(ctx, 16);
-  if (!dist || !pred || !lo || !hi || !width || !off || !bnd || !pathA || !pathB || !rev || !lenA || !lenB || !status) {
+  if (!dist || !pred || !lo || !hi || !width || !off || !bnd || !pathA || !pathB || !rev || !sinfo || !lenA || !lenB || !status) {
     ctx->err = "fastdtw: scratch arena too small";
     return KWY_ENOMEM;
   }
   *status_out = status;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
   const size_t bnd_bytes = sizeof(double) * DTW_WAVES * (Ty + 2);
-  // two back-trace staging buffers; the boundary rows of the DP phase share the second one and what follows it
-  const bool bnd_lds = DTW_BT_BYTES + bnd_bytes <= 130 * 1024;  // + 25 KB of static LDS in the kernel
-  size_t dp_lds = DTW_BT_BYTES + (bnd_lds ? bnd_bytes : 0);
-  if (dp_lds < 2 * (size_t)DTW_BT_BYTES) dp_lds = 2 * (size_t)DTW_BT_BYTES;
+  // the boundary rows of the strips live in LDS when they fit
+  const bool bnd_lds = bnd_bytes <= 150 * 1024;
+  const size_t dp_lds = bnd_lds ? bnd_bytes : 0;
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
 
@@ -526,11 +516,11 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
                        ys[l], dim, lo, hi, off, cap, dist, status));
     if (bnd_lds)
       KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<true>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
-                                                     lo, hi, off, cap, dist, pred, (double *)nullptr, opath, rev, olen,
+                                                     lo, hi, off, cap, dist, pred, (double *)nullptr, opath, rev, sinfo, olen,
                                                      d_dist, status, (long long *)ctx->dbg));
     else
       KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<false>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
-                                                     lo, hi, off, cap, dist, pred, bnd, opath, rev, olen, d_dist,
+                                                     lo, hi, off, cap, dist, pred, bnd, opath, rev, sinfo, olen, d_dist,
                                                      status, (long long *)ctx->dbg));
     cpath = opath;
     clen = olen;
