@@ -9,7 +9,7 @@
 //   kwy_gather_rows_dev     row gather of a (T, width) matrix
 //                           (reference: Feature.__getitem__, kwiiyatta/vocoder/abc/feature.py:170-194)
 //
-// All three are index/byte work: HBM-bound row copies and one short serial walk.
+// All three are index/byte work: HBM-bound row copies and a pass over the path.
 #include "kwy_internal.hpp"
 
 __global__ __launch_bounds__(KWY_THREADS) void k_align_power_threshold(const double *__restrict__ mc, int64_t T,
@@ -48,22 +48,51 @@ __global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__
   }
 }
 
-// serial walk over the path, exactly project_path_iter: the wavefront stages path tiles in LDS
-// (coalesced), lane 0 walks them, and the produced indices leave through LDS as well.
+// project_path_iter.  A DTW path moves by at most one row and one column per cell: then the generator
+// yields, for every target frame y in [trim, last_y - trim], the x of the first path cell with that y
+// -- independent per cell, done by all threads.  Any other path (a jump in y, a y that goes back) takes
+// the reference's loop literally: the first wavefront stages path tiles in LDS, lane 0 walks them, and
+// the produced indices leave through LDS as well.
 #define AL_TILE 1024
-__global__ __launch_bounds__(64) void k_align_project(const int32_t *__restrict__ path,
-                                                     const int64_t *__restrict__ path_len, int trim_len,
-                                                     int32_t *__restrict__ idx, int64_t cap,
-                                                     int64_t *__restrict__ n_out) {
+#define AL_NT 256
+__global__ __launch_bounds__(AL_NT) void k_align_project(const int32_t *__restrict__ path,
+                                                        const int64_t *__restrict__ path_len, int trim_len,
+                                                        int32_t *__restrict__ idx, int64_t cap,
+                                                        int64_t *__restrict__ n_out) {
   __shared__ int32_t sp[2 * AL_TILE];
   __shared__ int32_t so[AL_TILE];
   __shared__ long long st[4];  // prev_x, prev_y, n, stop
-  const int lane = threadIdx.x;
+  __shared__ int s_irregular;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int64_t L = *path_len;
-  if (L <= 0) { if (lane == 0) *n_out = 0; return; }
+  if (L <= 0) { if (tid == 0) *n_out = 0; return; }
   long long len_y = path[2 * (L - 1) + 1] + 1;
-  if (lane == 0) { st[0] = -1; st[1] = -1 + (trim_len > 0 ? trim_len : 0); st[2] = 0; st[3] = 0; }
+  const long long prev_y0 = -1 + (trim_len > 0 ? trim_len : 0);
   if (trim_len > 0) len_y -= trim_len;
+  if (tid == 0) s_irregular = 0;
+  __syncthreads();
+  {
+    bool bad = false;
+    for (int64_t k = tid; k < L; k += AL_NT) {
+      const long long y = path[2 * k + 1], yp = k > 0 ? path[2 * k - 1] : -1;
+      if (y < yp || y - yp > 1) bad = true;
+    }
+    if (bad) s_irregular = 1;
+  }
+  __syncthreads();
+  if (!s_irregular) {
+    for (int64_t k = tid; k < L; k += AL_NT) {
+      const long long y = path[2 * k + 1], yp = k > 0 ? path[2 * k - 1] : -1;
+      if (y > yp && y > prev_y0 && y < len_y) {
+        const long long n = y - (prev_y0 + 1);
+        if (n < cap) idx[n] = path[2 * k];
+      }
+    }
+    if (tid == 0) { const long long n = len_y - (prev_y0 + 1); *n_out = n > 0 ? n : 0; }
+    return;
+  }
+  if (tid >= 64) return;   // the general case: one wavefront, no workgroup barrier below
+  if (lane == 0) { st[0] = -1; st[1] = prev_y0; st[2] = 0; st[3] = 0; }
   int64_t k0 = 0;
   while (k0 < L) {
     const int nk = (int)min((int64_t)AL_TILE, L - k0);
@@ -157,7 +186,7 @@ extern "C" int kwy_align_project_dev(kwy_ctx *ctx, const int32_t *path, const in
     return KWY_EINVAL;
   }
   KWY_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_align_project, dim3(1), dim3(64), 0, ctx->stream, path, path_len, trim_len, idx,
+  hipLaunchKernelGGL(k_align_project, dim3(1), dim3(AL_NT), 0, ctx->stream, path, path_len, trim_len, idx,
                      idx_capacity, n_out);
   KWY_HIP(hipGetLastError());
   return KWY_OK;

@@ -92,3 +92,50 @@ def test_streams_are_independent(pair):
     assert torch.equal(ups[0].sp, ups[2].sp) and torch.equal(ups[0].ap, ups[2].ap)
     assert (ups[0].wave - ups[2].wave).abs().max().item() <= 1e-12
     assert ups[1].wave.shape != ups[0].wave.shape
+
+
+@pytest.mark.parametrize('kind', ['unit', 'unit_trim0', 'gaps', 'backsteps', 'late_start', 'long'])
+def test_align_project_matches_generator(kind):
+    """kwy_align_project_dev against project_path_iter: DTW-shaped paths (the all-thread case) and
+    paths with jumps / repeated rows (the literal walk)."""
+    import torch
+    from kwiiyatta_amd import _lib
+    from kwiiyatta_amd.vocoder.align import project_path_iter
+    rng = np.random.default_rng(5)
+
+    def dtw_like(n):
+        steps = rng.integers(0, 3, n)                    # 0: x+1, 1: y+1, 2: both
+        x = np.r_[0, np.cumsum(steps != 1)]
+        y = np.r_[0, np.cumsum(steps != 0)]
+        return np.stack([x, y], 1)
+
+    trim = 7
+    if kind == 'unit':
+        path = dtw_like(400)
+    elif kind == 'unit_trim0':
+        path, trim = dtw_like(300), 0
+    elif kind == 'gaps':
+        path = dtw_like(400)
+        path = np.delete(path, [50, 51, 52, 200, 201, 350], axis=0)
+    elif kind == 'backsteps':
+        path = dtw_like(300)
+        path[120:125, 1] = path[119, 1] - 2
+    elif kind == 'late_start':
+        path = dtw_like(300) + np.array([3, 4])
+    else:
+        path = dtw_like(9000)
+    ref = list(project_path_iter(path, trim=trim > 0, trim_len=trim))
+    dev = torch.device('cuda', 0)
+    ctx = _lib.default_context()
+    dpath = torch.from_numpy(np.ascontiguousarray(path.astype(np.int32))).to(dev)
+    dlen = torch.tensor([len(path)], dtype=torch.int64, device=dev)
+    cap = int(path[-1, 1]) + 8
+    idx = torch.full((cap,), -7, dtype=torch.int32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    rc = _lib.lib.kwy_align_project_dev(ctx.handle, _lib.c_vp(dpath.data_ptr()), _lib.c_vp(dlen.data_ptr()), trim,
+                                        _lib.c_vp(idx.data_ptr()), cap, _lib.c_vp(n_out.data_ptr()))
+    _lib.check(ctx, rc)
+    torch.cuda.synchronize()
+    n = int(n_out.item())
+    assert n == len(ref)
+    assert idx[:n].cpu().tolist() == ref
