@@ -112,13 +112,6 @@ __device__ __forceinline__ double dtw_wave_rol1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// value of lane `idx` (wave-uniform index) broadcast to all lanes (v_readlane, scalar path)
-__device__ __forceinline__ double dtw_readlane(double v, int idx) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), idx);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), idx);
-  return __hiloint2double(hi, lo);
-}
-
 // Packed predecessor codes: 2 bits per cell, 32 cells per 64-bit word; row i owns the
 // words starting at (off[i] >> 5) + i (rows never share a word).
 // Predecessor codes: 2 bits per cell, 16 cells per 32-bit word.
