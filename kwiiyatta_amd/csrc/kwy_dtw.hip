@@ -112,8 +112,6 @@ __device__ __forceinline__ double dtw_wave_rol1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// Packed predecessor codes: 2 bits per cell, 32 cells per 64-bit word; row i owns the
-// words starting at (off[i] >> 5) + i (rows never share a word).
 // Predecessor codes: 2 bits per cell, 16 cells per 32-bit word.
 // Words are cut at multiples of 16 of the STEP index s (cell (i, j) of strip i0 is handled at
 // step s = j - lo[i0] + (i - i0)), so that all lanes of a wavefront flush their word at the same
