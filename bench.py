@@ -98,6 +98,10 @@ def main():
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
     ap_.add_argument('--components', type=int, default=64)
     ap_.add_argument('--no-cpu-baseline', action='store_true')
+    ap_.add_argument('--no-graph', dest='graph', action='store_false',
+                     help='enqueue every kernel of a pass from the host (about 170 launches per pair) instead of '
+                          'replaying the pass as a captured HIP graph; the per-kernel HIP events are then recorded '
+                          'inside the timed region itself')
     ap_.add_argument('--gmm-prepare-per-pair', action='store_true',
                      help='redo the GMM-only precomputation of MLPG for every pair (the reference builds an MLPG '
                           'object per convert() call) instead of once per converter')
@@ -142,18 +146,25 @@ def main():
 
     def step():
         for p in pipes:
-            p.run()
+            if args.graph:
+                p.replay()
+            else:
+                p.run()
 
     def sync_all():
         for p in pipes:
             p.sync()
         torch.cuda.synchronize()
 
+    if args.graph:
+        for p in pipes:
+            p.capture()
     for _ in range(args.warmup):
         step()
     sync_all()
-    for p in pipes:
-        p.ctx.profile(True)
+    if not args.graph:
+        for p in pipes:
+            p.ctx.profile(True)
     if world > 1:
         dist.barrier()
     sync_all()
@@ -168,6 +179,20 @@ def main():
         tt = torch.tensor([el], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+
+    if args.graph:
+        # Per-kernel durations for the roofline object: HIP events cannot be recorded inside a captured graph here
+        # (hipEventRecord during capture: invalid resource handle), so the same passes are enqueued kernel by
+        # kernel on the same streams right after the timed region, with the library's events around the tracked
+        # kernels -- same kernels, same concurrency, not part of `value`.
+        for p in pipes:
+            p.ctx.profile(True)
+        for _ in range(min(args.steps, 3)):
+            for p in pipes:
+                p.run()
+        sync_all()
+        for p in pipes:
+            p.ctx.profile(False)
 
     frames_rank = sum(p.frames for p in pipes) * args.steps
     if world > 1:
@@ -195,6 +220,7 @@ def main():
         # (per-launch durations inside the timed region include the time a kernel shares the CUs with
         # the other streams' kernels)
         alone_ms = {}
+        pipes[0].ctx.profile(True)
         pipes[0].run(); pipes[0].sync()
         for nme in names:
             pipes[0].ctx.profile_read(nme)
@@ -236,8 +262,12 @@ def main():
                     'note': 'kernel is bound by f64 FFT arithmetic and barrier latency in LDS, not by HBM; the HBM '
                             'fraction is reported as asked (DESIGN.md section 5).  traffic = FETCH_SIZE+WRITE_SIZE of '
                             'profiles/r1_pmc_traffic.json scaled to the frames of one launch.  avg_launch_ms is '
-                            'measured inside the timed region, where a launch shares the CUs with the kernels of '
-                            'the other streams; alone_* is the same kernel measured after the timed region with '
+                            'measured with HIP events ' +
+                            ('in passes enqueued kernel by kernel on the same streams right after the timed region '
+                             '(events cannot be recorded inside the captured graphs the timed region replays)'
+                             if args.graph else 'inside the timed region') +
+                            ', where a launch shares the CUs with the kernels of '
+                            'the other streams; alone_* is the same kernel measured afterwards with '
                             'one stream running'}
         # the kernel with the largest SUMMED duration of all (what a rocprofv3 --stats table puts first)
         top = max(kernel_ms, key=lambda k: kernel_ms[k][0]) if kernel_ms else None
@@ -267,6 +297,9 @@ def main():
                 'gmm_model_prepared': ('per pair' if args.gmm_prepare_per_pair else
                                        'once per converter (the per-mixture matrices depend on the GMM only)')
                 if args.workload == 'pair' else None,
+                'launch': ('one captured HIP graph per pass and stream; per-kernel HIP-event durations from the same '
+                           'passes enqueued kernel by kernel right after the timed region') if args.graph else
+                          'one host launch per kernel; per-kernel HIP events inside the timed region',
                 'parallelism': f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective'},
             'real_time_factor': value / 200.0,
             'hbm_fraction_whole_path': value / world * path_bytes / 8e12,

@@ -90,7 +90,35 @@ class _Side:
         return self.sp_pad[:PAD_LEN], self.sp_pad[PAD_LEN + self.T:]
 
 
-class PairPipeline:
+class _Graphed:
+    """One pass of a pipeline as a HIP graph: `capture()` records the launches of `run()` once
+    (after a plain pass has filled the library's tables and sized its arena), `replay()` enqueues
+    them with a single call.  The pass has no host synchronisation and no data-dependent launch
+    sizes -- every size that depends on the data (pulse counts, path length) lives on the device."""
+    graph = None
+
+    def capture(self, profile=False):
+        """profile=True: the library's HIP events around its tracked kernels are captured with them; every
+        replay records them again, and `ctx.profile_read` (once, when the graph is no longer used) returns the
+        durations of the last replay."""
+        self.run()                  # a plain pass first: tables, arena
+        self.sync()
+        g = torch.cuda.CUDAGraph()
+        if profile:
+            self.ctx.profile(True)
+        with torch.cuda.graph(g, stream=self.stream):
+            self.run()
+        if profile:
+            self.ctx.profile(False)
+        self.graph = g
+        self.sync()
+
+    def replay(self):
+        with torch.cuda.stream(self.stream):
+            self.graph.replay()
+
+
+class PairPipeline(_Graphed):
     def __init__(self, device_index, fs, source, target, gmm, order=24, radius=32, frame_period=5.0,
                  stream=None, prepare_gmm_per_run=False):
         """source / target: (x, f0, timeaxis) numpy triples; gmm: DeviceGMM over 2*3*order dims.
@@ -180,7 +208,7 @@ class PairPipeline:
         self.ctx.sync()
 
 
-class UtterancePipeline:
+class UtterancePipeline(_Graphed):
     """analyse -> resynthesise of one utterance (BASELINE config 2), HBM-resident."""
 
     def __init__(self, device_index, fs, utterance, frame_period=5.0, stream=None):
