@@ -139,3 +139,32 @@ def test_align_project_matches_generator(kind):
     n = int(n_out.item())
     assert n == len(ref)
     assert idx[:n].cpu().tolist() == ref
+
+
+def test_graph_replay_matches_plain_pass(pair):
+    """A pass captured as a HIP graph and replayed (bench.py's default) does the work of the plain pass:
+    same path, same converted features, same waveform up to the order of the overlap-add atomics."""
+    import torch
+    from kwiiyatta_amd import pipeline as pl
+    fs, src, tgt = pair
+    gmm = pl.synthetic_gmm(order=24, components=8, seed=0, n_frames=4000)
+    dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
+    p = pl.PairPipeline(0, fs, src, tgt, dg)
+    p.run()
+    p.sync()
+    p._silence = lambda: None     # keep the pad frames' random spectra of the first pass: identical inputs from here on
+    p.run()
+    p.sync()
+    ref = {k: getattr(p, k).clone() for k in ('path', 'path_len', 'idx', 'mc_conv', 'sp_conv', 'wave')}
+    p.capture()
+    for k in ('path', 'idx', 'mc_conv', 'sp_conv', 'wave'):
+        getattr(p, k).zero_()
+    for _ in range(2):
+        p.replay()
+    p.sync()
+    n = int(ref['path_len'].item())
+    assert int(p.path_len.item()) == n
+    assert torch.equal(p.path[:n], ref['path'][:n]) and torch.equal(p.idx, ref['idx'])
+    assert torch.equal(p.mc_conv, ref['mc_conv']) and torch.equal(p.sp_conv, ref['sp_conv'])
+    w, wr = p.wave.cpu().numpy(), ref['wave'].cpu().numpy()
+    assert np.abs(w - wr).max() <= 1e-12 * max(1.0, np.abs(wr).max())
