@@ -157,8 +157,13 @@ def main():
         torch.cuda.synchronize()
 
     if args.graph:
-        for p in pipes:
-            p.capture()
+        try:
+            for p in pipes:
+                p.capture()
+        except Exception as exc:     # a runtime that cannot capture: enqueue kernel by kernel instead
+            sys.stderr.write(f'bench.py: HIP graph capture failed ({exc!r}); continuing with --no-graph\n')
+            torch.cuda.synchronize()
+            args.graph = False
     for _ in range(args.warmup):
         step()
     sync_all()
