@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, 'libkwy.so')
+_SO = os.environ.get('KWY_LIBKWY') or os.path.join(_HERE, 'libkwy.so')   # (override: A/B runs of two builds)
 
 if not os.path.exists(_SO):
     raise ImportError(
@@ -68,6 +68,7 @@ SIGNATURES = {
     'kwy_ctx_stream': (c_vp, [c_vp]),
     'kwy_ctx_profile': (c_int, [c_vp, c_int]),
     'kwy_ctx_debug_buffer': (c_int, [c_vp, c_vp]),
+    'kwy_debug_smallest_sum_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_ctx_profile_read': (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     'kwy_last_error': (ctypes.c_char_p, [c_vp]),
     'kwy_create_error': (ctypes.c_char_p, []),
