@@ -229,6 +229,40 @@ int kwy_gmm_em_finalize_dev(kwy_ctx *ctx, const double *stats, const double *sxx
                             double reg_covar, double *weights, double *covs);
 int kwy_gmm_em_scratch_bytes(int64_t n, int D, int M, int64_t *bytes);
 
+/* ---- converter fit: k-means initialisation ------------------------------------------------------
+ * The `init_params='kmeans'` step of the same GaussianMixture.fit (kwiiyatta/converter/gmm.py:14-23):
+ * sklearn.cluster.KMeans(n_clusters=M, n_init=1) -- centred input, k-means++ seeding with 2 + ln M
+ * candidates per centre, Lloyd iterations until the labels stop changing or the summed squared centre
+ * shift falls below 1e-4 mean(var(X)) -- whose labels become the one-hot responsibilities of the first
+ * M-step.  Sharded by rows like the EM blocks; the driver all-reduces / all-gathers shard totals,
+ * candidate rows, potentials and the centroid statistics ("k-means init likewise").
+ * All pointers are device pointers; D <= 160, M <= 256, at most 8 candidates per step. */
+/* out[0..D) = sum_t (X[t] - shift), out[D..2D) = sum_t (X[t] - shift)^2; shift may be NULL */
+int kwy_km_colstats_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, const double *shift, double *out);
+/* Xc = X - mean, xsq[t] = |Xc[t]|^2 */
+int kwy_km_center_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, const double *mean, double *Xc,
+                      double *xsq);
+/* k-means++: newd[c][t] = min(closest[t], max(0, |Xc[t] - cand[c]|^2)) for c < L (closest NULL: no min),
+ * pots[c] = sum_t newd[c][t] over this shard.  newd: L x n, pots: 8 doubles. */
+int kwy_km_pp_dist_dev(kwy_ctx *ctx, const double *Xc, const double *xsq, int64_t n, int D, const double *cand,
+                       int L, const double *closest, double *newd, double *pots);
+/* np.searchsorted(np.cumsum(closest), vals) over the global row order, shard by shard:
+ * kwy_km_pp_total_dev fills csums (kwy_km_chunks(n) chunk totals) and total[0]; with lo = the totals of
+ * the shards before this one, kwy_km_pp_pick_dev returns for each vals[c] the local row index of the hit,
+ * or -1 if it lies in another shard (first / last: position of this shard; beyond the end -> last row). */
+int64_t kwy_km_chunks(int64_t n);
+int kwy_km_pp_total_dev(kwy_ctx *ctx, const double *v, int64_t n, double *csums, double *total);
+int kwy_km_pp_pick_dev(kwy_ctx *ctx, const double *v, int64_t n, const double *csums, const double *lo,
+                       const double *vals, int L, int first, int last, int64_t *idx);
+/* Lloyd: labels[t] = argmin_j |c_j|^2 - 2 <Xc[t], c_j> (int32; in: previous labels), resp = one-hot rows
+ * (n x M, may be NULL), changed[0] = number of rows whose label changed (uint64).  The centroid sums are
+ * kwy_gmm_em_sums_dev(Xc, resp); kwy_km_update_dev turns the reduced [count, sums] into the new centres
+ * and the squared shift of every centre. */
+int kwy_km_assign_dev(kwy_ctx *ctx, const double *Xc, int64_t n, int D, const double *centers, int M,
+                      int32_t *labels, double *resp, unsigned long long *changed);
+int kwy_km_update_dev(kwy_ctx *ctx, const double *stats, const double *centers_old, int M, int D,
+                      double *centers_new, double *shift2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,14 @@ SIGNATURES = {
     'kwy_gmm_em_cov_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'kwy_gmm_em_finalize_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_vp, c_vp]),
     'kwy_gmm_em_scratch_bytes': (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
+    'kwy_km_colstats_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
+    'kwy_km_center_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    'kwy_km_pp_dist_dev': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    'kwy_km_chunks': (c_i64, [c_i64]),
+    'kwy_km_pp_total_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'kwy_km_pp_pick_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'kwy_km_assign_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    'kwy_km_update_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_mlpg_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_model_doubles': (c_i64, [c_int, c_int]),

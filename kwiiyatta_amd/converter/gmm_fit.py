@@ -1,22 +1,32 @@
-"""Full-covariance Gaussian-mixture EM on the GPU, data-parallel over frames.
+"""Full-covariance Gaussian-mixture fit on the GPU, data-parallel over frames.
 
 Stands in for ``sklearn.mixture.GaussianMixture(...).fit(X)`` as the reference
 uses it (/root/reference/kwiiyatta/converter/gmm.py:14-26): same hyper-parameters
 (``n_components, max_iter, tol, reg_covar, random_state``), same initialisation
-(one k-means run, hard assignments -> first M-step), same EM loop and stopping
-rule, same fitted attributes (``weights_, means_, covariances_, converged_,
-n_iter_, lower_bound_``), which is all that MLPG consumes afterwards.
+(one k-means run -- k-means++ seeding, Lloyd iterations -- whose hard assignments
+feed the first M-step), same EM loop and stopping rule, same fitted attributes
+(``weights_, means_, covariances_, converged_, n_iter_, lower_bound_``), which is
+all that MLPG consumes afterwards.
 
-Every rank holds a shard of the frames.  Per iteration each rank computes the
-E-step and the local sufficient statistics with the HIP kernels
-(kwy_gmm_em_*), and the statistics -- M*(1+D) doubles, then M*D*D doubles
-(10.6 MB for M=64, D=144) -- are summed over ranks with ``all_reduce``
-(RCCL over xGMI on GPUs; gloo in the CPU tests).  The M-step itself is
-replicated.  This is the only collective of the whole hot path.
+Every rank holds a shard of the frames; the global row order is rank 0's rows, then
+rank 1's, ...  Both phases compute on the local shard with the HIP kernels
+(kwy_km_*, kwy_gmm_em_*) and exchange only small quantities:
 
-The numerical work is delegated to a ``stats`` object with three methods
-(estep / sums / cov); ``HipStats`` is the product implementation, the tests
-inject a numpy one to exercise the distributed driver without a GPU.
+  k-means++   per centre: shard totals of the closest distances (all_gather), the
+              <= 8 candidate rows and their potentials (all_reduce)
+  Lloyd       per iteration: centroid sums and counts, M (D+1) doubles, and the number
+              of changed labels (all_reduce)
+  EM          per iteration: M (1+D) doubles, then M D D doubles (10.6 MB for M = 64,
+              D = 144), and the log-likelihood (all_reduce)
+
+over ``torch.distributed`` (RCCL over xGMI on GPUs: every reduced buffer is a device
+tensor; gloo in the CPU tests).  The random draws of the seeding come from the
+mixture's ``random_state`` on the host exactly as scikit-learn consumes them, and
+every decision is taken on globally reduced numbers, so the result does not depend on
+the number of ranks beyond the rounding of the sums.
+
+The numerical work is delegated to a ``stats`` object; ``HipStats`` is the product
+implementation, the tests inject a numpy one to exercise the driver without a GPU.
 """
 import numpy as np
 
@@ -26,33 +36,74 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
-def _all_reduce_sum(arr):
-    """In-place SUM all-reduce of a numpy array or torch tensor (no-op without a process group)."""
-    dist = _dist()
-    if dist is None:
-        return arr
-    import torch
-    if isinstance(arr, np.ndarray):
-        t = torch.from_numpy(arr)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return arr
-    dist.all_reduce(arr, op=dist.ReduceOp.SUM)
-    return arr
+class Comm:
+    """SUM all-reduce / all-gather of torch tensors living on the statistics' device.  RCCL takes
+    device tensors as they are; gloo (CPU tests) gets a host copy.  Without a process group every
+    operation is the identity."""
+
+    def __init__(self):
+        self.dist = _dist()
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.device_native = bool(self.dist) and self.dist.get_backend() == 'nccl'
+
+    def all_reduce(self, t):
+        """in place; returns t"""
+        if self.dist is None:
+            return t
+        if t.is_cuda and not self.device_native:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            if not t.is_cuda and self.device_native:
+                raise RuntimeError('RCCL reduces device tensors only: keep the statistics on the GPU')
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t
+
+    def all_gather_scalar(self, t):
+        """t: one-element tensor -> (world,) tensor on the same device, in rank order"""
+        import torch
+        if self.dist is None:
+            return t.reshape(1).clone()
+        out = torch.zeros(self.world, dtype=t.dtype, device=t.device)
+        out[self.rank] = t.reshape(())
+        return self.all_reduce(out)
 
 
 class HipStats:
-    """Local E-step and sufficient statistics on one GPU (device-resident shard)."""
+    """Local statistics on one GPU: the device-resident shard and the HIP kernels over it."""
 
     def __init__(self, X, n_components, device_index=0, ctx=None):
         import torch
         from .. import _lib
         self.torch, self._lib = torch, _lib
         self.dev = torch.device('cuda', device_index)
-        self.ctx = ctx or _lib.Context(device_index, stream=torch.cuda.current_stream(self.dev).cuda_stream)
-        X = np.ascontiguousarray(X, dtype=np.float64)
-        self.n, self.D = X.shape
+        # One stream for everything the fit does: the library's kernels, the driver's small torch ops and
+        # the collectives (torch.distributed orders RCCL work after the current stream).  `scope()` makes it
+        # torch's current stream; the fit entry points run inside it.
+        if ctx is None:
+            self.stream = torch.cuda.Stream(device=self.dev)
+            self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        else:
+            self.ctx = ctx
+            self.stream = torch.cuda.ExternalStream(_lib.lib.kwy_ctx_stream(ctx.handle), device=self.dev)
+        with self.scope():
+            self._allocate(X, n_components)
+
+    def scope(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def _allocate(self, X, n_components):
+        torch = self.torch
+        if isinstance(X, torch.Tensor):         # a shard already in HBM (the corpus driver writes it there)
+            if X.dtype != torch.float64 or not X.is_contiguous() or X.device != self.dev:
+                raise ValueError('HipStats: X must be a contiguous float64 tensor on the fit device')
+            self.X = X
+        else:
+            self.X = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(self.dev)
+        self.n, self.D = self.X.shape
         self.M = int(n_components)
-        self.X = torch.from_numpy(X).to(self.dev)
         f64 = dict(dtype=torch.float64, device=self.dev)
         self.resp = torch.empty((self.n, self.M), **f64)
         self.ll = torch.empty((self.n + 255) // 256, **f64)
@@ -64,11 +115,16 @@ class HipStats:
         self.covs = torch.empty((self.M, self.D, self.D), **f64)
 
     def _p(self, t):
-        return self._lib.c_vp(t.data_ptr())
+        return self._lib.c_vp(t.data_ptr()) if t is not None else None
 
     def _chk(self, rc):
         self._lib.check(self.ctx, rc)
 
+    def tensor(self, a, dtype=None):
+        t = self.torch.as_tensor(a, dtype=dtype)
+        return t.to(self.dev)
+
+    # ---- EM -----------------------------------------------------------------------------------
     def set_resp_from_labels(self, labels):
         self.resp.zero_()
         idx = self.torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(self.dev)
@@ -79,22 +135,22 @@ class HipStats:
             dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)))
 
     def estep(self):
-        """responsibilities (kept on the device) and the local sum of log-likelihoods."""
+        """responsibilities (kept on the device); returns the local sum of log-likelihoods as a
+        one-element device tensor"""
         lib = self._lib.lib
         self._chk(lib.kwy_gmm_em_estep_dev(self.ctx.handle, self._p(self.X), self.n, self.D, self.M,
                                            self._p(self.weights), self._p(self.means), self._p(self.covs),
                                            self._p(self.resp), self._p(self.ll), self._p(self.status)))
-        self.ctx.sync()
-        if int(self.status[0].item()) != 0:
-            raise ValueError('Fitting the mixture model failed because some components have '
-                             'ill-defined empirical covariance; increase reg_covar')
-        return float(self.ll.sum().item())
+        return self.ll.sum().reshape(1)
+
+    def estep_failed(self):
+        """one-element device tensor: nonzero if a covariance was not positive definite"""
+        return self.status[:1].to(self.torch.float64)
 
     def sums(self):
         """(M, 1+D) local [sum r, sum r x] as a device tensor."""
         self._chk(self._lib.lib.kwy_gmm_em_sums_dev(self.ctx.handle, self._p(self.X), self.n, self.D, self.M,
                                                     self._p(self.resp), self._p(self.stats)))
-        self.ctx.sync()
         return self.stats
 
     def means_from(self, stats):
@@ -105,37 +161,259 @@ class HipStats:
         """(M, D, D) local sum r (x - mu)(x - mu)' around self.means, device tensor."""
         self._chk(self._lib.lib.kwy_gmm_em_cov_dev(self.ctx.handle, self._p(self.X), self.n, self.D, self.M,
                                                    self._p(self.resp), self._p(self.means), self._p(self.sxx)))
-        self.ctx.sync()
         return self.sxx
 
     def finalize(self, stats, sxx, reg_covar):
         self._chk(self._lib.lib.kwy_gmm_em_finalize_dev(self.ctx.handle, self._p(stats), self._p(sxx), self.D,
                                                         self.M, float(reg_covar), self._p(self.weights),
                                                         self._p(self.covs)))
-        self.ctx.sync()
 
     def get_params(self):
-        return (self.weights.cpu().numpy(), self.means.cpu().numpy(), self.covs.cpu().numpy())
+        with self.scope():
+            out = (self.weights.cpu().numpy(), self.means.cpu().numpy(), self.covs.cpu().numpy())
+        self.ctx.sync()
+        return out
+
+    # ---- k-means --------------------------------------------------------------------------------
+    def km_colstats(self, shift=None):
+        """(2, D): column sums and sums of squares of X - shift over the shard"""
+        out = self.torch.empty((2, self.D), dtype=self.torch.float64, device=self.dev)
+        self._chk(self._lib.lib.kwy_km_colstats_dev(self.ctx.handle, self._p(self.X), self.n, self.D,
+                                                    self._p(shift), self._p(out)))
+        return out
+
+    def km_begin(self, mean):
+        """centred copy of the shard and its row norms; buffers of the seeding and of Lloyd's iterations"""
+        t = self.torch
+        f64 = dict(dtype=t.float64, device=self.dev)
+        self.Xc = t.empty_like(self.X)
+        self.xsq = t.empty(self.n, **f64)
+        self._chk(self._lib.lib.kwy_km_center_dev(self.ctx.handle, self._p(self.X), self.n, self.D, self._p(mean),
+                                                  self._p(self.Xc), self._p(self.xsq)))
+        self.closest = t.empty(self.n, **f64)
+        self.newd = t.empty((8, self.n), **f64)
+        self.pots = t.zeros(8, **f64)
+        self.csums = t.empty(int(self._lib.lib.kwy_km_chunks(self.n)), **f64)
+        self.total = t.zeros(1, **f64)
+        self.pick = t.empty(8, dtype=t.int64, device=self.dev)
+        self.labels = t.full((self.n,), -1, dtype=t.int32, device=self.dev)
+        self.changed = t.zeros(1, dtype=t.int64, device=self.dev)
+        self.shift2 = t.empty(self.M, **f64)
+
+    def km_end(self):
+        self.ctx.sync()      # nothing in flight still reads the buffers that go back to the allocator
+        for name in ('Xc', 'xsq', 'closest', 'newd', 'csums'):
+            setattr(self, name, None)
+
+    def km_row(self, i):
+        return self.Xc[i]
+
+    def km_closest_total(self):
+        self._chk(self._lib.lib.kwy_km_pp_total_dev(self.ctx.handle, self._p(self.closest), self.n,
+                                                    self._p(self.csums), self._p(self.total)))
+        return self.total
+
+    def km_pick(self, lo, vals, first, last):
+        """local row indices (int64 device tensor, -1: not in this shard) of searchsorted(lo + cumsum(closest), vals)"""
+        L = len(vals)
+        self._chk(self._lib.lib.kwy_km_pp_pick_dev(self.ctx.handle, self._p(self.closest), self.n, self._p(self.csums),
+                                                   self._p(lo), self._p(vals), L, int(first), int(last),
+                                                   self._p(self.pick)))
+        return self.pick[:L]
+
+    def km_candidates(self, cand, use_closest):
+        """newd (L, n) and the local potentials (L,) of the candidate rows `cand` (L, D)"""
+        L = cand.shape[0]
+        self._chk(self._lib.lib.kwy_km_pp_dist_dev(self.ctx.handle, self._p(self.Xc), self._p(self.xsq), self.n, self.D,
+                                                   self._p(cand), L, self._p(self.closest) if use_closest else None,
+                                                   self._p(self.newd), self._p(self.pots)))
+        return self.pots[:L]
+
+    def km_accept(self, best):
+        """closest <- newd[best]; best: one-element int64 device tensor"""
+        self.torch.index_select(self.newd, 0, best.reshape(1), out=self.closest.reshape(1, -1))
+
+    def km_assign(self, centers):
+        """labels of the nearest centres (one-hot into resp); returns the local number of changed labels
+        (one-element int64 device tensor)"""
+        self._chk(self._lib.lib.kwy_km_assign_dev(self.ctx.handle, self._p(self.Xc), self.n, self.D, self._p(centers),
+                                                  self.M, self._p(self.labels), self._p(self.resp),
+                                                  self._p(self.changed)))
+        return self.changed
+
+    def km_sums(self):
+        """(M, 1+D) local [count, sum of centred rows] per label"""
+        self._chk(self._lib.lib.kwy_gmm_em_sums_dev(self.ctx.handle, self._p(self.Xc), self.n, self.D, self.M,
+                                                    self._p(self.resp), self._p(self.stats)))
+        return self.stats
+
+    def km_update(self, stats, centers_old, centers_new):
+        self._chk(self._lib.lib.kwy_km_update_dev(self.ctx.handle, self._p(stats), self._p(centers_old), self.M, self.D,
+                                                  self._p(centers_new), self._p(self.shift2)))
+        return self.shift2
+
+    def km_labels_of(self, i):
+        return self.labels[i]
+
+    def km_far_rows(self, centers, k):
+        """the k rows farthest from their own centre: (distances, local indices), descending (empty-cluster relocation)"""
+        t = self.torch
+        d = (self.Xc - centers[self.labels.long()]).pow(2).sum(1)
+        v, i = t.topk(d, min(k, self.n))
+        return v, i
+
+
+def kmeans_init(stats, n_components, random_state, max_iter=300, tol=1e-4, verbose=0):
+    with stats.scope():
+        return _kmeans_init(stats, n_components, random_state, max_iter, tol, verbose)
+
+
+def _kmeans_init(stats, n_components, random_state, max_iter, tol, verbose):
+    """sklearn.cluster.KMeans(n_clusters=M, n_init=1, random_state=rs).fit(X).labels_ on the sharded rows
+    (sklearn/cluster/_kmeans.py: fit, _kmeans_plusplus, _kmeans_single_lloyd), left in `stats` as one-hot
+    responsibilities.  Returns (n_iter, centres as numpy, in the centred coordinates + the mean)."""
+    import torch
+    from sklearn.utils import check_random_state
+    comm = Comm()
+    rs = check_random_state(random_state)
+    M = int(n_components)
+    dev = stats.dev
+    f64 = dict(dtype=torch.float64, device=dev)
+    n_local = stats.n
+    counts = comm.all_gather_scalar(torch.tensor([float(n_local)], **f64))
+    n_total = int(round(float(counts.sum().item())))
+    row0 = int(round(float(counts[:comm.rank].sum().item())))      # global index of this shard's first row
+    if n_total < M:
+        raise ValueError(f'n_samples={n_total} should be >= n_clusters={M}.')
+
+    # KMeans.fit: centre the data, tolerance relative to the mean variance
+    s = comm.all_reduce(stats.km_colstats(None))
+    mean = s[0] / n_total
+    stats.km_begin(mean)
+    s2 = comm.all_reduce(stats.km_colstats(mean))
+    abs_tol = float((s2[1] / n_total - (s2[0] / n_total) ** 2).mean().item()) * tol
+
+    # the random numbers of _kmeans_plusplus, in its order: one for random_state.choice, then
+    # uniform(size=n_local_trials) per further centre
+    n_trials = 2 + int(np.log(M))
+    if n_trials > 8:
+        raise ValueError('k-means++ with more than 8 candidates per centre (n_components > 403) is not supported')
+    cdf = np.full(n_total, 1.0 / n_total).cumsum()
+    cdf /= cdf[-1]
+    first_id = int(cdf.searchsorted(rs.random_sample(), side='right'))
+    u = torch.from_numpy(rs.uniform(size=(M - 1, n_trials)) if M > 1 else np.zeros((0, n_trials))).to(dev)
+
+    def fetch_rows(idx):
+        """rows of the global matrix by local index (-1: another shard's): (L, D) on every rank"""
+        L = idx.shape[0]
+        buf = torch.zeros((L, stats.D), **f64)
+        mine = idx >= 0
+        safe = idx.clamp(0, n_local - 1)
+        buf.copy_(stats.km_row(safe) * mine.to(torch.float64)[:, None])
+        return comm.all_reduce(buf)
+
+    centers = torch.zeros((M, stats.D), **f64)
+    local_first = first_id - row0
+    idx0 = torch.tensor([local_first if 0 <= local_first < n_local else -1], dtype=torch.int64, device=dev)
+    centers[0] = fetch_rows(idx0)[0]
+    pot = comm.all_reduce(stats.km_candidates(centers[:1].contiguous(), use_closest=False).clone())
+    stats.km_accept(torch.zeros(1, dtype=torch.int64, device=dev))
+    current_pot = pot[0]
+    for c in range(1, M):
+        totals = comm.all_gather_scalar(stats.km_closest_total())
+        lo = totals[:comm.rank].sum().reshape(1)
+        vals = (u[c - 1] * current_pot).contiguous()
+        idx = stats.km_pick(lo, vals, first=comm.rank == 0, last=comm.rank == comm.world - 1)
+        cand = fetch_rows(idx)
+        pots = comm.all_reduce(stats.km_candidates(cand, use_closest=True).clone())
+        best = torch.argmin(pots).reshape(1)
+        stats.km_accept(best)
+        current_pot = pots[best[0]]
+        centers[c] = cand[best[0]]
+
+    # _kmeans_single_lloyd
+    centers_new = torch.empty_like(centers)
+    strict = False
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        changed = comm.all_reduce(stats.km_assign(centers).clone())
+        st = comm.all_reduce(stats.km_sums())
+        empty = (st[:, 0] == 0).nonzero().flatten()
+        if len(empty):
+            _relocate_empty_clusters(stats, comm, st, centers, empty, row0)
+        shift2 = stats.km_update(st, centers, centers_new)
+        centers, centers_new = centers_new, centers
+        n_changed = int(changed.item())
+        shift_tot = float(shift2.sum().item())
+        if verbose:
+            print(f'  k-means iteration {n_iter}: {n_changed} labels changed, centre shift {shift_tot:.3e}')
+        if n_changed == 0:
+            strict = True
+            break
+        if shift_tot <= abs_tol:
+            break
+    if not strict:
+        stats.km_assign(centers)            # labels that match the final centres
+    out = (centers + mean).cpu().numpy()
+    stats.km_end()
+    return n_iter, out
+
+
+def _relocate_empty_clusters(stats, comm, st, centers, empty, row0):
+    """sklearn's _relocate_empty_clusters_dense on the reduced [count, sums]: every empty cluster takes one of
+    the rows farthest from their own centre (largest first), which leaves its old cluster."""
+    import torch
+    k = len(empty)
+    v, i = stats.km_far_rows(centers, k)
+    rows = stats.km_row(i)
+    labs = stats.km_labels_of(i).to(torch.float64)
+    pack = torch.zeros((comm.world, k, stats.D + 3), dtype=torch.float64, device=stats.dev)
+    m = len(v)
+    pack[comm.rank, :m, 0] = v
+    pack[comm.rank, :m, 1] = (i + row0).to(torch.float64)
+    pack[comm.rank, :m, 2] = labs
+    pack[comm.rank, :m, 3:] = rows
+    pack[comm.rank, m:, 0] = -1.0
+    comm.all_reduce(pack)
+    flat = pack.reshape(-1, stats.D + 3)
+    order = torch.argsort(flat[:, 0], descending=True, stable=True)[:k]
+    for slot, j in zip(order.tolist(), empty.tolist()):
+        row, old = flat[slot, 3:], int(flat[slot, 2].item())
+        st[old, 1:] -= row
+        st[old, 0] -= 1.0
+        st[j, 1:] = row
+        st[j, 0] = 1.0
 
 
 def em_fit(stats, n_total, max_iter=100, tol=1e-3, reg_covar=1e-6, verbose=0):
-    """The EM loop of sklearn's BaseMixture.fit_predict, starting from the
-    responsibilities already stored in `stats` (hard k-means assignments).
-    `stats` computes on the local shard; sufficient statistics are all-reduced."""
+    with stats.scope():
+        return _em_fit(stats, n_total, max_iter, tol, reg_covar, verbose)
+
+
+def _em_fit(stats, n_total, max_iter, tol, reg_covar, verbose):
+    """The EM loop of sklearn's BaseMixture.fit_predict, starting from the responsibilities already
+    stored in `stats` (hard k-means assignments).  `stats` computes on the local shard; sufficient
+    statistics are all-reduced."""
+    comm = Comm()
+
     def m_step():
-        s = _all_reduce_sum(stats.sums())
+        s = comm.all_reduce(stats.sums())
         stats.means_from(s)
-        c = _all_reduce_sum(stats.cov())
+        c = comm.all_reduce(stats.cov())
         stats.finalize(s, c, reg_covar)
 
     m_step()                                    # initialisation from the hard assignments
     lower_bound, converged, n_iter = -np.inf, False, 0
     for n_iter in range(1, max_iter + 1):
         prev = lower_bound
-        ll = np.array([stats.estep()])
-        _all_reduce_sum(ll)
+        ll = stats.estep()
+        both = comm.all_reduce(stats.torch.cat((ll, stats.estep_failed())))
+        ll_total, failed = (float(v) for v in both.tolist())
+        if failed:
+            raise ValueError('Fitting the mixture model failed because some components have '
+                             'ill-defined empirical covariance; increase reg_covar')
         m_step()
-        lower_bound = float(ll[0]) / n_total
+        lower_bound = ll_total / n_total
         change = lower_bound - prev
         if verbose:
             print(f'  Iteration {n_iter}\t lower bound {lower_bound:.6f}\t change {change:.6f}')
@@ -158,44 +436,29 @@ class GaussianMixtureHIP:
         self.n_components, self.tol, self.reg_covar, self.max_iter = n_components, tol, reg_covar, max_iter
         self.random_state, self.verbose, self.device_index = random_state, verbose, device_index
 
-    def _initial_labels(self, X):
-        """sklearn's initialisation: one KMeans run with the mixture's random state.
-        With several ranks, rank 0's centres are broadcast and every rank labels its
-        own shard by the nearest centre."""
-        from sklearn.cluster import KMeans
-        from sklearn.utils import check_random_state
-        dist = _dist()
-        rs = check_random_state(self.random_state)
-        if dist is None:
-            return KMeans(n_clusters=self.n_components, n_init=1, random_state=rs).fit(X).labels_
+    def fit(self, X, y=None, stats=None, labels=None):
+        """X: the local shard, (n, D) numpy array or a float64 device tensor.  labels: optional initial hard
+        assignments of the local rows (skips the k-means run)."""
         import torch
-        centres = np.zeros((self.n_components, X.shape[1]))
-        if dist.get_rank() == 0:
-            centres[:] = KMeans(n_clusters=self.n_components, n_init=1, random_state=rs).fit(X).cluster_centers_
-        t = torch.from_numpy(centres)
-        if dist.get_backend() == 'nccl':
-            t = t.cuda()
-            dist.broadcast(t, 0)
-            centres = t.cpu().numpy()
-        else:
-            dist.broadcast(t, 0)
-        d2 = (X ** 2).sum(1)[:, None] - 2 * X @ centres.T + (centres ** 2).sum(1)[None, :]
-        return d2.argmin(1)
-
-    def fit(self, X, y=None, stats=None):
-        X = np.ascontiguousarray(X, dtype=np.float64)
-        if X.shape[0] < self.n_components:
-            raise ValueError(f'Expected n_samples >= n_components but got n_components = {self.n_components}, '
-                             f'n_samples = {X.shape[0]}')
         if stats is None:
             stats = HipStats(X, self.n_components, device_index=self.device_index)
-        stats.set_resp_from_labels(self._initial_labels(X))
-        n_total = np.array([float(X.shape[0])])
-        _all_reduce_sum(n_total)
+        comm = Comm()
+        with stats.scope():
+            n_total = comm.all_reduce(torch.tensor([float(stats.n)], dtype=torch.float64, device=stats.dev))
+            n_total = float(n_total.item())
+        if n_total < self.n_components:
+            raise ValueError(f'Expected n_samples >= n_components but got n_components = {self.n_components}, '
+                             f'n_samples = {int(n_total)}')
         if self.verbose:
             print('Initialization 0')
+        if labels is not None:
+            with stats.scope():
+                stats.set_resp_from_labels(labels)
+        else:
+            self.kmeans_n_iter_, self.kmeans_centers_ = kmeans_init(stats, self.n_components, self.random_state,
+                                                                    verbose=self.verbose > 1)
         self.lower_bound_, self.converged_, self.n_iter_ = em_fit(
-            stats, float(n_total[0]), self.max_iter, self.tol, self.reg_covar, self.verbose > 1)
+            stats, n_total, self.max_iter, self.tol, self.reg_covar, self.verbose > 1)
         if self.verbose:
             print(f'Initialization converged: {self.converged_}')
         self.weights_, self.means_, self.covariances_ = stats.get_params()

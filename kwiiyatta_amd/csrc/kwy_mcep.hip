@@ -169,6 +169,80 @@ __global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict_
   }
 }
 
+// ---- any transform length: the dense form ---------------------------------------------------
+// The reference resamples features between sampling rates by cutting or padding the spectral axis
+// (kwiiyatta/vocoder/abc/synthesizer.py:77-113, vocoder/mcep.py:31-58), so pysptk.sp2mc / mc2sp also see
+// spectra of 372, 1024, 3078 ... bins: numpy's irfft / rfft of any even length.  Both conversions are
+// linear maps around the log / exp, so for lengths the LDS FFT does not cover the map is
+// applied as one dense matrix, built once per (length, order, alpha) on the host in extended precision:
+//   sp2mc:  mc[j]    = sum_k G[k][j]  log P[k]        G  = freqt . (c[0] /= 2) . irfft     (K x 64)
+//   mc2sp:  log P[k] = sum_j G2[j][k] mc[j]           G2 = rfft.real . mirror . (c[0] *= 2) . freqt
+// A frame costs K (order+1) multiply-adds instead of an FFT: still far below its 8 K bytes of traffic.
+#define MCD_FR 4
+__global__ __launch_bounds__(KWY_THREADS) void k_sp2mc_dense(const double *__restrict__ sp, int64_t T, int K,
+                                                            int order, const double *__restrict__ G,
+                                                            double *__restrict__ mc) {
+  extern __shared__ double smem[];
+  double *lg = smem;                       // MCD_FR x K log-spectra
+  double *part = lg + (size_t)MCD_FR * K;  // MCD_FR x 4 x 64
+  const int tid = threadIdx.x;
+  const int64_t f0 = (int64_t)blockIdx.x * MCD_FR;
+  for (int fr = 0; fr < MCD_FR; ++fr) {
+    const int64_t frame = f0 + fr;
+    for (int k = tid; k < K; k += KWY_THREADS) lg[(size_t)fr * K + k] = frame < T ? log(sp[frame * K + k]) : 0.0;
+  }
+  __syncthreads();
+  const int j = tid & 63, q = tid >> 6;
+  double acc[MCD_FR];
+#pragma unroll
+  for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] = 0.0;
+  if (j <= order) {
+#pragma unroll 8
+    for (int k = q; k < K; k += 4) {
+      const double g = G[(size_t)k * MC_STRIDE + j];
+#pragma unroll
+      for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] += g * lg[(size_t)fr * K + k];
+    }
+  }
+#pragma unroll
+  for (int fr = 0; fr < MCD_FR; ++fr) part[fr * 256 + q * 64 + j] = acc[fr];
+  __syncthreads();
+  for (int e = tid; e < MCD_FR * 64; e += KWY_THREADS) {
+    const int fr = e >> 6, jj = e & 63;
+    const double *pp = part + fr * 256;
+    if (jj <= order && f0 + fr < T)
+      mc[(f0 + fr) * (order + 1) + jj] = ((pp[jj] + pp[64 + jj]) + pp[128 + jj]) + pp[192 + jj];
+  }
+}
+
+// G2: [order+1][K].  One workgroup per MCD_FR frames, thread = bins tid, tid + 256, ...
+__global__ __launch_bounds__(KWY_THREADS) void k_mc2sp_dense(const double *__restrict__ mc, int64_t T, int order,
+                                                            int K, const double *__restrict__ G2,
+                                                            double *__restrict__ sp) {
+  extern __shared__ double smem[];
+  double *m = smem;                        // MCD_FR x (order+1)
+  const int tid = threadIdx.x;
+  const int64_t f0 = (int64_t)blockIdx.x * MCD_FR;
+  for (int e = tid; e < MCD_FR * (order + 1); e += KWY_THREADS) {
+    const int fr = e / (order + 1), i = e - fr * (order + 1);
+    m[e] = (f0 + fr < T) ? mc[(f0 + fr) * (order + 1) + i] : 0.0;
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += KWY_THREADS) {
+    double acc[MCD_FR];
+#pragma unroll
+    for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] = 0.0;
+    for (int i = 0; i <= order; ++i) {
+      const double g = G2[(size_t)i * K + k];
+#pragma unroll
+      for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] += g * m[fr * (order + 1) + i];
+    }
+#pragma unroll
+    for (int fr = 0; fr < MCD_FR; ++fr)
+      if (f0 + fr < T) sp[(f0 + fr) * K + k] = exp(acc[fr]);
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------
 static int get_sp2mc_matrix(kwy_ctx *ctx, int N, int order, double alpha, const double **out, int *ncut) {
   char key[96];
@@ -247,18 +321,115 @@ static int launch_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, co
   return KWY_OK;
 }
 
+// cos(2 pi m / N), m < N, in extended precision (first octant evaluated, the rest by symmetry of the index)
+static void cos_table(int N, std::vector<long double> &c) {
+  c.resize(N);
+  const long double w = 2.0L * 3.141592653589793238462643383279502884L / (long double)N;
+  for (int m = 0; m < N; ++m) c[m] = cosl(w * (long double)(m <= N - m ? m : N - m));
+}
+
+// G[k][j] (K x MC_STRIDE): mel-cepstral coefficient j per unit of log P[k], any even N = 2 (K - 1)
+static int get_sp2mc_dense(kwy_ctx *ctx, int K, int order, double alpha, const double **out) {
+  char key[96];
+  snprintf(key, sizeof(key), "sp2mc_dense:%d:%d:%.17g", K, order, alpha);
+  auto it = ctx->d_mats.find(key);
+  if (it == ctx->d_mats.end()) {
+    const int N = 2 * (K - 1), H = K - 1;
+    std::vector<double> F;
+    freqt_matrix(N, order, alpha, F);        // cepstral index n (< N) -> coefficient j
+    int nc = N;
+    while (nc > 1) {
+      double mx = 0.0;
+      for (int j = 0; j <= order; ++j) mx = fmax(mx, fabs(F[(size_t)(nc - 1) * (order + 1) + j]));
+      if (mx > 1e-40) break;
+      --nc;
+    }
+    std::vector<long double> cs;
+    cos_table(N, cs);
+    std::vector<double> G((size_t)K * MC_STRIDE, 0.0);
+    std::vector<long double> acc(order + 1);
+    for (int k = 0; k < K; ++k) {
+      // irfft: c[n] = (1/N) sum_k w_k L[k] cos(2 pi n k / N), w = 1 at k = 0 and k = H, else 2
+      const long double wk = ((k == 0 || k == H) ? 1.0L : 2.0L) / (long double)N;
+      for (int j = 0; j <= order; ++j) acc[j] = 0.0L;
+      for (int n = 0; n < nc; ++n) {
+        const long double cn = wk * cs[(int)(((int64_t)n * k) % N)] * (n == 0 ? 0.5L : 1.0L);
+        const double *f = &F[(size_t)n * (order + 1)];
+        for (int j = 0; j <= order; ++j) acc[j] += cn * (long double)f[j];
+      }
+      for (int j = 0; j <= order; ++j) G[(size_t)k * MC_STRIDE + j] = (double)acc[j];
+    }
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(double) * G.size()));
+    KWY_HIP(hipMemcpy(d, G.data(), sizeof(double) * G.size(), hipMemcpyHostToDevice));
+    it = ctx->d_mats.emplace(key, d).first;
+  }
+  *out = it->second;
+  return KWY_OK;
+}
+
+// G2[j][k] ((order+1) x K): log P[k] per unit of mel-cepstral coefficient j
+static int get_mc2sp_dense(kwy_ctx *ctx, int K, int order, double alpha, const double **out) {
+  char key[96];
+  snprintf(key, sizeof(key), "mc2sp_dense:%d:%d:%.17g", K, order, alpha);
+  auto it = ctx->d_mats.find(key);
+  if (it == ctx->d_mats.end()) {
+    const int N = 2 * (K - 1), H = K - 1;
+    std::vector<double> F;                   // [order+1][H+1]: coefficient j -> cepstral index i
+    freqt_matrix(order + 1, H, -alpha, F);
+    std::vector<long double> cs;
+    cos_table(N, cs);
+    std::vector<double> G2((size_t)(order + 1) * K, 0.0);
+    std::vector<long double> acc(order + 1);
+    for (int k = 0; k < K; ++k) {
+      // rfft of the mirrored sequence: S[k] = 2 c0 + 2 sum_{0<i<H} c_i cos(2 pi i k / N) + c_H cos(pi k)
+      for (int j = 0; j <= order; ++j) acc[j] = 0.0L;
+      for (int i = 0; i <= H; ++i) {
+        const long double w = ((i == H) ? 1.0L : 2.0L) * cs[(int)(((int64_t)i * k) % N)];
+        for (int j = 0; j <= order; ++j) acc[j] += w * (long double)F[(size_t)j * (H + 1) + i];
+      }
+      for (int j = 0; j <= order; ++j) G2[(size_t)j * K + k] = (double)acc[j];
+    }
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(double) * G2.size()));
+    KWY_HIP(hipMemcpy(d, G2.data(), sizeof(double) * G2.size(), hipMemcpyHostToDevice));
+    it = ctx->d_mats.emplace(key, d).first;
+  }
+  *out = it->second;
+  return KWY_OK;
+}
+
+static int launch_sp2mc_dense(kwy_ctx *ctx, const double *sp, int64_t T, int K, int order, double alpha, double *mc) {
+  const double *G;
+  KWY_TRY(get_sp2mc_dense(ctx, K, order, alpha, &G));
+  const size_t lds = sizeof(double) * ((size_t)MCD_FR * K + MCD_FR * 256);
+  KWY_HIP(hipFuncSetAttribute((const void *)k_sp2mc_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  KWY_PROF(ctx, "k_sp2mc_dense", hipLaunchKernelGGL(k_sp2mc_dense, dim3((unsigned)((T + MCD_FR - 1) / MCD_FR)), dim3(KWY_THREADS), lds, ctx->stream, sp, T, K, order, G, mc));
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static int launch_mc2sp_dense(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, int K, double *sp) {
+  const double *G2;
+  KWY_TRY(get_mc2sp_dense(ctx, K, order, alpha, &G2));
+  const size_t lds = sizeof(double) * (size_t)MCD_FR * (order + 1);
+  KWY_PROF(ctx, "k_mc2sp_dense", hipLaunchKernelGGL(k_mc2sp_dense, dim3((unsigned)((T + MCD_FR - 1) / MCD_FR)), dim3(KWY_THREADS), lds, ctx->stream, mc, T, order, K, G2, sp));
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
 static int mcep_check(kwy_ctx *ctx, const void *a, const void *b, int64_t T, int K, int order, double alpha,
                       int *log2n) {
   if (!ctx) return KWY_EINVAL;
   const int N = 2 * (K - 1);
-  const int l = kwy_ilog2(N);
-  if (!a || !b || T <= 0 || K < 2 || (1 << l) != N || l < 9 || l > 13) {
-    ctx->err = "mcep: spectrum length must be 2^n+1 with 512 <= 2^(n+1) <= 8192";
+  if (!a || !b || T <= 0 || K < 2 || K > 4097) {
+    ctx->err = "mcep: need 2 <= spectrum length <= 4097";
     return KWY_EINVAL;
   }
   if (order < 1 || order > MC_MAX_ORDER || order > N / 2) { ctx->err = "mcep: order out of range"; return KWY_EINVAL; }
   if (!(fabs(alpha) < 1.0)) { ctx->err = "mcep: |alpha| must be < 1"; return KWY_EINVAL; }
-  *log2n = l;
+  const int l = kwy_ilog2(N);
+  *log2n = ((1 << l) == N && l >= 9 && l <= 13) ? l : 0;   // 0: no LDS FFT of that length -> dense form
   return KWY_OK;
 }
 
@@ -267,6 +438,7 @@ extern "C" int kwy_sp2mc_dev(kwy_ctx *ctx, const double *sp, int64_t T, int K, i
   int l;
   KWY_TRY(mcep_check(ctx, sp, mc, T, K, order, alpha, &l));
   KWY_HIP(hipSetDevice(ctx->device));
+  if (l == 0) return launch_sp2mc_dense(ctx, sp, T, K, order, alpha, mc);
   const double *F;
   int ncut;
   KWY_TRY(get_sp2mc_matrix(ctx, 1 << l, order, alpha, &F, &ncut));
@@ -284,6 +456,7 @@ extern "C" int kwy_mc2sp_dev(kwy_ctx *ctx, const double *mc, int64_t T, int orde
   int l;
   KWY_TRY(mcep_check(ctx, mc, sp, T, fftlen / 2 + 1, order, alpha, &l));
   KWY_HIP(hipSetDevice(ctx->device));
+  if (l == 0) return launch_mc2sp_dense(ctx, mc, T, order, alpha, fftlen / 2 + 1, sp);
   const double *F2T;
   KWY_TRY(get_mc2sp_matrix(ctx, 1 << l, order, alpha, &F2T));
   switch (l) {

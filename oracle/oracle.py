@@ -230,21 +230,46 @@ def freqt(c, order, alpha):
     return out
 
 
+def _pow2(n):
+    return n >= 2 and (n & (n - 1)) == 0
+
+
 def sp2mc(powerspec, order, alpha):
+    """pysptk.sp2mc: c = np.fft.irfft(log P); c[0] /= 2; freqt(c, order, alpha), row-wise.  Power-of-two
+    transform lengths run in C (ko_sp2mc); any other even length (the reference's resampled spectra,
+    kwiiyatta/vocoder/mcep.py:31-45) uses numpy's irfft -- upstream's own transform -- and the C freqt."""
     sp = np.ascontiguousarray(powerspec, dtype=np.float64)
     one = sp.ndim == 1
     sp2 = np.atleast_2d(sp)
     mc = np.zeros((sp2.shape[0], order + 1))
-    lib().ko_sp2mc(_dp(sp2), sp2.shape[0], sp2.shape[1], order, alpha, _dp(mc))
+    if _pow2(2 * (sp2.shape[1] - 1)):
+        lib().ko_sp2mc(_dp(sp2), sp2.shape[0], sp2.shape[1], order, alpha, _dp(mc))
+    else:
+        c = np.ascontiguousarray(np.fft.irfft(np.log(sp2), axis=1))
+        c[:, 0] /= 2.0
+        for t in range(len(c)):
+            lib().ko_freqt(_dp(c[t]), c.shape[1] - 1, _dp(mc[t]), order, alpha)
     return mc[0] if one else mc
 
 
 def mc2sp(mc, alpha, fftlen):
+    """pysptk.mc2sp: c = freqt(mc, fftlen/2, -alpha); c[0] *= 2; mirror; exp(np.fft.rfft(c).real)."""
     mc = np.ascontiguousarray(mc, dtype=np.float64)
     one = mc.ndim == 1
     mc2 = np.atleast_2d(mc)
-    sp = np.zeros((mc2.shape[0], fftlen // 2 + 1))
-    lib().ko_mc2sp(_dp(mc2), mc2.shape[0], mc2.shape[1] - 1, alpha, int(fftlen), _dp(sp))
+    half = int(fftlen) // 2
+    sp = np.zeros((mc2.shape[0], half + 1))
+    if _pow2(int(fftlen)):
+        lib().ko_mc2sp(_dp(mc2), mc2.shape[0], mc2.shape[1] - 1, alpha, int(fftlen), _dp(sp))
+    else:
+        c = np.zeros(half + 1)
+        symc = np.zeros((mc2.shape[0], int(fftlen)))
+        for t in range(len(mc2)):
+            lib().ko_freqt(_dp(mc2[t]), mc2.shape[1] - 1, _dp(c), half, -alpha)
+            symc[t, 0] = 2.0 * c[0]
+            symc[t, 1:half + 1] = c[1:]
+            symc[t, -1:-half - 1:-1] = c[1:]
+        sp = np.exp(np.fft.rfft(symc, axis=1).real)
     return sp[0] if one else sp
 
 

@@ -65,6 +65,25 @@ def test_mcep_48k(ko):
     assert np.max(np.abs(sptk.mc2sp(ref, alpha, 2048) / ko.mc2sp(ref, alpha, 2048) - 1)) <= 1e-11
 
 
+@pytest.mark.parametrize('K,order,alpha', [(372, 24, 0.41), (1024, 24, 0.554), (3078, 36, 0.63), (129, 24, 0.31)])
+def test_mcep_any_length(ko, K, order, alpha):
+    """Spectral lengths that are not 2^n + 1 (the reference's resampled spectra, vocoder/mcep.py:31-45):
+    the dense form of sp2mc / mc2sp against numpy's irfft / rfft + freqt."""
+    from kwiiyatta_amd.backend import sptk
+    rng = np.random.default_rng(K)
+    f = np.linspace(0, 1, K)
+    sp = np.exp(-6 * f[None, :] + 2 * np.cos(9 * f[None, :] + rng.uniform(0, 6, (37, 1)))
+                + 0.3 * rng.standard_normal((37, K))) * 1e-3
+    ref = ko.sp2mc(sp, order, alpha)
+    got = sptk.sp2mc(sp, order, alpha)
+    assert got.shape == ref.shape == (37, order + 1)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    ref2 = ko.mc2sp(ref, alpha, 2 * (K - 1))
+    got2 = sptk.mc2sp(ref, alpha, 2 * (K - 1))
+    assert got2.shape == ref2.shape == (37, K)
+    assert np.max(np.abs(got2 / ref2 - 1)) <= 1e-11
+
+
 def _series(rng, T, dim, warp):
     t = np.linspace(0, 1, T) ** warp
     base = np.stack([np.sin(2 * np.pi * (k + 1) * t * 3 + k) for k in range(dim)], 1)

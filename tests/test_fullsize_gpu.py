@@ -1,0 +1,92 @@
+"""Parity at the sizes bench.py actually times (BASELINE config 3): a 64-component joint GMM over D = 144
+with T = 2201 frames, and one full 10 s + 11 s source/target pair through the HBM-resident PairPipeline,
+every stage against the CPU oracle.  Same criteria as the miniature tests in test_pipeline_gpu.py /
+test_backends_gpu.py (FastDTW path, projection and gathers bit-exact; spectra 1e-8 of the frame maximum;
+aperiodicity 1e-4 absolute; MLPG 1e-9 relative; waveform 1e-9 RMS given identical features)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FS = 48000
+
+
+@pytest.fixture(scope='module')
+def gmm64():
+    from kwiiyatta_amd import pipeline as pl
+    return pl.synthetic_gmm(order=24, components=64, seed=0)
+
+
+@pytest.fixture(scope='module')
+def ko():
+    from oracle import oracle
+    return oracle
+
+
+def _trajectory(T, d, seed):
+    rng = np.random.default_rng(seed)
+    scale = 1.0 / (1.0 + np.arange(d)) ** 0.7
+    walk = np.cumsum(rng.standard_normal((T, d)), axis=0) * 0.05
+    return np.ascontiguousarray((walk - walk.mean(0)) * scale + rng.standard_normal((T, d)) * 0.02 * scale)
+
+
+@pytest.mark.parametrize('diff', [False, True])
+def test_gmm_mlpg_bench_size(ko, gmm64, diff):
+    """kwy_gmm_mlpg with the grid bench.py launches: M = 64, D = 144, T = 2201."""
+    from kwiiyatta_amd.backend import mlpg
+    mc = _trajectory(2201, 24, seed=11)
+    X = mlpg.delta_features(mc, mlpg.DELTA_WINDOWS)
+    ref, mix = ko.gmm_mlpg(mc, gmm64.weights_, gmm64.means_, gmm64.covariances_, diff=diff, return_mix=True)
+    got = mlpg.MLPG(gmm64, windows=mlpg.DELTA_WINDOWS, diff=diff).transform(X)
+    assert got.shape == ref.shape == (2201, 24)
+    assert np.abs(got - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1.0)
+    assert len(np.unique(mix)) >= 4             # the arg-max selection really switches mixtures
+
+
+def test_pair_pipeline_full_size(ko, gmm64):
+    """10 s source (T = 2001) + 11 s target (T = 2201), M = 64: what one bench step does for one pair."""
+    import torch
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.synthetic import make_utterance
+    from kwiiyatta_amd.vocoder.align import project_path_iter
+    src = make_utterance(seed=1234, fs=FS, seconds=10.0)
+    tgt = make_utterance(seed=4321, fs=FS, seconds=10.0, time_warp=1.1, formant_scale=1.12)
+    assert len(src[1]) == 2001 and len(tgt[1]) == 2201
+    dg = pl.DeviceGMM(gmm64.weights_, gmm64.means_, gmm64.covariances_, torch.device('cuda', 0))
+    p = pl.PairPipeline(0, FS, src, tgt, dg)
+    p.run()
+    p.sync()
+    P = pl.PAD_LEN
+    alpha = ko.mcepalpha(FS)
+    for side, (x, f0, t) in ((p.src, src), (p.tgt, tgt)):
+        sp_pad = side.sp_pad.cpu().numpy()
+        ap_pad = side.ap_pad.cpu().numpy()
+        sp_ref = ko.cheaptrick(x, f0, t, FS) / FS
+        d = np.abs(sp_pad[P:P + len(f0)] - sp_ref)
+        assert d.max() <= 1e-8 * sp_ref.max() and d.sum() <= 1e-9 * sp_ref.sum()
+        assert np.abs(ap_pad[P:P + len(f0)] - ko.d4c(x, f0, t, FS)).max() <= 1e-4
+        mc_ref = ko.sp2mc(sp_pad, 24, alpha)
+        mc = side.mc_pad.cpu().numpy()
+        assert np.abs(mc - mc_ref).max() <= 1e-11 * np.abs(mc_ref).max()
+    feat_s, feat_t = p.src.feat.cpu().numpy(), p.tgt.feat.cpu().numpy()
+    d_ref, path_ref = ko.fastdtw(feat_s, feat_t, radius=32, dist=2)
+    n = int(p.path_len.item())
+    assert [tuple(r) for r in p.path.cpu().numpy()[:n].tolist()] == path_ref and p.dist.item() == d_ref
+    idx_ref = list(project_path_iter(np.array(path_ref), trim=True, trim_len=P))
+    idx = p.idx.cpu().numpy()[:p.tgt.T]
+    assert int(p.n_idx.item()) == len(idx_ref) == p.tgt.T and idx.tolist() == idx_ref
+    mc_al = p.mc_al.cpu().numpy()
+    assert np.array_equal(mc_al, p.src.mc_pad.cpu().numpy()[idx])
+    assert np.array_equal(p.ap_al.cpu().numpy(), p.src.ap_pad.cpu().numpy()[idx])
+    y_ref, mix = ko.gmm_mlpg(np.ascontiguousarray(mc_al[:, 1:]), gmm64.weights_, gmm64.means_,
+                             gmm64.covariances_, return_mix=True)
+    assert len(np.unique(mix)) >= 4
+    mc_conv = p.mc_conv.cpu().numpy()
+    assert np.array_equal(mc_conv[:, 0], mc_al[:, 0])
+    assert np.abs(mc_conv[:, 1:] - y_ref).max() <= 1e-9 * max(np.abs(y_ref).max(), 1)
+    sp_conv = p.sp_conv.cpu().numpy()
+    assert np.max(np.abs(sp_conv / ko.mc2sp(mc_conv, alpha, 2048) - 1)) <= 1e-10
+    wave_ref = ko.synthesize(tgt[1], np.ascontiguousarray(sp_conv * FS), p.ap_al.cpu().numpy(), FS, 5.0)
+    wave = p.wave.cpu().numpy()
+    assert len(wave) == len(wave_ref) == 528240
+    assert np.sqrt(np.mean((wave - wave_ref) ** 2)) <= 1e-9

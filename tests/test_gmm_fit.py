@@ -26,8 +26,50 @@ def sklearn_fit(X, M, seed=0, max_iter=100, tol=1e-3):
                            random_state=seed).fit(X)
 
 
-def test_em_driver_matches_sklearn_single_process():
-    """Same initial labels, same loop => sklearn's n_iter, lower bound and parameters."""
+def kmeans_labels(X, M, seed):
+    from sklearn.cluster import KMeans
+    from sklearn.utils import check_random_state
+    km = KMeans(n_clusters=M, n_init=1, random_state=check_random_state(seed)).fit(X)
+    return km.labels_, km.cluster_centers_, km.n_iter_
+
+
+@pytest.mark.parametrize('n,D,M,seed', [(3000, 12, 4, 0), (5000, 30, 16, 1), (2500, 20, 64, 2)])
+def test_kmeans_driver_matches_sklearn(n, D, M, seed):
+    """The k-means initialisation (k-means++ with scikit-learn's random draws, Lloyd) reproduces
+    sklearn.cluster.KMeans(n_init=1) -- what GaussianMixture(init_params='kmeans') runs
+    (kwiiyatta/converter/gmm.py:14-23) -- label for label."""
+    from kwiiyatta_amd.converter.gmm_fit import kmeans_init
+    X = make_data(n, D, min(M, 8), seed=seed)
+    labels, centres, n_iter = kmeans_labels(X, M, seed)
+    st = NumpyStats(X, M)
+    it, c = kmeans_init(st, M, seed)
+    assert it == n_iter
+    assert np.array_equal(st.labels, labels)
+    assert np.abs(c - centres).max() <= 1e-12 * np.abs(centres).max()
+    assert np.array_equal(st.resp.argmax(1), labels) and (st.resp.sum(1) == 1).all()
+
+
+def test_kmeans_empty_cluster_relocation():
+    """More centres than distinct points in a region: Lloyd empties a cluster and it is re-seeded from the row
+    farthest from its centre, as sklearn does."""
+    from kwiiyatta_amd.converter import gmm_fit
+    import torch
+    rng = np.random.default_rng(0)
+    X = np.vstack([rng.standard_normal((200, 3)) * 0.01, rng.standard_normal((200, 3)) * 0.01 + 5])
+    st = NumpyStats(X, 3)
+    st.km_begin(torch.from_numpy(X.mean(0)))
+    centres = torch.from_numpy(np.array([[-2.5, -2.5, -2.5], [2.5, 2.5, 2.5], [50.0, 50, 50]]))
+    st.km_assign(centres)
+    s = st.km_sums()
+    assert s[2, 0] == 0
+    gmm_fit._relocate_empty_clusters(st, gmm_fit.Comm(), s, centres, (s[:, 0] == 0).nonzero().flatten(), 0)
+    assert s[2, 0] == 1 and s[:, 0].sum() == 400
+    far = ((st.Xc - centres.numpy()[st.labels]) ** 2).sum(1).argmax()
+    assert np.array_equal(s[2, 1:].numpy(), st.Xc[far])
+
+
+def test_fit_driver_matches_sklearn_single_process():
+    """Initialisation and EM loop together: sklearn's n_iter, lower bound and parameters."""
     from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
     X = make_data()
     ref = sklearn_fit(X, 4)
@@ -47,30 +89,36 @@ def _free_port():
     return p
 
 
+TWO_RANK = dict(n=4000, D=16, M=12, seed=5, max_iter=30)
+
+
 def _worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
     from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
-    from kwiiyatta_amd.parallel import shard_indices
     from numpy_em_stats import NumpyStats as NS
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    X = make_data()
-    mine = shard_indices(len(X), rank, world)
-    Xl = np.ascontiguousarray(X[mine])
-    g = GaussianMixtureHIP(n_components=4, random_state=0, max_iter=30)
-    g.fit(Xl, stats=NS(Xl, 4))
-    q.put((rank, g.n_iter_, g.lower_bound_, g.weights_, g.means_, g.covariances_))
+    c = TWO_RANK
+    X = make_data(c['n'], c['D'], 6, seed=c['seed'])
+    cut = [0, 1700, c['n']]                      # uneven contiguous shards: global row order = rank order
+    Xl = np.ascontiguousarray(X[cut[rank]:cut[rank + 1]])
+    st = NS(Xl, c['M'])
+    g = GaussianMixtureHIP(n_components=c['M'], random_state=c['seed'], max_iter=c['max_iter'])
+    g.fit(Xl, stats=st)
+    q.put((rank, g.n_iter_, g.lower_bound_, g.weights_, g.means_, g.covariances_, g.kmeans_n_iter_,
+           st.resp.argmax(1) if False else None, g.kmeans_centers_))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_em_two_ranks_gloo():
-    """Frames sharded over 2 ranks, statistics all-reduced: both ranks end with the
-    same model, and it equals the single-process run from the same initial labels."""
+def test_fit_two_ranks_gloo():
+    """Rows sharded over 2 ranks: both ranks end with the same model, and it equals the single-process fit of
+    the whole matrix INCLUDING the k-means initialisation (same seeding draws, same Lloyd iterations), and
+    scikit-learn's own fit."""
     from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
     world = 2
     ctx = mp.get_context('spawn')
@@ -83,27 +131,44 @@ def test_em_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, it0, lb0, w0, m0, c0), (_, it1, lb1, w1, m1, c1) = res
-    assert it0 == it1 and lb0 == lb1
+    (_, it0, lb0, w0, m0, c0, kit0, _, kc0), (_, it1, lb1, w1, m1, c1, kit1, _, kc1) = res
+    assert it0 == it1 and lb0 == lb1 and kit0 == kit1
     assert np.array_equal(w0, w1) and np.array_equal(m0, m1) and np.array_equal(c0, c1)
+    assert np.array_equal(kc0, kc1)
 
-    # single-process reference with the labels the distributed initialisation produces
-    from sklearn.cluster import KMeans
-    from sklearn.utils import check_random_state
-    from kwiiyatta_amd.parallel import shard_indices
-    X = make_data()
-    X0 = X[shard_indices(len(X), 0, world)]
-    centres = KMeans(n_clusters=4, n_init=1, random_state=check_random_state(0)).fit(X0).cluster_centers_
-    labels = ((X ** 2).sum(1)[:, None] - 2 * X @ centres.T + (centres ** 2).sum(1)[None, :]).argmin(1)
+    c = TWO_RANK
+    X = make_data(c['n'], c['D'], 6, seed=c['seed'])
+    one = GaussianMixtureHIP(n_components=c['M'], random_state=c['seed'], max_iter=c['max_iter'])
+    one.fit(X, stats=NumpyStats(X, c['M']))
+    assert one.kmeans_n_iter_ == kit0
+    assert np.abs(one.kmeans_centers_ - kc0).max() <= 1e-12 * np.abs(kc0).max()
+    assert one.n_iter_ == it0 and abs(one.lower_bound_ - lb0) < 1e-10
+    assert np.allclose(one.weights_, w0, rtol=1e-10) and np.allclose(one.means_, m0, rtol=1e-9, atol=1e-12)
+    assert np.allclose(one.covariances_, c0, rtol=1e-8, atol=1e-12)
+    ref = sklearn_fit(X, c['M'], seed=c['seed'], max_iter=c['max_iter'])
+    assert ref.n_iter_ == it0 and abs(ref.lower_bound_ - lb0) < 1e-9
+    assert np.allclose(ref.means_, m0, rtol=1e-7, atol=1e-9)
 
-    class Fixed(GaussianMixtureHIP):
-        def _initial_labels(self, X):
-            return labels
-    ref = Fixed(n_components=4, random_state=0, max_iter=30).fit(X, stats=NumpyStats(X, 4))
-    assert ref.n_iter_ == it0
-    assert abs(ref.lower_bound_ - lb0) < 1e-10
-    assert np.allclose(ref.weights_, w0, rtol=1e-10) and np.allclose(ref.means_, m0, rtol=1e-9, atol=1e-12)
-    assert np.allclose(ref.covariances_, c0, rtol=1e-8, atol=1e-12)
+
+def test_rccl_path_reduces_device_tensors_only():
+    """Under backend 'nccl' a host tensor must never reach all_reduce (RCCL has no CPU backend): the
+    communicator refuses it instead of letting torch.distributed raise half-way through a fit."""
+    from kwiiyatta_amd.converter import gmm_fit
+    import torch
+
+    class FakeDist:
+        class ReduceOp:
+            SUM = 0
+
+        def get_rank(self): return 0
+        def get_world_size(self): return 2
+        def get_backend(self): return 'nccl'
+        def all_reduce(self, t, op=None): raise AssertionError('host tensor reached RCCL')
+
+    c = gmm_fit.Comm.__new__(gmm_fit.Comm)
+    c.dist, c.rank, c.world, c.device_native = FakeDist(), 0, 2, True
+    with pytest.raises(RuntimeError):
+        c.all_reduce(torch.zeros(3))
 
 
 @pytest.mark.gpu
@@ -117,22 +182,108 @@ def test_hip_statistics_match_numpy(n, D, M):
     labels = rng.integers(0, M, n)
     labels[:M] = np.arange(M)
     hs, ns = HipStats(X, M), NumpyStats(X, M)
-    for s in (hs, ns):
-        s.set_resp_from_labels(labels)
-    sh, sn = hs.sums().cpu().numpy(), ns.sums()
-    assert np.allclose(sh, sn, rtol=1e-12, atol=1e-12)
-    hs.means_from(hs.stats)
-    ns.means_from(sn)
-    ch, cn = hs.cov().cpu().numpy(), ns.cov()
-    assert np.allclose(ch, cn, rtol=1e-10, atol=1e-10)
-    hs.finalize(hs.stats, hs.sxx, 1e-3)
-    ns.finalize(sn, cn, 1e-3)
-    wh, mh, covh = hs.get_params()
-    assert np.allclose(wh, ns.weights, rtol=1e-12) and np.allclose(mh, ns.means, rtol=1e-10, atol=1e-12)
-    assert np.allclose(covh, ns.covs, rtol=1e-9, atol=1e-10)
-    llh, lln = hs.estep(), ns.estep()
-    assert abs(llh - lln) <= 1e-9 * abs(lln)
-    assert np.allclose(hs.resp.cpu().numpy(), ns.resp, rtol=1e-7, atol=1e-10)
+    with hs.scope():
+        for s in (hs, ns):
+            s.set_resp_from_labels(labels)
+        sh, sn = hs.sums().cpu().numpy(), ns.sums().numpy()
+        assert np.allclose(sh, sn, rtol=1e-12, atol=1e-12)
+        hs.means_from(hs.stats)
+        ns.means_from(ns.sums())
+        ch, cn = hs.cov().cpu().numpy(), ns.cov().numpy()
+        assert np.allclose(ch, cn, rtol=1e-10, atol=1e-10)
+        hs.finalize(hs.stats, hs.sxx, 1e-3)
+        import torch
+        ns.finalize(torch.from_numpy(sn), torch.from_numpy(cn), 1e-3)
+        wh, mh, covh = hs.get_params()
+        assert np.allclose(wh, ns.weights, rtol=1e-12) and np.allclose(mh, ns.means, rtol=1e-10, atol=1e-12)
+        assert np.allclose(covh, ns.covs, rtol=1e-9, atol=1e-10)
+        llh, lln = float(hs.estep().item()), float(ns.estep().item())
+        assert abs(llh - lln) <= 1e-9 * abs(lln)
+        assert np.allclose(hs.resp.cpu().numpy(), ns.resp, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,D,M,seed', [(3000, 12, 4, 0), (20000, 144, 64, 1), (5000, 97, 130, 2), (300, 8, 3, 3)])
+def test_hip_kmeans_matches_sklearn(n, D, M, seed):
+    """kwy_km_* through the driver against sklearn.cluster.KMeans(n_init=1): same seeds, same labels."""
+    from kwiiyatta_amd.converter.gmm_fit import HipStats, kmeans_init
+    X = make_data(n, D, min(M, 8), seed=seed)
+    labels, centres, n_iter = kmeans_labels(X, M, seed)
+    st = HipStats(X, M)
+    it, c = kmeans_init(st, M, seed)
+    with st.scope():
+        got = st.labels.cpu().numpy()
+        resp = st.resp.cpu().numpy()
+    assert it == n_iter
+    assert np.array_equal(got, labels)
+    assert np.abs(c - centres).max() <= 1e-11 * np.abs(centres).max()
+    assert np.array_equal(resp.argmax(1), labels) and (resp.sum(1) == 1).all() and (resp.max(1) == 1).all()
+
+
+@pytest.mark.gpu
+def test_hip_kmeans_blocks_match_numpy():
+    """the individual k-means blocks against their numpy restatement (shard-local parts: colstats, centring,
+    candidate distances, the cumulative-sum search incl. the not-mine / clipped cases, assignment, update)"""
+    import torch
+    from kwiiyatta_amd.converter.gmm_fit import HipStats
+    n, D, M = 7001, 144, 64
+    X = make_data(n, D, 8, seed=4)
+    hs, ns = HipStats(X, M), NumpyStats(X, M)
+    with hs.scope():
+        s_h, s_n = hs.km_colstats(None).cpu().numpy(), ns.km_colstats(None).numpy()
+        assert np.allclose(s_h, s_n, rtol=1e-12, atol=1e-9)
+        mean = X.mean(0)
+        hs.km_begin(torch.from_numpy(mean).cuda())
+        ns.km_begin(torch.from_numpy(mean))
+        assert np.allclose(hs.Xc.cpu().numpy(), ns.Xc, rtol=0, atol=0)
+        assert np.allclose(hs.xsq.cpu().numpy(), ns.xsq, rtol=1e-13)
+        cand = ns.Xc[[5, 77, 3000, 6999, 12, 4000]]
+        p_h = hs.km_candidates(torch.from_numpy(cand).cuda(), use_closest=False).cpu().numpy()
+        p_n = ns.km_candidates(torch.from_numpy(cand), use_closest=False).numpy()
+        assert np.allclose(p_h, p_n, rtol=1e-12)
+        assert np.allclose(hs.newd[:6].cpu().numpy(), ns.newd, rtol=1e-11, atol=1e-9)
+        best = torch.tensor([2])
+        hs.km_accept(best.cuda())
+        ns.km_accept(best)
+        assert np.array_equal(hs.closest.cpu().numpy(), hs.newd[2].cpu().numpy())
+        tot_h = float(hs.km_closest_total().item())
+        assert abs(tot_h - ns.closest.sum()) <= 1e-12 * tot_h
+        cum = np.cumsum(ns.closest)
+        vals = np.array([0.0, cum[0] * 0.5, cum[10] * (1 - 1e-9), cum[3333] * (1 + 1e-12), cum[-1] * 0.999999, cum[-1] * 1.01])
+        for lo, first, last in ((0.0, True, True), (0.0, True, False), (cum[-1] * 0.25, False, False), (cum[-1] * 0.25, False, True)):
+            want = ns.km_pick(torch.tensor([lo]), torch.from_numpy(vals), first, last).numpy()
+            got = hs.km_pick(torch.tensor([lo]).cuda(), torch.from_numpy(vals).cuda(), first, last).cpu().numpy()
+            assert np.array_equal(got, want), (lo, first, last, got, want)
+        p_h = hs.km_candidates(torch.from_numpy(cand[:3].copy()).cuda(), use_closest=True).cpu().numpy()
+        p_n = ns.km_candidates(torch.from_numpy(cand[:3].copy()), use_closest=True).numpy()
+        assert np.allclose(p_h, p_n, rtol=1e-12)
+        centres = ns.Xc[np.random.default_rng(0).choice(n, M, replace=False)].copy()
+        ch_h = int(hs.km_assign(torch.from_numpy(centres).cuda()).item())
+        ch_n = int(ns.km_assign(torch.from_numpy(centres)).item())
+        assert ch_h == ch_n == n
+        assert np.array_equal(hs.labels.cpu().numpy(), ns.labels)
+        st_h, st_n = hs.km_sums(), ns.km_sums()
+        assert np.allclose(st_h.cpu().numpy(), st_n.numpy(), rtol=1e-12, atol=1e-12)
+        new_h, new_n = torch.empty((M, D), dtype=torch.float64, device='cuda'), torch.empty((M, D), dtype=torch.float64)
+        sh_h = hs.km_update(st_h, torch.from_numpy(centres).cuda(), new_h).cpu().numpy()
+        sh_n = ns.km_update(st_n, torch.from_numpy(centres), new_n).numpy()
+        assert np.allclose(new_h.cpu().numpy(), new_n.numpy(), rtol=1e-12, atol=1e-14) and np.allclose(sh_h, sh_n, rtol=1e-10)
+        assert int(hs.km_assign(torch.from_numpy(centres).cuda()).item()) == 0      # same centres: nothing changes
+
+
+@pytest.mark.gpu
+def test_hip_fit_matches_sklearn_bench_shape():
+    """D = 144, M = 64 (the reference's converter: 2 x 3 x 24 joint dims, 64 components), initialisation
+    included, against sklearn.mixture.GaussianMixture.fit."""
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
+    X = make_data(20000, 144, 8, seed=6)
+    ref = sklearn_fit(X, 64, seed=1, max_iter=8)
+    g = GaussianMixtureHIP(n_components=64, random_state=1, max_iter=8).fit(X)
+    assert g.n_iter_ == ref.n_iter_
+    assert abs(g.lower_bound_ - ref.lower_bound_) < 1e-8 * abs(ref.lower_bound_)
+    assert np.allclose(g.weights_, ref.weights_, rtol=1e-6, atol=1e-10)
+    assert np.allclose(g.means_, ref.means_, rtol=1e-6, atol=1e-8)
+    assert np.allclose(g.covariances_, ref.covariances_, rtol=1e-5, atol=1e-8)
 
 
 @pytest.mark.gpu
