@@ -57,10 +57,6 @@ int kwy_ctx_profile(kwy_ctx *ctx, int enable);
  * clock64() stamps for the workgroup whose index is stored in element 63 (NULL = off). */
 int kwy_ctx_debug_buffer(kwy_ctx *ctx, void *device_buffer);
 int kwy_ctx_profile_read(kwy_ctx *ctx, const char *kernel, double *total_ms, int64_t *count);
-/* Diagnostic only: the block-wide "sum of the m smallest of n" used by D4C's band aperiodicity, on caller data.
- * values: problems x n non-negative doubles (device); out: problems x {sum of the m smallest, sum of all} (device).
- * n <= 2304. */
-int kwy_debug_smallest_sum_dev(kwy_ctx *ctx, const double *values, int problems, int n, int m, double *out);
 const char *kwy_last_error(kwy_ctx *ctx);
 /* error text when kwy_ctx_create itself failed (no context to ask) */
 const char *kwy_create_error(void);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_decode_aperiodicity(const doubl
 
 static int codec_check(kwy_ctx *ctx, const void *a, const void *b, int64_t T, int fs, int fft_size, int nb) {
   if (!ctx) return KWY_EINVAL;
-  if (!a || !b || T <= 0 || fs <= 0 || fft_size < 4 || (fft_size & (fft_size - 1)) || nb < 0 || nb > CODEC_MAX_BANDS) {
+  if (!a || !b || T <= 0 || fs <= 0 || fft_size < 4 || (fft_size & 1) || nb < 0 || nb > CODEC_MAX_BANDS) {
     ctx->err = "aperiodicity codec: bad argument";
     return KWY_EINVAL;
   }

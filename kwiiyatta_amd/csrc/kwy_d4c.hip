@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kwy_internal.hpp"
+#include "kwy_selftest.h"
 
 #define D4C_SAFE 0.000000000001
 #define D4C_FLOOR_F0 47.0
@@ -135,16 +136,17 @@ __global__ void k_d4c_body_counts(const double *__restrict__ f0, const double *_
 
 // ------------------------------------------------------------------ LoveTrain
 // One FFT buffer (in-place transform, pass factors in registers): 33 KB of LDS, four frames per CU.
-template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
+// NT threads: 256, or 512 for the 8192-point transform of 96 kHz (one radix-8 butterfly per thread and pass).
+template <int LOG2N, int NT>
+__global__ __launch_bounds__(NT) void k_d4c_lovetrain(
     const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
     const double *__restrict__ f0, const uint32_t *__restrict__ ebase,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     double *__restrict__ ap0) {
   constexpr int N = 1 << LOG2N, H = N / 2;
-  constexpr int C = N / KWY_THREADS;
-  constexpr int HEX = 16 * KWY_THREADS / N;
-  constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
+  constexpr int C = N / NT;
+  constexpr int HEX = 16 * NT / N;
+  constexpr int RK = (H + 1 + NT - 1) / NT;
   extern __shared__ double smem[];
   double *red = smem;                                 // 8
   uint32_t *e = (uint32_t *)(red + 8);                // KWY_EBASE_WORDS
@@ -163,16 +165,16 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(tpos[frame] * fs + 0.001);
   kwy_c tw4[4];
-  kwy_fft_thread_twiddles<LOG2N - 1, KWY_THREADS>(twH, tw4);
+  kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
   const kwy_c twb = twN[tid];
 
-  for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
+  for (int i = tid; i < KWY_EBASE_WORDS; i += NT) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
   __syncthreads();
   // this thread draws the c noise values [c*tid, c*tid + c) of the frame (c adapts to the window)
-  const int c = (wl + KWY_THREADS - 1) / KWY_THREADS;
-  kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)B);
+  const int c = (wl + NT - 1) / NT;
+  kwy_rng_build_table<NT>(e, (uint4 *)B);
   __syncthreads();
-  kwy_rng rng = kwy_rng_combine_table((const uint4 *)B, poly[(c - 1) * KWY_THREADS + tid]);
+  kwy_rng rng = kwy_rng_combine_table((const uint4 *)B, poly[(c - 1) * NT + tid]);
   __syncthreads();  // the table is consumed: the buffer takes the draws
 #pragma unroll
   for (int j = 0; j < C; ++j) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < C; ++r) {
-    const int i = tid + KWY_THREADS * r;
+    const int i = tid + NT * r;
     double v = 0.0;
     if (i < wl) {
       double w = d4c_window(D4C_BLACKMAN, i, half, 3.0, fs, cf0);
@@ -200,16 +202,16 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
     }
     vv[r] = v;
   }
-  const double t1 = kwy_block_sum(s1, red);
-  const double t2 = kwy_block_sum(s2, red);
+  const double t1 = kwy_block_sum<NT>(s1, red);
+  const double t2 = kwy_block_sum<NT>(s2, red);
   const double coef = t1 / t2;
 #pragma unroll
   for (int r = 0; r < C; ++r) {
-    const int i = tid + KWY_THREADS * r;
+    const int i = tid + NT * r;
     Bd[i] = (i < wl) ? vv[r] - Bd[i] * coef : 0.0;
   }
   __syncthreads();
-  kwy_fft_inplace_w<LOG2N - 1, KWY_THREADS, false>(B, tw4);
+  kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
 
   const int boundary0 = (int)ceil(100.0 * N / fs);
   const int boundary1 = (int)ceil(4000.0 * N / fs);
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
   double c1 = 0.0, c2 = 0.0;
 #pragma unroll
   for (int r = 0; r < RK; ++r) {
-    const int k = tid + KWY_THREADS * r;
+    const int k = tid + NT * r;
     if (k > boundary0 && k <= boundary2 && k <= H) {
       const kwy_c v = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(twb, HEX * r));
       double pw = v.x * v.x + v.y * v.y;
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_lovetrain(
       if (k <= boundary1) c1 += pw;
     }
   }
-  const double n1 = kwy_block_sum(c1, red);
-  const double n2 = kwy_block_sum(c2, red);
+  const double n1 = kwy_block_sum<NT>(c1, red);
+  const double n2 = kwy_block_sum<NT>(c2, red);
   if (tid == 0) ap0[frame] = n1 / n2;
 }
 
@@ -397,26 +399,28 @@ __device__ __forceinline__ kwy_c d4c_opaque(kwy_c v) {
 // second FFT of a centroid, the smoothed power spectrum, the Nuttall window, the FFT pass factors.
 // The spectra themselves never go back to LDS: each thread pulls "its" bins k = tid + NT*r out of the
 // packed half-length transform into registers.
-#define D4C_NT 256
+// 96 kHz (N = 8192): 512 threads and 99 KB, one frame per CU.
+template <int LOG2N>
+struct d4c_nt { static constexpr int value = LOG2N >= 13 ? 512 : 256; };
 template <int LOG2N>
 static constexpr size_t d4c_body_lds() {
-  constexpr int N = 1 << LOG2N, H = N / 2;
+  constexpr int N = 1 << LOG2N, H = N / 2, NT = d4c_nt<LOG2N>::value;
   // tot | red | coarse | e | [jtab when it does not fit A0] | A0 | B (+2 doubles of smoothing overflow)
-  return sizeof(double) * (D4C_NT + 16 + D4C_MAX_BANDS + 2) + sizeof(uint32_t) * KWY_EBASE_WORDS +
-         (LOG2N == 12 ? 0 : 8192) + sizeof(double) * ((H + 2) + (2 * H + 2) + 2) +
+  return sizeof(double) * (NT + 16 + D4C_MAX_BANDS + 2) + sizeof(uint32_t) * KWY_EBASE_WORDS +
+         (LOG2N >= 12 ? 0 : 8192) + sizeof(double) * ((H + 2) + (2 * H + 2) + 2) +
          // the select scratch lives in B; short transforms need room for it
-         ((sizeof(uint32_t) * KWY_SELECT_WORDS(D4C_NT) > sizeof(double) * (2 * H + 4))
-              ? sizeof(uint32_t) * KWY_SELECT_WORDS(D4C_NT) - sizeof(double) * (2 * H + 4) : 0);
+         ((sizeof(uint32_t) * KWY_SELECT_WORDS(NT) > sizeof(double) * (2 * H + 4))
+              ? sizeof(uint32_t) * KWY_SELECT_WORDS(NT) - sizeof(double) * (2 * H + 4) : 0);
 }
 
 template <int LOG2N>
-__global__ __launch_bounds__(D4C_NT, 3) void k_d4c_body(
+__global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d4c_body(
     const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
     const double *__restrict__ ap0, d4c_params p, const uint32_t *__restrict__ ebase,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     const double *__restrict__ nuttall, double *__restrict__ out, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
-  constexpr int NT = D4C_NT;
+  constexpr int NT = d4c_nt<LOG2N>::value;
   constexpr int E = N / NT;                  // window elements per thread
   constexpr int RK = (H + 1 + NT - 1) / NT;  // spectrum bins per thread
   constexpr int HEX = 16 * NT / N;           // 16th-root index step of the bin twiddles
@@ -428,12 +432,12 @@ __global__ __launch_bounds__(D4C_NT, 3) void k_d4c_body(
   double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
   uint32_t *e = (uint32_t *)(coarse + D4C_MAX_BANDS + 2);  // KWY_EBASE_WORDS
   double *jt_own = (double *)(e + KWY_EBASE_WORDS);        // 1024 doubles unless the table fits A0
-  double *A0 = jt_own + (LOG2N == 12 ? 0 : 1024);          // H+2
+  double *A0 = jt_own + (LOG2N >= 12 ? 0 : 1024);          // H+2
   kwy_c *B = (kwy_c *)(A0 + (H + 2));        // H+1 complex (+2 doubles)
   double *Bd = (double *)B;
   double *P = A0, *Dv = A0;
   double *S = Bd;                            // <= 2H+3 doubles
-  uint4 *jtab = (uint4 *)((LOG2N == 12) ? A0 : jt_own);
+  uint4 *jtab = (uint4 *)((LOG2N >= 12) ? A0 : jt_own);
   uint32_t *hist = (uint32_t *)B;            // KWY_SELECT_WORDS(NT), band loop only
 
   const int tid = threadIdx.x;
@@ -637,11 +641,12 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly_multi(ctx, N / KWY_THREADS, KWY_THREADS, &poly));
+  constexpr int NT = d4c_nt<LOG2N>::value;
+  KWY_TRY(kwy_get_poly_multi(ctx, N / NT, NT, &poly));
   size_t lds = sizeof(kwy_c) * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
-  KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N>,
+  KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N, NT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_d4c_lovetrain", hipLaunchKernelGGL(k_d4c_lovetrain<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream,
+  KWY_PROF(ctx, "k_d4c_lovetrain", hipLaunchKernelGGL((k_d4c_lovetrain<LOG2N, NT>), dim3((unsigned)T), dim3(NT), lds, ctx->stream,
                      x, (int)x_length, fs, t, f0, ebase, poly, twH, twN, ap0));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
@@ -656,11 +661,12 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly_multi(ctx, N / D4C_NT, D4C_NT, &poly));
+  constexpr int NT = d4c_nt<LOG2N>::value;
+  KWY_TRY(kwy_get_poly_multi(ctx, N / NT, NT, &poly));
   size_t lds = d4c_body_lds<LOG2N>();
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(D4C_NT), lds, ctx->stream, x, t,
+  KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(NT), lds, ctx->stream, x, t,
                      f0, ap0, p, ebase, poly, twH, twN, nuttall, out, (long long *)ctx->dbg));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
@@ -696,8 +702,8 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   const int n4 = (int)pow(2.0, 1.0 + (int)(log(4.0 * fs / D4C_FLOOR_F0 + 1) / 0.69314718055994529));
   const int nl = (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / 40.0 + 1) / 0.69314718055994529));
   const int l4 = kwy_ilog2(n4), ll = kwy_ilog2(nl);
-  if (l4 < 10 || l4 > 12 || ll < 10 || ll > 12) {
-    ctx->err = "d4c: sampling rate outside the supported range (8 kHz .. 48 kHz)";
+  if (l4 < 10 || l4 > 13 || ll < 10 || ll > 13) {
+    ctx->err = "d4c: sampling rate outside the supported range (8 kHz .. 96 kHz)";
     return KWY_EINVAL;
   }
   d4c_params p;
@@ -732,7 +738,8 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   switch (ll) {
     case 10: KWY_TRY(launch_lt<10>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
     case 11: KWY_TRY(launch_lt<11>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
-    default: KWY_TRY(launch_lt<12>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
+    case 12: KWY_TRY(launch_lt<12>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
+    default: KWY_TRY(launch_lt<13>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
   }
   // general body; its noise continues where the LoveTrain pass stopped (offs_lt[T])
   hipLaunchKernelGGL(k_d4c_body_counts, dim3(gb), dim3(256), 0, ctx->stream, f0, ap0, T, fs,
@@ -745,7 +752,8 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   switch (l4) {
     case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
     case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
-    default: return launch_body<12>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
+    case 12: return launch_body<12>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
+    default: return launch_body<13>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
   }
 }
 
@@ -789,6 +797,8 @@ extern "C" int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, 
   KWY_HIP(hipStreamSynchronize(ctx->stream));
   return KWY_OK;
 }
+
+#define D4C_NT 256   // the self-test below runs the 256-thread select of the 16..48 kHz body
 
 // ---- diagnostic: the "sum of the m smallest" routine of kwy_device.hpp on caller-supplied data -------------
 // (one 256-thread workgroup per problem; out[p] = {sum of the m smallest, sum of all})

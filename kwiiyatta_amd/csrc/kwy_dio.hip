@@ -531,8 +531,9 @@ extern "C" int kwy_dio(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, 
                      dpart, nparts, dy);
   {
     size_t lds = sizeof(double) * (Nlc + DIO_CONV_OUT + Nlc);
-    KWY_HIP(hipFuncSetAttribute((const void *)k_dio_conv, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    if (lds > 64 * 1024) { ctx->err = "dio: low-cut filter too long for this sampling rate"; return KWY_EINVAL; }
+    // 96 kHz: 3841 low-cut taps -> 70 KB; the CU has 160 KB
+    KWY_HIP(hipFuncSetAttribute((const void *)k_dio_conv, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    if (lds > 152 * 1024) { ctx->err = "dio: low-cut filter too long for this sampling rate"; return KWY_EINVAL; }
     hipLaunchKernelGGL(k_dio_conv, dim3((unsigned)((ylen + DIO_CONV_OUT - 1) / DIO_CONV_OUT), 1), dim3(KWY_THREADS),
                        lds, ctx->stream, dy, dtaps, ddesc, dylc);
     size_t lds2 = sizeof(double) * (4 * max_hal + DIO_CONV_OUT + 4 * max_hal);

@@ -154,7 +154,7 @@ def test_gmm_mlpg_errors(clb):
         mlpg.MLPG(G()).transform(np.zeros((5, 2)))
 
 
-@pytest.mark.parametrize('path', [CLB_WAV, SLT_WAV, clb_variant('22'), clb_variant('48')])
+@pytest.mark.parametrize('path', [CLB_WAV, SLT_WAV, clb_variant('22'), clb_variant('48'), clb_variant('96')])
 @pytest.mark.parametrize('frame_period', [5.0, 3.0])
 def test_dio_stonemask(ko, path, frame_period):
     from kwiiyatta_amd.backend import world

@@ -90,7 +90,7 @@ def test_streams_are_independent(pair):
         u.sync()
     torch.cuda.synchronize()
     assert torch.equal(ups[0].sp, ups[2].sp) and torch.equal(ups[0].ap, ups[2].ap)
-    assert (ups[0].wave - ups[2].wave).abs().max().item() <= 1e-12
+    assert torch.equal(ups[0].wave, ups[2].wave)      # the overlap-add has a fixed summation order
     assert ups[1].wave.shape != ups[0].wave.shape
 
 
@@ -143,7 +143,7 @@ def test_align_project_matches_generator(kind):
 
 def test_graph_replay_matches_plain_pass(pair):
     """A pass captured as a HIP graph and replayed (bench.py's default) does the work of the plain pass:
-    same path, same converted features, same waveform up to the order of the overlap-add atomics."""
+    same path, same converted features, same waveform bit for bit."""
     import torch
     from kwiiyatta_amd import pipeline as pl
     fs, src, tgt = pair
@@ -166,5 +166,4 @@ def test_graph_replay_matches_plain_pass(pair):
     assert int(p.path_len.item()) == n
     assert torch.equal(p.path[:n], ref['path'][:n]) and torch.equal(p.idx, ref['idx'])
     assert torch.equal(p.mc_conv, ref['mc_conv']) and torch.equal(p.sp_conv, ref['sp_conv'])
-    w, wr = p.wave.cpu().numpy(), ref['wave'].cpu().numpy()
-    assert np.abs(w - wr).max() <= 1e-12 * max(1.0, np.abs(wr).max())
+    assert torch.equal(p.wave, ref['wave'])

@@ -53,7 +53,7 @@ def check_spectrum(got, ref):
     assert lsd.max() <= 1e-3, lsd.max()
 
 
-CASES = [CLB_WAV, SLT_WAV, clb_variant('22'), clb_variant('44'), clb_variant('48')]
+CASES = [CLB_WAV, SLT_WAV, clb_variant('22'), clb_variant('44'), clb_variant('48'), clb_variant('96')]
 
 
 @pytest.mark.parametrize('path', CASES)
@@ -75,7 +75,7 @@ def test_d4c_parity(ko, kw, path):
     assert np.median(np.abs(got - ref)) <= 1e-6
 
 
-@pytest.mark.parametrize('path', [CLB_WAV, clb_variant('22'), clb_variant('48')])
+@pytest.mark.parametrize('path', [CLB_WAV, clb_variant('22'), clb_variant('48'), clb_variant('96')])
 def test_synthesis_parity(ko, kw, path):
     fs, x = load(path)
     f0, t = f0_track(ko, x, fs)
@@ -85,6 +85,22 @@ def test_synthesis_parity(ko, kw, path):
     rms = np.sqrt(np.mean((got - ref) ** 2))
     assert rms <= 1e-9, rms
     assert np.abs(got - ref).max() <= 1e-8
+
+
+def test_synthesis_is_deterministic(ko, kw):
+    """Two runs give the same bits (ordered overlap-add, no floating-point atomics): what the reference asserts
+    with `(analyzer_wav.data == feature_wav.data).all()`, tests/kwiiyatta/test_vocoder.py:171."""
+    fs, x = load(clb_variant('48'))
+    f0, t = f0_track(ko, x, fs)
+    sp, ap = kw.cheaptrick(x, f0, t, fs), kw.d4c(x, f0, t, fs)
+    first = kw.synthesize(f0, sp, ap, fs, 5.0)
+    for _ in range(3):
+        assert np.array_equal(kw.synthesize(f0, sp, ap, fs, 5.0), first)
+    # many more pulses than items per tile: f0 near the upper limit
+    f0h = np.full_like(f0, 3000.0)
+    a = kw.synthesize(f0h, sp, ap, fs, 5.0)
+    assert np.array_equal(a, kw.synthesize(f0h, sp, ap, fs, 5.0))
+    assert np.sqrt(np.mean((a - ko.synthesize(f0h, sp, ap, fs, 5.0)) ** 2)) <= 1e-9
 
 
 def test_analysis_synthesis_end_to_end_rms(ko, kw):
