@@ -801,8 +801,8 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
                       int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length,
                       double *y) {
   const int log2n = kwy_ilog2(fft_size);
-  if ((1 << log2n) != fft_size || log2n < 9 || log2n > 12) {
-    ctx->err = "synthesize: fft_size must be a power of two in [512, 4096]";
+  if ((1 << log2n) != fft_size || log2n < 9 || log2n > 13) {
+    ctx->err = "synthesize: fft_size must be a power of two in [512, 8192]";
     return KWY_EINVAL;
   }
   KWY_HIP(hipMemsetAsync(y, 0, sizeof(double) * y_length, ctx->stream));
@@ -856,7 +856,10 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
     case 9: return launch_pulse<9>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
     case 10: return launch_pulse<10>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
     case 11: return launch_pulse<11>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
-    default: return launch_pulse<12>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
+    case 12: return launch_pulse<12>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
+    // 8192: features resampled up to 96 kHz (3078 bins -> 4097, kwiiyatta/vocoder/world.py:71-78); rare, runs
+    // with the 256-thread layout of the shorter transforms (register spills accepted)
+    default: return launch_pulse<13>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
   }
 }
 
