@@ -259,6 +259,34 @@ int kwy_km_assign_dev(kwy_ctx *ctx, const double *Xc, int64_t n, int D, const do
 int kwy_km_update_dev(kwy_ctx *ctx, const double *stats, const double *centers_old, int M, int D,
                       double *centers_new, double *shift2);
 
+/* ---- training-set path (device-resident) ---------------------------------------------------------
+ * What the reference does per parallel pair before the converter fit (Config.load_dataset ->
+ * align_dataset -> MelCepstrumDataset -> DeltaFeatureDataset -> make_dataset_to_array,
+ * kwiiyatta/config.py:83-104, converter/__init__.py:17-18, converter/dataset.py:49-77), as device
+ * calls so that the joint feature rows are produced in HBM.  Counts that depend on the data
+ * (path length, kept rows) are device scalars; buffers are sized by their capacities. */
+/* TrimmedDataset (dataset.py:49-52): n_out[0] = len(trim_zeros_frames(sp)), rows with L1 norm < eps
+ * (nnmnkwii: 1e-7) counting as zero; the caller keeps the FIRST n_out frames, as the reference does */
+int kwy_trim_length_dev(kwy_ctx *ctx, const double *sp, int64_t T, int K, double eps, int64_t *n_out);
+/* WorldSynthesizer.extract_is_voiced (world.py:147-151): voiced[t] = 1.0 / 0.0 */
+int kwy_is_voiced_dev(kwy_ctx *ctx, const double *f0, const double *ap, int64_t T, int K, int fs,
+                      double *voiced);
+/* dtw_feature's strict filter (align.py:73-92) and align_even's cut to [pad_len, T - pad_len)
+ * (align.py:134-146) on a FastDTW path over the DTW features feat_x (Tx x width) / feat_y:
+ * idx_x / idx_y <- the x and y of the surviving cells, n_out[0] their number (<= capacity). */
+int kwy_align_even_dev(kwy_ctx *ctx, const int32_t *path, const int64_t *path_len, const double *feat_x,
+                       const double *feat_y, int width, int strict, int use_power, int use_vuv, int64_t Tx,
+                       int64_t Ty, int pad_len, int32_t *idx_x, int32_t *idx_y, int64_t capacity,
+                       int64_t *n_out);
+/* nnmnkwii delta_features(x, DELTA_WINDOWS) (delta.py:8-12,30): x: n[0] x d (device count, <= capacity
+ * rows allocated) -> out: n x 3d = [static | delta | delta-delta], zero-padded at both ends */
+int kwy_delta_features_dev(kwy_ctx *ctx, const double *x, const int64_t *n, int64_t capacity, int d,
+                           double *out);
+/* make_dataset_to_array's np.hstack + remove_zeros_frames (dataset.py:61-77): joint <- [xd[t] | yd[t]]
+ * for the rows t < n[0] with L1 norm >= eps, in order; n_out[0] = rows written */
+int kwy_joint_rows_dev(kwy_ctx *ctx, const double *xd, const double *yd, const int64_t *n, int64_t capacity,
+                       int width, double eps, double *joint, int64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,12 @@ SIGNATURES = {
     'kwy_gmm_em_cov_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'kwy_gmm_em_finalize_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_vp, c_vp]),
     'kwy_gmm_em_scratch_bytes': (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
+    'kwy_trim_length_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
+    'kwy_is_voiced_dev': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    'kwy_align_even_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int,
+                                   c_vp, c_vp, c_i64, c_vp]),
+    'kwy_delta_features_dev': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+    'kwy_joint_rows_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_dbl, c_vp, c_vp]),
     'kwy_km_colstats_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp]),
     'kwy_km_center_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
     'kwy_km_pp_dist_dev': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),

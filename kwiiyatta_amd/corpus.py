@@ -1,0 +1,272 @@
+"""Corpus-level path (BASELINE config 5): a parallel corpus -> joint training matrix in HBM -> converter
+fit -> batch conversion, without the features ever visiting the host.
+
+What the reference does for `kwiiyatta --source A --target B files...`
+(/root/reference/kwiiyatta/config.py:83-104, convert_voice.py:6-46):
+
+  per pair    analyse both sides; TrimmedDataset; align_even (pad 100 silent frames, DTW features with
+              vuv='voiced' and a binarised power term, FastDTW radius 32, strict path filter, cut to the
+              un-padded stretch); mel-cepstra of the aligned frames without c0; delta features;
+              np.hstack + remove_zeros_frames; rows appended to one array (make_dataset_to_array)
+  fit         GaussianMixture(n_components, covariance_type='full', max_iter=100, random_state=seed)
+  per file    analyse; convert the mel-cepstrum (delta + GMM posterior + MLPG, c0 kept); synthesise
+
+Here every pair runs on its own HIP stream (`TrainPair`), ranks take contiguous blocks of pairs (the global
+row order is the pair order whatever the number of ranks), the rows land in one device tensor that
+`GaussianMixtureHIP.fit` uses as its shard, and the fitted model converts utterances stream-parallel
+(`ConvertPipeline`).  The only collectives are those of the fit.
+
+The silence padding of `align_even` draws from numpy's GLOBAL legacy generator in the reference
+(kwiiyatta/vocoder/world.py:158-161, quirk kept): the draws are made on the host, in the reference's order
+(source head, source tail, target head, target tail, pair after pair), and uploaded once per pair -- so this path
+and the Python API path produce the same matrix under `np.random.seed`.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, c_vp
+from .pipeline import EPS, PAD_LEN, POWER_THRESHOLD, POWER_WEIGHT, SAFE_GUARD_MINIMUM, VUV_WEIGHT, DeviceGMM, _Graphed
+
+TRIM_EPS = 1e-7       # nnmnkwii trim_zeros_frames / remove_zeros_frames
+
+
+def _p(t):
+    return c_vp(t.data_ptr())
+
+
+def draw_silence(fs, K, frame_len=PAD_LEN):
+    """WorldSynthesizer._silence_spectrum_envelope: |N(0, EPS / fs)| from numpy's global generator."""
+    return np.abs(np.random.normal(0, EPS / fs, (frame_len, K)))
+
+
+class _TrainSide:
+    def __init__(self, x, f0, t, fs, K, order, dev):
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.N, self.T = len(x), len(f0)
+        self.x = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        self.f0 = torch.from_numpy(np.ascontiguousarray(f0)).to(dev)
+        self.t = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+        Tp = self.T + 2 * PAD_LEN
+        self.sp_pad = torch.empty((Tp, K), **f64)
+        self.ap_pad = torch.full((Tp, K), 1 - SAFE_GUARD_MINIMUM, **f64)
+        self.f0_pad = torch.zeros(Tp, **f64)
+        self.n_keep_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.n = None          # frames kept by TrimmedDataset (host int, after analyse + sync)
+
+    @property
+    def sp(self):
+        return self.sp_pad[PAD_LEN:PAD_LEN + self.T]
+
+    @property
+    def ap(self):
+        return self.ap_pad[PAD_LEN:PAD_LEN + self.T]
+
+
+class TrainPair:
+    """One parallel pair -> its rows of the training matrix, on one stream.
+
+        p.analyse()   enqueue CheapTrick + D4C of both sides and the trim lengths
+        p.align()     (reads the two trim lengths: one 16-byte D2H) enqueue everything else
+        p.rows()      (synchronises) the pair's joint rows, an (n, 2*3*order) device tensor
+    """
+
+    def __init__(self, device_index, fs, source, target, order=24, radius=32, frame_period=5.0, stream=None,
+                 silence=None):
+        self.dev = torch.device('cuda', device_index)
+        self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
+        self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
+        self.K = self.fft // 2 + 1
+        from .backend import sptk
+        self.alpha = sptk.mcepalpha(self.fs)
+        if silence is None:        # the reference's order of draws: source head, source tail, target head, tail
+            silence = [draw_silence(self.fs, self.K) for _ in range(4)]
+        with torch.cuda.stream(self.stream):
+            self.src = _TrainSide(*source, self.fs, self.K, order, self.dev)
+            self.tgt = _TrainSide(*target, self.fs, self.K, order, self.dev)
+            self.silence = [torch.from_numpy(np.ascontiguousarray(s)).to(self.dev) for s in silence]
+        self.frames = self.src.T
+        self.n_rows = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.joint = None
+
+    def _chk(self, rc):
+        _lib.check(self.ctx, rc)
+
+    def analyse(self):
+        h, fs, fft, K = self.ctx.handle, self.fs, self.fft, self.K
+        with torch.cuda.stream(self.stream):
+            for s in (self.src, self.tgt):
+                self._chk(lib.kwy_cheaptrick_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, -0.15, 71.0, fft,
+                                                 float(fs), _p(s.sp)))
+                self._chk(lib.kwy_d4c_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft, _p(s.ap)))
+                self._chk(lib.kwy_trim_length_dev(h, _p(s.sp), s.T, K, TRIM_EPS, _p(s.n_keep_dev)))
+
+    def align(self):
+        h, fs, K, order, P = self.ctx.handle, self.fs, self.K, self.order, PAD_LEN
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        with torch.cuda.stream(self.stream):
+            keep = torch.cat((self.src.n_keep_dev, self.tgt.n_keep_dev)).cpu().tolist()   # waits for the analysis
+            for s, n, sil in ((self.src, keep[0], self.silence[:2]), (self.tgt, keep[1], self.silence[2:])):
+                s.n = int(n)
+                s.Tp = s.n + 2 * P
+                # pad_silence on the first n frames (TrimmedDataset keeps feature[:n])
+                s.sp_pad[:P].copy_(sil[0])
+                s.sp_pad[P + s.n:s.Tp].copy_(sil[1])
+                s.ap_pad[P + s.n:s.Tp].fill_(1 - SAFE_GUARD_MINIMUM)
+                s.f0_pad[P:P + s.n].copy_(s.f0[:s.n])
+                s.voiced = torch.empty(s.Tp, **f64)
+                s.mc_pad = torch.empty((s.Tp, order + 1), **f64)
+                s.feat = torch.empty((s.Tp, order + 2), **f64)
+                self._chk(lib.kwy_is_voiced_dev(h, _p(s.f0_pad), _p(s.ap_pad), s.Tp, K, fs, _p(s.voiced)))
+                self._chk(lib.kwy_sp2mc_dev(h, _p(s.sp_pad), s.Tp, K, order, self.alpha, _p(s.mc_pad)))
+                # make_feature(vuv='voiced', power='binalize', power_pivot='max')
+                self._chk(lib.kwy_align_features_dev(h, _p(s.mc_pad), s.Tp, order + 1, _p(s.voiced), POWER_WEIGHT,
+                                                     POWER_THRESHOLD, VUV_WEIGHT, _p(s.feat)))
+            a, b = self.src, self.tgt
+            cap = a.Tp + b.Tp + 2
+            self.cap = cap
+            self.path = torch.zeros((cap, 2), **i32)
+            self.path_len = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self.dist = torch.zeros(1, **f64)
+            self.idx_x, self.idx_y = torch.zeros(cap, **i32), torch.zeros(cap, **i32)
+            self.n_sel = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self._chk(lib.kwy_fastdtw_dev(h, _p(a.feat), a.Tp, _p(b.feat), b.Tp, order + 2, self.radius, _p(self.dist),
+                                          _p(self.path), _p(self.path_len)))
+            # dtw_feature(strict=True) + align_even's cut
+            self._chk(lib.kwy_align_even_dev(h, _p(self.path), _p(self.path_len), _p(a.feat), _p(b.feat), order + 2,
+                                             1, 1, 1, a.Tp, b.Tp, P, _p(self.idx_x), _p(self.idx_y), cap,
+                                             _p(self.n_sel)))
+            halves = []
+            for s, idx in ((a, self.idx_x), (b, self.idx_y)):
+                mc_sel = torch.empty((cap, order + 1), **f64)
+                self._chk(lib.kwy_gather_rows_dev(h, _p(s.mc_pad), s.Tp, order + 1, _p(idx), cap, _p(mc_sel)))
+                static = mc_sel[:, 1:].contiguous()                        # drop the power coefficient
+                delta = torch.empty((cap, 3 * order), **f64)
+                self._chk(lib.kwy_delta_features_dev(h, _p(static), _p(self.n_sel), cap, order, _p(delta)))
+                halves.append(delta)
+            self.joint = torch.empty((cap, 6 * order), **f64)
+            self._chk(lib.kwy_joint_rows_dev(h, _p(halves[0]), _p(halves[1]), _p(self.n_sel), cap, 3 * order, TRIM_EPS,
+                                             _p(self.joint), _p(self.n_rows)))
+            self._halves = halves        # alive until the stream is done with them
+
+    def rows(self):
+        with torch.cuda.stream(self.stream):
+            n = int(self.n_rows.item())
+            return self.joint[:n]
+
+
+class ConvertPipeline(_Graphed):
+    """convert_voice.convert(diffvc=False) of one utterance, HBM-resident: analyse -> mel-cepstrum -> GMM/MLPG
+    conversion (c0 kept) -> spectrum -> synthesis with the utterance's own f0 and aperiodicity."""
+
+    def __init__(self, device_index, fs, utterance, gmm, order=24, frame_period=5.0, stream=None):
+        self.dev = torch.device('cuda', device_index)
+        self.fs, self.order, self.frame_period = int(fs), int(order), float(frame_period)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
+        self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
+        self.K = self.fft // 2 + 1
+        from .backend import sptk
+        self.alpha = sptk.mcepalpha(self.fs)
+        self.gmm = gmm
+        assert gmm.D2 == 6 * order
+        with torch.cuda.stream(self.stream):
+            self.gmm_model = gmm.model(diff=False)
+        x, f0, t = utterance
+        self.N, self.T = len(x), len(f0)
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        with torch.cuda.stream(self.stream):
+            self.x, self.f0, self.t = (torch.from_numpy(np.ascontiguousarray(a)).to(self.dev) for a in (x, f0, t))
+            self.sp = torch.empty((self.T, self.K), **f64)
+            self.ap = torch.empty((self.T, self.K), **f64)
+            self.mc = torch.empty((self.T, order + 1), **f64)
+            self.mc_x = torch.empty((self.T, order), **f64)
+            self.mc_y = torch.empty((self.T, order), **f64)
+            self.mc_conv = torch.empty((self.T, order + 1), **f64)
+            self.sp_conv = torch.empty((self.T, self.K), **f64)
+            self.ylen = lib.kwy_synth_length(self.T, self.frame_period, self.fs)
+            self.wave = torch.empty(self.ylen, **f64)
+        self.stream.synchronize()
+        self.frames = self.T
+
+    def run(self):
+        h, fs, fft, K, order, T = self.ctx.handle, self.fs, self.fft, self.K, self.order, self.T
+        chk = lambda rc: _lib.check(self.ctx, rc)  # noqa: E731
+        with torch.cuda.stream(self.stream):
+            chk(lib.kwy_cheaptrick_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), T, -0.15, 71.0, fft,
+                                       float(fs), _p(self.sp)))
+            chk(lib.kwy_d4c_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), T, 0.85, fft, _p(self.ap)))
+            chk(lib.kwy_sp2mc_dev(h, _p(self.sp), T, K, order, self.alpha, _p(self.mc)))
+            self.mc_x.copy_(self.mc[:, 1:])
+            chk(lib.kwy_gmm_mlpg_model_dev(h, _p(self.mc_x), T, order, self.gmm.M, _p(self.gmm_model), _p(self.mc_y)))
+            self.mc_conv[:, 0].copy_(self.mc[:, 0])
+            self.mc_conv[:, 1:].copy_(self.mc_y)
+            chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), T, order, self.alpha, fft, _p(self.sp_conv)))
+            chk(lib.kwy_synthesize_dev(h, _p(self.f0), T, _p(self.sp_conv), _p(self.ap), fft, self.frame_period, fs,
+                                       float(fs), self.ylen, _p(self.wave)))
+
+    def sync(self):
+        self.ctx.sync()
+
+
+def shard_block(n_items, rank, world_size):
+    """Contiguous block of items for `rank`: the concatenation over ranks is the original order."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f'rank {rank} outside world of size {world_size}')
+    lo = n_items * rank // world_size
+    hi = n_items * (rank + 1) // world_size
+    return list(range(lo, hi))
+
+
+def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_period=5.0, streams=16,
+                          silence_for=None):
+    """pairs: list of ((x, f0, t), (x, f0, t)) numpy triples of THIS rank, in corpus order.  Returns the
+    (n, 2*3*order) float64 device tensor of make_dataset_to_array and the number of source frames analysed.
+    Pairs are processed `streams` at a time, each on its own stream."""
+    dev = torch.device('cuda', device_index)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))]
+    blocks, frames = [], 0
+    for w0 in range(0, len(pairs), len(pool)):
+        wave = []
+        for k, (src, tgt) in enumerate(pairs[w0:w0 + len(pool)]):
+            sil = silence_for(w0 + k) if silence_for is not None else None
+            wave.append(TrainPair(device_index, fs, src, tgt, order=order, radius=radius, frame_period=frame_period,
+                                  stream=pool[k], silence=sil))
+        for p in wave:
+            p.analyse()
+        for p in wave:
+            p.align()
+        for p in wave:
+            blocks.append(p.rows().clone())      # the clone is enqueued on the default stream after rows() has synchronised
+            frames += p.frames
+        torch.cuda.synchronize(dev)
+    if not blocks:
+        return torch.empty((0, 6 * order), dtype=torch.float64, device=dev), 0
+    return torch.cat(blocks).contiguous(), frames
+
+
+def fit_converter(X, components=64, seed=None, max_iter=100, device_index=0, verbose=0):
+    """GMMFeatureConverter._train on the device-resident matrix (this rank's shard)."""
+    from .converter.gmm_fit import GaussianMixtureHIP
+    return GaussianMixtureHIP(n_components=components, max_iter=max_iter, random_state=seed, verbose=verbose,
+                              device_index=device_index).fit(X)
+
+
+def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16):
+    """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors)."""
+    dev = torch.device('cuda', device_index)
+    dg = DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
+    pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))]
+    out = []
+    for w0 in range(0, len(utterances), len(pool)):
+        wave = [ConvertPipeline(device_index, fs, u, dg, order=order, frame_period=frame_period, stream=pool[k])
+                for k, u in enumerate(utterances[w0:w0 + len(pool)])]
+        for p in wave:
+            p.run()
+        for p in wave:
+            p.sync()
+            out.append(p.wave)
+    return out

@@ -25,14 +25,12 @@
 #define SYN_TILE_PER_THREAD 4
 #define SYN_TILE (KWY_THREADS * SYN_TILE_PER_THREAD)
 #define SYN_TWO_PI (2.0 * KWY_PI)
-// Overlap-add without atomics: the pulses of one SYN_TILE-sample stretch are dealt to at most SYN_MAXC work
-// items (consecutive runs of at least SYN_G0 pulses); an item adds its responses, in pulse order, into an LDS
-// accumulator of SYN_TILE + fft_size samples and stores it as one slot of `part`; k_syn_ola then sums, per
-// output sample, the slots that reach it in (tile, item) order.  Every sum has a fixed order: two runs give
-// the same bits (the reference asserts exactly that, tests/kwiiyatta/test_vocoder.py:171).
-#define SYN_MAXC 4
-#define SYN_G0 4
-__device__ __forceinline__ int syn_item_size(int cnt) { return max(SYN_G0, (cnt + SYN_MAXC - 1) / SYN_MAXC); }
+// Overlap-add without atomics: a pulse's response (fft_size samples) goes to its own slot of a response buffer;
+// k_syn_ola then adds, per output sample, the responses that reach it IN PULSE ORDER -- the order of the serial
+// reference loop.  Every sum has a fixed order: two runs give the same bits (the reference asserts exactly that,
+// tests/kwiiyatta/test_vocoder.py:171).  The buffer holds SYN_SLOTS(y_length) pulses (every signal whose f0 stays
+// at or below the 500 Hz of unvoiced stretches fits); more pulses take further rounds of the two kernels.
+#define SYN_SLOTS(y_length) ((y_length) / 96 + 64)
 
 struct syn_params {
   int64_t T, y_length;
@@ -516,45 +514,36 @@ __device__ __forceinline__ double syn_safe_ap(double x) {
   return fmax(0.001, fmin(0.999999999999, x));
 }
 
-// One work item (a run of pulses of one tile) per workgroup iteration.  LDS: one FFT buffer (in-place
-// transforms), a small twiddle table and the overlap-add accumulator -- 43 KB at 48 kHz, two workgroups per CU
-// (by registers: the interpolated envelope / aperiodic ratio of the thread's bins k = tid + 256 r and the noise
-// spectrum wait in registers while the buffer computes the minimum-phase responses).
+// One pulse per workgroup iteration; its response goes to slot (pulse - first_pulse) of `resp`.  LDS: one FFT buffer (in-place transforms), the
+// interpolated envelope / aperiodic ratio rows, a small twiddle table -- 35 KB at 48 kHz, four
+// workgroups per CU.  The noise spectrum waits in registers (bins tid + 256 r) while the
+// buffer computes the aperiodic minimum-phase response.
 template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS, 2) void k_syn_pulse(
+__global__ __launch_bounds__(KWY_THREADS, 3) void k_syn_pulse(
     const double *__restrict__ sp, const double *__restrict__ ap, syn_params p,
     const int32_t *__restrict__ pidx, const double *__restrict__ pshift,
     const unsigned char *__restrict__ vuv8, const int *__restrict__ npulse, int cap,
     const uint32_t *__restrict__ ebase, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    const double *__restrict__ dc_remover, const int *__restrict__ tile_off, int nt,
-    double *__restrict__ part) {
+    const double *__restrict__ dc_remover, int first_pulse, int slots, double *__restrict__ resp) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   constexpr int C = N / KWY_THREADS;  // draws / output samples per thread
   constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
   constexpr int TWL = (H / 8 > 1) ? H / 8 : 1;
-  constexpr int SPAN = SYN_TILE + N;       // samples an item's pulses can reach
   extern __shared__ double smem[];
   double *red = smem;                      // 8
   uint32_t *e = (uint32_t *)(red + 8);     // KWY_EBASE_WORDS
   kwy_c *twl = (kwy_c *)(e + KWY_EBASE_WORDS);  // exp(-2 pi i k / H), k < H/8
   kwy_c *buf = twl + TWL;                  // H+1 complex
-  double *acc = (double *)(buf + (H + 1)); // SPAN
-  double *ratio0 = acc + SPAN;             // 1: the aperiodic ratio of bin 0, for every thread
+  double *env = (double *)(buf + (H + 1)); // K
+  double *ratio = env + K + 1;             // K
 
   const int tid = threadIdx.x;
   for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
   const kwy_c twb = twN[tid];
   const int P = min(npulse[0], cap);
-  for (int it = blockIdx.x; it < nt * SYN_MAXC; it += gridDim.x) {
-   const int tile = it / SYN_MAXC, chunk = it - tile * SYN_MAXC;
-   const int t0 = min(tile_off[tile], P), t1 = tile + 1 < nt ? min(tile_off[tile + 1], P) : P;
-   const int gsz = syn_item_size(t1 - t0);
-   const int q0 = t0 + chunk * gsz, q1 = min(t1, q0 + gsz);
-   if (q0 >= q1) continue;   // uniform: no pulses for this item
-   __syncthreads();
-   for (int i = threadIdx.x; i < SPAN; i += KWY_THREADS) acc[i] = 0.0;
-   for (int pp = q0; pp < q1; ++pp) {
+  const int pend = min(P, first_pulse + slots);    // this round's pulses
+  for (int pp = first_pulse + blockIdx.x; pp < pend; pp += gridDim.x) {
     const int tid = kwy_tid_opaque();  // keeps address arithmetic local to the pulse (no spills across the FFTs)
     const int idx = pidx[pp];
     const int nxt = pidx[min(P - 1, pp + 1)];
@@ -576,37 +565,28 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_syn_pulse(
     const double interpolation = current_time / p.frame_period - fl;
     const double *s0 = sp + (int64_t)fl * K, *s1 = sp + (int64_t)ce * K;
     const double *a0 = ap + (int64_t)fl * K, *a1 = ap + (int64_t)ce * K;
-    double env[RK], ratio[RK];   // bins k = tid + 256 r
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + KWY_THREADS * r;
-      double ev = 1.0, rv = 1.0;
-      if (k < K) {
-        if (fl == ce) {
-          ev = fabs(s0[k] * p.sp_mul);
-          rv = syn_safe_ap(a0[k]);
-        } else {
-          ev = (1.0 - interpolation) * fabs(s0[k] * p.sp_mul) + interpolation * fabs(s1[k] * p.sp_mul);
-          rv = (1.0 - interpolation) * syn_safe_ap(a0[k]) + interpolation * syn_safe_ap(a1[k]);
-        }
+    for (int k = tid; k < K; k += KWY_THREADS) {
+      double ev, rv;
+      if (fl == ce) {
+        ev = fabs(s0[k] * p.sp_mul);
+        rv = syn_safe_ap(a0[k]);
+      } else {
+        ev = (1.0 - interpolation) * fabs(s0[k] * p.sp_mul) + interpolation * fabs(s1[k] * p.sp_mul);
+        rv = (1.0 - interpolation) * syn_safe_ap(a0[k]) + interpolation * syn_safe_ap(a1[k]);
       }
-      env[r] = ev;
-      ratio[r] = rv * rv;
+      env[k] = ev;
+      ratio[k] = rv * rv;
     }
-    if (tid == 0) ratio0[0] = ratio[0];
     __syncthreads();
 
     // ---- periodic response (kept in registers: sample i = tid + 256*m)
     double per[C];
 #pragma unroll
     for (int m = 0; m < C; ++m) per[m] = 0.0;
-    if (current_vuv > 0.5 && !(ratio0[0] > 0.999)) {
+    if (current_vuv > 0.5 && !(ratio[0] > 0.999)) {
       double *L = (double *)buf;
-#pragma unroll
-      for (int r = 0; r < RK; ++r) {
-        const int k = tid + KWY_THREADS * r;
-        if (k <= H) L[k] = log(env[r] * (1.0 - ratio[r]) + SYN_SAFE) / 2.0;
-      }
+      for (int k = tid; k <= H; k += KWY_THREADS)
+        L[k] = log(env[k] * (1.0 - ratio[k]) + SYN_SAFE) / 2.0;
       syn_min_phase<LOG2N>(buf, twl, twb, twN);
       const double coefficient = 2.0 * KWY_PI * shift * p.fs / N;
       for (int k = tid; k <= H; k += KWY_THREADS) {
@@ -668,10 +648,10 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_syn_pulse(
       }
       __syncthreads();
       double *L = (double *)buf;
-#pragma unroll
-      for (int r = 0; r < RK; ++r) {
-        const int k = tid + KWY_THREADS * r;
-        if (k <= H) L[k] = (current_vuv != 0.0 ? log(env[r] * ratio[r]) : log(env[r])) / 2.0;
+      if (current_vuv != 0.0) {
+        for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k] * ratio[k]) / 2.0;
+      } else {
+        for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k]) / 2.0;
       }
       syn_min_phase<LOG2N>(buf, twl, twb, twN);
 #pragma unroll
@@ -685,52 +665,56 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_syn_pulse(
       kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
       const double *w = (const double *)buf;
       const double sqrt_noise_size = sqrt((double)noise_size);
-      double *a = acc + (idx - tile * SYN_TILE);   // sample i of the response lands at idx - H + 1 + i
+      double *slot = resp + (size_t)(pp - first_pulse) * N;   // sample i lands at idx - H + 1 + i
 #pragma unroll
       for (int m = 0; m < C; ++m) {
         int i = tid + KWY_THREADS * m;
         double aper = (i < H) ? w[i + H] : w[i - H];
-        a[i] += (per[m] * sqrt_noise_size + aper) / N;   // one thread per position; pulses are barriers apart
+        slot[i] = (per[m] * sqrt_noise_size + aper) / N;
       }
     }
-   }
-   __syncthreads();
-   double *slot = part + (size_t)it * SPAN;
-   for (int i = threadIdx.x; i < SPAN; i += KWY_THREADS) slot[i] = acc[i];
   }
 }
 
-// y[n] = sum of the item slots that reach sample n, in (tile, item) order.  Slot (tile, c) holds the samples
-// tile * SYN_TILE - H + 1 + q, q < SYN_TILE + N.
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_ola(const double *__restrict__ part,
+
+// y[n] (+)= the responses of this round's pulses that reach sample n, in pulse order.  The pulses of the
+// SYN_TILE-sample tiles within `reach` tiles of the output tile are candidates (tile_off: first pulse of a tile).
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_ola(const double *__restrict__ resp,
+                                                        const int32_t *__restrict__ pidx,
                                                         const int *__restrict__ tile_off,
                                                         const int *__restrict__ npulse, int cap, int nt, int N,
-                                                        int64_t y_length, double *__restrict__ y) {
-  const int H = N / 2, span = SYN_TILE + N;
+                                                        int first_pulse, int slots, int64_t y_length,
+                                                        double *__restrict__ y) {
+  const int H = N / 2;
   const int tile = blockIdx.x;
   const int P = min(npulse[0], cap);
+  if (first_pulse >= P && first_pulse > 0) return;     // a round without pulses leaves y alone
   const int reach = (H + SYN_TILE - 1) / SYN_TILE;
+  const int ja = max(0, tile - reach), jb = min(nt - 1, tile + reach);
+  int p0 = min(tile_off[ja], P), p1 = jb + 1 < nt ? min(tile_off[jb + 1], P) : P;
+  p0 = max(p0, first_pulse);
+  p1 = min(p1, first_pulse + slots);
+  const int64_t n0 = (int64_t)tile * SYN_TILE + threadIdx.x;
   double v[SYN_TILE_PER_THREAD];
 #pragma unroll
-  for (int m = 0; m < SYN_TILE_PER_THREAD; ++m) v[m] = 0.0;
-  for (int jj = max(0, tile - reach); jj <= min(nt - 1, tile + reach); ++jj) {
-    const int t0 = min(tile_off[jj], P), t1 = jj + 1 < nt ? min(tile_off[jj + 1], P) : P;
-    const int cnt = t1 - t0;
-    if (cnt <= 0) continue;
-    const int gsz = syn_item_size(cnt);
-    const int items = (cnt + gsz - 1) / gsz;
-    for (int c = 0; c < items; ++c) {
-      const double *slot = part + (size_t)(jj * SYN_MAXC + c) * span;
+  for (int m = 0; m < SYN_TILE_PER_THREAD; ++m) {
+    const int64_t n = n0 + KWY_THREADS * m;
+    v[m] = (first_pulse > 0 && n < y_length) ? y[n] : 0.0;
+  }
+  for (int pp = p0; pp < p1; ++pp) {
+    const int idx = pidx[pp];
+    if (pidx[min(P - 1, pp + 1)] - idx <= 0) continue;      // the last pulse has no response
+    const double *slot = resp + (size_t)(pp - first_pulse) * N;
+    const int64_t base = (int64_t)idx - H + 1;
 #pragma unroll
-      for (int m = 0; m < SYN_TILE_PER_THREAD; ++m) {
-        const int q = (tile - jj) * SYN_TILE + (int)threadIdx.x + KWY_THREADS * m + H - 1;
-        if (q >= 0 && q < span) v[m] += slot[q];
-      }
+    for (int m = 0; m < SYN_TILE_PER_THREAD; ++m) {
+      const int64_t q = n0 + KWY_THREADS * m - base;
+      if (q >= 0 && q < N) v[m] += slot[q];
     }
   }
 #pragma unroll
   for (int m = 0; m < SYN_TILE_PER_THREAD; ++m) {
-    const int64_t n = (int64_t)tile * SYN_TILE + threadIdx.x + KWY_THREADS * m;
+    const int64_t n = n0 + KWY_THREADS * m;
     if (n < y_length) y[n] = v[m];
   }
 }
@@ -764,24 +748,27 @@ template <int LOG2N>
 static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const syn_params &p,
                         const int32_t *pidx, const double *pshift, const unsigned char *vuv8,
                         const int *npulse, int cap, const uint32_t *ebase, const double *dcrem,
-                        const int *tile_off, int nt, double *part, double *y) {
+                        const int *tile_off, int nt, int slots, double *resp, double *y) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   const kwy_c *twH, *twN;
   const uint4 *poly;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
-  (void)K;
-  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * ((SYN_TILE + N) + 2 + 8) +
+  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (2 * (K + 1) + 8) +
                sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int grid = nt * SYN_MAXC < 2048 ? nt * SYN_MAXC : 2048;
+  int grid = slots < 2048 ? slots : 2048;
   if (grid < 1) grid = 1;
-  KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
-                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, tile_off, nt, part));
-  KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, part, tile_off, npulse, cap,
-                     nt, N, p.y_length, y));
+  // rounds beyond the first only run when the signal has more pulses than slots (f0 above 500 Hz for long
+  // stretches); their kernels return at once otherwise
+  for (int first = 0; first < cap; first += slots) {
+    KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
+                       pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, first, slots, resp));
+    KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, resp, pidx, tile_off,
+                       npulse, cap, nt, N, first, slots, p.y_length, y));
+  }
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -794,7 +781,7 @@ static size_t syn_scratch_bytes(int64_t y_length, int fft_size) {
   return kwy_pad(sizeof(int) * (nt + 1)) + 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) +
          kwy_pad(y_length) + kwy_pad(sizeof(int32_t) * cap) + kwy_pad(sizeof(double) * cap) +
          kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * (size_t)cap) + kwy_pad(64) +
-         kwy_pad(sizeof(double) * (size_t)nt * SYN_MAXC * (SYN_TILE + fft_size));
+         kwy_pad(sizeof(double) * (size_t)SYN_SLOTS(y_length) * fft_size);
 }
 
 static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp, const double *ap,
@@ -825,8 +812,9 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
   double *pshift = kwy_arena<double>(ctx, cap);
   uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * cap);
   int *npulse = kwy_arena<int>(ctx, 16);
-  double *part = kwy_arena<double>(ctx, (size_t)nt * SYN_MAXC * (SYN_TILE + fft_size));
-  if (!part ||!incr || !ph_tsum || !ph_tin || !ph_summ || !tile_cnt || !wrap || !vuv8 || !pidx || !pshift || !ebase || !npulse) {
+  const int slots = (int)SYN_SLOTS(y_length);
+  double *resp = kwy_arena<double>(ctx, (size_t)slots * fft_size);
+  if (!resp || !incr || !ph_tsum || !ph_tin || !ph_summ || !tile_cnt || !wrap || !vuv8 || !pidx || !pshift || !ebase || !npulse) {
     ctx->err = "synthesize: scratch arena too small";
     return KWY_ENOMEM;
   }
@@ -853,13 +841,13 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
                      ctx->d_pow2, ebase);
   KWY_HIP(hipGetLastError());
   switch (log2n) {
-    case 9: return launch_pulse<9>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
-    case 10: return launch_pulse<10>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
-    case 11: return launch_pulse<11>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
-    case 12: return launch_pulse<12>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
+    case 9: return launch_pulse<9>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
+    case 10: return launch_pulse<10>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
+    case 11: return launch_pulse<11>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
+    case 12: return launch_pulse<12>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
     // 8192: features resampled up to 96 kHz (3078 bins -> 4097, kwiiyatta/vocoder/world.py:71-78); rare, runs
     // with the 256-thread layout of the shorter transforms (register spills accepted)
-    default: return launch_pulse<13>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, part, y);
+    default: return launch_pulse<13>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
   }
 }
 

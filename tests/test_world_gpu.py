@@ -219,3 +219,19 @@ def test_full_size_config2(ko, kw):
     assert np.abs(sp2[live] / sp[live] - 0.25).max() <= 1e-6
     assert np.array_equal(sp, kw.cheaptrick(x, f0, t, fs))
     assert ((ap > 0) & (ap <= 1)).all()
+
+
+def test_synthesis_8192_points(ko, kw):
+    """fft_size 8192 (K = 4097): what the reference synthesises after resampling features up to 96 kHz
+    (3078 bins are reshaped to 4097, kwiiyatta/vocoder/world.py:71-78)."""
+    from scipy.interpolate import interp1d
+    fs, x = load(clb_variant('96'))
+    f0, t = f0_track(ko, x, fs)
+    f0, t = np.ascontiguousarray(f0[:120]), t[:120]
+    sp, ap = ko.cheaptrick(x, f0, t, fs), ko.d4c(x, f0, t, fs)
+    grid, fine = np.linspace(0, 1, sp.shape[1]), np.linspace(0, 1, 4097)
+    sp8 = np.ascontiguousarray(np.exp(interp1d(grid, np.log(sp), axis=1)(fine)))
+    ap8 = np.ascontiguousarray(np.clip(interp1d(grid, ap, axis=1)(fine), 1e-3, 1 - 1e-12))
+    got, ref = kw.synthesize(f0, sp8, ap8, fs, 5.0), ko.synthesize(f0, sp8, ap8, fs, 5.0)
+    assert got.shape == ref.shape
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-9 * max(1.0, np.abs(ref).max())
