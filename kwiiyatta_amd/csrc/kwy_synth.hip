@@ -518,8 +518,9 @@ __device__ __forceinline__ double syn_safe_ap(double x) {
 // interpolated envelope / aperiodic ratio rows, a small twiddle table -- 35 KB at 48 kHz, four
 // workgroups per CU.  The noise spectrum waits in registers (bins tid + 256 r) while the
 // buffer computes the aperiodic minimum-phase response.
+// (workgroups per CU by LDS: three up to 2048 points, two at 4096, one at 8192 -- the register budget follows)
 template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS, 3) void k_syn_pulse(
+__global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1)) void k_syn_pulse(
     const double *__restrict__ sp, const double *__restrict__ ap, syn_params p,
     const int32_t *__restrict__ pidx, const double *__restrict__ pshift,
     const unsigned char *__restrict__ vuv8, const int *__restrict__ npulse, int cap,
@@ -764,9 +765,9 @@ static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const 
   // rounds beyond the first only run when the signal has more pulses than slots (f0 above 500 Hz for long
   // stretches); their kernels return at once otherwise
   for (int first = 0; first < cap; first += slots) {
-    KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
+    KWY_PROF(ctx, first == 0 ? "k_syn_pulse" : "k_syn_pulse_more", hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
                        pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, first, slots, resp));
-    KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, resp, pidx, tile_off,
+    KWY_PROF(ctx, first == 0 ? "k_syn_ola" : "k_syn_ola_more", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, resp, pidx, tile_off,
                        npulse, cap, nt, N, first, slots, p.y_length, y));
   }
   KWY_HIP(hipGetLastError());
