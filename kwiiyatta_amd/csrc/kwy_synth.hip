@@ -15,6 +15,7 @@
 //
 // Algorithmic HBM bytes per frame: 2*K*8 + 8 in, hop*8 out.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -29,8 +30,10 @@
 // k_syn_ola then adds, per output sample, the responses that reach it IN PULSE ORDER -- the order of the serial
 // reference loop.  Every sum has a fixed order: two runs give the same bits (the reference asserts exactly that,
 // tests/kwiiyatta/test_vocoder.py:171).  The buffer holds SYN_SLOTS(y_length) pulses (every signal whose f0 stays
-// at or below the 500 Hz of unvoiced stretches fits); more pulses take further rounds of the two kernels.
-#define SYN_SLOTS(y_length) ((y_length) / 96 + 64)
+// averages at most 640 Hz fits -- unvoiced stretches run at 500 Hz, DIO's ceiling is 800 Hz); pulses beyond that
+// are added afterwards by ONE workgroup, pulse by pulse in the same order (slow, but such signals do not occur in
+// speech), so the summation order is the serial one in every case.
+#define SYN_SLOTS(y_length, fs) ((int)((y_length) * 640 / (fs)) + 64)
 
 struct syn_params {
   int64_t T, y_length;
@@ -519,14 +522,15 @@ __device__ __forceinline__ double syn_safe_ap(double x) {
 // workgroups per CU.  The noise spectrum waits in registers (bins tid + 256 r) while the
 // buffer computes the aperiodic minimum-phase response.
 // (workgroups per CU by LDS: three up to 2048 points, two at 4096, one at 8192 -- the register budget follows)
-template <int LOG2N>
+template <int LOG2N, bool DIRECT>
 __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1)) void k_syn_pulse(
     const double *__restrict__ sp, const double *__restrict__ ap, syn_params p,
     const int32_t *__restrict__ pidx, const double *__restrict__ pshift,
     const unsigned char *__restrict__ vuv8, const int *__restrict__ npulse, int cap,
     const uint32_t *__restrict__ ebase, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    const double *__restrict__ dc_remover, int first_pulse, int slots, double *__restrict__ resp) {
+    const double *__restrict__ dc_remover, int first_pulse, int slots, double *__restrict__ resp,
+    double *__restrict__ y) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   constexpr int C = N / KWY_THREADS;  // draws / output samples per thread
   constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
@@ -666,12 +670,21 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
       kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
       const double *w = (const double *)buf;
       const double sqrt_noise_size = sqrt((double)noise_size);
-      double *slot = resp + (size_t)(pp - first_pulse) * N;   // sample i lands at idx - H + 1 + i
+      // sample i lands at idx - H + 1 + i: into this pulse's slot, or (DIRECT: the one workgroup that takes the
+      // pulses beyond the slots, in order) straight onto y
+      double *slot = DIRECT ? nullptr : resp + (size_t)(pp - first_pulse) * N;
+      const int64_t offset = (int64_t)idx - H + 1;
 #pragma unroll
       for (int m = 0; m < C; ++m) {
         int i = tid + KWY_THREADS * m;
         double aper = (i < H) ? w[i + H] : w[i - H];
-        slot[i] = (per[m] * sqrt_noise_size + aper) / N;
+        const double r = (per[m] * sqrt_noise_size + aper) / N;
+        if constexpr (DIRECT) {
+          const int64_t n = offset + i;
+          if (n >= 0 && n < p.y_length) y[n] += r;
+        } else {
+          slot[i] = r;
+        }
       }
     }
   }
@@ -758,31 +771,32 @@ static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const 
   KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
   size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (2 * (K + 1) + 8) +
                sizeof(uint32_t) * KWY_EBASE_WORDS;
-  KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N>,
+  KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = slots < 2048 ? slots : 2048;
   if (grid < 1) grid = 1;
-  // rounds beyond the first only run when the signal has more pulses than slots (f0 above 500 Hz for long
-  // stretches); their kernels return at once otherwise
-  for (int first = 0; first < cap; first += slots) {
-    KWY_PROF(ctx, first == 0 ? "k_syn_pulse" : "k_syn_pulse_more", hipLaunchKernelGGL(k_syn_pulse<LOG2N>, dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
-                       pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, first, slots, resp));
-    KWY_PROF(ctx, first == 0 ? "k_syn_ola" : "k_syn_ola_more", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, resp, pidx, tile_off,
-                       npulse, cap, nt, N, first, slots, p.y_length, y));
-  }
+  KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL((k_syn_pulse<LOG2N, false>), dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
+                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, 0, slots, resp, y));
+  KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, resp, pidx, tile_off,
+                     npulse, cap, nt, N, 0, slots, p.y_length, y));
+  // pulses beyond the slots (none for speech): one workgroup, serial, same order
+  KWY_PROF(ctx, "k_syn_pulse_more", hipLaunchKernelGGL((k_syn_pulse<LOG2N, true>), dim3(1), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
+                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, slots, cap, resp, y));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
 
 static int syn_pulse_cap(int64_t y_length) { return (int)(y_length / 8 + 16); }
 
-static size_t syn_scratch_bytes(int64_t y_length, int fft_size) {
+static size_t syn_scratch_bytes(int64_t y_length, int fft_size, int fs) {
   int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
   int cap = syn_pulse_cap(y_length);
   return kwy_pad(sizeof(int) * (nt + 1)) + 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) +
          kwy_pad(y_length) + kwy_pad(sizeof(int32_t) * cap) + kwy_pad(sizeof(double) * cap) +
          kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * (size_t)cap) + kwy_pad(64) +
-         kwy_pad(sizeof(double) * (size_t)SYN_SLOTS(y_length) * fft_size);
+         kwy_pad(sizeof(double) * (size_t)SYN_SLOTS(y_length, fs) * fft_size);
 }
 
 static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp, const double *ap,
@@ -813,7 +827,7 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
   double *pshift = kwy_arena<double>(ctx, cap);
   uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * cap);
   int *npulse = kwy_arena<int>(ctx, 16);
-  const int slots = (int)SYN_SLOTS(y_length);
+  const int slots = SYN_SLOTS(y_length, fs);
   double *resp = kwy_arena<double>(ctx, (size_t)slots * fft_size);
   if (!resp || !incr || !ph_tsum || !ph_tin || !ph_summ || !tile_cnt || !wrap || !vuv8 || !pidx || !pshift || !ebase || !npulse) {
     ctx->err = "synthesize: scratch arena too small";
@@ -869,7 +883,7 @@ extern "C" int kwy_synthesize_dev(kwy_ctx *ctx, const double *f0, int64_t T, con
   KWY_TRY(syn_check(ctx, f0, T, sp, ap, fft_size, frame_period_ms, fs, y_length, y));
   KWY_HIP(hipSetDevice(ctx->device));
   if (y_length == 0) return KWY_OK;
-  KWY_TRY(kwy_arena_begin(ctx, syn_scratch_bytes(y_length, fft_size)));
+  KWY_TRY(kwy_arena_begin(ctx, syn_scratch_bytes(y_length, fft_size, fs)));
   return synth_core(ctx, f0, T, sp, ap, fft_size, frame_period_ms, fs, sp_mul, y_length, y);
 }
 
@@ -884,7 +898,7 @@ extern "C" int kwy_synthesize(kwy_ctx *ctx, const double *f0, int64_t T, const d
   const int K = fft_size / 2 + 1;
   size_t bf = kwy_pad(sizeof(double) * T), bs = kwy_pad(sizeof(double) * T * K);
   size_t by = kwy_pad(sizeof(double) * y_length);
-  KWY_TRY(kwy_arena_begin(ctx, syn_scratch_bytes(y_length, fft_size) + bf + 2 * bs + by));
+  KWY_TRY(kwy_arena_begin(ctx, syn_scratch_bytes(y_length, fft_size, fs) + bf + 2 * bs + by));
   double *df0 = kwy_arena<double>(ctx, T), *dsp = kwy_arena<double>(ctx, (size_t)T * K);
   double *dap = kwy_arena<double>(ctx, (size_t)T * K), *dy = kwy_arena<double>(ctx, y_length);
   KWY_HIP(hipMemcpyAsync(df0, f0, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
