@@ -1,7 +1,9 @@
 """kwiiyatta_amd -- MI355X-native implementation of kwiiyatta's per-utterance
 conversion hot path (WORLD analysis, mel-cepstrum, FastDTW alignment, GMM/MLPG
 conversion, WORLD synthesis) behind the reference's own Python API
-(same export list as /root/reference/kwiiyatta/__init__.py:1-22).
+(same export list as /root/reference/kwiiyatta/__init__.py:1-22; the host-side
+feature model, converter stack and CLIs are this package's own code written
+to that API).
 
 The numerics run in hand-written gfx950 HIP kernels (``libkwy.so``, C ABI in
 ``include/kwy.h``) reached through the pyworld / pysptk / fastdtw / nnmnkwii

@@ -1,15 +1,15 @@
-"""`kwiiyatta.align` dispatcher: features are aligned directly, datasets become
-an aligned parallel dataset (mirrors /root/reference/kwiiyatta/align.py:7-19)."""
-import kwiiyatta_amd as kwiiyatta
+"""`kwiiyatta.align(a, b)`: two feature sets are aligned directly (vocoder.align), two datasets become the aligned
+parallel dataset of their common keys (/root/reference/kwiiyatta/align.py)."""
 from . import converter, vocoder
 
 
 def align(a, b, **kwargs):
-    for base, handler in ((vocoder.abc.Feature, lambda: vocoder.align(a, b, **kwargs)),
-                          (converter.abc.Dataset,
-                           lambda: kwiiyatta.align_dataset(kwiiyatta.ParallelDataset(a, b)))):
-        if isinstance(a, base):
-            if not isinstance(b, base):
-                raise TypeError(f'argument type mismatch: {type(a)!r} and {type(b)!r}')
-            return handler()
-    raise TypeError('argument should be Feature or Dataset')
+    if isinstance(a, vocoder.abc.Feature):
+        kind, run = vocoder.abc.Feature, lambda: vocoder.align(a, b, **kwargs)
+    elif isinstance(a, converter.abc.Dataset):
+        kind, run = converter.abc.Dataset, lambda: converter.align_dataset(converter.ParallelDataset(a, b))
+    else:
+        raise TypeError('argument should be Feature or Dataset')
+    if not isinstance(b, kind):
+        raise TypeError(f'argument type mismatch: {type(a)!r} and {type(b)!r}')
+    return run()

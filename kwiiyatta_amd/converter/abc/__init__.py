@@ -1,48 +1,28 @@
-"""Abstract bases of the converter layer (mirrors
-/root/reference/kwiiyatta/converter/abc/{converter,dataset}.py): lazily
-evaluated Mapping-style datasets that can be stacked as decorators, and
-feature converters that can be stacked the same way."""
+"""Composable building blocks of the converter layer.  API of kwiiyatta.converter.abc
+(/root/reference/kwiiyatta/converter/abc/): `Dataset` (a read-only mapping key -> item, evaluated on access),
+`MapDataset` / `map_dataset` (a dataset that applies a function to another dataset's items) and the matching pair
+for converters, `FeatureConverter` / `MapFeatureConverter`.
+
+Stacks are plain object chains: every wrapper holds its `base` and forwards unknown attributes to it, so the
+outermost object answers for the whole stack (`stack.frame_period`, `stack.gmm`, ...).  A wrapped dataset hands
+the *raw* item (what the innermost, non-mapping dataset produced) along with the processed one, because later
+stages need its metadata (frame period, sampling rate) after the arrays have lost it."""
 import abc
 import collections.abc
 
 __all__ = ['FeatureConverter', 'MapFeatureConverter', 'Dataset', 'MapDataset', 'map_dataset']
 
 
-class FeatureConverter(abc.ABC):
-    @abc.abstractmethod
-    def _train(self, dataarray, **kwargs):
-        raise NotImplementedError
-
-    def train(self, dataset, keys, **kwargs):
-        from ..dataset import make_dataset_to_array
-        self._train(make_dataset_to_array(dataset, keys), **kwargs)
-
-    @abc.abstractmethod
-    def convert(self, feature, **kwargs):
-        raise NotImplementedError
-
-
-class MapFeatureConverter(FeatureConverter):
-    """A converter that pre/post-processes features around a base converter."""
-
-    def __init__(self, base_converter):
-        self.base = base_converter
-
-    def _train(self, dataarray, **kwargs):
-        return self.base._train(dataarray, **kwargs)
+class _Forwarding:
+    """attribute look-ups that fail here continue at `self.base`"""
 
     def __getattr__(self, name):
+        if name == 'base':                       # not set yet (during construction / unpickling)
+            raise AttributeError(name)
         return getattr(self.base, name)
 
-    @abc.abstractmethod
-    def convert(self, feature, raw=None, **kwargs):
-        if raw is None:
-            raw = feature
-        if isinstance(self.base, MapFeatureConverter):
-            return self.base.convert(feature, raw, **kwargs)
-        return self.base.convert(feature, **kwargs)
 
-
+# ---- datasets ----------------------------------------------------------------------------------------------------
 class Dataset(collections.abc.Mapping):
     @abc.abstractmethod
     def keys(self):
@@ -55,51 +35,49 @@ class Dataset(collections.abc.Mapping):
     def __getitem__(self, key):
         return self.get_data(key)
 
-    def __iter__(self):
-        return ((key, self[key]) for key in self.keys())
-
     def __len__(self):
         return len(self.keys())
 
+    def __iter__(self):
+        for key in self.keys():
+            yield key, self[key]              # (key, item) pairs, as the reference iterates
 
-class MapDataset(Dataset):
-    """Applies `function` to every item of a base dataset, on access."""
-    expand_tuple = True   # apply to each member of a tuple item separately
-    with_key = False      # pass key=...
-    with_raw = False      # pass raw=<the undecorated item>
+
+class MapDataset(_Forwarding, Dataset):
+    """`function` applied to the items of `base`.  Class switches: `expand_tuple` -- apply to every member of a
+    tuple item (parallel data) instead of to the tuple; `with_key` / `with_raw` -- pass key= / raw= as well."""
+    expand_tuple = True
+    with_key = False
+    with_raw = False
 
     def __init__(self, base_dataset, **kwargs):
-        super().__init__()
         self.base = base_dataset
         self.kwargs = kwargs
 
     def keys(self):
         return self.base.keys()
 
-    def __getattr__(self, name):
-        return getattr(self.base, name)
+    def _source(self, key):
+        """(item to process, raw item)"""
+        if isinstance(self.base, MapDataset):
+            return self.base.get_data(key, with_raw=True)
+        item = self.base[key]
+        return item, item
 
     def get_data(self, key, with_raw=False):
-        if isinstance(self.base, MapDataset):
-            data, raw = self.base.get_data(key, with_raw=True)
-        else:
-            data = raw = self.base[key]
+        item, raw = self._source(key)
+        options = dict(self.kwargs, key=key) if self.with_key else dict(self.kwargs)
 
-        extra = dict(self.kwargs)
-        if self.with_key:
-            extra['key'] = key
-
-        if self.expand_tuple and isinstance(data, tuple):
+        def apply(member, member_raw):
             if self.with_raw:
-                result = tuple(self.function(d, raw=r, **extra) for d, r in zip(data, raw))
-            else:
-                result = tuple(self.function(d, **extra) for d in data)
-        else:
-            if self.with_raw:
-                extra['raw'] = raw
-            result = self.function(data, **extra)
+                return self.function(member, raw=member_raw, **options)
+            return self.function(member, **options)
 
-        return (result, raw) if with_raw else result
+        if self.expand_tuple and isinstance(item, tuple):
+            out = tuple(apply(m, r) for m, r in zip(item, raw))
+        else:
+            out = apply(item, raw)
+        return (out, raw) if with_raw else out
 
     @staticmethod
     @abc.abstractmethod
@@ -108,11 +86,44 @@ class MapDataset(Dataset):
 
 
 def map_dataset(expand_tuple=True, with_key=False, with_raw=False):
-    """Decorator: turn a plain function into a MapDataset subclass."""
-    def build(func):
-        return type(func.__name__, (MapDataset,), {
-            '__module__': func.__module__, '__doc__': func.__doc__,
-            'function': staticmethod(func),
-            'expand_tuple': expand_tuple, 'with_key': with_key, 'with_raw': with_raw,
-        })
-    return build
+    """decorator: `@map_dataset() def Name(item, **kw)` -> a MapDataset subclass called Name"""
+    switches = dict(expand_tuple=expand_tuple, with_key=with_key, with_raw=with_raw)
+
+    def subclass(func):
+        body = dict(switches, function=staticmethod(func), __module__=func.__module__, __doc__=func.__doc__)
+        return type(func.__name__, (MapDataset,), body)
+    return subclass
+
+
+# ---- converters ------------------------------------------------------------------------------------------------------
+class FeatureConverter(abc.ABC):
+    """train(dataset, keys) stacks the dataset's items into one matrix and hands it to `_train`"""
+
+    @abc.abstractmethod
+    def _train(self, dataarray, **kwargs):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def convert(self, feature, **kwargs):
+        raise NotImplementedError
+
+    def train(self, dataset, keys, **kwargs):
+        from ..dataset import make_dataset_to_array
+        self._train(make_dataset_to_array(dataset, keys), **kwargs)
+
+
+class MapFeatureConverter(_Forwarding, FeatureConverter):
+    """a conversion stage around `base`; subclasses transform the feature and call `super().convert`, which passes
+    the raw feature on only to stages that take one"""
+
+    def __init__(self, base_converter):
+        self.base = base_converter
+
+    def _train(self, dataarray, **kwargs):
+        return self.base._train(dataarray, **kwargs)
+
+    @abc.abstractmethod
+    def convert(self, feature, raw=None, **kwargs):
+        if isinstance(self.base, MapFeatureConverter):
+            return self.base.convert(feature, feature if raw is None else raw, **kwargs)
+        return self.base.convert(feature, **kwargs)

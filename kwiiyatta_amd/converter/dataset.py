@@ -1,38 +1,49 @@
-"""Datasets of analysed wav files and their alignment (mirrors
-/root/reference/kwiiyatta/converter/dataset.py:12-77)."""
-import copy
-
+"""Datasets of the training path: wav directories, parallel pairs, trimming, alignment, and the stacking of a
+dataset into the matrix the converter is fitted on.  API of kwiiyatta.converter.dataset
+(/root/reference/kwiiyatta/converter/dataset.py).  `kwiiyatta_amd.corpus` is the device-resident counterpart of
+this chain for whole corpora; this module is the per-item Python path (and the definition the other is tested
+against)."""
 import numpy as np
 
-import kwiiyatta_amd as kwiiyatta
 from . import abc
 
-
-# nnmnkwii.preprocessing helpers the reference imports (dataset.py:3), restated:
-def trim_zeros_frames(x, eps=1e-7):
-    """Drop all-zero frames at the ends; NOTE the kept length is applied from
-    the front (nnmnkwii behaviour the reference relies on, dataset.py:52)."""
-    s = np.sum(np.abs(x), axis=1)
-    s[s < eps] = 0.
-    return x[:len(np.trim_zeros(s))]
+FRAME_EPS = 1e-7        # nnmnkwii: a frame whose L1 norm is below this is "zero"
 
 
-def remove_zeros_frames(x, eps=1e-7):
-    s = np.sum(np.abs(x), axis=1)
-    s[s < eps] = 0.
-    return x[s > eps]
+def _pkg():
+    import kwiiyatta_amd
+    return kwiiyatta_amd
+
+
+def _frame_mass(x, eps):
+    mass = np.abs(x).sum(axis=1)
+    mass[mass < eps] = 0.
+    return mass
+
+
+def trim_zeros_frames(x, eps=FRAME_EPS):
+    """nnmnkwii.preprocessing.trim_zeros_frames: the zero frames at BOTH ends are counted off, but the remaining
+    length is taken from the FRONT (x[:n]) -- behaviour the reference inherits and documents with a strict xfail
+    (tests/kwiiyatta/test_dataset.py:78-99)"""
+    return x[:len(np.trim_zeros(_frame_mass(x, eps)))]
+
+
+def remove_zeros_frames(x, eps=FRAME_EPS):
+    """nnmnkwii.preprocessing.remove_zeros_frames: all zero frames are dropped"""
+    return x[_frame_mass(x, eps) > 0]
 
 
 class WavFileDataset(abc.Dataset):
+    """the *.wav files of a directory, analysed (lazily) on access; keys are paths relative to the directory"""
+
     def __init__(self, data_dir, Analyzer=None):
-        super().__init__()
-        self.Analyzer = Analyzer if Analyzer is not None else kwiiyatta.analyze_wav
+        if not data_dir.exists():
+            raise FileNotFoundError(f'wav files dir "{data_dir!s}" is not found')
+        if not data_dir.is_dir():
+            raise NotADirectoryError(f'wav files dir "{data_dir!s}" is not directory')
         self.data_dir = data_dir
-        if not self.data_dir.exists():
-            raise FileNotFoundError(f'wav files dir "{self.data_dir!s}" is not found')
-        if not self.data_dir.is_dir():
-            raise NotADirectoryError(f'wav files dir "{self.data_dir!s}" is not directory')
-        self.files = frozenset(f.relative_to(self.data_dir) for f in self.data_dir.glob('*.wav'))
+        self.Analyzer = Analyzer or _pkg().analyze_wav
+        self.files = frozenset(path.relative_to(data_dir) for path in data_dir.glob('*.wav'))
 
     def keys(self):
         return self.files
@@ -42,11 +53,11 @@ class WavFileDataset(abc.Dataset):
 
 
 class ParallelDataset(abc.Dataset):
+    """(item of dataset1, item of dataset2) for the keys both have"""
+
     def __init__(self, dataset1, dataset2):
-        super().__init__()
-        self.dataset1 = dataset1
-        self.dataset2 = dataset2
-        self.common_keys = self.dataset1.keys() & self.dataset2.keys()
+        self.dataset1, self.dataset2 = dataset1, dataset2
+        self.common_keys = dataset1.keys() & dataset2.keys()
 
     def keys(self):
         return self.common_keys
@@ -57,26 +68,21 @@ class ParallelDataset(abc.Dataset):
 
 @abc.map_dataset()
 def TrimmedDataset(feature):
-    kept = trim_zeros_frames(feature.spectrum_envelope)
-    return feature[:len(kept)]
+    """a feature set without its silent end frames (see trim_zeros_frames for which ones exactly)"""
+    return feature[:len(trim_zeros_frames(feature.spectrum_envelope))]
 
 
 @abc.map_dataset(expand_tuple=False)
 def AlignedDataset(features, **kwargs):
-    a, b = features
-    return kwiiyatta.align_even(a, b, **kwargs)
+    """a parallel pair, both sides along their common warping path"""
+    return _pkg().align_even(*features, **kwargs)
 
 
 def make_dataset_to_array(dataset, keys=None):
-    """Stack all items (tuples are joined column-wise) into one training matrix."""
-    if keys is None:
-        keys = sorted(dataset.keys())
-    parts = []
-    for key in keys:
-        d = dataset[key]
-        if isinstance(d, tuple):
-            d = np.hstack(d)
-        parts.append(remove_zeros_frames(d))
-    if not parts:
-        return None
-    return np.concatenate(parts, axis=0) if len(parts) > 1 else copy.copy(parts[0])
+    """rows of all items under `keys` (default: all, sorted), zero rows removed; a tuple item contributes its
+    members side by side.  None for no keys."""
+    blocks = []
+    for key in (sorted(dataset.keys()) if keys is None else keys):
+        item = dataset[key]
+        blocks.append(remove_zeros_frames(np.hstack(item) if isinstance(item, tuple) else item))
+    return np.concatenate(blocks) if blocks else None

@@ -1,29 +1,27 @@
-"""Joint-density GMM converter (mirrors
-/root/reference/kwiiyatta/converter/gmm.py:9-34).  Apply = MLPG kernels, fit = EM
-kernels (GaussianMixtureHIP reproduces sklearn.mixture.GaussianMixture.fit for the
-configuration the reference uses)."""
-from .gmm_fit import GaussianMixtureHIP as GaussianMixture
-
+"""Innermost stage of the converter stack: a joint-density Gaussian mixture over [source | target] dynamic features.
+API of kwiiyatta.converter.gmm (/root/reference/kwiiyatta/converter/gmm.py): the mixture object sits in `.gmm`,
+`_train` fits it, `convert` runs maximum-likelihood parameter generation.  Both run on the GPU: the fit is
+GaussianMixtureHIP (k-means + EM kernels, scikit-learn's GaussianMixture.fit semantics), the conversion the MLPG
+kernels behind kwiiyatta_amd.backend.mlpg (nnmnkwii's MLPG call signature)."""
 from ..backend.mlpg import MLPG
 from . import abc, delta
+from .gmm_fit import GaussianMixtureHIP as GaussianMixture
 
 
 class GMMFeatureConverter(abc.FeatureConverter):
     def __init__(self, components=64, max_iter=100, random_state=None, **kwargs):
-        super().__init__()
         self.init_gmm(components, max_iter, random_state, **kwargs)
 
     def init_gmm(self, components, max_iter=100, random_state=None, **kwargs):
-        kwargs.setdefault('verbose', 1)
-        kwargs.setdefault('covariance_type', 'full')
-        self.gmm = GaussianMixture(n_components=components, max_iter=max_iter,
-                                   random_state=random_state, **kwargs)
+        options = dict(verbose=1, covariance_type='full')
+        options.update(kwargs)
+        self.gmm = GaussianMixture(n_components=components, max_iter=max_iter, random_state=random_state, **options)
 
     def _train(self, dataarray, **kwargs):
         self.gmm.fit(dataarray, **kwargs)
 
     def convert(self, feature, mlpg=True, diff=False):
         if not mlpg:
-            raise NotImplementedError('frame-wise (mlpg=False) conversion is not used by the '
-                                      'reference CLIs and not implemented on the GPU')
+            raise NotImplementedError('frame-wise conversion (mlpg=False) is not used by the reference CLIs and '
+                                      'has no GPU implementation')
         return MLPG(self.gmm, windows=delta.DELTA_WINDOWS, diff=diff).transform(feature)

@@ -1,122 +1,129 @@
-"""DTW alignment of two features (mirrors
-/root/reference/kwiiyatta/vocoder/align.py:10-146).  The DTW itself runs on the
-GPU through kwiiyatta_amd.backend.dtw (fastdtw-shaped); the feature
-construction and the path projection are host-side index bookkeeping."""
+"""Time alignment of two feature sets by dynamic time warping.  API of kwiiyatta.vocoder.align
+(/root/reference/kwiiyatta/vocoder/align.py): `make_feature` / `dtw_feature` build the DTW features and the warping
+path, `align` re-times one feature set onto the other's frames, `align_even` re-times both onto the path.
+
+The warping itself is FastDTW on the GPU (kwiiyatta_amd.backend.dtw, fastdtw's call signature); this module is the
+index bookkeeping around it, done with numpy on whole paths.  Observable behaviour follows the reference,
+including what its tests and the training path rely on:
+  * DTW features are [power term, voicing term, c1 .. cN] of the mel-cepstrum at the lower of the two sampling
+    rates; the power term is c0 binarised against a pivot (9.4 above `max(c0) - 1.636` by default);
+  * `strict` drops inner path cells whose frames disagree in power class, or whose x-voicing disagrees with the
+    y-POWER class -- the second test reads column 0 of y, as the reference does (align.py:78), and defines what
+    a strict alignment is;
+  * one x per y (`project_path_iter`): the first x of a new y; a jump in y is filled by spreading the x range
+    with integer arithmetic; the silence pads are cut off the y axis."""
 import numpy as np
 
-import kwiiyatta_amd as kwiiyatta
 from ..backend import dtw as fastdtw
 
 
+def _pkg():
+    import kwiiyatta_amd
+    return kwiiyatta_amd
+
+
 def binalize(x, threshold, ceil, floor=0, out=None):
+    """two-level version of x: `ceil` where x >= threshold, `floor` elsewhere"""
+    levels = np.where(x >= threshold, ceil, floor)
     if out is None:
-        out = np.full_like(x, floor)
-    else:
-        out[:] = floor
-    out[x >= threshold] = ceil
+        return levels.astype(x.dtype)
+    out[...] = levels
     return out
 
 
-_POWER_PIVOTS = {
-    'max': lambda p, thr: p.max() - thr,
-    'median': lambda p, thr: np.median(p) - thr,
-    'min': lambda p, thr: p.min() + thr,
-    'fix': lambda p, thr: thr,
-}
+def _power_threshold(c0, pivot, offset):
+    if pivot == 'max':
+        return c0.max() - offset
+    if pivot == 'median':
+        return np.median(c0) - offset
+    if pivot == 'min':
+        return c0.min() + offset
+    if pivot == 'fix':
+        return offset
+    raise ValueError(f'Unknown power_pivot parameter: {pivot!r}')
 
 
-def make_feature(f, fs, vuv='voiced', vuv_weight=9.0, power='binalize', power_weight=9.4,
-                 power_pivot='max', power_threshold=1.636):
-    """DTW feature rows: [power term, voicing term, mc1 .. mcN]."""
-    mc = f.resample_mel_cepstrum(fs).data
-    power_track = mc[:, 0]
-    out = np.hstack((np.zeros((len(mc), 2)), mc[:, 1:]))
-
+def make_feature(f, fs, vuv='voiced', vuv_weight=9.0, power='binalize', power_weight=9.4, power_pivot='max',
+                 power_threshold=1.636):
+    coefficients = f.resample_mel_cepstrum(fs).data
+    c0 = coefficients[:, 0]
+    rows = np.zeros((len(coefficients), coefficients.shape[1] + 1))
+    rows[:, 2:] = coefficients[:, 1:]
     if power == 'binalize':
-        if power_pivot not in _POWER_PIVOTS:
-            raise ValueError(f'Unknown power_pivot parameter: {power_pivot!r}')
-        binalize(power_track, _POWER_PIVOTS[power_pivot](power_track, power_threshold),
-                 power_weight, out=out[:, 0])
+        binalize(c0, _power_threshold(c0, power_pivot, power_threshold), power_weight, out=rows[:, 0])
     elif power == 'raw':
-        out[:, 0] = power_track
+        rows[:, 0] = c0
     elif power is not None:
         raise ValueError(f'Unknown power parameter: {power!r}')
-
-    if vuv == 'voiced':
-        out[:, 1][f.is_voiced] = vuv_weight
-    elif vuv == 'f0':
-        out[:, 1][f.f0 > 0] = vuv_weight
+    if vuv in ('voiced', 'f0'):
+        rows[f.is_voiced if vuv == 'voiced' else f.f0 > 0, 1] = vuv_weight
     elif vuv is not None:
         raise ValueError(f'Unknown vuv parameter: {vuv!r}')
-    return out
+    return rows
 
 
 def dtw_feature(x, y, vuv='voiced', power='binalize', strict=True, radius=32, **kwargs):
+    """(FastDTW distance, path as an (L, 2) integer array) between the DTW features of x and y"""
     fs = min(x.fs, y.fs)
-    kwargs.update(vuv=vuv, power=power)
-    x_feature = make_feature(x, fs, **kwargs)
-    y_feature = make_feature(y, fs, **kwargs)
-
-    dist, path = fastdtw.fastdtw(x_feature, y_feature, dist=2, radius=radius)
-
-    def consistent(i, j):
-        # (sic) the voicing test compares x's voicing column with y's POWER column,
-        # exactly as the reference does (align.py:78)
-        if power == 'binalize' and ((x_feature[i, 0] > 0) ^ (y_feature[j, 0] > 0)):
-            return False
-        if vuv is not None and ((x_feature[i, 1] > 0) ^ (y_feature[j, 0] > 0)):
-            return False
-        return True
-
+    x_rows = make_feature(x, fs, vuv=vuv, power=power, **kwargs)
+    y_rows = make_feature(y, fs, vuv=vuv, power=power, **kwargs)
+    dist, cells = fastdtw.fastdtw(x_rows, y_rows, dist=2, radius=radius)
+    path = np.array(cells, dtype=int).reshape(-1, 2)
     if strict:
-        kept = [path[0]] + [(i, j) for i, j in path[1:-1] if consistent(i, j)] + [path[-1]]
-        path = np.array(kept, dtype=int).reshape((-1, 2))
-    else:
-        path = np.array(path)
+        # the end cells always stay -- a one-cell path therefore comes out twice, like the reference's chain()
+        inner = path[1:-1]
+        agree = np.ones(len(inner), dtype=bool)
+        y_power = y_rows[inner[:, 1], 0] > 0
+        if power == 'binalize':
+            agree &= (x_rows[inner[:, 0], 0] > 0) == y_power
+        if vuv is not None:
+            agree &= (x_rows[inner[:, 0], 1] > 0) == y_power
+        path = np.concatenate((path[:1], inner[agree], path[-1:]))
     return dist, path
 
 
 def project_path_iter(path, trim=True, trim_len=1):
-    """Walk a DTW path and yield, for every y index (pads trimmed), one x index."""
-    prev_x = prev_y = -1
-    len_y = path[-1][1] + 1
-    if trim:
-        prev_y += trim_len
-        len_y -= trim_len
+    """one x index per y index of the path: y indices below `trim_len` and the last `trim_len` ones are left out
+    when `trim` is set"""
+    margin = trim_len if trim else 0
+    stop_y = path[-1][1] + 1 - margin          # y indices from here on are not produced
+    last_x, last_y = -1, margin - 1
     for x, y in path:
-        if y <= prev_y:
-            continue
-        if y - prev_y > 1:                      # y jumped: spread x over the gap
-            y = min(y, len_y - 1)
-            diff_x, diff_y = x - prev_x, y - prev_y
-            for i in range(diff_y):
-                yield prev_x + diff_x * i // (diff_y - 1)
-        elif y >= len_y:
-            break
-        else:
+        if y <= last_y:
+            continue                           # still the same (or an earlier) y: its x is already out
+        if y - last_y == 1:
+            if y >= stop_y:
+                return
             yield x
-        prev_x, prev_y = x, y
+        else:                                  # the path skipped y values: ramp x over them
+            y = min(y, stop_y - 1)
+            steps, rise = y - last_y, x - last_x
+            for i in range(steps):
+                yield last_x + rise * i // (steps - 1)
+        last_x, last_y = x, y
 
 
 def align(feature, target, vuv='f0', strict=False, pad_silence=True, pad_len=100, **kwargs):
-    """`feature` re-timed onto `target`'s frame axis."""
+    """`feature` on `target`'s frame axis"""
     if pad_silence:
-        feature = kwiiyatta.pad_silence(feature, frame_len=pad_len)
-        target = kwiiyatta.pad_silence(target, frame_len=pad_len)
+        pad = _pkg().pad_silence
+        feature, target = pad(feature, frame_len=pad_len), pad(target, frame_len=pad_len)
     _, path = dtw_feature(feature, target, vuv=vuv, strict=strict, **kwargs)
     return feature[list(project_path_iter(path, trim=pad_silence, trim_len=pad_len))]
 
 
 def align_even(a, b, pad_silence=True, pad_len=100, **kwargs):
-    """Both features re-timed onto the common DTW path."""
+    """both feature sets along the warping path (same length), without the silence pads"""
     if pad_silence:
-        a = kwiiyatta.pad_silence(a, pad_len)
-        b = kwiiyatta.pad_silence(b, pad_len)
+        pad = _pkg().pad_silence
+        a, b = pad(a, pad_len), pad(b, pad_len)
     _, path = dtw_feature(a, b, **kwargs)
-    path = np.array(path).T
+    xs, ys = np.asarray(path).T
     if pad_silence:
-        begin = np.argmax(np.logical_and(path[0] >= pad_len, path[1] >= pad_len))
-        end = np.argmax(np.logical_and(path[0] >= a.frame_len - pad_len,
-                                       path[1] >= b.frame_len - pad_len))
-        path = path[:, begin:end]
-    return a[path[0]], b[path[1]]
+        # from the first cell inside both signals to the first cell inside both trailing pads; argmax of an
+        # all-False mask is 0, which the reference's code shares
+        inside = (xs >= pad_len) & (ys >= pad_len)
+        beyond = (xs >= a.frame_len - pad_len) & (ys >= b.frame_len - pad_len)
+        keep = slice(int(np.argmax(inside)), int(np.argmax(beyond)))
+        xs, ys = xs[keep], ys[keep]
+    return a[xs], b[ys]

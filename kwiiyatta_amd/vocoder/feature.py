@@ -1,15 +1,32 @@
-"""Concrete, mutable feature container plus the `feature()` / `pad_silence()`
-helpers (mirrors /root/reference/kwiiyatta/vocoder/feature.py:10-91)."""
+"""The materialised feature set -- all slots assignable, nothing computed behind the caller's back except the
+spectrum / mel-cepstrum conversions -- with its two constructors (`feature(fs)` empty, `feature(other)` a
+snapshot) and `pad_silence`.  API of kwiiyatta.vocoder.feature (/root/reference/kwiiyatta/vocoder/feature.py)."""
 import copy
 
 import numpy as np
 
-import kwiiyatta_amd as kwiiyatta
 from . import abc
 
 
+class Feature(abc.MutableFeature):
+    @classmethod
+    def init(cls, feature, **kwargs):
+        """Snapshot of another feature set: its arrays (extracted now if it is an analyzer) are shared, not copied;
+        frame period, mel-cepstrum order and vocoder are inherited unless overridden."""
+        inherited = dict(frame_period=feature.frame_period, mcep_order=feature.mel_cepstrum_order,
+                         Synthesizer=feature.Synthesizer)
+        snap = cls(feature.fs, **{**inherited, **kwargs})
+        for slot in abc.ARRAY_SLOTS:
+            snap._put(slot, getattr(feature, slot))
+        snap._mel_cepstrum = copy.copy(feature._mel_cepstrum)
+        return snap
+
+    def synthesize(self):
+        return self.Synthesizer.synthesize(self)
+
+
 def feature(arg, **kwargs):
-    """feature(fs) -> empty Feature; feature(other_feature) -> materialised copy."""
+    """feature(48000) -> an empty feature set at that sampling rate; feature(f) -> snapshot of f"""
     if isinstance(arg, int):
         return Feature(arg, **kwargs)
     if isinstance(arg, abc.Feature):
@@ -18,65 +35,18 @@ def feature(arg, **kwargs):
 
 
 def pad_silence(feature, frame_len):
-    """`frame_len` frames of silence before and after the feature."""
-    syn, fs, n_bins = feature.Synthesizer, feature.fs, feature.spectrum_len
-    padded = kwiiyatta.feature(feature)
-    # draw order matters for reproducibility under a seeded numpy RNG:
-    # leading block first, then trailing block, spectrum only
-    padded.f0 = np.concatenate((syn.silence_f0(frame_len, fs), feature.f0,
-                                syn.silence_f0(frame_len, fs)))
-    head = syn.silence_spectrum_envelope(frame_len, fs, n_bins)
-    body = feature.spectrum_envelope
-    tail = syn.silence_spectrum_envelope(frame_len, fs, n_bins)
-    padded.spectrum_envelope = np.concatenate((head, body, tail))
-    padded.aperiodicity = np.concatenate((syn.silence_aperiodicity(frame_len, fs, n_bins),
-                                          feature.aperiodicity,
-                                          syn.silence_aperiodicity(frame_len, fs, n_bins)))
+    """`frame_len` frames of the vocoder's silence before and after the feature set.  The silent envelopes are
+    random (numpy's global generator): leading block first, then the trailing one -- the order the reference
+    draws them in, which seeded runs depend on."""
+    vocoder, fs, bins = feature.Synthesizer, feature.fs, feature.spectrum_len
+
+    def framed(quiet, body):
+        head = quiet()
+        return np.concatenate((head, body, quiet()))
+
+    padded = Feature.init(feature)
+    padded.f0 = framed(lambda: vocoder.silence_f0(frame_len, fs), feature.f0)
+    padded.spectrum_envelope = framed(lambda: vocoder.silence_spectrum_envelope(frame_len, fs, bins),
+                                      feature.spectrum_envelope)
+    padded.aperiodicity = framed(lambda: vocoder.silence_aperiodicity(frame_len, fs, bins), feature.aperiodicity)
     return padded
-
-
-class Feature(abc.MutableFeature):
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self._f0 = self._spectrum_envelope = self._aperiodicity = None
-
-    @classmethod
-    def init(cls, feature, **kwargs):
-        """Copy another feature's arrays (forces their extraction)."""
-        kwargs.setdefault('frame_period', feature.frame_period)
-        kwargs.setdefault('mcep_order', feature.mel_cepstrum_order)
-        kwargs.setdefault('Synthesizer', feature.Synthesizer)
-        other = cls(feature.fs, **kwargs)
-        other._f0 = feature.f0
-        other._spectrum_envelope = feature.spectrum_envelope
-        other._aperiodicity = feature.aperiodicity
-        other._mel_cepstrum = copy.copy(feature._mel_cepstrum)
-        return other
-
-    @property
-    def spectrum_len(self):
-        for arr in (self._spectrum_envelope, self._aperiodicity):
-            if arr is not None:
-                return arr.shape[-1]
-        return super().spectrum_len
-
-    def _get_f0(self):
-        return self._f0
-
-    def _set_f0(self, value):
-        self._f0 = value
-
-    def _get_spectrum_envelope(self):
-        return self._spectrum_envelope
-
-    def _set_spectrum_envelope(self, value):
-        self._spectrum_envelope = value
-
-    def _get_aperiodicity(self):
-        return self._aperiodicity
-
-    def _set_aperiodicity(self, value):
-        self._aperiodicity = value
-
-    def synthesize(self):
-        return self.Synthesizer.synthesize(self)

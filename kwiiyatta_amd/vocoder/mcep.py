@@ -1,61 +1,60 @@
-"""Mel-cepstrum container (mirrors kwiiyatta.vocoder.mcep.MelCepstrum,
-/root/reference/kwiiyatta/vocoder/mcep.py:6-75).  spectrum <-> mel-cepstrum
-runs on the GPU through kwiiyatta_amd.backend.sptk (pysptk-shaped)."""
-import kwiiyatta_amd as kwiiyatta
+"""Mel-cepstrum record: the coefficient matrix of an utterance together with the sampling rate and frame period it
+belongs to (the all-pass constant alpha follows from the rate).  API of kwiiyatta.vocoder.mcep.MelCepstrum
+(/root/reference/kwiiyatta/vocoder/mcep.py:6-75); spectrum <-> mel-cepstrum runs on the GPU through
+kwiiyatta_amd.backend.sptk (sp2mc / mc2sp kernels, any even transform length)."""
 from ..backend import sptk
+
+
+def _default_synthesizer():
+    import kwiiyatta_amd
+    return kwiiyatta_amd.Synthesizer
 
 
 class MelCepstrum:
     def __init__(self, fs, frame_period, data=None):
-        self._fs = fs
-        self._frame_period = frame_period
-        self.data = data
+        self._fs, self._frame_period, self.data = fs, frame_period, data
 
     fs = property(lambda self: self._fs)
     frame_period = property(lambda self: self._frame_period)
+    order = property(lambda self: self.data.shape[-1] - 1)
 
-    @property
-    def order(self):
-        return self.data.shape[-1] - 1
-
-    @staticmethod
-    def fs_alpha(fs):
-        return sptk.mcepalpha(fs)
+    fs_alpha = staticmethod(sptk.mcepalpha)
 
     def alpha(self):
-        return self.fs_alpha(self.fs)
+        return self.fs_alpha(self._fs)
 
+    # ---- to and from power spectra ----------------------------------------------------------------------
     def extract_spectrum(self, spectrum_len=None, Synthesizer=None):
+        """(T, spectrum_len) power spectrum of the stored coefficients; default: the vocoder's bin count at fs"""
         if spectrum_len is None:
-            Synthesizer = Synthesizer or kwiiyatta.Synthesizer
-            spectrum_len = Synthesizer.fs_spectrum_len(self.fs)
-        return sptk.mc2sp(self.data, fftlen=(spectrum_len - 1) * 2, alpha=self.alpha())
+            spectrum_len = (Synthesizer or _default_synthesizer()).fs_spectrum_len(self._fs)
+        return sptk.mc2sp(self.data, fftlen=2 * (spectrum_len - 1), alpha=self.alpha())
 
     def extract_data(self, spectrum, order=24, fs=None):
-        return sptk.sp2mc(spectrum, order=order, alpha=self.fs_alpha(self.fs if fs is None else fs))
+        """coefficients of a spectrum sampled at `fs` (default: this record's rate); nothing is stored"""
+        return sptk.sp2mc(spectrum, order=order, alpha=self.fs_alpha(self._fs if fs is None else fs))
 
     def extract(self, spectrum, order=24):
         self.data = self.extract_data(spectrum, order)
         return self.data
 
+    # ---- another sampling rate ---------------------------------------------------------------------------------
     def resample_data(self, new_fs, spectrum_len=None, Synthesizer=None, order=None):
-        """Mel-cepstrum at another sampling rate, going through the spectrum."""
-        Synthesizer = Synthesizer or kwiiyatta.Synthesizer
-        if spectrum_len is None:
-            spectrum_len = Synthesizer.fs_spectrum_len(self.fs)
-        if order is None:
-            order = self.order
-        spec = Synthesizer.resample_spectrum_envelope(self.extract_spectrum(spectrum_len), self.fs, new_fs)
-        return self.extract_data(spec, order, fs=new_fs)
+        """the coefficients this record would have at `new_fs`: through its spectrum, cut or extended along the
+        frequency axis by the vocoder's rule"""
+        syn = Synthesizer or _default_synthesizer()
+        here = self.extract_spectrum(syn.fs_spectrum_len(self._fs) if spectrum_len is None else spectrum_len)
+        there = syn.resample_spectrum_envelope(here, self._fs, new_fs)
+        return self.extract_data(there, self.order if order is None else order, fs=new_fs)
 
     def resample(self, new_fs, spectrum=None, order=None, **kwargs):
+        """in place.  With `spectrum` (already at new_fs) the coefficients are taken from it; otherwise they go
+        through `resample_data` (a no-op when the rate does not change)."""
         if order is None:
             order = self.order
         if spectrum is not None:
             self._fs = new_fs
-            if order is not None:
-                kwargs['order'] = order
-            self.extract(spectrum, **kwargs)
-        elif new_fs != self.fs:
+            self.extract(spectrum, order=order, **kwargs)
+        elif new_fs != self._fs:
             self.data = self.resample_data(new_fs, order=order, **kwargs)
             self._fs = new_fs

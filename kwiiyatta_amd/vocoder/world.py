@@ -1,10 +1,15 @@
-"""WORLD vocoder backend of the feature model (mirrors
-/root/reference/kwiiyatta/vocoder/world.py:13-166), running on the HIP kernels
-through kwiiyatta_amd.backend.world (pyworld-shaped)."""
+"""WORLD as the vocoder of the feature model: `WorldAnalyzer` fills the slots with DIO + StoneMask, CheapTrick and
+D4C, `WorldSynthesizer` turns feature sets back into waveforms and carries WORLD's conventions (bin count per
+sampling rate, band-coded aperiodicity, voicing rule, silence).  API of kwiiyatta.vocoder.world
+(/root/reference/kwiiyatta/vocoder/world.py:13-166); the signal processing runs in the HIP kernels behind
+kwiiyatta_amd.backend.world, which has pyworld's call signatures.
+
+Two conventions of the reference are folded into kernel arguments instead of separate array passes: the envelope
+is stored divided by the sampling rate (world.py:50; `out_div`) and multiplied back for synthesis (world.py:88;
+`sp_mul`)."""
 import numpy as np
 import scipy.interpolate
 
-import kwiiyatta_amd as kwiiyatta
 from ..backend import world as pyworld
 from ..wavfile import Wavdata
 from . import abc
@@ -13,48 +18,39 @@ from . import abc
 class WorldAnalyzer(abc.Analyzer):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self._data = np.ascontiguousarray(self._data)
+        self._data = np.ascontiguousarray(self._data)      # pyworld's contract: C-contiguous float64
         self._timeaxis = None
 
     @property
     def frame_len(self):
-        # integer arithmetic, as the reference: N*1000 // fs // frame_period + 1
-        return self.data.shape[0] * 1000 // self.fs // self.frame_period + 1
-
-    @property
-    def spectrum_len(self):
-        if self._spectrum_envelope is not None:
-            return self._spectrum_envelope.shape[-1]
-        return WorldSynthesizer.fs_spectrum_len(self.fs)
-
-    def clear_features(self):
-        super().clear_features()
-        self._f0 = self._spectrum_envelope = self._aperiodicity = None
+        samples = self.data.shape[0]
+        return samples * 1000 // self.fs // self.frame_period + 1      # integer arithmetic throughout
 
     def extract_f0(self, **kwargs):
         if self._f0 is None:
-            f0, self._timeaxis = pyworld.dio(self.data, self.fs, frame_period=self.frame_period,
-                                             **kwargs)
-            self._f0 = pyworld.stonemask(self.data, f0, self._timeaxis, self.fs)
+            coarse, self._timeaxis = pyworld.dio(self.data, self.fs, frame_period=self.frame_period, **kwargs)
+            self._f0 = pyworld.stonemask(self.data, coarse, self._timeaxis, self.fs)
         return self._f0
+
+    def _frame_grid(self):
+        """(f0, frame times): the spectral analyses run on the f0 analysis' frames"""
+        return self.f0, self._timeaxis
 
     def extract_spectrum_envelope(self, **kwargs):
         if self._spectrum_envelope is None:
-            # kwiiyatta stores the envelope divided by fs (world.py:49-50); the
-            # division is folded into the kernel's epilogue.
-            f0 = self.f0
-            self._spectrum_envelope = pyworld.cheaptrick(self.data, f0, self._timeaxis, self.fs,
-                                                         out_div=float(self.fs), **kwargs)
+            f0, times = self._frame_grid()
+            self._spectrum_envelope = pyworld.cheaptrick(self.data, f0, times, self.fs, out_div=float(self.fs),
+                                                         **kwargs)
         return self._spectrum_envelope
 
     def extract_aperiodicity(self, **kwargs):
         if self._aperiodicity is None:
-            f0 = self.f0
-            self._aperiodicity = pyworld.d4c(self.data, f0, self._timeaxis, self.fs, **kwargs)
+            f0, times = self._frame_grid()
+            self._aperiodicity = pyworld.d4c(self.data, f0, times, self.fs, **kwargs)
         return self._aperiodicity
 
     def ascontiguousarray(self):
-        pass  # the kernels already produce C-contiguous float64 arrays
+        pass        # what the kernels return is contiguous already
 
 
 class WorldSynthesizer(abc.Synthesizer):
@@ -64,74 +60,67 @@ class WorldSynthesizer(abc.Synthesizer):
     UPPER_LIMIT = 15000.0
 
     @staticmethod
+    def fs_spectrum_len(fs):
+        return pyworld.get_cheaptrick_fft_size(fs) // 2 + 1
+
+    # ---- waveform -------------------------------------------------------------------------------------------
+    @staticmethod
     def reshape_feature(feature):
-        """WORLD synthesis needs 2^n + 1 bins: round the bin count up to that."""
-        n = feature.spectrum_len
-        pow2 = 1 << (n.bit_length() - 1)
-        if pow2 < n - 1:
-            pow2 *= 2
-        return kwiiyatta.reshape(feature, pow2 + 1)
+        """WORLD synthesises from 2^n + 1 bins: a feature set with any other count (after a change of sampling
+        rate) is stretched to the next such count"""
+        import kwiiyatta_amd
+        span = feature.spectrum_len - 1
+        pow2 = max(2, 1 << (span - 1).bit_length())          # the smallest power of two >= span
+        return kwiiyatta_amd.reshape(feature, pow2 + 1)
 
     @classmethod
     def _synthesize(cls, feature):
         f = cls.reshape_feature(feature)
         f.ascontiguousarray()
-        # the stored envelope is 1/fs-scaled (world.py:88 multiplies it back);
-        # the multiplication is folded into the kernel's spectrum load.
-        y = pyworld.synthesize(f.f0, f.spectrum_envelope, f.aperiodicity, f.fs, f.frame_period,
-                               sp_mul=float(f.fs))
-        return Wavdata(f.fs, y)
+        samples = pyworld.synthesize(f.f0, f.spectrum_envelope, f.aperiodicity, f.fs, f.frame_period,
+                                     sp_mul=float(f.fs))
+        return Wavdata(f.fs, samples)
 
-    @staticmethod
-    def fs_spectrum_len(fs):
-        return pyworld.get_cheaptrick_fft_size(fs) // 2 + 1
-
-    # ---- aperiodicity across sampling rates: through WORLD's band coding -----------------------
+    # ---- aperiodicity between sampling rates: through WORLD's band code (one dB value per 3 kHz band) ---------
     @classmethod
     def _get_aperiodicity_num(cls, fs):
         return int(min(cls.UPPER_LIMIT, fs / 2 - cls.FREQUENCY_INTERVAL) / cls.FREQUENCY_INTERVAL)
 
     @classmethod
-    def _reshape_aperiodicity(cls, feature, fs, new_spectrum_len):
-        coded = pyworld.code_aperiodicity(np.ascontiguousarray(feature), fs)
-        return pyworld.decode_aperiodicity(coded, fs, (new_spectrum_len - 1) * 2)
+    def _recode_aperiodicity(cls, feature, fs, new_fs, new_spectrum_len):
+        bands = pyworld.code_aperiodicity(np.ascontiguousarray(feature), fs)
+        have, want = bands.shape[1], cls._get_aperiodicity_num(new_fs)
+        if want < have:
+            bands = np.ascontiguousarray(bands[:, :want])
+        elif want > have:
+            # extend towards the new Nyquist frequency, where WORLD pins the contour at -1e-12 dB
+            knots = np.append(np.arange(have), new_fs / 2 / cls.FREQUENCY_INTERVAL - 1)
+            values = np.hstack((bands, np.full((len(bands), 1), -cls.SAFE_GUARD_MINIMUM)))
+            bands = np.ascontiguousarray(scipy.interpolate.interp1d(knots, values, axis=1)(np.arange(want)))
+        return pyworld.decode_aperiodicity(bands, new_fs, 2 * (new_spectrum_len - 1))
+
+    _resample_up_aperiodicity = _recode_aperiodicity
+    _resample_down_aperiodicity = _recode_aperiodicity
 
     @classmethod
     def _resample_up_spectrum_envelope(cls, feature, fs, new_fs, new_spectrum_len):
-        extra = new_spectrum_len - feature.shape[1]
-        return np.hstack((feature, cls.silence_spectrum_envelope(feature.shape[0], fs, extra)))
+        """the band above the old Nyquist frequency is silence"""
+        missing = new_spectrum_len - feature.shape[1]
+        return np.hstack((feature, cls.silence_spectrum_envelope(len(feature), fs, missing)))
 
-    @classmethod
-    def _resample_down_aperiodicity(cls, feature, fs, new_fs, new_spectrum_len):
-        coded = pyworld.code_aperiodicity(np.ascontiguousarray(feature), fs)
-        num = cls._get_aperiodicity_num(new_fs)
-        if num < coded.shape[1]:
-            coded = np.ascontiguousarray(coded[:, :num])
-        return pyworld.decode_aperiodicity(coded, new_fs, (new_spectrum_len - 1) * 2)
-
-    @classmethod
-    def _resample_up_aperiodicity(cls, feature, fs, new_fs, new_spectrum_len):
-        coded = pyworld.code_aperiodicity(np.ascontiguousarray(feature), fs)
-        num = cls._get_aperiodicity_num(new_fs)
-        if num > coded.shape[1]:
-            axis = np.hstack((np.arange(coded.shape[1]), new_fs / 2 / cls.FREQUENCY_INTERVAL - 1))
-            coded = np.hstack((coded, np.full((coded.shape[0], 1), -cls.SAFE_GUARD_MINIMUM)))
-            coded = np.ascontiguousarray(
-                scipy.interpolate.interp1d(axis, coded, axis=1)(np.arange(num)))
-        return pyworld.decode_aperiodicity(coded, new_fs, (new_spectrum_len - 1) * 2)
-
+    # ---- voicing, silence ----------------------------------------------------------------------------------------
     @staticmethod
     def extract_is_voiced(feature):
-        lowest_f0 = feature.fs / ((feature.spectrum_len - 1) / 2) + 1.0
-        return np.logical_and(feature.f0 >= lowest_f0, feature.aperiodicity[:, 0] <= 0.999)
+        floor = feature.fs / ((feature.spectrum_len - 1) / 2) + 1.0      # kwiiyatta's own threshold, not WORLD's
+        return np.logical_and(feature.f0 >= floor, feature.aperiodicity[:, 0] <= 0.999)
 
     @staticmethod
     def silence_f0(frame_len, fs):
-        return np.zeros((frame_len))
+        return np.zeros(frame_len)
 
     @classmethod
     def _silence_spectrum_envelope(cls, frame_len, fs, spectrum_len):
-        # numpy's global legacy RNG on purpose: the reference's tests seed it
+        # the reference draws from numpy's GLOBAL generator (its tests seed it): kept
         return np.abs(np.random.normal(0, cls.EPS / fs, (frame_len, spectrum_len)))
 
     @classmethod
