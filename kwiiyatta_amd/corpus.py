@@ -72,11 +72,11 @@ class TrainPair:
     """
 
     def __init__(self, device_index, fs, source, target, order=24, radius=32, frame_period=5.0, stream=None,
-                 silence=None):
+                 silence=None, ctx=None):
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
-        self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.ctx = ctx if ctx is not None else _lib.Context(device_index, stream=self.stream.cuda_stream)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
         self.K = self.fft // 2 + 1
         from .backend import sptk
@@ -162,11 +162,11 @@ class ConvertPipeline(_Graphed):
     """convert_voice.convert(diffvc=False) of one utterance, HBM-resident: analyse -> mel-cepstrum -> GMM/MLPG
     conversion (c0 kept) -> spectrum -> synthesis with the utterance's own f0 and aperiodicity."""
 
-    def __init__(self, device_index, fs, utterance, gmm, order=24, frame_period=5.0, stream=None):
+    def __init__(self, device_index, fs, utterance, gmm, order=24, frame_period=5.0, stream=None, ctx=None):
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.frame_period = int(fs), int(order), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
-        self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.ctx = ctx if ctx is not None else _lib.Context(device_index, stream=self.stream.cuda_stream)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
         self.K = self.fft // 2 + 1
         from .backend import sptk
@@ -192,6 +192,15 @@ class ConvertPipeline(_Graphed):
         self.stream.synchronize()
         self.frames = self.T
 
+    def load(self, utterance):
+        """another utterance of the same shape into the existing buffers (asynchronous on the pipeline's stream)"""
+        x, f0, t = utterance
+        if len(x) != self.N or len(f0) != self.T:
+            raise ValueError('ConvertPipeline.load: shape differs from the pipeline\'s')
+        with torch.cuda.stream(self.stream):
+            for dst, src in ((self.x, x), (self.f0, f0), (self.t, t)):
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(src)), non_blocking=True)
+
     def run(self):
         h, fs, fft, K, order, T = self.ctx.handle, self.fs, self.fft, self.K, self.order, self.T
         chk = lambda rc: _lib.check(self.ctx, rc)  # noqa: E731
@@ -212,6 +221,19 @@ class ConvertPipeline(_Graphed):
         self.ctx.sync()
 
 
+class StreamPool:
+    """`n` HIP streams with one library context each (a context owns constant tables and a scratch arena: built
+    once per stream, not once per utterance)"""
+
+    def __init__(self, device_index, n):
+        self.dev = torch.device('cuda', device_index)
+        self.streams = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, n))]
+        self.contexts = [_lib.Context(device_index, stream=s.cuda_stream) for s in self.streams]
+
+    def __len__(self):
+        return len(self.streams)
+
+
 def shard_block(n_items, rank, world_size):
     """Contiguous block of items for `rank`: the concatenation over ranks is the original order."""
     if not (0 <= rank < world_size):
@@ -227,14 +249,14 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
     (n, 2*3*order) float64 device tensor of make_dataset_to_array and the number of source frames analysed.
     Pairs are processed `streams` at a time, each on its own stream."""
     dev = torch.device('cuda', device_index)
-    pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))]
+    pool = StreamPool(device_index, streams)
     blocks, frames = [], 0
     for w0 in range(0, len(pairs), len(pool)):
         wave = []
         for k, (src, tgt) in enumerate(pairs[w0:w0 + len(pool)]):
             sil = silence_for(w0 + k) if silence_for is not None else None
             wave.append(TrainPair(device_index, fs, src, tgt, order=order, radius=radius, frame_period=frame_period,
-                                  stream=pool[k], silence=sil))
+                                  stream=pool.streams[k], ctx=pool.contexts[k], silence=sil))
         for p in wave:
             p.analyse()
         for p in wave:
@@ -256,17 +278,31 @@ def fit_converter(X, components=64, seed=None, max_iter=100, device_index=0, ver
 
 
 def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16):
-    """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors)."""
+    """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors).  Every stream
+    keeps one pipeline per utterance shape, captured as a HIP graph: an utterance of a shape seen before costs an
+    upload, one graph launch and a device copy of the result."""
     dev = torch.device('cuda', device_index)
     dg = DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
-    pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))]
-    out = []
+    pool = StreamPool(device_index, streams)
+    cache = [dict() for _ in range(len(pool))]
+    out = [None] * len(utterances)
     for w0 in range(0, len(utterances), len(pool)):
-        wave = [ConvertPipeline(device_index, fs, u, dg, order=order, frame_period=frame_period, stream=pool[k])
-                for k, u in enumerate(utterances[w0:w0 + len(pool)])]
-        for p in wave:
-            p.run()
-        for p in wave:
+        wave = []
+        for k, u in enumerate(utterances[w0:w0 + len(pool)]):
+            shape = (len(u[0]), len(u[1]))
+            p = cache[k].get(shape)
+            if p is None:
+                p = ConvertPipeline(device_index, fs, u, dg, order=order, frame_period=frame_period,
+                                    stream=pool.streams[k], ctx=pool.contexts[k])
+                p.capture()
+                cache[k][shape] = p
+            else:
+                p.load(u)
+            p.replay()
+            wave.append((w0 + k, p))
+        for i, p in wave:
+            with torch.cuda.stream(p.stream):
+                out[i] = p.wave.clone()
+        for _, p in wave:
             p.sync()
-            out.append(p.wave)
     return out
