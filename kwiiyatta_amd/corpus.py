@@ -26,18 +26,14 @@ import torch
 
 from . import _lib
 from ._lib import lib, c_vp
-from .pipeline import EPS, PAD_LEN, POWER_THRESHOLD, POWER_WEIGHT, SAFE_GUARD_MINIMUM, VUV_WEIGHT, DeviceGMM, _Graphed
+from .pipeline import (PAD_LEN, POWER_THRESHOLD, POWER_WEIGHT, SAFE_GUARD_MINIMUM, VUV_WEIGHT, DeviceGMM, _Graphed,
+                       draw_silence)
 
 TRIM_EPS = 1e-7       # nnmnkwii trim_zeros_frames / remove_zeros_frames
 
 
 def _p(t):
     return c_vp(t.data_ptr())
-
-
-def draw_silence(fs, K, frame_len=PAD_LEN):
-    """WorldSynthesizer._silence_spectrum_envelope: |N(0, EPS / fs)| from numpy's global generator."""
-    return np.abs(np.random.normal(0, EPS / fs, (frame_len, K)))
 
 
 class _TrainSide:

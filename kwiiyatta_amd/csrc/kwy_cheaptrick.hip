@@ -18,14 +18,14 @@
 #define CT_EPS 0.00000000000000022204460492503131
 #define CT_DEFAULT_F0 500.0
 
-// per-frame draw counts: window length + K
-__global__ void k_ct_counts(const double *__restrict__ f0, int64_t T, int fs, double f0_floor_eff,
-                            int K, uint32_t *__restrict__ counts) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= T) return;
-  double cf0 = f0[i] <= f0_floor_eff ? CT_DEFAULT_F0 : f0[i];
-  int half = kwy_matlab_round(1.5 * fs / cf0);
-  counts[i] = (uint32_t)(2 * half + 1 + K);
+// per-frame draw counts (window length + K) and their exclusive prefix sums, in one single-workgroup launch
+__global__ __launch_bounds__(KWY_THREADS) void k_ct_scan(const double *__restrict__ f0, int64_t T, int fs,
+                                                        double f0_floor_eff, int K, uint64_t *__restrict__ offsets) {
+  __shared__ uint64_t tot[KWY_THREADS];
+  kwy_block_count_scan<KWY_THREADS>([&](int64_t i) -> uint64_t {
+    const double cf0 = f0[i] <= f0_floor_eff ? CT_DEFAULT_F0 : f0[i];
+    return (uint64_t)(2 * kwy_matlab_round(1.5 * fs / cf0) + 1 + K);
+  }, T, offsets, tot);
 }
 
 // y(x) on the regular grid x0 + shift*j (WORLD interp1Q); delta of the last node is 0
@@ -261,14 +261,11 @@ static int cheaptrick_core(kwy_ctx *ctx, const double *x, int64_t x_length, int 
   }
   const int K = fft_size / 2 + 1;
   const double floor_eff = 3.0 * fs / (fft_size - 3.0);
-  uint32_t *counts = kwy_arena<uint32_t>(ctx, T);
   uint64_t *offsets = kwy_arena<uint64_t>(ctx, T + 1);
   uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * T);
-  if (!counts || !offsets || !ebase) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
-  hipLaunchKernelGGL(k_ct_counts, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, f0, T,
-                     fs, floor_eff, K, counts);
+  if (!offsets || !ebase) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
+  hipLaunchKernelGGL(k_ct_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, T, fs, floor_eff, K, offsets);
   KWY_HIP(hipGetLastError());
-  KWY_TRY(kwy_launch_scan(ctx, counts, offsets, T));
   KWY_TRY(kwy_launch_ebase(ctx, offsets, nullptr, T, ebase));
   switch (log2n) {
     case 9: return launch_ct<9>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);

@@ -101,37 +101,36 @@ __device__ inline void d4c_linear_smoothing(const double *in, double *out, doubl
   __syncthreads();
 }
 
-// per-frame draw counts for the LoveTrain pass
-__global__ void k_d4c_lt_counts(const double *__restrict__ f0, int64_t T, int fs,
-                                uint32_t *__restrict__ counts) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= T) return;
-  double f = f0[i];
-  if (f == 0.0) { counts[i] = 0; return; }
-  double cf0 = f > 40.0 ? f : 40.0;
-  counts[i] = (uint32_t)(kwy_matlab_round(1.5 * fs / cf0) * 2 + 1);
+// LoveTrain pass: per-frame draw counts and their exclusive prefix sums, one single-workgroup launch
+__global__ __launch_bounds__(KWY_THREADS) void k_d4c_lt_scan(const double *__restrict__ f0, int64_t T, int fs,
+                                                            uint64_t *__restrict__ offsets) {
+  __shared__ uint64_t tot[KWY_THREADS];
+  kwy_block_count_scan<KWY_THREADS>([&](int64_t i) -> uint64_t {
+    const double f = f0[i];
+    if (f == 0.0) return 0;
+    return (uint64_t)(kwy_matlab_round(1.5 * fs / (f > 40.0 ? f : 40.0)) * 2 + 1);
+  }, T, offsets, tot);
 }
 
-// draw offsets of the three windows of every gated frame (~0 = no work) from the frame offsets
-__global__ void k_d4c_window_offsets(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ counts,
-                                     int64_t T, uint64_t *__restrict__ offs3) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= T) return;
-  const uint32_t wl = counts[i] / 3;
+// General body: per-frame draw counts (three windows; none for ungated frames), their prefix sums, and the draw
+// offsets of the three windows of every frame (~0 = no work), one single-workgroup launch
+__global__ __launch_bounds__(KWY_THREADS) void k_d4c_body_scan(const double *__restrict__ f0,
+                                                              const double *__restrict__ ap0, int64_t T, int fs,
+                                                              double threshold, uint64_t *__restrict__ offs,
+                                                              uint64_t *__restrict__ offs3) {
+  __shared__ uint64_t tot[KWY_THREADS];
+  auto window = [&](int64_t i) -> uint64_t {      // draws of ONE window of frame i
+    const double f = f0[i];
+    if (f == 0.0 || ap0[i] <= threshold) return 0;
+    return (uint64_t)(kwy_matlab_round(2.0 * fs / (f > D4C_FLOOR_F0 ? f : D4C_FLOOR_F0)) * 2 + 1);
+  };
+  kwy_block_count_scan<KWY_THREADS>([&](int64_t i) -> uint64_t { return 3 * window(i); }, T, offs, tot);
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < T; i += KWY_THREADS) {
+    const uint64_t wl = window(i), o = offs[i];
 #pragma unroll
-  for (int w = 0; w < 3; ++w) offs3[3 * i + w] = wl ? offs[i] + (uint64_t)w * wl : ~0ull;
-}
-
-// per-frame draw counts for the general body (0 for ungated frames)
-__global__ void k_d4c_body_counts(const double *__restrict__ f0, const double *__restrict__ ap0,
-                                  int64_t T, int fs, double threshold,
-                                  uint32_t *__restrict__ counts) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= T) return;
-  double f = f0[i];
-  if (f == 0.0 || ap0[i] <= threshold) { counts[i] = 0; return; }
-  double cf0 = f > D4C_FLOOR_F0 ? f : D4C_FLOOR_F0;
-  counts[i] = (uint32_t)(3 * (kwy_matlab_round(2.0 * fs / cf0) * 2 + 1));
+    for (int w = 0; w < 3; ++w) offs3[3 * i + w] = wl ? o + (uint64_t)w * wl : ~0ull;
+  }
 }
 
 // ------------------------------------------------------------------ LoveTrain
@@ -719,21 +718,18 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   p.window_length = (int)(D4C_FREQ_INTERVAL * n4 / fs) * 2 + 1;
   p.threshold = threshold;
 
-  uint32_t *counts = kwy_arena<uint32_t>(ctx, T);
   uint64_t *offs_lt = kwy_arena<uint64_t>(ctx, T + 1);
   uint64_t *offs_b = kwy_arena<uint64_t>(ctx, T + 1);
   uint64_t *offs3 = kwy_arena<uint64_t>(ctx, 3 * T);
   uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * 3 * T);
   double *ap0 = kwy_arena<double>(ctx, T);
-  if (!counts || !offs_lt || !offs_b || !offs3 || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
+  if (!offs_lt || !offs_b || !offs3 || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
   const double *nuttall;
   KWY_TRY(get_nuttall(ctx, p.window_length, &nuttall));
-  const unsigned gb = (unsigned)((T + 255) / 256);
 
   // LoveTrain pass
-  hipLaunchKernelGGL(k_d4c_lt_counts, dim3(gb), dim3(256), 0, ctx->stream, f0, T, fs, counts);
+  hipLaunchKernelGGL(k_d4c_lt_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, T, fs, offs_lt);
   KWY_HIP(hipGetLastError());
-  KWY_TRY(kwy_launch_scan(ctx, counts, offs_lt, T));
   KWY_TRY(kwy_launch_ebase(ctx, offs_lt, nullptr, T, ebase));
   switch (ll) {
     case 10: KWY_TRY(launch_lt<10>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
@@ -742,11 +738,8 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
     default: KWY_TRY(launch_lt<13>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
   }
   // general body; its noise continues where the LoveTrain pass stopped (offs_lt[T])
-  hipLaunchKernelGGL(k_d4c_body_counts, dim3(gb), dim3(256), 0, ctx->stream, f0, ap0, T, fs,
-                     threshold, counts);
-  KWY_HIP(hipGetLastError());
-  KWY_TRY(kwy_launch_scan(ctx, counts, offs_b, T));
-  hipLaunchKernelGGL(k_d4c_window_offsets, dim3(gb), dim3(256), 0, ctx->stream, offs_b, counts, T, offs3);
+  hipLaunchKernelGGL(k_d4c_body_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, ap0, T, fs, threshold, offs_b,
+                     offs3);
   KWY_HIP(hipGetLastError());
   KWY_TRY(kwy_launch_ebase(ctx, offs3, offs_lt + T, 3 * T, ebase));
   switch (l4) {

@@ -280,6 +280,39 @@ __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
   __syncthreads();
 }
 
+// offsets[i] = sum_{j<i} count(j) for i <= n, the counts given by a function of the index (evaluated twice: once for
+// the chunk totals, once for the offsets) -- counting and scanning in ONE single-workgroup launch.  tot: NT uint64 of LDS.
+template <int NT, class F>
+__device__ inline void kwy_block_count_scan(F count, int64_t n, uint64_t *__restrict__ offsets, uint64_t *tot) {
+  const int t = threadIdx.x;
+  const int64_t chunk = (n + NT - 1) / NT;
+  const int64_t b0 = t * chunk, b1 = min(n, b0 + chunk);
+  uint64_t run = 0;
+  for (int64_t i = b0; i < b1; ++i) run += count(i);
+  tot[t] = run;
+  __syncthreads();
+  if (t < 64) {                      // wave 0: exclusive scan of the NT chunk totals, NT/64 per lane
+    constexpr int PER = NT / 64;
+    uint64_t a[PER], acc = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { a[q] = acc; acc += tot[PER * t + q]; }
+    uint64_t inc = acc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t up = __shfl_up(inc, o);
+      if (t >= o) inc += up;
+    }
+    const uint64_t excl = inc - acc;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) tot[PER * t + q] = excl + a[q];
+  }
+  __syncthreads();
+  run = tot[t];
+  for (int64_t i = b0; i < b1; ++i) { offsets[i] = run; run += count(i); }
+  if (b0 < n && b1 == n) offsets[n] = run;
+  if (n == 0 && t == 0) offsets[0] = 0;
+}
+
 // sums of two values over the block in one exchange; red: >= 2*NT/64 doubles
 template <int NT = KWY_THREADS>
 __device__ __forceinline__ void kwy_block_sum2(double a, double b, double *red, double *ta, double *tb) {

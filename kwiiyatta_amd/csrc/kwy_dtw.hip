@@ -33,6 +33,45 @@ __global__ void k_dtw_halve(const double *__restrict__ in, int n_out, int dim, d
   out[e] = (in[(int64_t)(2 * i) * dim + k] + in[(int64_t)(2 * i + 1) * dim + k]) / 2;
 }
 
+// All coarsening levels of both series in ONE launch.  A workgroup owns 2^levels consecutive frames of one series
+// and halves them level by level in LDS (ping-pong), storing every level: element i of level l is the pairwise
+// average tree over the original frames [i 2^l, (i+1) 2^l) -- the same operations in the same order as halving
+// level after level, so the values are bit-identical to k_dtw_halve's.  (n_l = n >> l: the odd frame left over at
+// a level is dropped there, as fastdtw's x[:len(x) // 2 * 2] does.)
+#define DTW_MAXLV 12
+struct dtw_halve_desc {
+  const double *src[2];
+  double *lv[2][DTW_MAXLV];     // lv[s][l - 1]: level l of series s
+  int n[2];
+  int chunks0;                  // workgroups of series 0
+  int levels, dim;
+};
+__global__ __launch_bounds__(KWY_THREADS) void k_dtw_halve_all(dtw_halve_desc d) {
+  extern __shared__ double hb[];
+  const int s = blockIdx.x < d.chunks0 ? 0 : 1;
+  const int c = s == 0 ? blockIdx.x : blockIdx.x - d.chunks0;
+  const int C = 1 << d.levels, dim = d.dim, n = d.n[s];
+  double *A = hb, *B = hb + (size_t)C * dim;
+  const int64_t f0 = (int64_t)c * C;
+  const int have = (int)min((int64_t)C, (int64_t)n - f0);
+  for (int e = threadIdx.x; e < have * dim; e += KWY_THREADS) A[e] = d.src[s][f0 * dim + e];
+  __syncthreads();
+  for (int l = 1; l <= d.levels; ++l) {
+    const int nl = n >> l, per = C >> l;
+    const int i0 = c * per;
+    const int cnt = min(per, nl - i0);           // level-l elements of this workgroup (may be <= 0)
+    double *out = d.lv[s][l - 1];
+    for (int e = threadIdx.x; e < cnt * dim; e += KWY_THREADS) {
+      const int i = e / dim, k = e - i * dim;
+      const double v = (A[(2 * i) * dim + k] + A[(2 * i + 1) * dim + k]) / 2;
+      B[e] = v;
+      out[(int64_t)(i0 + i) * dim + k] = v;
+    }
+    __syncthreads();
+    double *t = A; A = B; B = t;
+  }
+}
+
 // window rows.  cpath == nullptr: full window (base case).  Otherwise cpath is the
 // coarser level's path (cn = *cpath_len cells, both coordinates non-decreasing).
 __global__ void k_dtw_window(const int32_t *__restrict__ cpath, const int64_t *__restrict__ cpath_len,
@@ -61,6 +100,35 @@ __global__ void k_dtw_window(const int32_t *__restrict__ cpath, const int64_t *_
   lo[i] = l;
   hi[i] = h;
   width[i] = (uint32_t)(h - l + 1);
+}
+
+// The same windows for all rows, and the rows' offsets in the band storage (exclusive prefix sums of the widths), in
+// one single-workgroup launch.
+#define DTW_WS_NT 1024
+__global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(const int32_t *__restrict__ cpath,
+                                                              const int64_t *__restrict__ cpath_len, int radius,
+                                                              int len_x, int len_y, int32_t *__restrict__ lo,
+                                                              int32_t *__restrict__ hi, uint64_t *__restrict__ off) {
+  __shared__ uint64_t tot[DTW_WS_NT];
+  const int cn = cpath ? (int)*cpath_len : 0;
+  for (int i = threadIdx.x; i < len_x; i += DTW_WS_NT) {
+    int l = 0, h = len_y - 1;
+    if (cpath && cn > 0) {
+      const int a = i / 2;
+      int b0 = 0, b1 = cn;
+      while (b0 < b1) { int mid = (b0 + b1) >> 1; if (cpath[2 * mid] >= a - radius) b1 = mid; else b0 = mid + 1; }
+      const int first = min(b0, cn - 1);
+      b0 = 0; b1 = cn;
+      while (b0 < b1) { int mid = (b0 + b1) >> 1; if (cpath[2 * mid] > a + radius) b1 = mid; else b0 = mid + 1; }
+      const int last = max(b0 - 1, 0);
+      l = max(0, 2 * (cpath[2 * first + 1] - radius));
+      h = min(len_y - 1, 2 * (cpath[2 * last + 1] + radius) + 1);
+    }
+    lo[i] = l;
+    hi[i] = h;
+  }
+  __syncthreads();
+  kwy_block_count_scan<DTW_WS_NT>([&](int64_t i) -> uint64_t { return (uint64_t)(hi[i] - lo[i] + 1); }, len_x, off, tot);
 }
 
 // Band storage: row i holds width[i] distances at dist[DTW_PAD + off[i] + 16 i + 8 ...], with DTW_ROWPAD +inf
@@ -461,11 +529,29 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     double *cx = kwy_arena<double>(ctx, (size_t)c.len_x * dim);
     double *cy = kwy_arena<double>(ctx, (size_t)c.len_y * dim);
     if (!cx || !cy) { ctx->err = "fastdtw: scratch arena too small"; return KWY_ENOMEM; }
-    hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)c.len_x * dim + 255) / 256)), dim3(256), 0,
-                       ctx->stream, xs.back(), c.len_x, dim, cx);
-    hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)c.len_y * dim + 255) / 256)), dim3(256), 0,
-                       ctx->stream, ys.back(), c.len_y, dim, cy);
     lv.push_back(c); xs.push_back(cx); ys.push_back(cy);
+  }
+  {
+    const int levels = (int)lv.size() - 1;
+    const size_t halve_lds = levels > 0 ? sizeof(double) * (((size_t)3 << levels) / 2) * dim : 0;
+    if (levels > 0 && levels <= DTW_MAXLV && halve_lds <= 64 * 1024) {
+      dtw_halve_desc d;
+      d.src[0] = x; d.src[1] = y;
+      d.n[0] = (int)Tx; d.n[1] = (int)Ty;
+      d.levels = levels; d.dim = dim;
+      for (int l = 1; l <= levels; ++l) { d.lv[0][l - 1] = (double *)xs[l]; d.lv[1][l - 1] = (double *)ys[l]; }
+      const int C = 1 << levels;
+      d.chunks0 = (int)((Tx + C - 1) / C);
+      const int chunks1 = (int)((Ty + C - 1) / C);
+      hipLaunchKernelGGL(k_dtw_halve_all, dim3(d.chunks0 + chunks1), dim3(KWY_THREADS), halve_lds, ctx->stream, d);
+    } else {
+      for (int l = 1; l <= levels; ++l) {      // long series / wide features: level by level
+        hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)lv[l].len_x * dim + 255) / 256)), dim3(256), 0,
+                           ctx->stream, xs[l - 1], lv[l].len_x, dim, (double *)xs[l]);
+        hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)lv[l].len_y * dim + 255) / 256)), dim3(256), 0,
+                           ctx->stream, ys[l - 1], lv[l].len_y, dim, (double *)ys[l]);
+      }
+    }
   }
   const uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
   double *dist = kwy_arena<double>(ctx, cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD);   // + the +inf cells of every row
@@ -500,9 +586,8 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     const bool top = (l == 0);
     int32_t *opath = top ? d_path : ((l & 1) ? pathA : pathB);
     int64_t *olen = top ? d_path_len : ((l & 1) ? lenA : lenB);
-    hipLaunchKernelGGL(k_dtw_window, dim3((len_x + 255) / 256), dim3(256), 0, ctx->stream, cpath, clen, radius,
-                       len_x, len_y, lo, hi, width);
-    KWY_TRY(kwy_launch_scan(ctx, width, off, len_x));
+    hipLaunchKernelGGL(k_dtw_window_scan, dim3(1), dim3(DTW_WS_NT), 0, ctx->stream, cpath, clen, radius, len_x, len_y,
+                       lo, hi, off);
     KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3(len_x), dim3(KWY_THREADS), sizeof(double) * dim, ctx->stream, xs[l],
                        ys[l], dim, lo, hi, off, cap, dist, status));
     if (bnd_lds)

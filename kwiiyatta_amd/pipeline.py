@@ -118,13 +118,25 @@ class _Graphed:
             self.graph.replay()
 
 
+def draw_silence(fs, K, frame_len=PAD_LEN):
+    """WorldSynthesizer._silence_spectrum_envelope (kwiiyatta/vocoder/world.py:158-161): |N(0, EPS / fs)| from
+    numpy's GLOBAL legacy generator, which the reference's tests seed"""
+    return np.abs(np.random.normal(0, EPS / fs, (frame_len, K)))
+
+
 class PairPipeline(_Graphed):
     def __init__(self, device_index, fs, source, target, gmm, order=24, radius=32, frame_period=5.0,
-                 stream=None, prepare_gmm_per_run=False):
+                 stream=None, prepare_gmm_per_run=False, silence=None, keep_aligned_spectrum=False):
         """source / target: (x, f0, timeaxis) numpy triples; gmm: DeviceGMM over 2*3*order dims.
         prepare_gmm_per_run: redo the GMM-only part of MLPG (nnmnkwii's MLPG.__init__) in every run(),
-        as the reference does per convert() call, instead of once per converter."""
+        as the reference does per convert() call, instead of once per converter.
+        silence: the four (100, K) silent spectra of pad_silence (source head, source tail, target head, target
+        tail); default: drawn here from numpy's global generator in that order, as `align` would -- uploaded once,
+        so the pipeline and the Python API path see the same pads under `np.random.seed`.
+        keep_aligned_spectrum: also gather the aligned source spectrum (`align` returns it; the conversion flow
+        replaces it by the converted one and never reads it)."""
         self.prepare_gmm_per_run = bool(prepare_gmm_per_run)
+        self.keep_aligned_spectrum = bool(keep_aligned_spectrum)
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
@@ -147,8 +159,8 @@ class PairPipeline(_Graphed):
             self.dist = torch.zeros(1, **f64)
             self.idx = torch.zeros(self.tgt.Tp, dtype=torch.int32, device=self.dev)
             self.n_idx = torch.zeros(1, dtype=torch.int64, device=self.dev)
-            self.sp_al = torch.empty((Tt, self.K), **f64)     # not needed by the conversion flow itself,
-            self.ap_al = torch.empty((Tt, self.K), **f64)     # kept: align() gathers every feature array
+            self.sp_al = torch.empty((Tt, self.K), **f64) if self.keep_aligned_spectrum else None
+            self.ap_al = torch.empty((Tt, self.K), **f64)
             self.mc_al = torch.empty((Tt, order + 1), **f64)
             self.mc_x = torch.empty((Tt, order), **f64)
             self.mc_y = torch.empty((Tt, order), **f64)
@@ -156,14 +168,14 @@ class PairPipeline(_Graphed):
             self.sp_conv = torch.empty((Tt, self.K), **f64)
             self.ylen = lib.kwy_synth_length(Tt, self.frame_period, self.fs)
             self.wave = torch.empty(self.ylen, **f64)
+            # kwiiyatta.pad_silence: |N(0, EPS/fs)| spectra on the padding frames, host-drawn, uploaded once
+            if silence is None:
+                silence = [draw_silence(self.fs, self.K) for _ in range(4)]
+            rows = self.src.silence_rows() + self.tgt.silence_rows()
+            for dst, sil in zip(rows, silence):
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(sil)))
         self.stream.synchronize()
         self.frames = self.src.T   # the metric counts source frames
-
-    def _silence(self):
-        # kwiiyatta.pad_silence: |N(0, EPS/fs)| spectra on the padding frames
-        for side in (self.src, self.tgt):
-            for rows in side.silence_rows():
-                rows.normal_(0.0, EPS / self.fs).abs_()
 
     def _chk(self, rc):
         _lib.check(self.ctx, rc)
@@ -176,7 +188,6 @@ class PairPipeline(_Graphed):
                 self._chk(lib.kwy_cheaptrick_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, -0.15, 71.0,
                                                  fft, float(fs), _p(s.sp)))
                 self._chk(lib.kwy_d4c_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft, _p(s.ap)))
-            self._silence()
             for s in (self.src, self.tgt):
                 self._chk(lib.kwy_sp2mc_dev(h, _p(s.sp_pad), s.Tp, K, order, self.alpha, _p(s.mc_pad)))
                 self._chk(lib.kwy_align_features_dev(h, _p(s.mc_pad), s.Tp, order + 1, _p(s.f0_pad),
@@ -189,7 +200,8 @@ class PairPipeline(_Graphed):
             Tt = self.tgt.T
             for src_arr, dst, w in ((self.src.sp_pad, self.sp_al, K), (self.src.ap_pad, self.ap_al, K),
                                     (self.src.mc_pad, self.mc_al, order + 1)):
-                self._chk(lib.kwy_gather_rows_dev(h, _p(src_arr), self.src.Tp, w, _p(self.idx), Tt, _p(dst)))
+                if dst is not None:
+                    self._chk(lib.kwy_gather_rows_dev(h, _p(src_arr), self.src.Tp, w, _p(self.idx), Tt, _p(dst)))
             self.mc_x.copy_(self.mc_al[:, 1:])
             g = self.gmm
             if self.prepare_gmm_per_run:

@@ -24,7 +24,7 @@ def test_pair_pipeline_stages(pair):
     fs, src, tgt = pair
     gmm = pl.synthetic_gmm(order=24, components=8, seed=0, n_frames=4000)
     dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
-    p = pl.PairPipeline(0, fs, src, tgt, dg)
+    p = pl.PairPipeline(0, fs, src, tgt, dg, keep_aligned_spectrum=True)
     p.run()
     p.sync()
     P = pl.PAD_LEN
@@ -152,7 +152,6 @@ def test_graph_replay_matches_plain_pass(pair):
     p = pl.PairPipeline(0, fs, src, tgt, dg)
     p.run()
     p.sync()
-    p._silence = lambda: None     # keep the pad frames' random spectra of the first pass: identical inputs from here on
     p.run()
     p.sync()
     ref = {k: getattr(p, k).clone() for k in ('path', 'path_len', 'idx', 'mc_conv', 'sp_conv', 'wave')}
@@ -167,3 +166,32 @@ def test_graph_replay_matches_plain_pass(pair):
     assert torch.equal(p.path[:n], ref['path'][:n]) and torch.equal(p.idx, ref['idx'])
     assert torch.equal(p.mc_conv, ref['mc_conv']) and torch.equal(p.sp_conv, ref['sp_conv'])
     assert torch.equal(p.wave, ref['wave'])
+
+
+def test_pipeline_matches_api_path_under_seed():
+    """The silence pads are drawn on the host from numpy's global generator in the reference's order, so the
+    HBM-resident pipeline and the package's Python API (`kwiiyatta.align`, the path the reference's CLIs take)
+    see the same padded features under `np.random.seed`: same DTW path, same aligned mel-cepstra, bit for bit."""
+    import torch
+    import kwiiyatta_amd as kwiiyatta
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.backend import world
+    from kwiiyatta_amd.synthetic import make_utterance
+    fs = 16000
+    sides = []
+    for seed, warp, form in ((31, 1.0, 1.0), (32, 1.1, 1.12)):
+        x, _, _ = make_utterance(seed=seed, fs=fs, seconds=1.3, time_warp=warp, formant_scale=form)
+        f0, t = world.dio(x, fs, frame_period=5)
+        sides.append((x, world.stonemask(x, f0, t, fs), t))
+    np.random.seed(7)
+    a, b = (kwiiyatta.Analyzer(kwiiyatta.Wavdata(fs, s[0])) for s in sides)
+    aligned = kwiiyatta.align(a, b)
+    gmm = pl.synthetic_gmm(order=24, components=4, seed=0, n_frames=3000)
+    dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
+    np.random.seed(7)
+    p = pl.PairPipeline(0, fs, sides[0], sides[1], dg, keep_aligned_spectrum=True)
+    p.run()
+    p.sync()
+    assert np.array_equal(p.mc_al.cpu().numpy(), aligned.mel_cepstrum.data)
+    assert np.array_equal(p.sp_al.cpu().numpy(), aligned.spectrum_envelope)
+    assert np.array_equal(p.ap_al.cpu().numpy(), aligned.aperiodicity)
