@@ -40,55 +40,90 @@ def make_pair(index, seconds):
     return src, tgt
 
 
-def cpu_baseline_pair(src, tgt, gmm, budget_s=25.0):
-    """The CPU oracle (C restatement of the reference's pyworld / pysptk /
-    fastdtw / nnmnkwii path), one thread, on a bounded sample: the first 2.0 s of
-    the source and 2.2 s of the target of the same workload."""
+def cpu_pair_once(src, tgt, gmm_params, seconds=None):
+    """One pass of the config-3 path for one pair on the CPU oracle (C restatement of the reference's pyworld /
+    pysptk / fastdtw / nnmnkwii path), one thread.  seconds: use only the first `seconds` of the source
+    (and 1.1x that of the target).  Returns (source frames, wall seconds)."""
     from oracle import oracle as ko
     from kwiiyatta_amd.vocoder.align import project_path_iter
 
     def cut(u, sec):
+        if sec is None:
+            return u
         x, f0, t = u
         n, T = int(FS * sec), int(sec * 1000 / FRAME_PERIOD) + 1
         return np.ascontiguousarray(x[:n]), np.ascontiguousarray(f0[:T]), np.ascontiguousarray(t[:T])
 
-    (xs, f0s, ts), (xt, f0t, tt) = cut(src, 2.0), cut(tgt, 2.2)
+    (xs, f0s, ts), (xt, f0t, tt) = cut(src, seconds), cut(tgt, None if seconds is None else 1.1 * seconds)
+    weights, means, covs = gmm_params
     alpha = ko.mcepalpha(FS)
     P, K = 100, 1025
     rng = np.random.RandomState(0)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        feats = []
-        for x, f0, t in ((xs, f0s, ts), (xt, f0t, tt)):
-            sp = ko.cheaptrick(x, f0, t, FS) / FS
-            ap = ko.d4c(x, f0, t, FS)
-            sil = lambda: np.abs(rng.normal(0, 2.220446049250313e-16 / FS, (P, K)))  # noqa: E731
-            sp_pad = np.ascontiguousarray(np.concatenate((sil(), sp, sil())))
-            ap_pad = np.concatenate((np.full((P, K), 1 - 1e-12), ap, np.full((P, K), 1 - 1e-12)))
-            f0_pad = np.r_[np.zeros(P), f0, np.zeros(P)]
-            mc = ko.sp2mc(sp_pad, 24, alpha)
-            feat = np.hstack((np.zeros((len(mc), 2)), mc[:, 1:]))
-            feat[:, 0][mc[:, 0] >= mc[:, 0].max() - 1.636] = 9.4
-            feat[:, 1][f0_pad > 0] = 9.0
-            feats.append((sp_pad, ap_pad, mc, feat))
-        _, path = ko.fastdtw(feats[0][3], feats[1][3], radius=32, dist=2)
-        idx = np.fromiter(project_path_iter(np.array(path), trim=True, trim_len=P), dtype=np.int64)
-        mc_al, ap_al = feats[0][2][idx], np.ascontiguousarray(feats[0][1][idx])
-        y = ko.gmm_mlpg(np.ascontiguousarray(mc_al[:, 1:]), gmm.weights_, gmm.means_, gmm.covariances_)
-        sp_conv = ko.mc2sp(np.hstack((mc_al[:, :1], y)), alpha, 2048)
-        ko.synthesize(f0t, np.ascontiguousarray(sp_conv * FS), ap_al, FS, FRAME_PERIOD)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or reps >= 6:
-            break
-    frames = len(f0s)
-    return {'value': reps * frames / el, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{reps}x the first 2.0 s of one source (401 frames) + 2.2 s of its target through the '
-                      f'same analyse->align->convert->synth path on oracle/liboracle.so '
-                      f'(C restatement of pyworld 0.2.8 / pysptk / fastdtw / nnmnkwii), 1 thread'}
+    t0 = time.perf_counter()
+    feats = []
+    for x, f0, t in ((xs, f0s, ts), (xt, f0t, tt)):
+        sp = ko.cheaptrick(x, f0, t, FS) / FS
+        ap = ko.d4c(x, f0, t, FS)
+        sil = lambda: np.abs(rng.normal(0, 2.220446049250313e-16 / FS, (P, K)))  # noqa: E731
+        sp_pad = np.ascontiguousarray(np.concatenate((sil(), sp, sil())))
+        ap_pad = np.concatenate((np.full((P, K), 1 - 1e-12), ap, np.full((P, K), 1 - 1e-12)))
+        f0_pad = np.r_[np.zeros(P), f0, np.zeros(P)]
+        mc = ko.sp2mc(sp_pad, 24, alpha)
+        feat = np.hstack((np.zeros((len(mc), 2)), mc[:, 1:]))
+        feat[:, 0][mc[:, 0] >= mc[:, 0].max() - 1.636] = 9.4
+        feat[:, 1][f0_pad > 0] = 9.0
+        feats.append((sp_pad, ap_pad, mc, feat))
+    _, path = ko.fastdtw(feats[0][3], feats[1][3], radius=32, dist=2)
+    idx = np.fromiter(project_path_iter(np.array(path), trim=True, trim_len=P), dtype=np.int64)
+    mc_al, ap_al = feats[0][2][idx], np.ascontiguousarray(feats[0][1][idx])
+    y = ko.gmm_mlpg(np.ascontiguousarray(mc_al[:, 1:]), weights, means, covs)
+    sp_conv = ko.mc2sp(np.hstack((mc_al[:, :1], y)), alpha, 2048)
+    ko.synthesize(f0t, np.ascontiguousarray(sp_conv * FS), ap_al, FS, FRAME_PERIOD)
+    return len(f0s), time.perf_counter() - t0
+
+
+def cpu_worker(path):
+    """`bench.py --cpu-worker FILE`: a fresh process (no torch, no GPU) that runs the pair stored in FILE once and
+    prints its wall time; the all-core figure starts one of these per host core."""
+    d = np.load(path)
+    frames, sec = cpu_pair_once((d['xs'], d['f0s'], d['ts']), (d['xt'], d['f0t'], d['tt']),
+                                (d['weights'], d['means'], d['covs']))
+    print(json.dumps({'frames': frames, 'seconds': sec}))
+
+
+def cpu_baseline_pair(src, tgt, gmm, budget_s=25.0):
+    """The CPU oracle on the host cores of this box: the FULL 10 s + 11 s pair of the benchmark workload, once on
+    one core, then once per core on all cores at the same time (utterance-parallel, one process each)."""
+    import subprocess
+    import tempfile
+    params = (gmm.weights_, gmm.means_, gmm.covariances_)
+    frames, sec1 = cpu_pair_once(src, tgt, params)
+    out = {'value': frames / sec1, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+           'sample': f'one full pair of the workload ({frames} source frames: 10 s source + 11 s target) through the same '
+                     f'analyse->align->convert->synth path on oracle/liboracle.so (C restatement of pyworld 0.2.8 / '
+                     f'pysptk / fastdtw / nnmnkwii), 1 thread, {sec1:.1f} s'}
+    nproc = os.cpu_count() or 1
+    if sec1 * 1.5 <= budget_s and nproc > 1:
+        with tempfile.TemporaryDirectory() as tmp:
+            f = os.path.join(tmp, 'pair.npz')
+            np.savez(f, xs=src[0], f0s=src[1], ts=src[2], xt=tgt[0], f0t=tgt[1], tt=tgt[2], weights=params[0],
+                     means=params[1], covs=params[2])
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', f],
+                                      stdout=subprocess.PIPE, env=dict(os.environ, OMP_NUM_THREADS='1'))
+                     for _ in range(nproc)]
+            done = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
+            wall = time.perf_counter() - t0
+        out['all_cores'] = {'value': sum(d['frames'] for d in done) / wall, 'unit': 'frames/s', 'cores': nproc,
+                            'processes': nproc, 'wall_seconds': wall,
+                            'sample': f'{nproc} processes (os.cpu_count() = {nproc}), the same full pair each, started '
+                                      f'together; wall time includes process start-up'}
+    return out
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == '--cpu-worker':
+        return cpu_worker(sys.argv[2])
     ap_ = argparse.ArgumentParser()
     ap_.add_argument('--gpus', type=int, default=1)
     ap_.add_argument('--steps', type=int, default=10)
@@ -98,6 +133,9 @@ def main():
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
     ap_.add_argument('--components', type=int, default=64)
     ap_.add_argument('--no-cpu-baseline', action='store_true')
+    ap_.add_argument('--distinct', type=int, default=8, help='distinct synthetic signal pairs per rank (cycled over the batch)')
+    ap_.add_argument('--no-pcie-variant', action='store_true',
+                     help='skip the second timed loop that uploads the waveforms and downloads the result inside the step')
     ap_.add_argument('--no-graph', dest='graph', action='store_false',
                      help='enqueue every kernel of a pass from the host (about 170 launches per pair) instead of '
                           'replaying the pass as a captured HIP graph; the per-kernel HIP events are then recorded '
@@ -130,7 +168,7 @@ def main():
 
     # global utterance indices of this rank (weak scaling: `batch` per rank)
     mine = shard_indices(world * args.batch, rank, world)
-    nbase = min(len(mine), 2)      # distinct host-generated signals, reused round-robin
+    nbase = min(len(mine), args.distinct)      # distinct host-generated signal pairs, reused round-robin
     base = [make_pair(mine[i], args.seconds) for i in range(nbase)]
     gmm = pl.synthetic_gmm(order=24, components=args.components, seed=0) if args.workload == 'pair' else None
     dgmm = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev) if gmm is not None else None
@@ -185,6 +223,46 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
+    # ---- variant: the boundary hands over HOST buffers -- H2D of both waveforms and D2H of the result inside the step
+    pcie = None
+    if args.workload == 'pair' and not args.no_pcie_variant:
+        host = []
+        for p in pipes:
+            host.append((p.src.x.cpu().pin_memory(), p.tgt.x.cpu().pin_memory(),
+                         torch.empty(p.wave.shape, dtype=p.wave.dtype).pin_memory()))
+
+        def step_pcie():
+            for p, (hs, ht, hw) in zip(pipes, host):
+                with torch.cuda.stream(p.stream):
+                    p.src.x.copy_(hs, non_blocking=True)
+                    p.tgt.x.copy_(ht, non_blocking=True)
+                if args.graph:
+                    p.replay()
+                else:
+                    p.run()
+                with torch.cuda.stream(p.stream):
+                    hw.copy_(p.wave, non_blocking=True)
+        step_pcie()
+        sync_all()
+        if world > 1:
+            dist.barrier()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            step_pcie()
+        sync_all()
+        if world > 1:
+            dist.barrier()
+        elp = time.perf_counter() - tp
+        if world > 1:
+            tt = torch.tensor([elp], dtype=torch.float64, device=rdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elp = float(tt.item())
+        pcie = {'ms_per_step': 1000.0 * elp / args.steps,
+                'bytes_per_pair': int(sum(h.numel() * 8 for h in host[0])),
+                'note': 'same steps with the two waveforms uploaded (pinned host memory) and the synthesised waveform '
+                        'downloaded on the pair\'s stream inside the timed region; never `value`'}
+        del host
+
     if args.graph:
         # Per-kernel durations for the roofline object: HIP events cannot be recorded inside a captured graph here
         # (hipEventRecord during capture: invalid resource handle), so the same passes are enqueued kernel by
@@ -211,7 +289,7 @@ def main():
     if rank == 0:
         T = pipes[0].frames
         K = pipes[0].K
-        names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_syn_phase', 'k_syn_pulse', 'k_sp2mc',
+        names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_syn_phase', 'k_syn_pulse', 'k_syn_ola', 'k_sp2mc',
                  'k_mc2sp', 'k_dtw_dist', 'k_dtw_dp', 'k_gmm_prep', 'k_gmm_logp', 'k_mlpg_solve', 'k_align_project']
         kernel_ms = {}
         for p in pipes:
@@ -255,13 +333,13 @@ def main():
         achieved = bytes_per_launch / avg_s / 1e9 if launches else None
         traffic = None
         try:        # PMC-measured HBM bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) per launch
-            with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as fh:
+            with open(os.path.join(ROOT, 'profiles', 'r2_pmc_traffic.json')) as fh:
                 pmc = json.load(fh)
             traffic = pmc['kernels'][dom]['hbm_bytes_per_launch_raw'] * fpl / pmc['frames_per_launch']
         except (OSError, KeyError, ValueError):
             pass
         # The roofline line is priced on the kernel's own duration: HIP events around launches of one stream with
-        # the GPU to itself (they agree with rocprofv3's per-dispatch durations, profiles/r1_pair_b1_kernel_stats.csv).
+        # the GPU to itself (they agree with rocprofv3's per-dispatch durations, profiles/r2_pair_b1_kernel_stats.csv).
         # Events around a launch that competes with 31 other streams also span the time the dispatch waits in its
         # hardware queue -- about 3x what rocprofv3 reports for the same dispatches -- and are kept in `shared`.
         alone_achieved = (bytes_per_launch / (alone_ms[dom] * 1e-3) / 1e9) if dom in alone_ms else None
@@ -276,8 +354,22 @@ def main():
                                             'the timed region replays)') if args.graph else 'inside the timed region'},
                     'note': 'kernel is bound by f64 FFT arithmetic and barrier latency in LDS, not by HBM; the HBM '
                             'fraction is reported as asked (DESIGN.md section 5).  traffic = FETCH_SIZE+WRITE_SIZE of '
-                            'profiles/r1_pmc_traffic.json scaled to the frames of one launch.  avg_launch_ms: HIP events '
+                            'profiles/r2_pmc_traffic.json scaled to the frames of one launch.  avg_launch_ms: HIP events '
                             'on the launching stream, one stream running, right after the timed region'}
+        # Compute roofline of the same kernel family: algorithmic f64 flop (5 N log2 N per real FFT of
+        # size N; k_d4c_body runs 10 transforms of 4096 per frame that passes the voicing gate) / kernel time /
+        # the f64 vector peak (1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s).
+        roofline_compute = None
+        if args.workload == 'pair' and 'k_d4c_body' in alone_ms:
+            voiced = (float((pipes[0].src.f0 > 0).sum().item()) + float((pipes[0].tgt.f0 > 0).sum().item())) / 2.0
+            flop = voiced * 10 * 5 * 4096 * 12
+            tf = flop / (alone_ms['k_d4c_body'] * 1e-3) / 1e12
+            roofline_compute = {'bound': 'f64 vector', 'kernel': 'k_d4c_body', 'achieved': tf, 'peak': 78.6,
+                                'unit': 'TFLOP/s', 'frac': tf / 78.6, 'avg_launch_ms': alone_ms['k_d4c_body'],
+                                'frames_with_work_per_launch': voiced,
+                                'algorithmic_flop_per_frame': 10 * 5 * 4096 * 12,
+                                'note': 'FFT flop only (windows, RNG, smoothing, selects not counted); frames with '
+                                        'work = frames with f0 > 0 (upper bound of the frames that pass the gate)'}
         # the kernel with the largest SUMMED duration of all (what a rocprofv3 --stats table puts first)
         top = max(kernel_ms, key=lambda k: kernel_ms[k][0]) if kernel_ms else None
         by_sum = None
@@ -315,6 +407,9 @@ def main():
             'kernel_ms_per_launch': {k: v[0] / v[1] for k, v in sorted(kernel_ms.items())},
             'kernel_ms_per_launch_alone': {k: v for k, v in sorted(alone_ms.items())},
             'roofline': roofline,
+            'roofline_compute': roofline_compute,
+            'with_pcie': ({'value': frames_total / (pcie['ms_per_step'] * 1e-3 * args.steps), **pcie} if pcie else None),
+            'distinct_pairs_per_gpu': nbase,
             'largest_summed_kernel': by_sum,
             'cpu_baseline': None,
         }

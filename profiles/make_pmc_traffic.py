@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only)
 of  `bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline`
-into per-launch HBM traffic of the frame kernels:  profiles/r1_pmc_traffic.json.
+into per-launch HBM traffic of the frame kernels:  profiles/<round>_pmc_traffic.json.
 
-    python profiles/make_pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv
+    python profiles/make_pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv [round, default r2]
 
 FETCH_SIZE / WRITE_SIZE are in KB (MI355X_MICROARCH.md, HBM section).  That guide calibrates
 FETCH_SIZE only for 16 B/lane streaming reads (it then shows 1/2 of the bytes); these kernels read
@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-KERNELS = ('k_d4c_body', 'k_cheaptrick', 'k_d4c_lovetrain', 'k_syn_pulse')
+KERNELS = ('k_d4c_body', 'k_cheaptrick', 'k_d4c_lovetrain', 'k_syn_pulse', 'k_syn_ola')
 FRAMES = 2001
 
 
@@ -46,7 +46,8 @@ def main():
                                  'hbm_bytes_per_launch_raw': (fetch[k] + write[k]) * 1024,
                                  'hbm_bytes_per_launch_fetch_doubled': (2 * fetch[k] + write[k]) * 1024}
     here = os.path.dirname(os.path.abspath(__file__))
-    json.dump(out, open(os.path.join(here, 'r1_pmc_traffic.json'), 'w'), indent=1)
+    rnd = sys.argv[3] if len(sys.argv) > 3 else 'r2'
+    json.dump(out, open(os.path.join(here, f'{rnd}_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps(out['kernels'], indent=1))
 
 

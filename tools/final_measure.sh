@@ -5,7 +5,7 @@ O=${KWY_MEASURE_OUT:-$R/gpurun_out/final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 set -e
-timeout -k 10 600 python -m pytest $R/tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
+timeout -k 10 900 python -m pytest $R/tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
 python -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 python $R/bench.py --batch 16 --no-cpu-baseline > $O/bench_b16.json 2>/dev/null
@@ -14,6 +14,7 @@ python $R/bench.py --batch 1 --steps 5 --no-cpu-baseline > $O/bench_b1.json 2>/d
 python $R/bench.py --workload utterance --batch 1 > $O/bench_utt_b1.json 2>/dev/null
 python $R/bench.py --workload utterance --batch 16 --no-cpu-baseline > $O/bench_utt_b16.json 2>/dev/null
 python $R/bench_fit.py > $O/bench_fit.json 2>/dev/null
+python $R/bench_corpus.py > $O/bench_corpus.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b32 -- python $R/bench.py --no-cpu-baseline > $O/stats_pair_b32.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b1 -- python $R/bench.py --batch 1 --steps 5 --no-cpu-baseline > $O/stats_pair_b1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
