@@ -176,6 +176,12 @@ int kwy_gmm_prepare_dev(kwy_ctx *ctx, const double *weights, const double *means
                         int d, int M, int diff, double *model);
 int kwy_gmm_mlpg_model_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *model,
                            double *y);
+/* MelCepstrumFeatureConverter.convert(mel_cepstrum) at the converter's sampling rate
+ *                                                    kwiiyatta/converter/mcep.py:47-61
+ * mc, mc_out: T x (d+1); column 0 (the power coefficient) is kept, columns 1..d are converted (delta features,
+ * GMM, MLPG) with a prepared model (diff = 0 or 1 as given to kwy_gmm_prepare_dev). */
+int kwy_convert_mcep_dev(kwy_ctx *ctx, const double *mc, int64_t T, int d, int M, const double *model,
+                         double *mc_out);
 
 /* ---- cross-rate aperiodicity codec ------------------------------------------------------
  * pyworld.code_aperiodicity(ap, fs) / pyworld.decode_aperiodicity(coded, fs, fft_size)

@@ -131,6 +131,7 @@ SIGNATURES = {
     'kwy_mlsa_synthesis_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),
     'kwy_gmm_prepare_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_gmm_mlpg_model_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    'kwy_convert_mcep_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
 }
 
 MISSING = []

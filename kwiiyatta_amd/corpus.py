@@ -205,10 +205,7 @@ class ConvertPipeline(_Graphed):
                                        float(fs), _p(self.sp)))
             chk(lib.kwy_d4c_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), T, 0.85, fft, _p(self.ap)))
             chk(lib.kwy_sp2mc_dev(h, _p(self.sp), T, K, order, self.alpha, _p(self.mc)))
-            self.mc_x.copy_(self.mc[:, 1:])
-            chk(lib.kwy_gmm_mlpg_model_dev(h, _p(self.mc_x), T, order, self.gmm.M, _p(self.gmm_model), _p(self.mc_y)))
-            self.mc_conv[:, 0].copy_(self.mc[:, 0])
-            self.mc_conv[:, 1:].copy_(self.mc_y)
+            chk(lib.kwy_convert_mcep_dev(h, _p(self.mc), T, order, self.gmm.M, _p(self.gmm_model), _p(self.mc_conv)))
             chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), T, order, self.alpha, fft, _p(self.sp_conv)))
             chk(lib.kwy_synthesize_dev(h, _p(self.f0), T, _p(self.sp_conv), _p(self.ap), fft, self.frame_period, fs,
                                        float(fs), self.ylen, _p(self.wave)))

@@ -12,9 +12,13 @@
 // All three are index/byte work: HBM-bound row copies and a pass over the path.
 #include "kwy_internal.hpp"
 
-__global__ __launch_bounds__(KWY_THREADS) void k_align_power_threshold(const double *__restrict__ mc, int64_t T,
-                                                                      int ncoef, double power_threshold,
-                                                                      double *__restrict__ thr_out) {
+// Every workgroup finds the power threshold (max over all frames of c0, minus the offset) for itself -- T loads of
+// an L2-resident column -- and then writes the feature rows of its 8 frames: one launch instead of a reduction
+// kernel followed by a row kernel.
+__global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__restrict__ mc, int64_t T,
+                                                               int ncoef, const double *__restrict__ f0,
+                                                               double power_threshold, double power_weight,
+                                                               double vuv_weight, double *__restrict__ out) {
   __shared__ double red[KWY_WAVES];
   const int tid = threadIdx.x;
   double mx = -INFINITY;
@@ -23,23 +27,13 @@ __global__ __launch_bounds__(KWY_THREADS) void k_align_power_threshold(const dou
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o));
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
-  if (tid == 0) {
-    double m = red[0];
-    for (int i = 1; i < KWY_WAVES; ++i) m = fmax(m, red[i]);
-    thr_out[0] = m - power_threshold;
-  }
-}
-
-__global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__restrict__ mc, int64_t T,
-                                                               int ncoef, const double *__restrict__ f0,
-                                                               const double *__restrict__ thr_in,
-                                                               double power_weight, double vuv_weight,
-                                                               double *__restrict__ out) {
-  const int64_t t = blockIdx.x * 8 + (threadIdx.x >> 5);  // 8 frames per workgroup, 32 lanes per frame
+  double m = red[0];
+  for (int i = 1; i < KWY_WAVES; ++i) m = fmax(m, red[i]);
+  const double thr = m - power_threshold;
+  const int64_t t = (int64_t)blockIdx.x * 8 + (tid >> 5);  // 8 frames per workgroup, 32 lanes per frame
   if (t >= T) return;
-  const double thr = thr_in[0];
   const int w = ncoef + 1;
-  for (int c = threadIdx.x & 31; c < w; c += 32) {
+  for (int c = tid & 31; c < w; c += 32) {
     double v;
     if (c == 0) v = mc[t * ncoef] >= thr ? power_weight : 0.0;
     else if (c == 1) v = f0[t] > 0 ? vuv_weight : 0.0;
@@ -168,12 +162,8 @@ extern "C" int kwy_align_features_dev(kwy_ctx *ctx, const double *mc, int64_t T,
   if (!ctx) return KWY_EINVAL;
   if (!mc || !f0 || !out || T <= 0 || ncoef < 1) { ctx->err = "align_features: bad argument"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
-  KWY_TRY(kwy_arena_begin(ctx, 256));
-  double *thr = kwy_arena<double>(ctx, 8);
-  hipLaunchKernelGGL(k_align_power_threshold, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, mc, T, ncoef,
-                     power_threshold, thr);
   hipLaunchKernelGGL(k_align_features, dim3((unsigned)((T + 7) / 8)), dim3(KWY_THREADS), 0, ctx->stream, mc, T,
-                     ncoef, f0, thr, power_weight, vuv_weight, out);
+                     ncoef, f0, power_threshold, power_weight, vuv_weight, out);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

@@ -329,38 +329,53 @@ __device__ __forceinline__ void kwy_block_sum2(double a, double b, double *red, 
 
 // Sum of the m smallest of n non-negative doubles, and the sum of all of them,
 // without sorting.  Thread t holds the IEEE bit patterns of elements t, t+NT, ...
-// in key[] (~0 for slots beyond n).  An MSB-first radix select (up to 8 rounds of
-// 8 bits; the patterns order like the values for x >= 0) finds the m-th smallest
+// in key[] (~0 for slots beyond n).  An MSB-first radix select (KWY_SELECT_BITS bits a
+// round; the patterns order like the values for x >= 0) finds the m-th smallest
 // value v*; then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.  Two barriers per
-// round: the 256-bin histogram and the control words are double-buffered.
+// round: the histogram and the control words are double-buffered.
 // hist: KWY_SELECT_WORDS uint32 of LDS (8-byte aligned) that no thread touches
 // any more when the call starts; red: >= 2*NT/64 doubles.
-#define KWY_SELECT_WORDS(NT) (2 * 256 + 16)
+// Digit width: KWY_SELECT_BITS bits per round.  With 11 bits the first round resolves the whole exponent of an
+// IEEE double (non-negative keys: bit 63 is 0, bits 62..52 are the first digit) and the second 11 mantissa bits,
+// which isolates the wanted key of a 2049-bin spectrum in two or three rounds instead of four with 8-bit digits:
+// the rounds cost two workgroup barriers each, and the barriers are what the selections spend their time on.
+#ifndef KWY_SELECT_BITS
+#define KWY_SELECT_BITS 11
+#endif
+#define KWY_SELECT_BINS (1 << KWY_SELECT_BITS)
+#define KWY_SELECT_WORDS(NT) (2 * KWY_SELECT_BINS + 16)
 template <int RMAX, int NT = KWY_THREADS>
 __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RMAX], int n, int m,
                                               uint32_t *hist, double *red, double *sum_small,
                                               double *sum_all) {
+  constexpr int BITS = KWY_SELECT_BITS, BINS = 1 << BITS;
+  constexpr int ROUNDS = (63 + BITS - 1) / BITS;          // bit 63 (the sign) is never set
+  constexpr int PERLANE = BINS / 64;                      // bins scanned per lane of wavefront 0
+  static_assert(PERLANE % 4 == 0 && PERLANE >= 4, "bins per lane must be a multiple of 4");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  uint32_t *ctlb = hist + 2 * 256;  // 2 x {digit, new rank, population}, then one 64-bit key
-  if (tid < 256) hist[tid] = 0;
+  uint32_t *ctlb = hist + 2 * BINS;  // 2 x {digit, new rank, population}, then one 64-bit key
+  for (int i = tid; i < BINS; i += NT) hist[i] = 0;
   __syncthreads();
   unsigned long long prefix = 0ull;
   int kk = m;  // 1-based rank of the wanted element among the still-matching keys
   bool alive[RMAX];  // key still carries the prefix found so far
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) alive[r] = tid + NT * r < n;
-  for (int round = 0; round < 8; ++round) {
-    const int shift = 56 - 8 * round;
-    uint32_t *h = hist + (round & 1) * 256, *hn = hist + ((round + 1) & 1) * 256;
+  for (int round = 0; round < ROUNDS; ++round) {
+    // digits are taken from bit 62 downwards; the last one may be narrower
+    const int top = 63 - BITS * round;                    // one past the digit's highest bit
+    const int shift = top - BITS > 0 ? top - BITS : 0;
+    const unsigned long long mask = (top - shift >= 64) ? ~0ull : ((1ull << (top - shift)) - 1ull);
+    uint32_t *h = hist + (round & 1) * BINS, *hn = hist + ((round + 1) & 1) * BINS;
     uint32_t *ctl = ctlb + (round & 1) * 4;
-    if (tid < 256) hn[tid] = 0;
+    for (int i = tid; i < BINS; i += NT) hn[i] = 0;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       if (NT * r + (tid & ~63) >= n) continue;  // nothing in this slot for the whole wavefront
       // spectra are smooth: most lanes of a wavefront carry the same leading digits, and 64
       // atomics on one LDS word serialise.  The lanes that share the first live lane's digit
       // are counted with one atomic, the others go one by one.
-      const int d = (int)((key[r] >> shift) & 255ull);
+      const int d = (int)((key[r] >> shift) & mask);
       const unsigned long long mm = __ballot(alive[r]);
       if (mm != 0ull) {
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
@@ -373,18 +388,28 @@ __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RM
     }
     __syncthreads();
     if (wv == 0) {
-      const uint4 c4 = ((const uint4 *)h)[lane];
-      const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
-      const uint32_t tot = c[0] + c[1] + c[2] + c[3];
-      uint32_t before = kwy_wave_scan_u32(tot) - tot;
+      // lane l owns bins [PERLANE l, PERLANE (l + 1)): their total first, then only the lane whose range holds the
+      // wanted rank walks its bins again (the counts are not kept in registers)
+      const uint4 *hp = (const uint4 *)h + lane * (PERLANE / 4);
+      uint32_t tot = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if ((uint32_t)kk > before && (uint32_t)kk <= before + c[q]) {
-          ctl[0] = 4 * lane + q;
-          ctl[1] = (uint32_t)kk - before;
-          ctl[2] = c[q];  // population of the chosen bin
+      for (int q = 0; q < PERLANE / 4; ++q) {
+        const uint4 c4 = hp[q];
+        tot += (c4.x + c4.y) + (c4.z + c4.w);
+      }
+      uint32_t before = kwy_wave_scan_u32(tot) - tot;
+      if ((uint32_t)kk > before && (uint32_t)kk <= before + tot) {
+        const uint32_t *hb = h + PERLANE * lane;
+        for (int q = 0; q < PERLANE; ++q) {
+          const uint32_t c = hb[q];
+          if ((uint32_t)kk <= before + c) {
+            ctl[0] = PERLANE * lane + q;
+            ctl[1] = (uint32_t)kk - before;
+            ctl[2] = c;  // population of the chosen bin
+            break;
+          }
+          before += c;
         }
-        before += c[q];
       }
     }
     __syncthreads();
@@ -392,8 +417,8 @@ __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RM
     prefix |= (unsigned long long)chosen << shift;
     kk = (int)ctl[1];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) alive[r] = alive[r] && (int)((key[r] >> shift) & 255ull) == chosen;
-    if (ctl[2] == 1u && round < 7) {
+    for (int r = 0; r < RMAX; ++r) alive[r] = alive[r] && (int)((key[r] >> shift) & mask) == chosen;
+    if (ctl[2] == 1u && round < ROUNDS - 1) {
       // exactly one key carries this prefix: it IS the wanted element, skip the remaining rounds
       unsigned long long *k64 = (unsigned long long *)(ctlb + 8);
 #pragma unroll

@@ -110,14 +110,18 @@ __global__ __launch_bounds__(KWY_THREADS) void k_gmm_prep(const double *__restri
 
 // ---- delta features -----------------------------------------------------------------
 // DELTA_WINDOWS (kwiiyatta/converter/delta.py:8-12): [1], [-0.5, 0, 0.5], [1, -2, 1]
-__global__ void k_delta(const double *__restrict__ x, ml_dims dm, double *__restrict__ X) {
+// x rows are ldx doubles apart.  keep_in / keep_out (may be null): one more column that is copied through
+// unchanged (the power coefficient c0 of a mel-cepstrum, kwiiyatta/converter/mcep.py:57-59), ldx / ldy apart.
+__global__ void k_delta(const double *__restrict__ x, int ldx, ml_dims dm, double *__restrict__ X,
+                        const double *__restrict__ keep_in, double *__restrict__ keep_out, int ldy) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= dm.T * dm.d) return;
   const int64_t t = e / dm.d;
   const int c = (int)(e % dm.d);
-  const double xm = t > 0 ? x[(t - 1) * dm.d + c] : 0.0;
-  const double x0 = x[t * dm.d + c];
-  const double xp = t + 1 < dm.T ? x[(t + 1) * dm.d + c] : 0.0;
+  if (keep_out && c == 0) keep_out[t * ldy] = keep_in[t * ldx];
+  const double xm = t > 0 ? x[(t - 1) * ldx + c] : 0.0;
+  const double x0 = x[t * ldx + c];
+  const double xp = t + 1 < dm.T ? x[(t + 1) * ldx + c] : 0.0;
   double *o = X + t * dm.D;
   o[c] = 0.0 + x0 * 1.0;
   double s = 0.0;
@@ -323,8 +327,18 @@ __device__ __forceinline__ void ml_tile_copy(double *__restrict__ dst, const dou
   for (int e = first; e < n; e += nthreads) dst[e] = src[e];
 }
 
+// y rows are ldy doubles apart
+__device__ __forceinline__ void ml_rows_out(double *__restrict__ y, int ldy, const double *__restrict__ src, int rows,
+                                            int d, int first, int nthreads) {
+  if (ldy == d) { ml_tile_copy(y, src, rows * d, first, nthreads); return; }
+  for (int e = first; e < rows * d; e += nthreads) {
+    const int r = e / d, c = e - r * d;
+    y[(int64_t)r * ldy + c] = src[e];
+  }
+}
+
 __global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__ band, double *__restrict__ rhs,
-                                                           ml_dims dm, int tile, double *__restrict__ y,
+                                                           ml_dims dm, int tile, double *__restrict__ y, int ldy,
                                                            int *__restrict__ status) {
   extern __shared__ double sm[];  // 2 x { band tile [tile][d][3], rhs tile [tile][d] }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = dm.d;
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__
     const int64_t t0 = k * tile;
     if (wv > 0) {
       const int h = tid - 64;
-      if (k + 1 < ntiles) ml_tile_copy(y + (k + 1) * tile * d, SR(k + 1), NT_OF(k + 1) * d, h, ML_SOLVE_NT - 64);
+      if (k + 1 < ntiles) ml_rows_out(y + (k + 1) * tile * ldy, ldy, SR(k + 1), NT_OF(k + 1), d, h, ML_SOLVE_NT - 64);
       if (k > 0) {
         ml_tile_copy(SB(k - 1), band + (k - 1) * tile * d * 3, tile * d * 3, h, ML_SOLVE_NT - 64);
         ml_tile_copy(SR(k - 1), rhs + (k - 1) * tile * d, tile * d, h, ML_SOLVE_NT - 64);
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__
     }
     __syncthreads();
   }
-  ml_tile_copy(y, SR(0), NT_OF(0) * d, tid, ML_SOLVE_NT);
+  ml_rows_out(y, ldy, SR(0), NT_OF(0), d, tid, ML_SOLVE_NT);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -453,9 +467,13 @@ static int ml_logp_splits(int64_t T, int M) {
 }
 
 // `prepared`: a model made by kwy_gmm_prepare_dev (then weights/means/covs are unused), or null
+// x / y: T x d with rows ldx / ldy doubles apart (0: packed); keep_in / keep_out: see k_delta
 static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,
                      const double *means, const double *covs, int diff, double *y, int **status_out,
-                     const double *prepared = nullptr) {
+                     const double *prepared = nullptr, int ldx = 0, int ldy = 0, const double *keep_in = nullptr,
+                     double *keep_out = nullptr) {
+  if (ldx <= 0) ldx = d;
+  if (ldy <= 0) ldy = d;
   const int D = 3 * d;
   ml_dims dm = {d, D, M, T};
   double *model = prepared ? const_cast<double *>(prepared) : kwy_arena<double>(ctx, ml_model_stride(D) * M);
@@ -489,12 +507,12 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
     hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
                        diff, model, status);
   const unsigned ge = (unsigned)((T * d + 255) / 256);
-  hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, x, dm, X);
+  hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, x, ldx, dm, X, keep_in, keep_out, ldy);
   KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)ml_logp_splits(T, M), M), dim3(KWY_THREADS), lds_logp,
                      ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
   hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band, rhs);
-  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(ML_SOLVE_NT), lds_solve, ctx->stream, band, rhs, dm, solve_tile, y, status));
+  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(ML_SOLVE_NT), lds_solve, ctx->stream, band, rhs, dm, solve_tile, y, ldy, status));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -557,6 +575,18 @@ extern "C" int kwy_gmm_mlpg_model_dev(kwy_ctx *ctx, const double *x, int64_t T, 
   KWY_TRY(kwy_arena_begin(ctx, ml_scratch_bytes(T, d, M)));
   int *status;
   return mlpg_core(ctx, x, T, d, M, nullptr, nullptr, nullptr, 0, y, &status, model);
+}
+
+// MelCepstrumFeatureConverter.convert at the converter's own sampling rate (kwiiyatta/converter/mcep.py:47-61):
+// mc, mc_out: T x (d + 1) mel-cepstra; column 0 (power) is copied, columns 1..d go through delta + GMM + MLPG.
+extern "C" int kwy_convert_mcep_dev(kwy_ctx *ctx, const double *mc, int64_t T, int d, int M, const double *model,
+                                    double *mc_out) {
+  KWY_TRY(ml_check(ctx, mc, T, d, M, model, model, model, mc_out));
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, ml_scratch_bytes(T, d, M)));
+  int *status;
+  return mlpg_core(ctx, mc + 1, T, d, M, nullptr, nullptr, nullptr, 0, mc_out + 1, &status, model, d + 1, d + 1, mc,
+                   mc_out);
 }
 
 extern "C" int kwy_gmm_mlpg(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,

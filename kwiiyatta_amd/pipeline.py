@@ -202,16 +202,16 @@ class PairPipeline(_Graphed):
                                     (self.src.mc_pad, self.mc_al, order + 1)):
                 if dst is not None:
                     self._chk(lib.kwy_gather_rows_dev(h, _p(src_arr), self.src.Tp, w, _p(self.idx), Tt, _p(dst)))
-            self.mc_x.copy_(self.mc_al[:, 1:])
             g = self.gmm
             if self.prepare_gmm_per_run:
+                self.mc_x.copy_(self.mc_al[:, 1:])
                 self._chk(lib.kwy_gmm_mlpg_dev(h, _p(self.mc_x), Tt, order, g.M, _p(g.weights), _p(g.means),
                                                _p(g.covs), 0, _p(self.mc_y)))
-            else:
-                self._chk(lib.kwy_gmm_mlpg_model_dev(h, _p(self.mc_x), Tt, order, g.M, _p(self.gmm_model),
-                                                     _p(self.mc_y)))
-            self.mc_conv[:, 0].copy_(self.mc_al[:, 0])
-            self.mc_conv[:, 1:].copy_(self.mc_y)
+                self.mc_conv[:, 0].copy_(self.mc_al[:, 0])
+                self.mc_conv[:, 1:].copy_(self.mc_y)
+            else:       # c0 kept, c1.. converted, in one call on the strided rows
+                self._chk(lib.kwy_convert_mcep_dev(h, _p(self.mc_al), Tt, order, g.M, _p(self.gmm_model),
+                                                   _p(self.mc_conv)))
             self._chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), Tt, order, self.alpha, fft, _p(self.sp_conv)))
             self._chk(lib.kwy_synthesize_dev(h, _p(self.tgt.f0), Tt, _p(self.sp_conv), _p(self.ap_al), fft,
                                              self.frame_period, fs, float(fs), self.ylen, _p(self.wave)))
