@@ -335,12 +335,12 @@ __device__ __forceinline__ void kwy_block_sum2(double a, double b, double *red, 
 // round: the histogram and the control words are double-buffered.
 // hist: KWY_SELECT_WORDS uint32 of LDS (8-byte aligned) that no thread touches
 // any more when the call starts; red: >= 2*NT/64 doubles.
-// Digit width: KWY_SELECT_BITS bits per round.  With 11 bits the first round resolves the whole exponent of an
-// IEEE double (non-negative keys: bit 63 is 0, bits 62..52 are the first digit) and the second 11 mantissa bits,
-// which isolates the wanted key of a 2049-bin spectrum in two or three rounds instead of four with 8-bit digits:
-// the rounds cost two workgroup barriers each, and the barriers are what the selections spend their time on.
+// Digit width: KWY_SELECT_BITS bits per round.  8 (256 bins) is what the kernels use.  11 bits -- the whole
+// exponent of a non-negative IEEE double in the first round, then 11 mantissa bits: two or three rounds instead of
+// four on a 2049-bin spectrum -- was measured and is SLOWER (k_d4c_body 0.44 ms against 0.39 ms per launch): what
+// the rounds save in barriers is lost clearing and scanning 2048 bins per round.
 #ifndef KWY_SELECT_BITS
-#define KWY_SELECT_BITS 11
+#define KWY_SELECT_BITS 8
 #endif
 #define KWY_SELECT_BINS (1 << KWY_SELECT_BITS)
 #define KWY_SELECT_WORDS(NT) (2 * KWY_SELECT_BINS + 16)
