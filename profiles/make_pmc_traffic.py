@@ -25,7 +25,10 @@ def per_launch(path, counter):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
-        base = r['Kernel_Name'].split('(')[0].split('<')[0].replace('void ', '').strip()
+        name = r['Kernel_Name'].split('(')[0]
+        if name.rstrip().endswith(', true>'):      # k_syn_pulse<N, true>: the (normally empty) overflow pass
+            continue
+        base = name.split('<')[0].replace('void ', '').strip()
         if base in KERNELS:     # exact kernel name (k_d4c_body, not k_d4c_body_counts)
             tot[base] += float(r['Counter_Value'])
             n[base] += 1

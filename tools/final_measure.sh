@@ -5,7 +5,7 @@ O=${KWY_MEASURE_OUT:-$R/gpurun_out/final}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 set -e
-timeout -k 10 900 python -m pytest $R/tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
+KWY_KAT_DUMP=$O/kat_envelopes timeout -k 10 900 python -m pytest $R/tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
 python -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 python $R/bench.py --batch 16 --no-cpu-baseline > $O/bench_b16.json 2>/dev/null
