@@ -286,7 +286,7 @@ def test_mlsa_filter(kwiiyatta, request, fs1, fs2):
 
 
 # ---- the second half of every envelope ----------------------------------------------------------------
-# Two of the 124 published extremes are not reproduced -- by the oracle and the HIP kernels alike (both give
+# Two of the 66 published extremes (33 envelopes) are not reproduced -- by the oracle and the HIP kernels alike (both give
 # 0.05432 and 0.08816).  Both belong to the MLSA-filter envelope, the one scenario whose upstream output is
 # partly undefined: pysptk's Synthesizer.synthesis fills an np.empty_like() buffer and never writes the last,
 # incomplete hop, so the analysed waveform ends in whatever the allocator returned (zeros here).
