@@ -417,7 +417,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
     const double *__restrict__ ap0, d4c_params p, const uint32_t *__restrict__ ebase,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    const double *__restrict__ nuttall, double *__restrict__ out, long long *__restrict__ dbg) {
+    double *__restrict__ dvbuf, double *__restrict__ out, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int NT = d4c_nt<LOG2N>::value;
   constexpr int E = N / NT;                  // window elements per thread
@@ -437,7 +437,6 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   double *P = A0, *Dv = A0;
   double *S = Bd;                            // <= 2H+3 doubles
   uint4 *jtab = (uint4 *)((LOG2N >= 12) ? A0 : jt_own);
-  uint32_t *hist = (uint32_t *)B;            // KWY_SELECT_WORDS(NT), band loop only
 
   const int tid = threadIdx.x;
   const int64_t frame = blockIdx.x;
@@ -539,14 +538,65 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   d4c_subtract_smoothed<NT>(Dv, S, tot, cf0, p.fs, N);
 
   D4C_STAMP(10);
-  // ---- coarse aperiodicity per band
+  // ---- hand the static group delay to the band items (k_d4c_bands): one row of H+1 doubles per frame
+  {
+    double *dv = dvbuf + (size_t)frame * (H + 1);
+    for (int k = tid; k <= H; k += NT) dv[k] = Dv[k];
+  }
+  D4C_STAMP(15);
+#undef D4C_STAMP
+}
+
+// The band half of D4C, one workgroup per frame: per 3 kHz band a Nuttall-windowed slice of the static group delay
+// -> FFT -> power spectrum -> sum of the (H - boundary) smallest bins against the sum of all (radix select, no sort)
+// -> coarse aperiodicity; then the band values are interpolated to the K output bins.  33 KB of LDS and no window /
+// RNG state: four workgroups per CU instead of the body's three.  (One work item per (frame, band) with an atomic
+// hand-off to a finishing item was measured: 0.32 ms per launch against 0.1 ms -- the per-item start-up loads and
+// the device-scope atomics cost more than the finer balance gains.)
+template <int LOG2N>
+static constexpr size_t d4c_bands_lds() {
+  constexpr int N = 1 << LOG2N, H = N / 2, NT = d4c_nt<LOG2N>::value;
+  return sizeof(double) * (16 + D4C_MAX_BANDS + 2) + sizeof(double) * ((2 * H + 2) + 2) +
+         ((sizeof(uint32_t) * KWY_SELECT_WORDS(NT) > sizeof(double) * (2 * H + 4))
+              ? sizeof(uint32_t) * KWY_SELECT_WORDS(NT) - sizeof(double) * (2 * H + 4) : 0);
+}
+
+// SPARSE: the window fits the first H/8 (+1) packed points (compile-time, so that the two input paths do not share
+// one register budget)
+template <int LOG2N, bool SPARSE>
+__global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d4c_bands(
+    const double *__restrict__ f0, const double *__restrict__ ap0, d4c_params p, const kwy_c *__restrict__ twH,
+    const kwy_c *__restrict__ twN, const double *__restrict__ nuttall, const double *__restrict__ dvbuf,
+    double *__restrict__ out) {
+  constexpr int N = 1 << LOG2N, H = N / 2;
+  constexpr int NT = d4c_nt<LOG2N>::value;
+  constexpr int E = N / NT;
+  constexpr int RK = (H + 1 + NT - 1) / NT;
+  constexpr int HEX = 16 * NT / N;
+  extern __shared__ double smem[];
+  double *red = smem;                        // 16
+  double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
+  kwy_c *B = (kwy_c *)(coarse + D4C_MAX_BANDS + 2);   // H+1 complex (+2 doubles)
+  double *Bd = (double *)B;
+  uint32_t *hist = (uint32_t *)B;
+
+  const int tid = threadIdx.x;
+  const int64_t frame = blockIdx.x;
+  const double f0v = kwy_uniform(f0[frame]);
+  if (f0v == 0.0 || kwy_uniform(ap0[frame]) <= p.threshold) return;   // the body wrote the frame's row
+  const double cf0 = kwy_uniform(f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0);
+  kwy_c tw4[4];
+  kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
+  const kwy_c twb = twN[tid];
+  const double *Dv = dvbuf + (size_t)frame * (H + 1);
+
   const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
   const int half_window_length = p.window_length / 2;
-  const bool sparse = p.window_length <= 2 * (H / 8) + 1;
-  // the Nuttall window stays in registers: elements 2 tid, 2 tid + 1 (and the last one) for the
-  // copy-only first pass, elements tid + NT r otherwise
+  constexpr bool sparse = SPARSE;
+  // the Nuttall window stays in registers: elements 2 tid, 2 tid + 1 (and the last one) for the copy-only first
+  // pass, elements tid + NT r otherwise
   double ns0 = 0.0, ns1 = 0.0, ns2 = 0.0, nutr[4] = {0.0, 0.0, 0.0, 0.0};
-  if (sparse) {
+  if constexpr (sparse) {
     if (2 * tid < p.window_length) ns0 = nuttall[2 * tid];
     if (2 * tid + 1 < p.window_length) ns1 = nuttall[2 * tid + 1];
     if (2 * (H / 8) < p.window_length) ns2 = nuttall[2 * (H / 8)];
@@ -555,19 +605,27 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     for (int r = 0; r < 4; ++r)
       if (tid + NT * r < p.window_length) nutr[r] = nuttall[tid + NT * r];
   }
+  // the group-delay slice of band b + 1 is fetched while band b is transformed and selected (its latency would
+  // otherwise sit at the head of every band): in the sparse case a thread needs two values per band
+  const bool mine0 = sparse && tid < H / 8 && 2 * tid < p.window_length;
+  const bool mine1 = sparse && tid < H / 8 && 2 * tid + 1 < p.window_length;
+  const double *Dfirst = Dv + ((int)(D4C_FREQ_INTERVAL * N / p.fs) - half_window_length);
+  double nx0 = (mine0 && p.nbands > 0) ? Dfirst[2 * tid] : 0.0;
+  double nx1 = (mine1 && p.nbands > 0) ? Dfirst[2 * tid + 1] : 0.0;
   for (int b = 0; b < p.nbands; ++b) {
     const int tid = kwy_tid_opaque();
-    const int center = (int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs);
-    const double *Dc = Dv + (center - half_window_length);
-    if (sparse) {
+    const double *Dc = Dv + ((int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs) - half_window_length);
+    const double c0 = nx0, c1 = nx1;
+    {
+      const double *Dn = Dv + ((int)(D4C_FREQ_INTERVAL * (b + 2) * N / p.fs) - half_window_length);
+      const bool more = b + 1 < p.nbands;
+      nx0 = (mine0 && more) ? Dn[2 * tid] : 0.0;
+      nx1 = (mine1 && more) ? Dn[2 * tid + 1] : 0.0;
+    }
+    if constexpr (sparse) {
       // only the first H/8 (+1) packed points are non-zero: the first pass needs no input buffer
-      kwy_c a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
-      if (tid < H / 8) {
-        a0.x = (2 * tid < p.window_length) ? Dc[2 * tid] * ns0 : 0.0;
-        a0.y = (2 * tid + 1 < p.window_length) ? Dc[2 * tid + 1] * ns1 : 0.0;
-        if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * ns2;
-      }
-      if (b == 0) D4C_STAMP(11);
+      kwy_c a0 = {c0 * ns0, c1 * ns1}, a1 = {0.0, 0.0};
+      if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * ns2;
       kwy_fft_pass8_first_sparse_core<LOG2N - 1, NT, false>(B, kwy_tw_reg{tw4[0]}, a0, a1);
       kwy_fft_inplace_rest_w<LOG2N - 1, NT, false>(B, tw4);
     } else {
@@ -577,10 +635,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
         Bd[j] = (r < 4 && j < p.window_length) ? Dc[j] * nutr[r < 4 ? r : 0] : 0.0;
       }
       __syncthreads();
-      if (b == 0) D4C_STAMP(11);
       kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
     }
-    if (b == 0) D4C_STAMP(12);
     // CPU: power spectrum, sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
     unsigned long long key[RK];
 #pragma unroll
@@ -595,7 +651,6 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     __syncthreads();
     double nsmall, nall;
     kwy_block_smallest_sum<RK, NT>(key, H + 1, H - boundary, hist, red, &nsmall, &nall);
-    if (b == 0) D4C_STAMP(13);
     if (tid == 0) {
       double cv = 10 * log10(nsmall / nall);
       cv = cv + (cf0 - 100) / 50.0;
@@ -608,9 +663,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     coarse[p.nbands + 1] = -D4C_SAFE;
   }
   __syncthreads();
-
-  D4C_STAMP(14);
   // ---- interp1 of the (nbands+2)-point contour onto the K output bins
+  double *o = out + frame * p.K;
   const int nn = p.nbands + 2;
   for (int k = tid; k < p.K; k += NT) {
     double xi = (double)k * p.fs / p.fft_size;
@@ -623,12 +677,10 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     if (seg > nn - 1) seg = nn - 1;
     double xa = (seg - 1 <= p.nbands) ? (seg - 1) * D4C_FREQ_INTERVAL : p.fs / 2.0;
     double xb = (seg <= p.nbands) ? seg * D4C_FREQ_INTERVAL : p.fs / 2.0;
-    double s = (xi - xa) / (xb - xa);
-    double v = coarse[seg - 1] + s * (coarse[seg] - coarse[seg - 1]);
+    double sfrac = (xi - xa) / (xb - xa);
+    double v = coarse[seg - 1] + sfrac * (coarse[seg] - coarse[seg - 1]);
     o[k] = exp10(v / 20.0);
   }
-  D4C_STAMP(15);
-#undef D4C_STAMP
 }
 
 // ------------------------------------------------------------------ host side
@@ -654,7 +706,7 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
 template <int LOG2N>
 static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const double *f0,
                        const double *ap0, const d4c_params &p, int64_t T, const uint32_t *ebase,
-                       const double *nuttall, double *out) {
+                       const double *nuttall, double *dvbuf, double *out) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   const kwy_c *twH, *twN;
   const uint4 *poly;
@@ -666,7 +718,19 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(NT), lds, ctx->stream, x, t,
-                     f0, ap0, p, ebase, poly, twH, twN, nuttall, out, (long long *)ctx->dbg));
+                     f0, ap0, p, ebase, poly, twH, twN, dvbuf, out, (long long *)ctx->dbg));
+  const size_t lds_b = d4c_bands_lds<LOG2N>();
+  if (p.window_length <= 2 * (H / 8) + 1) {
+    KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_bands<LOG2N, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, true>), dim3((unsigned)T), dim3(NT), lds_b, ctx->stream,
+                       f0, ap0, p, twH, twN, nuttall, dvbuf, out));
+  } else {
+    KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_bands<LOG2N, false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, false>), dim3((unsigned)T), dim3(NT), lds_b, ctx->stream,
+                       f0, ap0, p, twH, twN, nuttall, dvbuf, out));
+  }
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -690,15 +754,20 @@ static int get_nuttall(kwy_ctx *ctx, int window_length, const double **out) {
   return KWY_OK;
 }
 
-static size_t d4c_scratch_bytes(int64_t T) {
-  return 2 * (kwy_pad(sizeof(uint32_t) * T) + kwy_pad(sizeof(uint64_t) * (T + 1))) +
+static int d4c_fft_size(int fs) {
+  return (int)pow(2.0, 1.0 + (int)(log(4.0 * fs / D4C_FLOOR_F0 + 1) / 0.69314718055994529));
+}
+
+static size_t d4c_scratch_bytes(int64_t T, int fs) {
+  const size_t H = (size_t)d4c_fft_size(fs) / 2;
+  return kwy_pad(sizeof(double) * (size_t)T * (H + 1)) + 2 * (kwy_pad(sizeof(uint32_t) * T) + kwy_pad(sizeof(uint64_t) * (T + 1))) +
          kwy_pad(sizeof(uint64_t) * 3 * T) + kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * 3 * T) +
          kwy_pad(sizeof(double) * T);
 }
 
 static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
                     const double *f0, int64_t T, double threshold, int fft_size, double *out) {
-  const int n4 = (int)pow(2.0, 1.0 + (int)(log(4.0 * fs / D4C_FLOOR_F0 + 1) / 0.69314718055994529));
+  const int n4 = d4c_fft_size(fs);
   const int nl = (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / 40.0 + 1) / 0.69314718055994529));
   const int l4 = kwy_ilog2(n4), ll = kwy_ilog2(nl);
   if (l4 < 10 || l4 > 13 || ll < 10 || ll > 13) {
@@ -714,7 +783,7 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   if (lim > D4C_UPPER_LIMIT) lim = D4C_UPPER_LIMIT;
   p.nbands = (int)(lim / D4C_FREQ_INTERVAL);
   if (p.nbands < 0) p.nbands = 0;
-  if (p.nbands > D4C_MAX_BANDS) { ctx->err = "d4c: too many bands"; return KWY_EINVAL; }
+  if (p.nbands > 5) { ctx->err = "d4c: too many bands"; return KWY_EINVAL; }
   p.window_length = (int)(D4C_FREQ_INTERVAL * n4 / fs) * 2 + 1;
   p.threshold = threshold;
 
@@ -723,7 +792,8 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   uint64_t *offs3 = kwy_arena<uint64_t>(ctx, 3 * T);
   uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * 3 * T);
   double *ap0 = kwy_arena<double>(ctx, T);
-  if (!offs_lt || !offs_b || !offs3 || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
+  double *dvbuf = kwy_arena<double>(ctx, (size_t)T * (n4 / 2 + 1));
+  if (!dvbuf || !offs_lt || !offs_b || !offs3 || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
   const double *nuttall;
   KWY_TRY(get_nuttall(ctx, p.window_length, &nuttall));
 
@@ -743,10 +813,10 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   KWY_HIP(hipGetLastError());
   KWY_TRY(kwy_launch_ebase(ctx, offs3, offs_lt + T, 3 * T, ebase));
   switch (l4) {
-    case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
-    case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
-    case 12: return launch_body<12>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
-    default: return launch_body<13>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, out);
+    case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
+    case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
+    case 12: return launch_body<12>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
+    default: return launch_body<13>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
   }
 }
 
@@ -766,7 +836,7 @@ extern "C" int kwy_d4c_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int 
                            double *out) {
   KWY_TRY(d4c_check(ctx, x, x_length, fs, t, f0, T, out, &fft_size));
   KWY_HIP(hipSetDevice(ctx->device));
-  KWY_TRY(kwy_arena_begin(ctx, d4c_scratch_bytes(T)));
+  KWY_TRY(kwy_arena_begin(ctx, d4c_scratch_bytes(T, fs)));
   return d4c_core(ctx, x, x_length, fs, t, f0, T, threshold, fft_size, out);
 }
 
@@ -779,7 +849,7 @@ extern "C" int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, 
   const int K = fft_size / 2 + 1;
   size_t bx = kwy_pad(sizeof(double) * x_length), bt = kwy_pad(sizeof(double) * T);
   size_t bo = kwy_pad(sizeof(double) * T * K);
-  KWY_TRY(kwy_arena_begin(ctx, d4c_scratch_bytes(T) + bx + 2 * bt + bo));
+  KWY_TRY(kwy_arena_begin(ctx, d4c_scratch_bytes(T, fs) + bx + 2 * bt + bo));
   double *dx = kwy_arena<double>(ctx, x_length), *dt = kwy_arena<double>(ctx, T);
   double *df0 = kwy_arena<double>(ctx, T), *dout = kwy_arena<double>(ctx, (size_t)T * K);
   KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * x_length, hipMemcpyHostToDevice, ctx->stream));

@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-KERNELS = ('k_d4c_body', 'k_cheaptrick', 'k_d4c_lovetrain', 'k_syn_pulse', 'k_syn_ola')
+KERNELS = ('k_d4c_body', 'k_d4c_bands', 'k_cheaptrick', 'k_d4c_lovetrain', 'k_syn_pulse', 'k_syn_ola')
 FRAMES = 2001
 
 
