@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.environ.get('KWY_LIBKWY') or os.path.join(_HERE, 'libkwy.so')   # (override: A/B runs of two builds)
+_SO = os.path.join(_HERE, 'libkwy.so')
 
 if not os.path.exists(_SO):
     raise ImportError(
@@ -41,11 +41,6 @@ def _preload_hip_runtime():
                 pass
 
 
-# The batch drivers give every utterance its own HIP stream; streams beyond the runtime's default of
-# 4 hardware queues would share a queue and run one after the other.  Only effective if the HIP
-# runtime has not started yet (it reads the variable once); an explicit setting wins.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')
-
 _preload_hip_runtime()
 lib = ctypes.CDLL(_SO)
 
@@ -68,7 +63,6 @@ SIGNATURES = {
     'kwy_ctx_stream': (c_vp, [c_vp]),
     'kwy_ctx_profile': (c_int, [c_vp, c_int]),
     'kwy_ctx_debug_buffer': (c_int, [c_vp, c_vp]),
-    'kwy_debug_smallest_sum_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_ctx_profile_read': (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     'kwy_last_error': (ctypes.c_char_p, [c_vp]),
     'kwy_create_error': (ctypes.c_char_p, []),

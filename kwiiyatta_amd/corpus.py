@@ -216,7 +216,11 @@ class ConvertPipeline(_Graphed):
 
 class StreamPool:
     """`n` HIP streams with one library context each (a context owns constant tables and a scratch arena: built
-    once per stream, not once per utterance)"""
+    once per stream, not once per utterance).
+
+    Streams only overlap when they land on different hardware queues; the HIP runtime creates 4 unless the
+    application exports GPU_MAX_HW_QUEUES before HIP starts (bench.py and bench_corpus.py set 32).  The package does
+    not touch the environment: with fewer queues than streams the pool still works, the streams just share."""
 
     def __init__(self, device_index, n):
         self.dev = torch.device('cuda', device_index)

@@ -16,3 +16,8 @@ done
 for p in "${PIDS[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT obj/*.o
 echo "built $OUT"
+# test-only helper library (device-side building blocks on caller data); not loaded by the package
+if [ ! -f ../libkwy_selftest.so ] || [ selftest/kwy_selftest.hip -nt ../libkwy_selftest.so ] || [ kwy_device.hpp -nt ../libkwy_selftest.so ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -shared -o ../libkwy_selftest.so selftest/kwy_selftest.hip
+  echo "built ../libkwy_selftest.so"
+fi

@@ -18,7 +18,6 @@
 #include <vector>
 
 #include "kwy_internal.hpp"
-#include "kwy_selftest.h"
 
 #define D4C_SAFE 0.000000000001
 #define D4C_FLOOR_F0 47.0
@@ -858,40 +857,5 @@ extern "C" int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, 
   KWY_TRY(d4c_core(ctx, dx, x_length, fs, dt, df0, T, threshold, fft_size, dout));
   KWY_HIP(hipMemcpyAsync(out, dout, sizeof(double) * T * K, hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipStreamSynchronize(ctx->stream));
-  return KWY_OK;
-}
-
-#define D4C_NT 256   // the self-test below runs the 256-thread select of the 16..48 kHz body
-
-// ---- diagnostic: the "sum of the m smallest" routine of kwy_device.hpp on caller-supplied data -------------
-// (one 256-thread workgroup per problem; out[p] = {sum of the m smallest, sum of all})
-__global__ __launch_bounds__(D4C_NT) void k_select_selftest(const double *__restrict__ v, int n, int m,
-                                                           double *__restrict__ out) {
-  constexpr int RK = 9;
-  __shared__ __attribute__((aligned(16))) uint32_t hist[KWY_SELECT_WORDS(D4C_NT)];
-  __shared__ double red[2 * D4C_NT / 64];
-  const int tid = threadIdx.x;
-  const double *x = v + (size_t)blockIdx.x * n;
-  unsigned long long key[RK];
-#pragma unroll
-  for (int r = 0; r < RK; ++r) {
-    const int k = tid + D4C_NT * r;
-    key[r] = k < n ? (unsigned long long)__double_as_longlong(x[k]) : ~0ull;
-  }
-  double s_small, s_all;
-  kwy_block_smallest_sum<RK, D4C_NT>(key, n, m, hist, red, &s_small, &s_all);
-  if (tid == 0) { out[2 * blockIdx.x] = s_small; out[2 * blockIdx.x + 1] = s_all; }
-}
-
-extern "C" int kwy_debug_smallest_sum_dev(kwy_ctx *ctx, const double *values, int problems, int n, int m,
-                                          double *out) {
-  if (!ctx) return KWY_EINVAL;
-  if (!values || !out || problems <= 0 || n <= 0 || n > 9 * D4C_NT || m <= 0 || m > n) {
-    ctx->err = "debug_smallest_sum: need 0 < m <= n <= 2304";
-    return KWY_EINVAL;
-  }
-  KWY_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_select_selftest, dim3(problems), dim3(D4C_NT), 0, ctx->stream, values, n, m, out);
-  KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

@@ -32,15 +32,20 @@ def _cases():
 @pytest.mark.parametrize('n,m', [(N, M), (N, N), (N, 1), (1025, 1025 - 33), (300, 290), (2304, 2000)])
 def test_smallest_sum_matches_sort(n, m):
     import torch
-    from kwiiyatta_amd import _lib
+    import ctypes
+    import os
+    from conftest import ROOT
+    from kwiiyatta_amd import _lib                   # loads the HIP runtime the way the package does
+    st = ctypes.CDLL(os.path.join(ROOT, 'kwiiyatta_amd', 'libkwy_selftest.so'))
+    st.kwy_debug_smallest_sum_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p]
     cases = [c[:n] if len(c) >= n else np.resize(c, n) for c in _cases()]
     X = np.stack(cases)
     dev = torch.device('cuda', 0)
-    ctx = _lib.default_context()
     dx = torch.from_numpy(X).to(dev)
     out = torch.zeros((len(cases), 2), dtype=torch.float64, device=dev)
-    _lib.check(ctx, _lib.lib.kwy_debug_smallest_sum_dev(ctx.handle, _lib.c_vp(dx.data_ptr()), len(cases), n, m,
-                                                        _lib.c_vp(out.data_ptr())))
+    assert st.kwy_debug_smallest_sum_dev(torch.cuda.current_stream().cuda_stream, dx.data_ptr(), len(cases), n, m,
+                                         out.data_ptr()) == 0
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     for i, x in enumerate(cases):
