@@ -12,7 +12,7 @@
 //   k_gmm_logp   (frame tile x mixture) workgroups: ||L^-1 (x - mu)||^2 from LDS
 //   k_gmm_cond   per frame: arg-max mixture, conditional mean E and variance D
 //   k_mlpg_build per (frame, dim): the pentadiagonal normal equations W'PW, W'P mu
-//   k_mlpg_solve per static dim: banded Cholesky + two triangular sweeps
+//   k_mlpg_solve per static dim: banded Cholesky, partitioned into chunks (nested dissection)
 //
 // Algorithmic HBM bytes per frame: d*8 in, d*8 out (+ the GMM once per call).
 #include <math.h>
@@ -277,7 +277,9 @@ __global__ __launch_bounds__(128) void k_gmm_cond(const double *__restrict__ X, 
 }
 
 // ---- MLPG: normal equations ---------------------------------------------------------------------
-// band[t][c][0..2] = P[t][t], P[t][t-1], P[t][t-2];  rhs[t][c]
+// rec[t][c][0..3] = P[t][t], P[t][t-1], P[t][t-2], rhs[t]: one 32-byte record per (row, dimension), so that the
+// solver moves it with two 16-byte accesses per lane (its sweeps are bound by the vector-memory instruction rate of
+// the one CU they run on)
 __device__ __forceinline__ double ml_wcoef(int w, int k) {  // window w at offset k in [-1, 1]
   if (w == 0) return k == 0 ? 1.0 : 0.0;
   if (w == 1) return k == -1 ? -0.5 : (k == 0 ? 0.0 : 0.5);
@@ -285,7 +287,7 @@ __device__ __forceinline__ double ml_wcoef(int w, int k) {  // window w at offse
 }
 
 __global__ void k_mlpg_build(const double *__restrict__ E, const double *__restrict__ Dv, ml_dims dm,
-                             double *__restrict__ band, double *__restrict__ rhs) {
+                             double *__restrict__ rec) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= dm.T * dm.d) return;
   const int64_t a = e / dm.d;
@@ -309,153 +311,341 @@ __global__ void k_mlpg_build(const double *__restrict__ E, const double *__restr
       }
     }
   }
-  band[(a * dm.d + c) * 3 + 0] = p0;
-  band[(a * dm.d + c) * 3 + 1] = p1;
-  band[(a * dm.d + c) * 3 + 2] = p2;
-  rhs[a * dm.d + c] = b;
+  double2 *o = (double2 *)rec + e * 2;
+  o[0] = make_double2(p0, p1);
+  o[1] = make_double2(p2, b);
 }
 
-// ---- MLPG: banded Cholesky + forward/backward sweeps, one lane per static dimension ------------------
-// The recurrence is serial in t and only d (24) systems wide: wavefront 0 walks the frames, one
-// lane per dimension, on a tile of frames held in LDS, while wavefronts 1..3 stream the band
-// through two LDS buffers around it -- write the finished tile back, fetch the next one -- so the
-// walk never waits for HBM.  (One wavefront doing both spent 90 % of its time on the copies.)
-#define ML_SOLVE_NT 256
-__device__ __forceinline__ void ml_tile_copy(double *__restrict__ dst, const double *__restrict__ src, int n,
-                                             int first, int nthreads) {
-#pragma unroll 8
-  for (int e = first; e < n; e += nthreads) dst[e] = src[e];
+// ---- MLPG: the T x T pentadiagonal SPD systems (one per static dimension), partitioned --------------------
+// Round 1 walked the T rows serially, one lane per dimension: 2 x 2201 dependent steps of ~170 ns (0.76 ms, the
+// longest kernel on the latency path of a pair).  Now the rows are cut into P chunks with a separator of two rows
+// between neighbours (bandwidth 2: removing two rows decouples the chunks), and the elimination runs in
+// nested-dissection order:
+//   1. every (chunk, dimension) lane -- 64/d chunks per wavefront -- factors its chunk (banded Cholesky) and solves
+//      it for five right-hand sides: the chunk's part of b, and the two columns that couple it to the separator
+//      above and below.  The reciprocal square root on the serial chain is v_rsq_f64 + two Newton steps instead of
+//      an IEEE square root and division (chain of ~9 instead of ~25 dependent operations per row).
+//   2. one lane per dimension assembles the Schur complement on the 2 (P-1) separator unknowns from the chunks'
+//      first and last two solution rows (it is SPD, block tridiagonal with 2 x 2 blocks = bandwidth 3) and solves it.
+//   3. all threads: x = g - Y_top x_sep_above - Y_bottom x_sep_below, written straight to the (strided) output.
+// Same arithmetic as a Cholesky solve in another elimination order: differences to the serial CPU order are rounding
+// (tests: <= 1e-10 relative).  Rows stream from and to global memory as 32-byte records (two 16-byte accesses per
+// lane) through register double buffers.  Measured at T = 2201, d = 24 (in-kernel stamps, 2.4 GHz): sweeps 0.13 ms
+// for the slowest wavefront, separators 0.011 ms, recovery 0.032 ms; 0.176 ms in all against 0.76 ms.  What bounds it
+// now is one CU's memory concurrency: the sweeps move 8.9 MB (written by other XCDs just before, so every line comes
+// over the fabric) at ~30 B/clk.  Several workgroups would divide that, at the price of a second launch for the
+// separator stage.
+#define ML_SOLVE_NT 512
+#define ML_U 8    // rows per register buffer, forward sweep (4 values per row)
+#define ML_UB 4   // backward sweep (6 values per row, 10 running values)
+#define ML_G 16   // the unguarded middle section is a multiple of this many rows (2 ML_U, 4 ML_UB)
+#define ML_BD 24   // doubles kept per (chunk, dimension) for step 2 (global scratch bnd[P][d][ML_BD])
+
+__device__ __forceinline__ double ml_rsqrt(double v) {
+  double r = __builtin_amdgcn_rsq(v);
+  double e = fma(-v * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-v * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  return r;
 }
 
-// y rows are ldy doubles apart
-__device__ __forceinline__ void ml_rows_out(double *__restrict__ y, int ldy, const double *__restrict__ src, int rows,
-                                            int d, int first, int nthreads) {
-  if (ldy == d) { ml_tile_copy(y, src, rows * d, first, nthreads); return; }
-  for (int e = first; e < rows * d; e += nthreads) {
-    const int r = e / d, c = e - r * d;
-    y[(int64_t)r * ldy + c] = src[e];
-  }
+struct ml_part { int P, base, extra; };
+__device__ __forceinline__ int ml_chunk_rows(const ml_part &q, int j) { return q.base + (j < q.extra ? 1 : 0); }
+__device__ __forceinline__ int64_t ml_chunk_start(const ml_part &q, int j) {
+  return (int64_t)j * q.base + (j < q.extra ? j : q.extra) + 2 * j;
 }
 
-__global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__ band, double *__restrict__ rhs,
-                                                           ml_dims dm, int tile, double *__restrict__ y, int ldy,
-                                                           int *__restrict__ status) {
-  extern __shared__ double sm[];  // 2 x { band tile [tile][d][3], rhs tile [tile][d] }
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = dm.d;
+__global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__ rec, double *__restrict__ zz,
+                                                           double *__restrict__ Y, double *__restrict__ bnd, ml_dims dm,
+                                                           ml_part pt,
+                                                           double *__restrict__ y, int ldy,
+                                                           int *__restrict__ status, long long *__restrict__ dbg) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = dm.d, P = pt.P;
+#define ML_STAMP(n) do { if (dbg && tid == 0) dbg[n] = clock64(); } while (0)
+  ML_STAMP(0);
   const int64_t T = dm.T;
-  const int c = lane;
-  const int bufsz = tile * d * 4;
-  const int64_t ntiles = (T + tile - 1) / tile;
-  auto SB = [&](int64_t k) { return sm + (k & 1) * bufsz; };
-  auto SR = [&](int64_t k) { return sm + (k & 1) * bufsz + tile * d * 3; };
-  auto NT_OF = [&](int64_t k) { return (int)min((int64_t)tile, T - k * tile); };
-
-  // ---------------- forward: L L' = A, z = L^-1 b ----------------
-  // stored per row: 1/L[t][t], L[t][t-1], L[t][t-2]
-  double r1 = 0, l1_1 = 0, z1 = 0;  // row t-1: 1/diag, sub1; z[t-1]
-  double r2 = 0, z2 = 0;            // row t-2: 1/diag; z[t-2]
-  ml_tile_copy(SB(0), band, NT_OF(0) * d * 3, tid, ML_SOLVE_NT);
-  ml_tile_copy(SR(0), rhs, NT_OF(0) * d, tid, ML_SOLVE_NT);
-  __syncthreads();
-  for (int64_t k = 0; k < ntiles; ++k) {
-    const int nt = NT_OF(k);
-    const int64_t t0 = k * tile;
-    if (wv > 0) {
-      const int h = tid - 64;
-      if (k > 0) {  // tile k-1 is finished: back to memory, its buffer is then free for tile k+1
-        ml_tile_copy(band + (k - 1) * tile * d * 3, SB(k - 1), tile * d * 3, h, ML_SOLVE_NT - 64);
-        ml_tile_copy(rhs + (k - 1) * tile * d, SR(k - 1), tile * d, h, ML_SOLVE_NT - 64);
-      }
-      if (k + 1 < ntiles) {
-        ml_tile_copy(SB(k + 1), band + (k + 1) * tile * d * 3, NT_OF(k + 1) * d * 3, h, ML_SOLVE_NT - 64);
-        ml_tile_copy(SR(k + 1), rhs + (k + 1) * tile * d, NT_OF(k + 1) * d, h, ML_SOLVE_NT - 64);
-      }
-    } else if (c < d) {
-      double *sb = SB(k), *sr = SR(k);
-      // Row t needs 1/L[t-1][t-1] and 1/L[t-2][t-2] twice and 1/L[t][t] once: the reciprocal of
-      // the diagonal is formed once per row (and stored instead of the diagonal for the backward
-      // sweep), which leaves one division and one square root on the serial chain instead of three
-      // divisions and a square root.  Each quotient then rounds twice instead of once
-      // (~1e-16 relative per row against the CPU's divisions).
-#pragma unroll 4
-      for (int tt = 0; tt < nt; ++tt) {
-        const int64_t t = t0 + tt;
-        double *q = sb + (tt * d + c) * 3;
-        double p0 = q[0], p1 = q[1], p2 = q[2];
-        double L2 = 0.0, L1 = 0.0;
-        if (t >= 2) L2 = p2 * r2;
-        if (t >= 1) {
-          double v = p1;
-          if (t >= 2) v -= L2 * l1_1;  // L[t][t-2] * L[t-1][t-2]
-          L1 = v * r1;
+  const int m = 2 * (P - 1);
+  double *red = sm;                    // [d][m][5]: lower band (diag, 3 sub-diagonals) and right-hand side
+  const int cpw = 64 / d;
+  const int slot = lane / d, c = lane - slot * d;
+  const int j = wv * cpw + slot;
+  if (slot < cpw && j < P) {
+    const int nj = ml_chunk_rows(pt, j);
+    const int64_t st = ml_chunk_start(pt, j);
+    const bool has_top = j > 0, has_bot = j < P - 1;
+    // row i of this lane: records rq[i * 2 d] = {1/diag | P0, L1 | P1}, rq[i * 2 d + 1] = {L2 | P2, z or y of b | b};
+    // zq[i * d] = z of the two top columns; yq[i * 2 d], yq[i * 2 d + 1] = y of the top and the bottom columns
+    double2 *rq = (double2 *)rec + (st * d + c) * 2;
+    double2 *zq = (double2 *)zz + st * d + c;
+    double2 *yq = (double2 *)Y + (st * d + c) * 2;
+    const int s2 = d * 2;
+    // ---------------- forward: L L' = A_jj, z = L^-1 [b, top columns]; stored per row: 1/L[t][t], L[t][t-1], L[t][t-2]
+    // Rows 0, 1 (which carry the top columns' right-hand sides) and the last rows (at least two: the bottom columns
+    // start there) go through a guarded path; the rows between -- the same count, a multiple of ML_G, in every lane --
+    // run without any divergent branch, two register buffers taking turns: while one is consumed the other one's
+    // loads are in flight.  (With guards in that loop the compiler's wait counts degrade to "everything issued".)
+    const int nmain = pt.base > 4 ? ((pt.base - 4) / ML_G) * ML_G : 0;      // rows [2, 2 + nmain)
+    double r1 = 0, r2 = 0, l11 = 0;
+    double zg1 = 0, zg2 = 0, za1 = 0, za2 = 0, zb1 = 0, zb2 = 0;
+    double p2f = 0, p1f = 0, p2f1 = 0;
+    bool bad = false;
+    auto fwd_row = [&](int i, double p0, double p1, double p2, double b, double ra, double rb) {
+      const double L2 = p2 * r2;
+      const double L1 = (p1 - L2 * l11) * r1;
+      double v = p0 - L2 * L2;
+      v -= L1 * L1;
+      if (!(v > 0.0)) { bad = true; v = 1.0; }
+      const double r0 = ml_rsqrt(v);
+      const double zg = ((b - L1 * zg1) - L2 * zg2) * r0;
+      const double za = ((ra - L1 * za1) - L2 * za2) * r0;
+      const double zb = ((rb - L1 * zb1) - L2 * zb2) * r0;
+      rq[i * s2] = make_double2(r0, L1);
+      rq[i * s2 + 1] = make_double2(L2, zg);
+      zq[i * d] = make_double2(za, zb);
+      r2 = r1; r1 = r0; l11 = L1;
+      zg2 = zg1; zg1 = zg; za2 = za1; za1 = za; zb2 = zb1; zb1 = zb;
+    };
+    auto fwd_guarded = [&](int lo, int hi) {      // rows [lo, hi), a few at a time, not pipelined
+      for (int i0 = lo; i0 < hi; i0 += ML_U) {
+        double2 A[ML_U], B[ML_U];
+#pragma unroll
+        for (int u = 0; u < ML_U; ++u) {
+          const int i = i0 + u < hi ? i0 + u : hi - 1;
+          A[u] = rq[i * s2]; B[u] = rq[i * s2 + 1];
         }
-        double v = p0;
-        if (t >= 2) v -= L2 * L2;
-        if (t >= 1) v -= L1 * L1;
-        if (!(v > 0.0)) { atomicExch(status, 2); v = 1.0; }
-        const double r0 = 1.0 / sqrt(v);
-        double zz = sr[tt * d + c];
-        if (t >= 1) zz -= L1 * z1;
-        if (t >= 2) zz -= L2 * z2;
-        zz = zz * r0;
-        q[0] = r0; q[1] = L1; q[2] = L2;
-        sr[tt * d + c] = zz;
-        r2 = r1; z2 = z1;
-        r1 = r0; l1_1 = L1; z1 = zz;
+#pragma unroll
+        for (int u = 0; u < ML_U; ++u) {
+          const int i = i0 + u;
+          if (i < hi) {
+            double ra = 0.0, rb = 0.0;       // the columns of the separator above: x[u], x[u+1]
+            if (i == 0) { p2f = B[u].x; p1f = A[u].y; if (has_top) { ra = B[u].x; rb = A[u].y; } }
+            if (i == 1) { p2f1 = B[u].x; if (has_top) rb = B[u].x; }
+            fwd_row(i, A[u].x, A[u].y, B[u].x, B[u].y, ra, rb);
+          }
+        }
+      }
+    };
+    auto fwd_load = [&](double2 (&A)[ML_U], double2 (&B)[ML_U], int i0, int last) {   // rows clamped to <= last
+#pragma unroll
+      for (int u = 0; u < ML_U; ++u) {
+        const int i = i0 + u < last ? i0 + u : last;
+        A[u] = rq[i * s2]; B[u] = rq[i * s2 + 1];
+      }
+    };
+    auto fwd_rows = [&](const double2 (&A)[ML_U], const double2 (&B)[ML_U], int i0) {
+#pragma unroll
+      for (int u = 0; u < ML_U; ++u) fwd_row(i0 + u, A[u].x, A[u].y, B[u].x, B[u].y, 0.0, 0.0);
+    };
+    fwd_guarded(0, nj < 2 ? nj : 2);
+    if (nmain > 0) {
+      double2 A0[ML_U], B0[ML_U], A1[ML_U], B1[ML_U];
+      const int last = 1 + nmain;
+      fwd_load(A0, B0, 2, last);
+      for (int i0 = 2; i0 < 2 + nmain; i0 += 2 * ML_U) {
+        fwd_load(A1, B1, i0 + ML_U, last);
+        fwd_rows(A0, B0, i0);
+        fwd_load(A0, B0, i0 + 2 * ML_U, last);
+        fwd_rows(A1, B1, i0 + ML_U);
       }
     }
-    __syncthreads();
+    fwd_guarded(2 + nmain, nj);
+    if (bad) atomicExch(status, 2);
+    ML_STAMP(1);
+    // the columns of the separator below are zero until the last two rows of the chunk
+    double zc0 = 0, zc1 = 0, zd1 = 0;     // z of column x[s] at rows n-2, n-1; of column x[s+1] at row n-1
+    if (has_bot) {
+      const double *sq = rec + ((st + nj) * d + c) * 4;
+      const double p1s = sq[1], p2s = sq[2], p2s1 = sq[4 * d + 2];
+      zc0 = p2s * r2;
+      zc1 = (p1s - l11 * zc0) * r1;
+      zd1 = p2s1 * r1;
+    }
+    // ---------------- backward: y = L^-T z, five columns; the same three sections in reverse
+    double *bo = bnd + ((size_t)j * d + c) * ML_BD;
+    bo[20] = p2f; bo[21] = p1f; bo[22] = p2f1;
+    double n11 = 0, n22 = 0, n12 = 0;
+    double yg1 = 0, yg2 = 0, ya1 = 0, ya2 = 0, yb1 = 0, yb2 = 0, yc1 = 0, yc2 = 0, yd1 = 0, yd2 = 0;
+    double yg, ya, yb, yc, yd;
+    auto bwd_row = [&](int i, double2 A, double2 B, double2 Z, double zc, double zd) {
+      const double r0 = A.x;
+      yg = ((B.y - n11 * yg1) - n22 * yg2) * r0;
+      ya = ((Z.x - n11 * ya1) - n22 * ya2) * r0;
+      yb = ((Z.y - n11 * yb1) - n22 * yb2) * r0;
+      yc = ((zc - n11 * yc1) - n22 * yc2) * r0;
+      yd = ((zd - n11 * yd1) - n22 * yd2) * r0;
+      ((double *)(rq + i * s2 + 1))[1] = yg;
+      yq[i * s2] = make_double2(ya, yb);
+      yq[i * s2 + 1] = make_double2(yc, yd);
+      n22 = n12; n11 = A.y; n12 = B.x;
+      yg2 = yg1; yg1 = yg; ya2 = ya1; ya1 = ya; yb2 = yb1; yb1 = yb; yc2 = yc1; yc1 = yc; yd2 = yd1; yd1 = yd;
+    };
+    auto bwd_guarded = [&](int lo, int hi) {      // rows hi-1 down to lo
+      for (int i0 = hi - 1; i0 >= lo; i0 -= ML_UB) {
+        double2 A[ML_UB], B[ML_UB], Z[ML_UB];
+#pragma unroll
+        for (int u = 0; u < ML_UB; ++u) {
+          const int i = i0 - u >= lo ? i0 - u : lo;
+          A[u] = rq[i * s2]; B[u] = rq[i * s2 + 1]; Z[u] = zq[i * d];
+        }
+#pragma unroll
+        for (int u = 0; u < ML_UB; ++u) {
+          const int i = i0 - u;
+          if (i >= lo) {
+            bwd_row(i, A[u], B[u], Z[u], i == nj - 1 ? zc1 : (i == nj - 2 ? zc0 : 0.0), i == nj - 1 ? zd1 : 0.0);
+            if (i >= nj - 2) { double *o = bo + 15 - 5 * (nj - 1 - i); o[0] = yg; o[1] = ya; o[2] = yb; o[3] = yc; o[4] = yd; }
+            if (i <= 1) { double *o = bo + 5 * i; o[0] = yg; o[1] = ya; o[2] = yb; o[3] = yc; o[4] = yd; }
+          }
+        }
+      }
+    };
+    auto bwd_load = [&](double2 (&A)[ML_UB], double2 (&B)[ML_UB], double2 (&Z)[ML_UB], int i0) {   // rows i0, i0-1, ..., >= 2
+#pragma unroll
+      for (int u = 0; u < ML_UB; ++u) {
+        const int i = i0 - u >= 2 ? i0 - u : 2;
+        A[u] = rq[i * s2]; B[u] = rq[i * s2 + 1]; Z[u] = zq[i * d];
+      }
+    };
+    auto bwd_rows = [&](const double2 (&A)[ML_UB], const double2 (&B)[ML_UB], const double2 (&Z)[ML_UB], int i0) {
+#pragma unroll
+      for (int u = 0; u < ML_UB; ++u) bwd_row(i0 - u, A[u], B[u], Z[u], 0.0, 0.0);
+    };
+    bwd_guarded(2 + nmain, nj);
+    if (nmain > 0) {
+      double2 A0[ML_UB], B0[ML_UB], Z0[ML_UB], A1[ML_UB], B1[ML_UB], Z1[ML_UB];
+      bwd_load(A0, B0, Z0, 1 + nmain);
+      for (int i0 = 1 + nmain; i0 >= 2; i0 -= 2 * ML_UB) {
+        bwd_load(A1, B1, Z1, i0 - ML_UB);
+        bwd_rows(A0, B0, Z0, i0);
+        bwd_load(A0, B0, Z0, i0 - 2 * ML_UB);
+        bwd_rows(A1, B1, Z1, i0 - ML_UB);
+      }
+    }
+    bwd_guarded(0, nj < 2 ? nj : 2);
   }
-  {  // the last tile
-    const int64_t k = ntiles - 1;
-    ml_tile_copy(band + k * tile * d * 3, SB(k), NT_OF(k) * d * 3, tid, ML_SOLVE_NT);
-    ml_tile_copy(rhs + k * tile * d, SR(k), NT_OF(k) * d, tid, ML_SOLVE_NT);
-  }
-  __threadfence();  // the tiles are read back below: past this CU's L1
-  __syncthreads();
+  ML_STAMP(2);
+  __syncthreads();   // (workgroup scope: the wavefronts of a workgroup share the CU's L1, no device-scope fence)
+  ML_STAMP(3);
 
-  // ---------------- backward: y = L^-T z ----------------
-  double y1 = 0, y2 = 0, n1_1 = 0, n2_2 = 0, n1_2 = 0;  // y[t+1], y[t+2]; L[t+1][1], L[t+2][2]
-  // the last tile is still in its buffer
-  for (int64_t k = ntiles - 1; k >= 0; --k) {
-    const int nt = NT_OF(k);
-    const int64_t t0 = k * tile;
-    if (wv > 0) {
-      const int h = tid - 64;
-      if (k + 1 < ntiles) ml_rows_out(y + (k + 1) * tile * ldy, ldy, SR(k + 1), NT_OF(k + 1), d, h, ML_SOLVE_NT - 64);
-      if (k > 0) {
-        ml_tile_copy(SB(k - 1), band + (k - 1) * tile * d * 3, tile * d * 3, h, ML_SOLVE_NT - 64);
-        ml_tile_copy(SR(k - 1), rhs + (k - 1) * tile * d, tile * d, h, ML_SOLVE_NT - 64);
+  // ---------------- the separators: Schur complement (bandwidth 3) on 2 (P-1) unknowns per dimension
+  // assembly: one thread per (separator, dimension); R[r][q] = S[r][r-q], R[r][4] = right-hand side
+  for (int e = tid; e < (P - 1) * d; e += ML_SOLVE_NT) {
+    const int k = e / d, cc = e - k * d;
+    const int na = ml_chunk_rows(pt, k);
+    const int64_t s = ml_chunk_start(pt, k) + na;
+    const double *A = bnd + ((size_t)k * d + cc) * ML_BD, *B = bnd + ((size_t)(k + 1) * d + cc) * ML_BD;
+    const double *q0 = rec + (s * d + cc) * 4, *q1 = q0 + d * 4;
+    const double p0s = q0[0], p1s = q0[1], p2s = q0[2], p0s1 = q1[0], p1s1 = q1[1], p2s1 = q1[2];
+    // cb(col) = C_bottom' (column of the chunk above); ct(col) = C_top' (column of the chunk below);
+    // at(col) = C_top' of the chunk above applied to its own columns: the coupling to the previous separator
+    auto cb0 = [&](int col) { return p2s * A[10 + col] + p1s * A[15 + col]; };
+    auto cb1 = [&](int col) { return p2s1 * A[15 + col]; };
+    auto ct0 = [&](int col) { return B[20] * B[col]; };
+    auto ct1 = [&](int col) { return B[21] * B[col] + B[22] * B[5 + col]; };
+    auto at0 = [&](int col) { return A[20] * A[col]; };
+    auto at1 = [&](int col) { return A[21] * A[col] + A[22] * A[5 + col]; };
+    double *R0 = red + ((size_t)cc * m + 2 * k) * 5, *R1 = R0 + 5;
+    R0[0] = (p0s - cb0(3)) - ct0(1);
+    R0[1] = k > 0 ? -at1(3) : 0.0;
+    R0[2] = k > 0 ? -at0(3) : 0.0;
+    R0[3] = 0.0;
+    R0[4] = (q0[3] - cb0(0)) - ct0(0);
+    R1[0] = (p0s1 - cb1(4)) - ct1(2);
+    R1[1] = (p1s1 - cb1(3)) - ct1(1);
+    R1[2] = k > 0 ? -at1(4) : 0.0;
+    R1[3] = k > 0 ? -at0(4) : 0.0;
+    R1[4] = (q1[3] - cb1(0)) - ct1(0);
+  }
+  __syncthreads();
+  // banded Cholesky and the two sweeps, one lane per dimension; the last three rows stay in registers.
+  // In place: R[r][0] = 1 / L[r][r], R[r][q] = L[r][r-q], R[r][4] = solution.
+  if (m > 0 && tid < d) {
+    double *R = red + (size_t)tid * m * 5;
+    double ri1 = 0, ri2 = 0, ri3 = 0, a1 = 0, a2 = 0, b1 = 0, z1 = 0, z2 = 0, z3 = 0;   // a: row r-1, b: row r-2
+    for (int r = 0; r < m; ++r) {
+      double *Rr = R + (size_t)r * 5;
+      const double s0 = Rr[0], s1 = Rr[1], s2 = Rr[2], s3 = Rr[3], bb = Rr[4];
+      const double l3 = s3 * ri3;
+      const double l2 = (s2 - l3 * b1) * ri2;
+      const double l1 = ((s1 - l3 * a2) - l2 * a1) * ri1;
+      double dd = ((s0 - l3 * l3) - l2 * l2) - l1 * l1;
+      if (!(dd > 0.0)) { atomicExch(status, 2); dd = 1.0; }
+      const double ri = ml_rsqrt(dd);
+      const double z = (((bb - l1 * z1) - l2 * z2) - l3 * z3) * ri;
+      Rr[0] = ri; Rr[1] = l1; Rr[2] = l2; Rr[3] = l3; Rr[4] = z;
+      ri3 = ri2; ri2 = ri1; ri1 = ri;
+      b1 = a1; a1 = l1; a2 = l2;
+      z3 = z2; z2 = z1; z1 = z;
+    }
+    double x1 = 0, x2 = 0, x3 = 0, u1 = 0, v2 = 0, w3 = 0, v1n = 0, w1n = 0, w2n = 0;
+    // u1 = L[r+1][r], v2 = L[r+2][r], w3 = L[r+3][r]
+    for (int r = m - 1; r >= 0; --r) {
+      double *Rr = R + (size_t)r * 5;
+      const double x = (((Rr[4] - u1 * x1) - v2 * x2) - w3 * x3) * Rr[0];
+      Rr[4] = x;
+      // row r's sub-diagonals become: L[r][r-1] -> u1 of row r-1; L[r][r-2] -> v2 of row r-2; L[r][r-3] -> w3 of row r-3
+      w3 = w2n; w2n = w1n; w1n = Rr[3];
+      v2 = v1n; v1n = Rr[2];
+      u1 = Rr[1];
+      x3 = x2; x2 = x1; x1 = x;
+    }
+  }
+  __syncthreads();
+  ML_STAMP(4);
+
+  // ---------------- every row: x = g - Y_top x_above - Y_bottom x_below; separator rows take the reduced solution.
+  // Four elements per thread and pass, all loads issued before the first use; the multipliers of a missing
+  // separator are the zero columns computed above, so the index is merely clamped.
+  const int big = pt.base + 3, small_ = pt.base + 2;
+  const int total = (int)(T * d);
+  if (P == 1) {
+    for (int e = tid; e < total; e += ML_SOLVE_NT) { const int t = e / d; y[(int64_t)t * ldy + (e - t * d)] = rec[(size_t)e * 4 + 3]; }
+  } else {
+    for (int e0 = tid; e0 < total; e0 += 4 * ML_SOLVE_NT) {
+      double g[4];
+      double2 ya[4], yb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * ML_SOLVE_NT < total ? e0 + q * ML_SOLVE_NT : tid;
+        g[q] = rec[(size_t)e * 4 + 3];
+        ya[q] = ((const double2 *)Y)[(size_t)e * 2];
+        yb[q] = ((const double2 *)Y)[(size_t)e * 2 + 1];
       }
-    } else if (c < d) {
-      const double *sb = SB(k);
-      double *sr = SR(k);
-#pragma unroll 4
-      for (int tt = nt - 1; tt >= 0; --tt) {
-        const int64_t t = t0 + tt;
-        const double *q = sb + (tt * d + c) * 3;
-        double v = sr[tt * d + c];
-        if (t + 1 < T) v -= n1_1 * y1;
-        if (t + 2 < T) v -= n2_2 * y2;
-        v = v * q[0];  // q[0] holds 1/L[t][t]
-        n2_2 = n1_2;  // L[t+1][2] becomes L[(t-1)+2][2]
-        y2 = y1;
-        n1_1 = q[1]; n1_2 = q[2];
-        y1 = v;
-        sr[tt * d + c] = v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * ML_SOLVE_NT;
+        if (e < total) {
+          const int t = e / d;
+          const int cc = e - t * d;
+          int jj, off, nrows;
+          if (t < pt.extra * big) { jj = t / big; off = t - jj * big; nrows = pt.base + 1; }
+          else {
+            const int t2 = t - pt.extra * big;
+            jj = pt.extra + t2 / small_;
+            off = t2 - (jj - pt.extra) * small_;
+            nrows = pt.base;
+          }
+          const double *R = red + (size_t)cc * m * 5;
+          const int ka = jj > 0 ? jj - 1 : 0, kb = jj < P - 1 ? jj : P - 2;
+          double v = ((g[q] - ya[q].x * R[(2 * ka) * 5 + 4]) - ya[q].y * R[(2 * ka + 1) * 5 + 4]);
+          v = (v - yb[q].x * R[(2 * kb) * 5 + 4]) - yb[q].y * R[(2 * kb + 1) * 5 + 4];
+          if (off >= nrows) v = R[(2 * jj + (off - nrows)) * 5 + 4];
+          y[(int64_t)t * ldy + cc] = v;
+        }
       }
     }
-    __syncthreads();
   }
-  ml_rows_out(y, ldy, SR(0), NT_OF(0), d, tid, ML_SOLVE_NT);
+  ML_STAMP(5);
+#undef ML_STAMP
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
 static size_t ml_scratch_bytes(int64_t T, int d, int M) {
   const int D = 3 * d;
   return kwy_pad(sizeof(double) * ml_model_stride(D) * M) + 3 * kwy_pad(sizeof(double) * T * D) +
-         kwy_pad(sizeof(double) * T * M) + kwy_pad(sizeof(int) * T) + kwy_pad(sizeof(double) * T * d * 3) +
-         kwy_pad(sizeof(double) * T * d) + kwy_pad(64);
+         kwy_pad(sizeof(double) * T * M) + kwy_pad(sizeof(int) * T) + kwy_pad(sizeof(double) * T * d * 4) +
+         kwy_pad(sizeof(double) * T * d * 2) + kwy_pad(sizeof(double) * T * d * 4) + kwy_pad(sizeof(double) * ML_SOLVE_NT * ML_BD) + kwy_pad(64);
 }
 
 // frame-tile walkers per mixture: enough workgroups for every CU (one fits per CU), not more than tiles
@@ -482,10 +672,12 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   double *Dv = kwy_arena<double>(ctx, (size_t)T * D);
   double *logp = kwy_arena<double>(ctx, (size_t)T * M);
   int *mix = kwy_arena<int>(ctx, T);
-  double *band = kwy_arena<double>(ctx, (size_t)T * d * 3);
-  double *rhs = kwy_arena<double>(ctx, (size_t)T * d);
+  double *band = kwy_arena<double>(ctx, (size_t)T * d * 4);   // records {P0, P1, P2, rhs}
+  double *rhs = kwy_arena<double>(ctx, (size_t)T * d * 2);    // forward solutions of the two top columns
+  double *Ysp = kwy_arena<double>(ctx, (size_t)T * d * 4);
+  double *bnd = kwy_arena<double>(ctx, (size_t)ML_SOLVE_NT * ML_BD);
   int *status = kwy_arena<int>(ctx, 16);
-  if (!model || !X || !E || !Dv || !logp || !mix || !band || !rhs || !status) {
+  if (!model || !X || !E || !Dv || !logp || !mix || !band || !rhs || !Ysp || !bnd || !status) {
     ctx->err = "gmm_mlpg: scratch arena too small";
     return KWY_ENOMEM;
   }
@@ -496,10 +688,14 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024) { ctx->err = "gmm_mlpg: feature dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
-  // frames per LDS tile of the solve: two buffers of tile x d x 4 doubles within 128 KB
-  int solve_tile = 64;
-  while (solve_tile > 4 && (size_t)2 * solve_tile * d * 4 * sizeof(double) > 128 * 1024) solve_tile /= 2;
-  const size_t lds_solve = (size_t)2 * solve_tile * d * 4 * sizeof(double);
+  // chunks of the partitioned solve: 64/d per wavefront, at least 16 rows each
+  ml_part pt;
+  pt.P = (ML_SOLVE_NT / 64) * (64 / d);
+  if ((int64_t)pt.P > T / 16) pt.P = (int)(T / 16);
+  if (pt.P < 1) pt.P = 1;
+  pt.base = (int)((T - 2 * (pt.P - 1)) / pt.P);
+  pt.extra = (int)((T - 2 * (pt.P - 1)) % pt.P);
+  const size_t lds_solve = sizeof(double) * ((size_t)d * 2 * (pt.P - 1) * 5 + 8);
   if (lds_solve > 160 * 1024) { ctx->err = "gmm_mlpg: static dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_mlpg_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_solve));
@@ -511,8 +707,8 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)ml_logp_splits(T, M), M), dim3(KWY_THREADS), lds_logp,
                      ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
-  hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band, rhs);
-  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(ML_SOLVE_NT), lds_solve, ctx->stream, band, rhs, dm, solve_tile, y, ldy, status));
+  hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band);
+  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(ML_SOLVE_NT), lds_solve, ctx->stream, band, rhs, Ysp, bnd, dm, pt, y, ldy, status, (long long *)ctx->dbg));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
