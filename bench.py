@@ -137,6 +137,9 @@ def main():
     ap_.add_argument('--distinct', type=int, default=8, help='distinct synthetic signal pairs per rank (cycled over the batch)')
     ap_.add_argument('--no-pcie-variant', action='store_true',
                      help='skip the second timed loop that uploads the waveforms and downloads the result inside the step')
+    ap_.add_argument('--side-stream', choices=['auto', 'on', 'off'], default='auto',
+                     help='pair workload: D4C on a second stream beside the alignment (a latency option; auto = only '
+                          'when one pair runs alone, i.e. --batch 1)')
     ap_.add_argument('--no-graph', dest='graph', action='store_false',
                      help='enqueue every kernel of a pass from the host (about 170 launches per pair) instead of '
                           'replaying the pass as a captured HIP graph; the per-kernel HIP events are then recorded '
@@ -147,6 +150,8 @@ def main():
     ap_.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo lets '
                                                         'several ranks share one GPU when rehearsing the launch)')
     args = ap_.parse_args()
+
+    args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.batch == 1)
 
     import torch
     import torch.distributed as dist
@@ -178,7 +183,8 @@ def main():
     for i in range(len(mine)):
         src, tgt = base[i % nbase]
         if args.workload == 'pair':
-            pipes.append(pl.PairPipeline(local_rank, FS, src, tgt, dgmm, prepare_gmm_per_run=args.gmm_prepare_per_pair))
+            pipes.append(pl.PairPipeline(local_rank, FS, src, tgt, dgmm, prepare_gmm_per_run=args.gmm_prepare_per_pair,
+                                         side_stream=args.side_stream))
         else:
             pipes.append(pl.UtterancePipeline(local_rank, FS, src))
     torch.cuda.synchronize()
@@ -208,7 +214,7 @@ def main():
     sync_all()
     if not args.graph:
         for p in pipes:
-            p.ctx.profile(True)
+            p.profile(True)
     if world > 1:
         dist.barrier()
     sync_all()
@@ -230,13 +236,13 @@ def main():
         # kernel on the same streams right after the timed region, with the library's events around the tracked
         # kernels -- same kernels, same concurrency, not part of `value`.
         for p in pipes:
-            p.ctx.profile(True)
+            p.profile(True)
         for _ in range(min(args.steps, 3)):
             for p in pipes:
                 p.run()
         sync_all()
         for p in pipes:
-            p.ctx.profile(False)
+            p.profile(False)
 
     def run_pcie_variant():
         pcie = None
@@ -297,7 +303,7 @@ def main():
         kernel_ms = {}
         for p in pipes:
             for nme in names:
-                ms, n = p.ctx.profile_read(nme)
+                ms, n = p.profile_read(nme)
                 if n:
                     a = kernel_ms.setdefault(nme, [0.0, 0])
                     a[0] += ms
@@ -306,15 +312,20 @@ def main():
         # (per-launch durations inside the timed region include the time a kernel shares the CUs with
         # the other streams' kernels)
         alone_ms = {}
-        pipes[0].ctx.profile(True)
-        pipes[0].run(); pipes[0].sync()
+        if args.workload == 'pair':      # one kernel at a time: everything on one stream (no side stream for D4C)
+            lone = pl.PairPipeline(local_rank, FS, *base[0], dgmm, prepare_gmm_per_run=args.gmm_prepare_per_pair,
+                                   side_stream=False)
+        else:
+            lone = pipes[0]
+        lone.profile(True)
+        lone.run(); lone.sync()
         for nme in names:
-            pipes[0].ctx.profile_read(nme)
+            lone.profile_read(nme)
         alone_n = {}
         for _ in range(4):
-            pipes[0].run(); pipes[0].sync()
+            lone.run(); lone.sync()
         for nme in names:
-            ms, n = pipes[0].ctx.profile_read(nme)
+            ms, n = lone.profile_read(nme)
             if n:
                 alone_ms[nme] = ms / n
                 alone_n[nme] = n
@@ -410,6 +421,7 @@ def main():
                             'config2: 48 kHz 10 s utterances (T=2001, K=1025): CheapTrick + D4C + WORLD synthesis',
                 'pairs_per_gpu' if args.workload == 'pair' else 'utterances_per_gpu': args.batch,
                 'source_frames_per_pair': T, 'streams_per_gpu': args.batch,
+                'd4c_on_side_stream': bool(args.side_stream) if args.workload == 'pair' else None,
                 'gmm_model_prepared': ('per pair' if args.gmm_prepare_per_pair else
                                        'once per converter (the per-mixture matrices depend on the GMM only)')
                 if args.workload == 'pair' else None,

@@ -105,17 +105,34 @@ class _Graphed:
         self.sync()
         g = torch.cuda.CUDAGraph()
         if profile:
-            self.ctx.profile(True)
+            self.profile(True)
         with torch.cuda.graph(g, stream=self.stream):
             self.run()
         if profile:
-            self.ctx.profile(False)
+            self.profile(False)
         self.graph = g
         self.sync()
 
     def replay(self):
         with torch.cuda.stream(self.stream):
             self.graph.replay()
+
+    def contexts(self):
+        """the library contexts this pipeline launches on (one per stream)"""
+        return [c for c in (self.ctx, getattr(self, 'side_ctx', None)) if c is not None]
+
+    def profile(self, enable=True):
+        for c in self.contexts():
+            c.profile(enable)
+
+    def profile_read(self, kernel):
+        """(summed milliseconds, launches) of `kernel` over the pipeline's streams since the last read"""
+        ms, n = 0.0, 0
+        for c in self.contexts():
+            a, b = c.profile_read(kernel)
+            ms += a
+            n += b
+        return ms, n
 
 
 def draw_silence(fs, K, frame_len=PAD_LEN):
@@ -126,7 +143,8 @@ def draw_silence(fs, K, frame_len=PAD_LEN):
 
 class PairPipeline(_Graphed):
     def __init__(self, device_index, fs, source, target, gmm, order=24, radius=32, frame_period=5.0,
-                 stream=None, prepare_gmm_per_run=False, silence=None, keep_aligned_spectrum=False):
+                 stream=None, prepare_gmm_per_run=False, silence=None, keep_aligned_spectrum=False,
+                 side_stream=False):
         """source / target: (x, f0, timeaxis) numpy triples; gmm: DeviceGMM over 2*3*order dims.
         prepare_gmm_per_run: redo the GMM-only part of MLPG (nnmnkwii's MLPG.__init__) in every run(),
         as the reference does per convert() call, instead of once per converter.
@@ -134,13 +152,20 @@ class PairPipeline(_Graphed):
         tail); default: drawn here from numpy's global generator in that order, as `align` would -- uploaded once,
         so the pipeline and the Python API path see the same pads under `np.random.seed`.
         keep_aligned_spectrum: also gather the aligned source spectrum (`align` returns it; the conversion flow
-        replaces it by the converted one and never reads it)."""
+        replaces it by the converted one and never reads it).
+        side_stream: D4C (which needs only waveform, f0 and frame times) runs on a second stream beside
+        CheapTrick -> sp2mc -> FastDTW and is joined before the aligned aperiodicity is gathered: the alignment is a
+        chain of single-workgroup kernels, so the two overlap almost completely.  A latency option (one pair alone:
+        3.5 -> 3.15 ms); with many pairs in flight the extra streams cost throughput (32 pairs: 1.49 M -> 1.30 M
+        frames/s), hence off by default."""
         self.prepare_gmm_per_run = bool(prepare_gmm_per_run)
         self.keep_aligned_spectrum = bool(keep_aligned_spectrum)
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
         self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.side = torch.cuda.Stream(device=self.dev) if side_stream else None
+        self.side_ctx = _lib.Context(device_index, stream=self.side.cuda_stream) if side_stream else None
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
         self.K = self.fft // 2 + 1
         from .backend import sptk
@@ -184,10 +209,17 @@ class PairPipeline(_Graphed):
         """Enqueue one pass of the hot path on this pipeline's stream (asynchronous)."""
         h, fs, fft, K, order = self.ctx.handle, self.fs, self.fft, self.K, self.order
         with torch.cuda.stream(self.stream):
+            if self.side is not None:
+                self.side.wait_stream(self.stream)              # fork (inside a capture: a second branch of the graph)
+                hs = self.side_ctx.handle
+                for s in (self.src, self.tgt):
+                    _lib.check(self.side_ctx, lib.kwy_d4c_dev(hs, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft,
+                                                              _p(s.ap)))
             for s in (self.src, self.tgt):
                 self._chk(lib.kwy_cheaptrick_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, -0.15, 71.0,
                                                  fft, float(fs), _p(s.sp)))
-                self._chk(lib.kwy_d4c_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft, _p(s.ap)))
+                if self.side is None:
+                    self._chk(lib.kwy_d4c_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft, _p(s.ap)))
             for s in (self.src, self.tgt):
                 self._chk(lib.kwy_sp2mc_dev(h, _p(s.sp_pad), s.Tp, K, order, self.alpha, _p(s.mc_pad)))
                 self._chk(lib.kwy_align_features_dev(h, _p(s.mc_pad), s.Tp, order + 1, _p(s.f0_pad),
@@ -198,6 +230,8 @@ class PairPipeline(_Graphed):
             self._chk(lib.kwy_align_project_dev(h, _p(self.path), _p(self.path_len), PAD_LEN, _p(self.idx),
                                                 self.tgt.Tp, _p(self.n_idx)))
             Tt = self.tgt.T
+            if self.side is not None:
+                self.stream.wait_stream(self.side)              # join: the aperiodicities are complete
             for src_arr, dst, w in ((self.src.sp_pad, self.sp_al, K), (self.src.ap_pad, self.ap_al, K),
                                     (self.src.mc_pad, self.mc_al, order + 1)):
                 if dst is not None:

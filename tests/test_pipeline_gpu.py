@@ -168,6 +168,36 @@ def test_graph_replay_matches_plain_pass(pair):
     assert torch.equal(p.wave, ref['wave'])
 
 
+def test_side_stream_pass_matches_single_stream(pair):
+    """D4C on a second stream beside the alignment (the latency option) changes the order of execution only:
+    plain and captured passes give the single-stream results bit for bit."""
+    import numpy as np
+    import torch
+    from kwiiyatta_amd import pipeline as pl
+    fs, src, tgt = pair
+    gmm = pl.synthetic_gmm(order=24, components=8, seed=0, n_frames=4000)
+    dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
+    silence = [pl.draw_silence(fs, 1025) for _ in range(4)]
+    one = pl.PairPipeline(0, fs, src, tgt, dg, silence=silence)
+    two = pl.PairPipeline(0, fs, src, tgt, dg, silence=silence, side_stream=True)
+    assert len(two.contexts()) == 2 and len(one.contexts()) == 1
+    one.run(); one.sync()
+    two.run(); two.sync()
+    keys = ('path', 'idx', 'ap_al', 'mc_conv', 'sp_conv', 'wave')
+    for k in keys:
+        assert torch.equal(getattr(one, k), getattr(two, k)), k
+    assert torch.equal(one.tgt.ap, two.tgt.ap)
+    two.capture()
+    for k in keys:
+        getattr(two, k).zero_()
+    two.src.ap.zero_()
+    for _ in range(2):
+        two.replay()
+    two.sync()
+    for k in keys:
+        assert torch.equal(getattr(one, k), getattr(two, k)), k
+
+
 def test_pipeline_matches_api_path_under_seed():
     """The silence pads are drawn on the host from numpy's global generator in the reference's order, so the
     HBM-resident pipeline and the package's Python API (`kwiiyatta.align`, the path the reference's CLIs take)
