@@ -104,14 +104,12 @@ __global__ void k_dtw_window(const int32_t *__restrict__ cpath, const int64_t *_
 
 // The same windows for all rows, and the rows' offsets in the band storage (exclusive prefix sums of the widths), in
 // one single-workgroup launch.
-#define DTW_WS_NT 1024
-__global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(const int32_t *__restrict__ cpath,
-                                                              const int64_t *__restrict__ cpath_len, int radius,
-                                                              int len_x, int len_y, int32_t *__restrict__ lo,
-                                                              int32_t *__restrict__ hi, uint64_t *__restrict__ off) {
-  __shared__ uint64_t tot[DTW_WS_NT];
-  const int cn = cpath ? (int)*cpath_len : 0;
-  for (int i = threadIdx.x; i < len_x; i += DTW_WS_NT) {
+// cpath: the coarser level's path (cn cells), or null for the full window of the coarsest level.  tot: NT uint64 of LDS.
+template <int NT>
+__device__ __forceinline__ void dtw_window_scan_body(const int32_t *__restrict__ cpath, int cn, int radius, int len_x,
+                                                     int len_y, int32_t *__restrict__ lo, int32_t *__restrict__ hi,
+                                                     uint64_t *__restrict__ off, uint64_t *tot) {
+  for (int i = threadIdx.x; i < len_x; i += NT) {
     int l = 0, h = len_y - 1;
     if (cpath && cn > 0) {
       const int a = i / 2;
@@ -128,7 +126,21 @@ __global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(const int32_t *__
     hi[i] = h;
   }
   __syncthreads();
-  kwy_block_count_scan<DTW_WS_NT>([&](int64_t i) -> uint64_t { return (uint64_t)(hi[i] - lo[i] + 1); }, len_x, off, tot);
+  kwy_block_count_scan<NT>([&](int64_t i) -> uint64_t { return (uint64_t)(hi[i] - lo[i] + 1); }, len_x, off, tot);
+}
+
+// The coarsest level (full window) has its own launch, which also clears the status words of the call; every other
+// level's windows are computed by the tail of the previous level's k_dtw_dp (same workgroup, path still hot).
+#define DTW_WS_NT 1024
+__global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(const int32_t *__restrict__ cpath,
+                                                              const int64_t *__restrict__ cpath_len, int radius,
+                                                              int len_x, int len_y, int32_t *__restrict__ lo,
+                                                              int32_t *__restrict__ hi, uint64_t *__restrict__ off,
+                                                              int *__restrict__ status_clear) {
+  __shared__ uint64_t tot[DTW_WS_NT];
+  if (status_clear && threadIdx.x < 16) status_clear[threadIdx.x] = 0;
+  const int cn = cpath ? (int)*cpath_len : 0;
+  dtw_window_scan_body<DTW_WS_NT>(cpath, cn, radius, len_x, len_y, lo, hi, off, tot);
 }
 
 // Band storage: row i holds width[i] distances at dist[DTW_PAD + off[i] + 16 i + 8 ...], with DTW_ROWPAD +inf
@@ -211,17 +223,19 @@ __device__ __forceinline__ uint64_t dtw_row_words_end(const uint64_t *__restrict
 typedef double dtw_d2 __attribute__((ext_vector_type(2), aligned(8)));
 typedef int dtw_i4 __attribute__((ext_vector_type(4), aligned(4)));
 template <bool BND_LDS>
-__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y, const int32_t *__restrict__ lo,
-                                              const int32_t *__restrict__ hi,
-                                              const uint64_t *__restrict__ off, uint64_t cap,
+__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y, const int32_t *lo, const int32_t *hi,
+                                              const uint64_t *off /* = lo_w, hi_w, off_w: rewritten by the tail */,
+                                              uint64_t cap,
                                               double *dist /* the strips' last rows get their cells' entry columns */,
                                               uint32_t *__restrict__ predw,
                                               double *__restrict__ bnd_global /* DTW_WAVES x (len_y+2) or null */,
                                               int32_t *__restrict__ path, int32_t *__restrict__ rev,
                                               int32_t *__restrict__ sinfo /* 3 x strips */,
                                               int64_t *__restrict__ path_len, double *__restrict__ out_dist,
-                                              const int *__restrict__ status, long long *__restrict__ dbg) {
-  extern __shared__ unsigned char bt[];  // boundary rows (BND_LDS)
+                                              const int *__restrict__ status, long long *__restrict__ dbg,
+                                              int lds_bytes, int next_len_x, int next_len_y, int radius,
+                                              int32_t *lo_w, int32_t *hi_w, uint64_t *off_w) {
+  extern __shared__ unsigned char bt[];  // boundary rows (BND_LDS); the back-trace's tables afterwards
   const long long t_start = dbg ? clock64() : 0;
   __shared__ int s_n;
   // (strip << 32) | (last finished column + 1).  Plain LDS words written/read with relaxed
@@ -232,10 +246,19 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
   __shared__ long long s_prog[DTW_WAVES];
 #define DTW_PROG_LOAD(b) __hip_atomic_load(&s_prog[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define DTW_PROG_STORE(b, v) __hip_atomic_store(&s_prog[b], (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define DTW_RELEASE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); else __threadfence(); } while (0)
-#define DTW_ACQUIRE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); else __threadfence(); } while (0)
+// (one workgroup = one CU: its wavefronts share the L1, so global data needs workgroup scope only; a device-scope
+// fence writes the L2 back and costs ~20 us each)
+#define DTW_RELEASE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); } while (0)
+#define DTW_ACQUIRE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (*status != 0) { if (threadIdx.x == 0) { *path_len = 0; *out_dist = NAN; } return; }
+  if (*status != 0) {
+    if (threadIdx.x == 0) { *path_len = 0; *out_dist = NAN; }
+    // keep the next level's tables defined (full windows: its distance kernel sees the overflow and leaves the status)
+    if (next_len_x > 0)
+      dtw_window_scan_body<64 * DTW_WAVES>((const int32_t *)nullptr, 0, radius, next_len_x, next_len_y, lo_w, hi_w, off_w,
+                                           (uint64_t *)bt);
+    return;
+  }
   const double INF = INFINITY;
   const int rowlen = len_y + 2;  // boundary rows are indexed by j + 1 (entry 0 is column -1)
   double *const lds_rows = (double *)bt;
@@ -406,30 +429,48 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     if (dbg && lane == 0 && k < 48) dbg[64 + 4 * k + 1] = clock64() - t_start;
   }
   __syncthreads();
-  if (!BND_LDS) __threadfence();
   // D[len_x-1][len_y-1]: the last strip's last row is in its boundary buffer
   const double last_val = BROW((nstrips - 1) % DTW_WAVES, len_y);
 #undef BROW
   __syncthreads();   // every thread holds last_val: the back-trace staging may overwrite the boundary rows
   const long long t_dp = dbg ? clock64() : 0;
   if (threadIdx.x == 0) *out_dist = last_val;
-  __threadfence();  // predecessor codes and entry columns written above are read back below through global memory
-  __syncthreads();
+  __syncthreads();   // predecessor codes and entry columns written above are read back below through global memory
+                     // (by this workgroup only: the barrier's workgroup-scope fence is enough)
 
   // ---- back-trace.  (1) one thread hops from strip to strip: the path leaves strip k through
   //      (last row, exitc[k]) and the entry column stored there is where it leaves strip k-1.
   //      (2) every strip is walked by its own lane, all at once, over the predecessor codes.
   //      (3) the strips' cell counts are summed, (4) the segments are copied to their places.
+  // A walk is a chain of dependent loads (row window -> word address -> predecessor word), ~1500 cycles per cell
+  // from global memory: the per-row table {lo, hi, first word} and, when they fit, the predecessor words are
+  // staged in LDS first (the boundary rows are dead by now).
   int32_t *exitc = sinfo, *sbase = sinfo + nstrips, *cnt = sinfo + 2 * nstrips;
-  if (threadIdx.x == 0) {
+  const bool tbl_ok = (size_t)lds_bytes >= 12ull * (size_t)len_x;
+  int32_t *t_lo = (int32_t *)bt, *t_hi = t_lo + len_x;
+  uint32_t *t_wb = (uint32_t *)(t_hi + len_x), *t_pw = t_wb + len_x;
+  const uint64_t nwords = dtw_row_words_end(off, lo, hi, len_x - 1);
+  const bool pw_ok = tbl_ok && nwords <= (uint64_t)(((size_t)lds_bytes - 12ull * (size_t)len_x) / 4);
+  if (tbl_ok) {
+    for (int i = threadIdx.x; i < len_x; i += 64 * DTW_WAVES) {
+      t_lo[i] = lo[i]; t_hi[i] = hi[i]; t_wb[i] = (uint32_t)dtw_word_base(off, i);
+    }
+    if (pw_ok) for (uint32_t w = threadIdx.x; w < (uint32_t)nwords; w += 64 * DTW_WAVES) t_pw[w] = predw[w];
+  }
+  __syncthreads();
+  if (dbg && threadIdx.x == 0) dbg[20] = clock64() - t_dp;
+  // Two instances of hop and walk: on the LDS tables (ds_ loads: they do not share a wait counter with the global
+  // stores of the walk's output) or on the arrays in global memory.  A flat pointer serving both would turn every
+  // load into a flat_ instruction that waits for all outstanding stores.
+  auto hop = [&](const int32_t *LO, const int32_t *HI) {
     int cj = len_y - 1, base = 0;
     for (int k = nstrips - 1; k >= 0; --k) {
       const int i0 = 64 * k, il = min(i0 + 63, len_x - 1);
       exitc[k] = cj;
       int e = 0;
       if (k > 0) {
-        const int l = lo[il];
-        const int c = min(max(cj, l), hi[il]);
+        const int l = LO[il];
+        const int c = min(max(cj, l), HI[il]);
         e = ((const int32_t *)(dist + dtw_row_base(off, il)))[c - l];
         e = min(max(e, 0), cj);
       }
@@ -437,11 +478,14 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
       base += (il - i0 + 1) + (cj - e) + 1;   // rows + columns: more cells than the strip can hold
       cj = e;
     }
+  };
+  if (threadIdx.x == 0) {
+    if (tbl_ok) hop(t_lo, t_hi); else hop(lo, hi);
   }
-  __threadfence();
   __syncthreads();
-  for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
-    const int i0 = 64 * k, lo0 = lo[i0];
+  if (dbg && threadIdx.x == 0) dbg[21] = clock64() - t_dp;
+  auto walk = [&](int k, const int32_t *LO, const int32_t *HI, const uint32_t *WB, const uint32_t *PW) {
+    const int i0 = 64 * k, lo0 = LO[i0];
     int i = min(i0 + 63, len_x - 1), j = exitc[k], m = 0;
     int32_t *out = rev + 2 * (int64_t)sbase[k];
     int crow = -1, l = 0, h = -1, sh = 0;
@@ -450,29 +494,38 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     while (i >= i0) {
       out[2 * m] = i; out[2 * m + 1] = j; ++m;
       if (i == 0 && j == 0) break;
-      if (i != crow) { crow = i; l = lo[i]; h = hi[i]; sh = (i - i0) + l - lo0; wb = dtw_word_base(off, i); cw = ~0ull; }
+      if (i != crow) {
+        crow = i; l = LO[i]; h = HI[i]; sh = (i - i0) + l - lo0;
+        wb = WB ? (uint64_t)WB[i] : dtw_word_base(off, i);
+        cw = ~0ull;
+      }
       unsigned int pb = 0;
       if (j >= l && j <= h) {
         const int st = sh + (j - l);  // the step at which this cell was computed
         const uint64_t w = wb + (uint64_t)((st >> 4) - (sh >> 4));
-        if (w != cw) { cw = w; word = predw[w]; }
+        if (w != cw) { cw = w; word = PW[w]; }
         pb = (word >> (2 * (st & 15))) & 3u;
       }
       if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
       if (j < 0) break;
     }
     cnt[k] = m;
+  };
+  for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
+    if (pw_ok) walk(k, t_lo, t_hi, t_wb, t_pw);
+    else if (tbl_ok) walk(k, t_lo, t_hi, t_wb, predw);
+    else walk(k, lo, hi, (const uint32_t *)nullptr, predw);
   }
-  __threadfence();
   __syncthreads();
+  if (dbg && threadIdx.x == 0) dbg[22] = clock64() - t_dp;
   if (threadIdx.x == 0) {
     int n = 0;
     for (int k = 0; k < nstrips; ++k) { const int c = cnt[k]; exitc[k] = n; n += c; }   // exitc: now the output offset
     s_n = n;
     *path_len = n;
   }
-  __threadfence();
   __syncthreads();
+  if (dbg && threadIdx.x == 0) dbg[23] = clock64() - t_dp;
   for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
     const int c = cnt[k];
     const int32_t *in = rev + 2 * (int64_t)sbase[k];
@@ -487,6 +540,11 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t_dp - t_start));
     atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(t_end - t_dp));
     dbg[2] = t_dp - t_start; dbg[3] = t_end - t_dp; dbg[4] = s_n;
+  }
+  // ---- the next (finer) level's windows from this path: lo / hi / off of this level are dead now
+  if (next_len_x > 0) {
+    __syncthreads();    // the path is complete (workgroup scope), the LDS tables are free
+    dtw_window_scan_body<64 * DTW_WAVES>(path, s_n, radius, next_len_x, next_len_y, lo_w, hi_w, off_w, (uint64_t *)bt);
   }
 }
 
@@ -571,11 +629,13 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     return KWY_ENOMEM;
   }
   *status_out = status;
-  KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
   const size_t bnd_bytes = sizeof(double) * DTW_WAVES * (Ty + 2);
   // the boundary rows of the strips live in LDS when they fit
   const bool bnd_lds = bnd_bytes <= 150 * 1024;
-  const size_t dp_lds = bnd_lds ? bnd_bytes : 0;
+  // ... and the back-trace stages its row table and predecessor words in the same LDS: ask for all a workgroup may
+  // have beside the static variables (the kernel takes what fits)
+  const size_t dp_lds = 150 * 1024;
+  (void)bnd_bytes;
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
 
@@ -586,18 +646,22 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     const bool top = (l == 0);
     int32_t *opath = top ? d_path : ((l & 1) ? pathA : pathB);
     int64_t *olen = top ? d_path_len : ((l & 1) ? lenA : lenB);
-    hipLaunchKernelGGL(k_dtw_window_scan, dim3(1), dim3(DTW_WS_NT), 0, ctx->stream, cpath, clen, radius, len_x, len_y,
-                       lo, hi, off);
+    if (l == (int)lv.size() - 1)
+      hipLaunchKernelGGL(k_dtw_window_scan, dim3(1), dim3(DTW_WS_NT), 0, ctx->stream, (const int32_t *)nullptr,
+                         (const int64_t *)nullptr, radius, len_x, len_y, lo, hi, off, status);
+    const int nlx = top ? 0 : lv[l - 1].len_x, nly = top ? 0 : lv[l - 1].len_y;
     KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3(len_x), dim3(KWY_THREADS), sizeof(double) * dim, ctx->stream, xs[l],
                        ys[l], dim, lo, hi, off, cap, dist, status));
     if (bnd_lds)
       KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<true>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
                                                      lo, hi, off, cap, dist, pred, (double *)nullptr, opath, rev, sinfo, olen,
-                                                     d_dist, status, (long long *)ctx->dbg));
+                                                     d_dist, status, (long long *)ctx->dbg, (int)dp_lds, nlx, nly, radius,
+                                                     lo, hi, off));
     else
       KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<false>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
                                                      lo, hi, off, cap, dist, pred, bnd, opath, rev, sinfo, olen, d_dist,
-                                                     status, (long long *)ctx->dbg));
+                                                     status, (long long *)ctx->dbg, (int)dp_lds, nlx, nly, radius, lo, hi,
+                                                     off));
     cpath = opath;
     clen = olen;
   }

@@ -142,6 +142,36 @@ def test_gmm_mlpg(ko, clb, M, diff):
         assert len(np.unique(mix_ref)) > 1   # the selection step is exercised
 
 
+class _RandomGMM:
+    """joint GMM with random SPD covariances (no fit: any static dimension, any size)"""
+    covariance_type = 'full'
+
+    def __init__(self, d, M, seed):
+        rng = np.random.default_rng(seed)
+        D2 = 6 * d
+        self.weights_ = rng.dirichlet(np.ones(M))
+        self.means_ = rng.standard_normal((M, D2))
+        a = rng.standard_normal((M, D2, D2)) * 0.2
+        self.covariances_ = a @ a.transpose(0, 2, 1) + np.eye(D2) * rng.uniform(0.5, 2.0, (M, 1, 1))
+
+
+@pytest.mark.parametrize('d', [1, 3, 24, 27])       # 27: the largest static dimension whose model fits the LDS
+@pytest.mark.parametrize('T', [1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 48, 64, 100, 255, 256, 257, 520, 1031])
+def test_mlpg_solve_partition_edges(ko, T, d):
+    """The pentadiagonal solve is partitioned into up to 8 * (64 // d) chunks of >= 16 rows with two-row
+    separators (kwy_mlpg.hip): every chunk count from 1 up, chunks of unequal length, two to 64 chunks per
+    wavefront, against the serial CPU elimination."""
+    from kwiiyatta_amd.backend import mlpg
+    gmm = _RandomGMM(d, 2, seed=7 * d + T)
+    rng = np.random.default_rng(T)
+    x = np.cumsum(rng.standard_normal((T, d)) * 0.3, axis=0)
+    for diff in (False, True):
+        ref = ko.gmm_mlpg(x, gmm.weights_, gmm.means_, gmm.covariances_, diff=diff)
+        got = mlpg.MLPG(gmm, windows=mlpg.DELTA_WINDOWS, diff=diff).transform(x)
+        assert got.shape == ref.shape == (T, d)
+        assert np.abs(got - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1.0), (T, d, diff)
+
+
 def test_gmm_mlpg_errors(clb):
     from kwiiyatta_amd.backend import mlpg
 
