@@ -299,7 +299,7 @@ def main():
         T = pipes[0].frames
         K = pipes[0].K
         names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_d4c_bands', 'k_syn_phase', 'k_syn_pulse', 'k_syn_ola', 'k_sp2mc',
-                 'k_mc2sp', 'k_dtw_dist', 'k_dtw_dp', 'k_gmm_prep', 'k_gmm_logp', 'k_mlpg_solve', 'k_align_project']
+                 'k_mc2sp', 'k_dtw_dist', 'k_dtw_dp', 'k_gmm_prep', 'k_gmm_logp', 'k_mlpg_chunks', 'k_mlpg_finish', 'k_align_project']
         kernel_ms = {}
         for p in pipes:
             for nme in names:
@@ -406,7 +406,7 @@ def main():
                       'note': ('one workgroup per launch: a serial recurrence (FastDTW DP + back-trace, critical path '
                                'Tx+Ty steps) that holds 1 of 256 CUs and overlaps with the other streams; it bounds the '
                                'latency of one pair, not the throughput, and has no HBM or MFMA roofline')
-                              if top in ('k_dtw_dp', 'k_mlpg_solve', 'k_syn_phase', 'k_align_project') else
+                              if top in ('k_dtw_dp', 'k_syn_phase', 'k_align_project') else
                               'whole-chip kernel'}
         # whole-path algorithmic bytes per source frame
         path_bytes = 36664 if args.workload == 'utterance' else 81000

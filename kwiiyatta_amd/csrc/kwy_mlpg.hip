@@ -12,7 +12,7 @@
 //   k_gmm_logp   (frame tile x mixture) workgroups: ||L^-1 (x - mu)||^2 from LDS
 //   k_gmm_cond   per frame: arg-max mixture, conditional mean E and variance D
 //   k_mlpg_build per (frame, dim): the pentadiagonal normal equations W'PW, W'P mu
-//   k_mlpg_solve per static dim: banded Cholesky, partitioned into chunks (nested dissection)
+//   k_mlpg_chunks / k_mlpg_finish  per static dim: banded Cholesky, partitioned into chunks (nested dissection)
 //
 // Algorithmic HBM bytes per frame: d*8 in, d*8 out (+ the GMM once per call).
 #include <math.h>
@@ -330,12 +330,16 @@ __global__ void k_mlpg_build(const double *__restrict__ E, const double *__restr
 //   3. all threads: x = g - Y_top x_sep_above - Y_bottom x_sep_below, written straight to the (strided) output.
 // Same arithmetic as a Cholesky solve in another elimination order: differences to the serial CPU order are rounding
 // (tests: <= 1e-10 relative).  Rows stream from and to global memory as 32-byte records (two 16-byte accesses per
-// lane) through register double buffers.  Measured at T = 2201, d = 24 (in-kernel stamps, 2.4 GHz): sweeps 0.13 ms
-// for the slowest wavefront, separators 0.011 ms, recovery 0.032 ms; 0.176 ms in all against 0.76 ms.  What bounds it
-// now is one CU's memory concurrency: the sweeps move 8.9 MB (written by other XCDs just before, so every line comes
-// over the fabric) at ~30 B/clk.  Several workgroups would divide that, at the price of a second launch for the
-// separator stage.
-#define ML_SOLVE_NT 512
+// lane) through register double buffers.
+// Two launches: k_mlpg_chunks does step 1 with ONE wavefront per workgroup (ML_CHUNK_WGS of them at most), so the
+// chunks spread over that many CUs -- as a single workgroup the sweeps were bound by one CU's memory concurrency
+// (8.9 MB written by other XCDs just before, every line over the fabric: ~30 B/clk, 0.13 ms of a 0.18 ms kernel);
+// k_mlpg_finish does steps 2 and 3 on a small grid, every workgroup solving the (tiny) separator system for itself
+// and recovering its share of the rows.
+#define ML_CHUNK_WGS 16
+#define ML_MAX_CHUNKS 64      // bounds the serial separator solve (2 (P-1) rows of bandwidth 3 per dimension)
+#define ML_FIN_NT 256
+#define ML_FIN_WGS 8
 #define ML_U 8    // rows per register buffer, forward sweep (4 values per row)
 #define ML_UB 4   // backward sweep (6 values per row, 10 running values)
 #define ML_G 16   // the unguarded middle section is a multiple of this many rows (2 ML_U, 4 ML_UB)
@@ -356,21 +360,15 @@ __device__ __forceinline__ int64_t ml_chunk_start(const ml_part &q, int j) {
   return (int64_t)j * q.base + (j < q.extra ? j : q.extra) + 2 * j;
 }
 
-__global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__ rec, double *__restrict__ zz,
-                                                           double *__restrict__ Y, double *__restrict__ bnd, ml_dims dm,
-                                                           ml_part pt,
-                                                           double *__restrict__ y, int ldy,
-                                                           int *__restrict__ status, long long *__restrict__ dbg) {
-  extern __shared__ double sm[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = dm.d, P = pt.P;
-#define ML_STAMP(n) do { if (dbg && tid == 0) dbg[n] = clock64(); } while (0)
+__global__ __launch_bounds__(64) void k_mlpg_chunks(double *__restrict__ rec, double *__restrict__ zz,
+                                                    double *__restrict__ Y, double *__restrict__ bnd, ml_dims dm,
+                                                    ml_part pt, int *__restrict__ status, long long *__restrict__ dbg) {
+  const int lane = threadIdx.x, d = dm.d, P = pt.P;
+#define ML_STAMP(n) do { if (dbg && lane == 0 && blockIdx.x == 0) dbg[n] = clock64(); } while (0)
   ML_STAMP(0);
-  const int64_t T = dm.T;
-  const int m = 2 * (P - 1);
-  double *red = sm;                    // [d][m][5]: lower band (diag, 3 sub-diagonals) and right-hand side
   const int cpw = 64 / d;
   const int slot = lane / d, c = lane - slot * d;
-  const int j = wv * cpw + slot;
+  const int j = blockIdx.x * cpw + slot;
   if (slot < cpw && j < P) {
     const int nj = ml_chunk_rows(pt, j);
     const int64_t st = ml_chunk_start(pt, j);
@@ -525,17 +523,29 @@ __global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__
     bwd_guarded(0, nj < 2 ? nj : 2);
   }
   ML_STAMP(2);
-  __syncthreads();   // (workgroup scope: the wavefronts of a workgroup share the CU's L1, no device-scope fence)
+#undef ML_STAMP
+}
+
+__global__ __launch_bounds__(ML_FIN_NT) void k_mlpg_finish(const double *__restrict__ rec, const double *__restrict__ Y,
+                                                          const double *__restrict__ bnd, ml_dims dm, ml_part pt,
+                                                          double *__restrict__ y, int ldy, int *__restrict__ status,
+                                                          long long *__restrict__ dbg) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, d = dm.d, P = pt.P;
+#define ML_STAMP(n) do { if (dbg && tid == 0 && blockIdx.x == 0) dbg[n] = clock64(); } while (0)
   ML_STAMP(3);
+  const int64_t T = dm.T;
+  const int m = 2 * (P - 1);
+  double *red = sm;                    // [d][m][5]: lower band (diag, 3 sub-diagonals) and right-hand side
 
   // ---------------- the separators: Schur complement (bandwidth 3) on 2 (P-1) unknowns per dimension
   // assembly: one thread per (separator, dimension); R[r][q] = S[r][r-q], R[r][4] = right-hand side
-  for (int e = tid; e < (P - 1) * d; e += ML_SOLVE_NT) {
+  for (int e = tid; e < (P - 1) * d; e += ML_FIN_NT) {
     const int k = e / d, cc = e - k * d;
     const int na = ml_chunk_rows(pt, k);
     const int64_t s = ml_chunk_start(pt, k) + na;
     const double *A = bnd + ((size_t)k * d + cc) * ML_BD, *B = bnd + ((size_t)(k + 1) * d + cc) * ML_BD;
-    const double *q0 = rec + (s * d + cc) * 4, *q1 = q0 + d * 4;
+    const double *q0 = rec + (s * d + cc) * 4, *q1 = q0 + d * 4;   // separator rows: untouched by the chunks
     const double p0s = q0[0], p1s = q0[1], p2s = q0[2], p0s1 = q1[0], p1s1 = q1[1], p2s1 = q1[2];
     // cb(col) = C_bottom' (column of the chunk above); ct(col) = C_top' (column of the chunk below);
     // at(col) = C_top' of the chunk above applied to its own columns: the coupling to the previous separator
@@ -599,23 +609,25 @@ __global__ __launch_bounds__(ML_SOLVE_NT) void k_mlpg_solve(double *__restrict__
   // separator are the zero columns computed above, so the index is merely clamped.
   const int big = pt.base + 3, small_ = pt.base + 2;
   const int total = (int)(T * d);
+  const int share = (total + gridDim.x - 1) / gridDim.x;
+  const int e_lo = blockIdx.x * share, e_hi = min(total, e_lo + share);
   if (P == 1) {
-    for (int e = tid; e < total; e += ML_SOLVE_NT) { const int t = e / d; y[(int64_t)t * ldy + (e - t * d)] = rec[(size_t)e * 4 + 3]; }
+    for (int e = e_lo + tid; e < e_hi; e += ML_FIN_NT) { const int t = e / d; y[(int64_t)t * ldy + (e - t * d)] = rec[(size_t)e * 4 + 3]; }
   } else {
-    for (int e0 = tid; e0 < total; e0 += 4 * ML_SOLVE_NT) {
+    for (int e0 = e_lo + tid; e0 < e_hi; e0 += 4 * ML_FIN_NT) {
       double g[4];
       double2 ya[4], yb[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int e = e0 + q * ML_SOLVE_NT < total ? e0 + q * ML_SOLVE_NT : tid;
+        const int e = e0 + q * ML_FIN_NT < e_hi ? e0 + q * ML_FIN_NT : e_lo;
         g[q] = rec[(size_t)e * 4 + 3];
         ya[q] = ((const double2 *)Y)[(size_t)e * 2];
         yb[q] = ((const double2 *)Y)[(size_t)e * 2 + 1];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int e = e0 + q * ML_SOLVE_NT;
-        if (e < total) {
+        const int e = e0 + q * ML_FIN_NT;
+        if (e < e_hi) {
           const int t = e / d;
           const int cc = e - t * d;
           int jj, off, nrows;
@@ -645,7 +657,7 @@ static size_t ml_scratch_bytes(int64_t T, int d, int M) {
   const int D = 3 * d;
   return kwy_pad(sizeof(double) * ml_model_stride(D) * M) + 3 * kwy_pad(sizeof(double) * T * D) +
          kwy_pad(sizeof(double) * T * M) + kwy_pad(sizeof(int) * T) + kwy_pad(sizeof(double) * T * d * 4) +
-         kwy_pad(sizeof(double) * T * d * 2) + kwy_pad(sizeof(double) * T * d * 4) + kwy_pad(sizeof(double) * ML_SOLVE_NT * ML_BD) + kwy_pad(64);
+         kwy_pad(sizeof(double) * T * d * 2) + kwy_pad(sizeof(double) * T * d * 4) + kwy_pad(sizeof(double) * ML_CHUNK_WGS * 64 * ML_BD) + kwy_pad(64);
 }
 
 // frame-tile walkers per mixture: enough workgroups for every CU (one fits per CU), not more than tiles
@@ -675,7 +687,7 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   double *band = kwy_arena<double>(ctx, (size_t)T * d * 4);   // records {P0, P1, P2, rhs}
   double *rhs = kwy_arena<double>(ctx, (size_t)T * d * 2);    // forward solutions of the two top columns
   double *Ysp = kwy_arena<double>(ctx, (size_t)T * d * 4);
-  double *bnd = kwy_arena<double>(ctx, (size_t)ML_SOLVE_NT * ML_BD);
+  double *bnd = kwy_arena<double>(ctx, (size_t)ML_CHUNK_WGS * 64 * ML_BD);
   int *status = kwy_arena<int>(ctx, 16);
   if (!model || !X || !E || !Dv || !logp || !mix || !band || !rhs || !Ysp || !bnd || !status) {
     ctx->err = "gmm_mlpg: scratch arena too small";
@@ -690,14 +702,16 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
   // chunks of the partitioned solve: 64/d per wavefront, at least 16 rows each
   ml_part pt;
-  pt.P = (ML_SOLVE_NT / 64) * (64 / d);
+  const int cpw = 64 / d;
+  pt.P = ML_CHUNK_WGS * cpw;
+  if (pt.P > ML_MAX_CHUNKS) pt.P = ML_MAX_CHUNKS;
   if ((int64_t)pt.P > T / 16) pt.P = (int)(T / 16);
   if (pt.P < 1) pt.P = 1;
   pt.base = (int)((T - 2 * (pt.P - 1)) / pt.P);
   pt.extra = (int)((T - 2 * (pt.P - 1)) % pt.P);
   const size_t lds_solve = sizeof(double) * ((size_t)d * 2 * (pt.P - 1) * 5 + 8);
   if (lds_solve > 160 * 1024) { ctx->err = "gmm_mlpg: static dimension too large"; return KWY_EINVAL; }
-  KWY_HIP(hipFuncSetAttribute((const void *)k_mlpg_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+  KWY_HIP(hipFuncSetAttribute((const void *)k_mlpg_finish, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_solve));
   if (!prepared)
     hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
@@ -708,7 +722,14 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
                      ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
   hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band);
-  KWY_PROF(ctx, "k_mlpg_solve", hipLaunchKernelGGL(k_mlpg_solve, dim3(1), dim3(ML_SOLVE_NT), lds_solve, ctx->stream, band, rhs, Ysp, bnd, dm, pt, y, ldy, status, (long long *)ctx->dbg));
+  KWY_PROF(ctx, "k_mlpg_chunks", hipLaunchKernelGGL(k_mlpg_chunks, dim3((unsigned)((pt.P + cpw - 1) / cpw)), dim3(64), 0, ctx->stream,
+                                                     band, rhs, Ysp, bnd, dm, pt, status, (long long *)ctx->dbg));
+  {
+    int fin = (int)((T * d + 4 * ML_FIN_NT - 1) / (4 * ML_FIN_NT));
+    if (fin > ML_FIN_WGS) fin = ML_FIN_WGS;
+    KWY_PROF(ctx, "k_mlpg_finish", hipLaunchKernelGGL(k_mlpg_finish, dim3((unsigned)fin), dim3(ML_FIN_NT), lds_solve, ctx->stream,
+                                                       band, Ysp, bnd, dm, pt, y, ldy, status, (long long *)ctx->dbg));
+  }
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
