@@ -87,6 +87,27 @@ def test_synthesis_parity(ko, kw, path):
     assert np.abs(got - ref).max() <= 1e-8
 
 
+def test_synthesis_leading_silence(ko, kw):
+    """Recorded speech starts with silence: the excitation phase stays exactly 0 over those samples.  The phase
+    scan must take such a run in one step per tile (it once took the samples one per workgroup round: ~0.6 us per
+    silent sample), and the result must not change."""
+    import time
+    fs, x = load(clb_variant('48'))
+    f0, t = f0_track(ko, x, fs)
+    sp, ap = ko.cheaptrick(x, f0, t, fs), ko.d4c(x, f0, t, fs)
+    lead = 1600                                         # 8 s of unvoiced frames in front
+    f0s = np.r_[np.zeros(lead), f0]
+    sps = np.ascontiguousarray(np.r_[np.repeat(sp[:1], lead, axis=0), sp])
+    aps = np.ascontiguousarray(np.r_[np.repeat(ap[:1], lead, axis=0), ap])
+    kw.synthesize(f0s, sps, aps, fs, 5.0)               # tables, arena
+    t0 = time.perf_counter(); got = kw.synthesize(f0s, sps, aps, fs, 5.0); t_sil = time.perf_counter() - t0
+    v = np.where(f0s > 0, f0s, 120.0)                   # the same length, voiced throughout
+    t0 = time.perf_counter(); kw.synthesize(v, sps, aps, fs, 5.0); t_voiced = time.perf_counter() - t0
+    ref = ko.synthesize(f0s, sps, aps, fs, 5.0)
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-9
+    assert t_sil < t_voiced + 0.1, (t_sil, t_voiced)
+
+
 def test_synthesis_is_deterministic(ko, kw):
     """Two runs give the same bits (ordered overlap-add, no floating-point atomics): what the reference asserts
     with `(analyzer_wav.data == feature_wav.data).all()`, tests/kwiiyatta/test_vocoder.py:171."""
