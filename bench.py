@@ -23,10 +23,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# One HIP stream per utterance only overlaps if the streams land on different hardware queues; the
-# runtime's default of 4 serialises the rest (measured: 4 -> 470k, 16 -> 673k, 32 -> 682k frames/s).
-# Must be in the environment before the HIP runtime starts (kwiiyatta_amd._lib sets the same default).
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')
+# One HIP stream per pair only overlaps with the others if the streams land on different hardware queues; the runtime's
+# default of 4 serialises the rest.  Measured at 32 pairs per step (frames/s, three runs each, round 2): 8 queues
+# 1.34 M, 16: 1.48 M, 24: 1.60 M, 28: 1.49 M, 32: 1.51 M, 36 and more: 1.60-1.63 M -- as many queues as streams still
+# leaves some of them sharing with the process's other streams, so ask for more than that.
+# Must be in the environment before the HIP runtime starts; the package itself leaves the environment alone.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '64')
 
 FS = 48000
 FRAME_PERIOD = 5.0

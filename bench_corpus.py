@@ -23,8 +23,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-# one hardware queue per stream (the runtime's default of 4 serialises the rest); read once when HIP starts
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '32')
+# one hardware queue per stream and a few to spare (bench.py has the measurements); read once when HIP starts
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '64')
 
 
 def main():

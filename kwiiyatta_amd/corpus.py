@@ -219,7 +219,8 @@ class StreamPool:
     once per stream, not once per utterance).
 
     Streams only overlap when they land on different hardware queues; the HIP runtime creates 4 unless the
-    application exports GPU_MAX_HW_QUEUES before HIP starts (bench.py and bench_corpus.py set 32).  The package does
+    application exports GPU_MAX_HW_QUEUES before HIP starts (bench.py and bench_corpus.py set 64: more than they
+    have streams, see bench.py).  The package does
     not touch the environment: with fewer queues than streams the pool still works, the streams just share."""
 
     def __init__(self, device_index, n):

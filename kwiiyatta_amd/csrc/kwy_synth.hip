@@ -148,7 +148,6 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_inc(const double *__restric
 #define SYN_PH_THREADS 1024
 #define SYN_PH_PER_THREAD 4
 #define SYN_PH_TILE (SYN_PH_THREADS * SYN_PH_PER_THREAD)
-#define SYN_PH_STAGED 1024   // tile summaries kept in LDS by the chain kernel (87 s at 48 kHz; the rest from memory)
 
 struct syn_ff { long long d0, d1; };  // delta when the incoming mantissa is even / odd
 
@@ -281,24 +280,15 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
   __shared__ syn_ff wtot[SYN_PH_THREADS / 64];
   __shared__ int s_cross;
   __shared__ double s_tp;
-  // the tiles' summaries, staged once: the chain below would otherwise pay a global-memory latency per tile
-  __shared__ long long s_summ[3 * SYN_PH_STAGED];
   const int tid = threadIdx.x;
-  {
-    const int64_t ntiles = (y_length + SYN_PH_TILE - 1) / SYN_PH_TILE;
-    const int ns = (int)min(ntiles, (int64_t)SYN_PH_STAGED) * 3;
-    for (int i = tid; i < ns; i += SYN_PH_THREADS) s_summ[i] = summ[i];
-    __syncthreads();
-  }
   double tp = 0.0;  // running phase (uniform across the block)
   int tix = 0;
   for (int64_t tile0 = 0; tile0 < y_length; tile0 += SYN_PH_TILE, ++tix) {
     const int tile_n = (int)min((int64_t)SYN_PH_TILE, y_length - tile0);
-    // ---- fast tile?
+    // ---- fast tile?  (the summaries come through the scalar cache: staging them in LDS was measured slower)
     {
-      const bool staged = tix < SYN_PH_STAGED;
-      const long long d0 = staged ? s_summ[3 * tix] : summ[3 * tix], d1 = staged ? s_summ[3 * tix + 1] : summ[3 * tix + 1];
-      const int k = (int)(staged ? s_summ[3 * tix + 2] : summ[3 * tix + 2]);
+      const long long d0 = summ[3 * tix], d1 = summ[3 * tix + 1];
+      const int k = (int)summ[3 * tix + 2];
       if (k != SYN_SLOW && tp > 0.0 && syn_exponent(tp) == k) {
         const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
         const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);

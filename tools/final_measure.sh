@@ -19,5 +19,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b32 -- pyt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b1 -- python $R/bench.py --batch 1 --steps 5 --no-cpu-baseline > $O/stats_pair_b1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+KWY_MEASURE_OUT=$O/pmc_sq bash $R/tools/pmc_sq.sh
 bash $R/tools/prof_fit.sh
 echo done > $O/DONE
