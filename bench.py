@@ -323,14 +323,19 @@ def main():
         lone.run(); lone.sync()
         for nme in names:
             lone.profile_read(nme)
+        # median over passes: now and then a pass is held up for ~10 ms by the queue scheduler (seen in rocprofv3 traces
+        # as one dispatch of an otherwise 0.04 ms kernel lasting 11 ms); a mean would carry that into the roofline
         alone_n = {}
-        for _ in range(4):
+        per_pass = {}
+        for _ in range(7):
             lone.run(); lone.sync()
-        for nme in names:
-            ms, n = lone.profile_read(nme)
-            if n:
-                alone_ms[nme] = ms / n
-                alone_n[nme] = n
+            for nme in names:
+                ms, n = lone.profile_read(nme)
+                if n:
+                    per_pass.setdefault(nme, []).append(ms / n)
+                    alone_n[nme] = alone_n.get(nme, 0) + n
+        for nme, vals in per_pass.items():
+            alone_ms[nme] = sorted(vals)[len(vals) // 2]
         # D4C's per-frame work is two launches (k_d4c_body: centroids, power spectrum, group delay -> one H+1 row of
         # scratch per frame; k_d4c_bands: band FFTs, selection, interpolation -> the K-bin row).  The roofline prices
         # the stage: both durations summed against the stage's algorithmic bytes and flop.

@@ -26,7 +26,7 @@ def per_launch(path, counter):
         if r['Counter_Name'] != counter:
             continue
         name = r['Kernel_Name'].split('(')[0]
-        if name.rstrip().endswith(', true>'):      # k_syn_pulse<N, true>: the (normally empty) overflow pass
+        if 'k_syn_pulse' in name and name.rstrip().endswith(', true>'):      # k_syn_pulse<N, true>: the (normally empty) overflow pass
             continue
         base = name.split('<')[0].replace('void ', '').strip()
         if base in KERNELS:     # exact kernel name (k_d4c_body, not k_d4c_body_counts)
