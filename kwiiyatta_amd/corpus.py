@@ -241,18 +241,39 @@ def shard_block(n_items, rank, world_size):
     return list(range(lo, hi))
 
 
+def _silence_ahead(n_pairs, fs, depth):
+    """The pad spectra of `n_pairs` pairs, drawn by a helper thread in pair order from numpy's global legacy generator
+    (the reference's source, `draw_silence`) while the caller enqueues GPU work: the generator is serial (4.6 ms per
+    pair at 48 kHz) and numpy releases the GIL inside it.  The caller must not use `np.random` meanwhile."""
+    import queue
+    import threading
+    K = lib.kwy_cheaptrick_fft_size(int(fs), 71.0) // 2 + 1
+    q = queue.Queue(maxsize=max(1, depth))
+
+    def work():
+        for _ in range(n_pairs):
+            q.put([draw_silence(fs, K) for _ in range(4)])
+
+    threading.Thread(target=work, daemon=True).start()
+    return q
+
+
 def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_period=5.0, streams=16,
-                          silence_for=None):
+                          silence_for=None, pool=None):
     """pairs: list of ((x, f0, t), (x, f0, t)) numpy triples of THIS rank, in corpus order.  Returns the
     (n, 2*3*order) float64 device tensor of make_dataset_to_array and the number of source frames analysed.
-    Pairs are processed `streams` at a time, each on its own stream."""
+    Pairs are processed `streams` at a time, each on its own stream (`pool`: a StreamPool to use instead of a new one).
+    silence_for(i): the four pad spectra of pair i; default: numpy's global generator in pair order, as the reference
+    draws them, one wave of pairs ahead of the GPU."""
     dev = torch.device('cuda', device_index)
-    pool = StreamPool(device_index, streams)
+    if pool is None:
+        pool = StreamPool(device_index, streams)
+    ahead = _silence_ahead(len(pairs), fs, 2 * len(pool)) if silence_for is None and pairs else None
     blocks, frames = [], 0
     for w0 in range(0, len(pairs), len(pool)):
         wave = []
         for k, (src, tgt) in enumerate(pairs[w0:w0 + len(pool)]):
-            sil = silence_for(w0 + k) if silence_for is not None else None
+            sil = silence_for(w0 + k) if silence_for is not None else ahead.get()
             wave.append(TrainPair(device_index, fs, src, tgt, order=order, radius=radius, frame_period=frame_period,
                                   stream=pool.streams[k], ctx=pool.contexts[k], silence=sil))
         for p in wave:
@@ -275,32 +296,31 @@ def fit_converter(X, components=64, seed=None, max_iter=100, device_index=0, ver
                               device_index=device_index).fit(X)
 
 
-def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16):
+def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16, pool=None):
     """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors).  Every stream
     keeps one pipeline per utterance shape, captured as a HIP graph: an utterance of a shape seen before costs an
-    upload, one graph launch and a device copy of the result."""
+    upload, one graph launch and a device copy of the result, all enqueued on the pipeline's stream -- the streams
+    run independently of each other and the host waits once, at the end."""
     dev = torch.device('cuda', device_index)
     dg = DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
-    pool = StreamPool(device_index, streams)
+    if pool is None:
+        pool = StreamPool(device_index, streams)
     cache = [dict() for _ in range(len(pool))]
     out = [None] * len(utterances)
-    for w0 in range(0, len(utterances), len(pool)):
-        wave = []
-        for k, u in enumerate(utterances[w0:w0 + len(pool)]):
-            shape = (len(u[0]), len(u[1]))
-            p = cache[k].get(shape)
-            if p is None:
-                p = ConvertPipeline(device_index, fs, u, dg, order=order, frame_period=frame_period,
-                                    stream=pool.streams[k], ctx=pool.contexts[k])
-                p.capture()
-                cache[k][shape] = p
-            else:
-                p.load(u)
-            p.replay()
-            wave.append((w0 + k, p))
-        for i, p in wave:
-            with torch.cuda.stream(p.stream):
-                out[i] = p.wave.clone()
-        for _, p in wave:
-            p.sync()
+    for i, u in enumerate(utterances):
+        k = i % len(pool)
+        shape = (len(u[0]), len(u[1]))
+        p = cache[k].get(shape)
+        if p is None:
+            p = ConvertPipeline(device_index, fs, u, dg, order=order, frame_period=frame_period,
+                                stream=pool.streams[k], ctx=pool.contexts[k])
+            p.capture()
+            cache[k][shape] = p
+        else:
+            p.load(u)
+        p.replay()
+        with torch.cuda.stream(p.stream):
+            out[i] = p.wave.clone()
+    for s_ in pool.streams:
+        s_.synchronize()
     return out
