@@ -19,6 +19,9 @@ CONVERTER_OPTIONS = (
     ('--mcep-fs', dict(type=int, help='Sampling rate of training mel cepstrum')),
     ('--converter-components', dict(type=int, default=64, help='Components num for feature converter')),
     ('--converter-seed', dict(type=int, help='Random seed for feature converter')),
+    # an addition to the reference's options: keep the trained converter between runs
+    ('--converter-model', dict(type=str, help='File of the trained converter: loaded when it exists (no training, '
+                                              '--source/--target not needed), written after training otherwise')),
 )
 
 
@@ -76,6 +79,15 @@ class Config:
 
     def train_converter(self, **kwargs):
         converter = self.create_converter(**kwargs)
+        model = getattr(self, 'converter_model', None)
+        if model is not None and pathlib.Path(model).is_file():
+            return converter.load(model)
+        converter = self._train(converter)
+        if model is not None:
+            converter.save(model)
+        return converter
+
+    def _train(self, converter):
         dataset = self.load_dataset()
         keys = sorted(dataset.keys())[slice(self.skip_files, None)]
         converter.train(dataset, keys[:self.max_files])

@@ -1,7 +1,10 @@
 """`kwiiyatta`: train a converter on a parallel corpus (--source / --target directories with equally named wav
 files) and convert wav files with it.  Command line and outputs of the reference's kwiiyatta/convert_voice.py:
 for every input <name>.wav a <name>.diff.wav (the input waveform through the differential MLSA filter) and a
-<name>.synth.wav (WORLD synthesis from the converted mel-cepstrum).  `--no-diffvc` (an addition) skips the first."""
+<name>.synth.wav (WORLD synthesis from the converted mel-cepstrum).  Additions: `--no-diffvc` skips the first;
+`--converter-model FILE` keeps the trained converter between runs; `--batch` renders the .synth.wav outputs of all
+input files through the HBM-resident batch path (kwiiyatta_amd.corpus.convert_batch: one stream per file in flight,
+features never leave the GPU) instead of file by file."""
 import pathlib
 
 OUTPUTS = (('diff', True), ('synth', False))          # suffix, differential?
@@ -19,15 +22,50 @@ def convert(conf, converter, src_path, diffvc=True):
     return rendered.synthesize()
 
 
+def convert_synth_batch(conf, converter, paths):
+    """{path: Wavdata} of the .synth.wav outputs.  Files whose sampling rate or frame period differ from the
+    converter's go through `convert` one by one (the batch path has no resampling stage)."""
+    import kwiiyatta_amd as k
+    from . import corpus
+    from .converter.delta import DeltaFeatureConverter
+    out, batch = {}, []
+    period = next((s.frame_period for s in _stages(converter) if isinstance(s, DeltaFeatureConverter)), None)
+    for path in paths:
+        a = conf.create_analyzer(path, Analyzer=k.analyze_wav)
+        if a.fs != converter.fs or a.mel_cepstrum_order != converter.order or \
+                (period is not None and a.frame_period != period):
+            out[path] = convert(conf, converter, path, diffvc=False)
+        else:
+            batch.append((path, a))
+    if batch:
+        fs = batch[0][1].fs
+        triples = [(a.wavdata.data, a.f0, a._timeaxis) for _, a in batch]      # f0: DIO + StoneMask on the GPU
+        waves = corpus.convert_batch(triples, fs, converter.gmm, order=converter.order,
+                                     frame_period=float(batch[0][1].frame_period))
+        for (path, a), w in zip(batch, waves):
+            out[path] = k.Synthesizer.finish(k.Wavdata(fs, w.cpu().numpy()), a.frame_len)
+    return out
+
+
+def _stages(converter):
+    stage = converter
+    while stage is not None:
+        yield stage
+        stage = getattr(stage, '__dict__', {}).get('base')
+
+
 def main():
     import kwiiyatta_amd as k
     conf = k.Config()
     conf.add_argument('--result-dir', type=str, help='Path to write result wav files')
     conf.add_argument('files', type=str, nargs='+', help='Wav files to convert voice')
     conf.add_argument('--no-diffvc', action='store_true', help='Write only the .synth.wav outputs')
+    conf.add_argument('--batch', action='store_true',
+                      help='Render the .synth.wav outputs of all files through the GPU-resident batch path')
     conf.add_converter_arguments()
     conf.parse_args()
     converter = conf.train_converter(use_delta=True)
+    batched = convert_synth_batch(conf, converter, [pathlib.Path(n) for n in conf.files]) if conf.batch else {}
     for name in conf.files:
         wav_path = pathlib.Path(name)
         stem = wav_path if conf.result_dir is None else pathlib.Path(conf.result_dir) / wav_path.name
@@ -37,7 +75,10 @@ def main():
                 continue
             out = stem.with_suffix(f'.{suffix}.wav')
             print(f'{suffix} MLPG: {out!s}')
-            convert(conf, converter, wav_path, diffvc=differential).save(out)
+            if not differential and wav_path in batched:
+                batched[wav_path].save(out)
+            else:
+                convert(conf, converter, wav_path, diffvc=differential).save(out)
 
 
 if __name__ == '__main__':

@@ -330,11 +330,17 @@ class Synthesizer(abc.ABC):
     def synthesize(cls, feature, normalize=True, **kwargs):
         wavdata = cls._synthesize(feature)
         if normalize:
-            wavdata.normalize(None)                      # DC only
-            # peak limiting in 1 ms pieces -- as many pieces as the feature has FRAMES (the reference's loop)
-            fs, limit = feature.fs, _pkg().wavfile.normalize_data
-            for piece in range(feature.frame_len):
-                limit(wavdata.data[fs * piece // 1000:fs * (piece + 1) // 1000], **kwargs)
+            cls.finish(wavdata, feature.frame_len, **kwargs)
+        return wavdata
+
+    @staticmethod
+    def finish(wavdata, frame_len, **kwargs):
+        """the post-step of `synthesize` on a raw waveform (also applied to the batch path's waveforms)"""
+        wavdata.normalize(None)                          # DC only
+        # peak limiting in 1 ms pieces -- as many pieces as the feature has FRAMES (the reference's loop)
+        fs, limit = wavdata.fs, _pkg().wavfile.normalize_data
+        for piece in range(frame_len):
+            limit(wavdata.data[fs * piece // 1000:fs * (piece + 1) // 1000], **kwargs)
         return wavdata
 
     @staticmethod

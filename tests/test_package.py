@@ -301,6 +301,40 @@ def test_cli_voice_conversion_kat(kwiiyatta, tmp_path):
     assert 0.077 < mcd < 0.11, mcd
 
 
+def test_cli_converter_model_and_batch(kwiiyatta, request, tmp_path):
+    """Additions to the reference's command line: `--converter-model` writes the trained converter and a later run
+    loads it instead of training (no --source / --target): same outputs bit for bit.  `--batch` renders the
+    .synth.wav outputs through the HBM-resident batch path: same samples as file by file."""
+    import kwiiyatta_amd.convert_voice as cv
+    from scipy.io import wavfile as sio
+    src = tmp_path / 'src'
+    src.mkdir()
+    for n in range(1, 5):
+        shutil.copy(pathlib.Path(CLB_DIR) / f'arctic_a{n:04}.wav', src)
+    model = tmp_path / 'converter.npz'
+    inputs = [str(pathlib.Path(CLB_DIR) / f'arctic_a{n:04}.wav') for n in (8, 9)]
+    np.random.seed(0)
+    _run_cli(cv.main, ['--source', str(src), '--target', SLT_DIR, '--result-dir', str(tmp_path / 'a'),
+                       '--converter-seed', '0', '--converter-components', '2', '--max-files', '4',
+                       '--converter-model', str(model)] + inputs)
+    assert model.is_file()
+    _run_cli(cv.main, ['--result-dir', str(tmp_path / 'b'), '--converter-model', str(model)] + inputs)
+    for name in ('arctic_a0008', 'arctic_a0009'):
+        for kind in ('synth', 'diff'):
+            fa, a = sio.read(tmp_path / 'a' / f'{name}.{kind}.wav')
+            fb, b = sio.read(tmp_path / 'b' / f'{name}.{kind}.wav')
+            assert fa == fb and np.array_equal(a, b), (name, kind)
+    if request.node.callspec.params['kwiiyatta'] == 'hip':
+        _run_cli(cv.main, ['--result-dir', str(tmp_path / 'c'), '--converter-model', str(model), '--batch',
+                           '--no-diffvc'] + inputs)
+        for name in ('arctic_a0008', 'arctic_a0009'):
+            _, a = sio.read(tmp_path / 'a' / f'{name}.synth.wav')
+            _, c = sio.read(tmp_path / 'c' / f'{name}.synth.wav')
+            assert a.shape == c.shape
+            assert np.abs(a.astype(np.int64) - c.astype(np.int64)).max() <= 1, name      # 16-bit samples
+        assert not (tmp_path / 'c' / 'arctic_a0009.diff.wav').exists()
+
+
 def test_converter_stack_checks(kwiiyatta):
     """test_converter.py:28-62: error messages and identity pass-through"""
     import kwiiyatta_amd.converter.abc as cabc
