@@ -309,10 +309,11 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, c
     }
   }
   if (normalise) {
-    const double sq = sqrt(kwy_block_sum<NT>(pw, red));
+    // one division, then products (each element within an ulp of the CPU's quotient)
+    const double isq = 1.0 / sqrt(kwy_block_sum<NT>(pw, red));
 #pragma unroll
     for (int r = 0; r < E; ++r)
-      if (tid + NT * r < wl) av[r] = av[r] / sq;
+      if (tid + NT * r < wl) av[r] = av[r] * isq;
   }
 }
 

@@ -524,7 +524,9 @@ __device__ inline void syn_min_phase(kwy_c *buf, const kwy_c *__restrict__ twl, 
     const kwy_c R = buf[k];
     const double tmp = exp(R.x / N);
     const double ph = R.y / N;
-    buf[k] = {tmp * cos(ph), tmp * sin(ph)};
+    double sn, cs;
+    sincos(ph, &sn, &cs);       // one argument reduction for both
+    buf[k] = {tmp * cs, tmp * sn};
   }
   __syncthreads();
 }
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
       const double coefficient = 2.0 * KWY_PI * shift * p.fs / N;
       for (int k = tid; k <= H; k += KWY_THREADS) {
         const double re = buf[k].x, im = buf[k].y;
-        const double re2 = cos(coefficient * k);
+        const double re2 = kwy_cos_pi_range(coefficient * k);   // shift * fs < 1: the argument stays in [0, pi]
         const double im2 = sqrt(1.0 - re2 * re2);
         buf[k] = {re * re2 + im * im2, im * re2 - re * im2};
       }
