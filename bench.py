@@ -354,7 +354,7 @@ def main():
         algo = {D4C: fpl * (hop * 8 + 16 + K * 8), 'k_cheaptrick': fpl * (hop * 8 + 16 + K * 8),
                 'k_d4c_lovetrain': fpl * (hop * 8 + 16 + 8), 'k_syn_pulse': fpl * (2 * K * 8 + hop * 8)}
         # The dominant kernel = the whole-chip kernel with the largest summed duration.  The single-workgroup
-        # serial kernels (k_dtw_dp, k_mlpg_solve, ...) occupy one CU each and overlap with other streams;
+        # serial kernels (k_dtw_dp, k_syn_phase, ...) occupy one CU each and overlap with other streams;
         # they bound latency, not throughput, and are listed in kernel_ms_per_launch.
         cand = [k for k in algo if k in kernel_ms]
         dom = max(cand, key=lambda k: kernel_ms[k][0]) if cand else D4C

@@ -72,36 +72,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dtw_halve_all(dtw_halve_desc d)
   }
 }
 
-// window rows.  cpath == nullptr: full window (base case).  Otherwise cpath is the
-// coarser level's path (cn = *cpath_len cells, both coordinates non-decreasing).
-__global__ void k_dtw_window(const int32_t *__restrict__ cpath, const int64_t *__restrict__ cpath_len,
-                             int radius, int len_x, int len_y, int32_t *__restrict__ lo,
-                             int32_t *__restrict__ hi, uint32_t *__restrict__ width) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= len_x) return;
-  int l = 0, h = len_y - 1;
-  if (cpath) {
-    const int cn = (int)*cpath_len;
-    if (cn <= 0) { lo[i] = 0; hi[i] = len_y - 1; width[i] = (uint32_t)len_y; return; }
-    const int a = i / 2;
-    // first cell with pi >= a - radius  -> smallest pj among cells within +-radius rows
-    int b0 = 0, b1 = cn;
-    while (b0 < b1) { int mid = (b0 + b1) >> 1; if (cpath[2 * mid] >= a - radius) b1 = mid; else b0 = mid + 1; }
-    const int first = min(b0, cn - 1);
-    // last cell with pi <= a + radius
-    b0 = 0; b1 = cn;
-    while (b0 < b1) { int mid = (b0 + b1) >> 1; if (cpath[2 * mid] > a + radius) b1 = mid; else b0 = mid + 1; }
-    const int last = max(b0 - 1, 0);
-    l = 2 * (cpath[2 * first + 1] - radius);
-    h = 2 * (cpath[2 * last + 1] + radius) + 1;
-    if (l < 0) l = 0;
-    if (h > len_y - 1) h = len_y - 1;
-  }
-  lo[i] = l;
-  hi[i] = h;
-  width[i] = (uint32_t)(h - l + 1);
-}
-
+// Window rows.  cpath == nullptr: full window (the coarsest level).  Otherwise cpath is the coarser level's path (cn
+// cells, both coordinates non-decreasing): row i takes the columns of the path cells within +-radius rows of i / 2,
+// widened by the radius and doubled.
 // The same windows for all rows, and the rows' offsets in the band storage (exclusive prefix sums of the widths), in
 // one single-workgroup launch.
 // cpath: the coarser level's path (cn cells), or null for the full window of the coarsest level.  tot: NT uint64 of LDS.

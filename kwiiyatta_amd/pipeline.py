@@ -153,11 +153,12 @@ class PairPipeline(_Graphed):
         so the pipeline and the Python API path see the same pads under `np.random.seed`.
         keep_aligned_spectrum: also gather the aligned source spectrum (`align` returns it; the conversion flow
         replaces it by the converted one and never reads it).
-        side_stream: D4C (which needs only waveform, f0 and frame times) runs on a second stream beside
-        CheapTrick -> sp2mc -> FastDTW and is joined before the aligned aperiodicity is gathered: the alignment is a
-        chain of single-workgroup kernels, so the two overlap almost completely.  A latency option (one pair alone:
-        3.5 -> 3.15 ms); with many pairs in flight the extra streams cost throughput (32 pairs: 1.49 M -> 1.30 M
-        frames/s), hence off by default."""
+        side_stream: a second stream takes the target's CheapTrick -> sp2mc -> DTW features and then D4C of both
+        utterances (which needs only waveform, f0 and frame times), while the first does the source's envelope and
+        features and starts FastDTW as soon as the target's features are there; joined before the aligned
+        aperiodicity is gathered.  The alignment is a chain of single-workgroup kernels, so D4C overlaps with it
+        almost completely.  A latency option (one pair alone: 3.5 -> 3.0 ms); with many pairs in flight the extra
+        streams cost throughput (32 pairs: 1.49 M -> 1.30 M frames/s), hence off by default."""
         self.prepare_gmm_per_run = bool(prepare_gmm_per_run)
         self.keep_aligned_spectrum = bool(keep_aligned_spectrum)
         self.dev = torch.device('cuda', device_index)
@@ -208,22 +209,43 @@ class PairPipeline(_Graphed):
     def run(self):
         """Enqueue one pass of the hot path on this pipeline's stream (asynchronous)."""
         h, fs, fft, K, order = self.ctx.handle, self.fs, self.fft, self.K, self.order
+        def envelope(ctx, s):          # CheapTrick -> mel-cepstrum -> DTW feature rows of one utterance
+            hh = ctx.handle
+            _lib.check(ctx, lib.kwy_cheaptrick_dev(hh, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, -0.15, 71.0, fft,
+                                                   float(fs), _p(s.sp)))
+            return hh
+
+        def features(ctx, s):
+            hh = ctx.handle
+            _lib.check(ctx, lib.kwy_sp2mc_dev(hh, _p(s.sp_pad), s.Tp, K, order, self.alpha, _p(s.mc_pad)))
+            _lib.check(ctx, lib.kwy_align_features_dev(hh, _p(s.mc_pad), s.Tp, order + 1, _p(s.f0_pad), POWER_WEIGHT,
+                                                       POWER_THRESHOLD, VUV_WEIGHT, _p(s.feat)))
+
+        def d4c(ctx, s):
+            _lib.check(ctx, lib.kwy_d4c_dev(ctx.handle, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft, _p(s.ap)))
+
         with torch.cuda.stream(self.stream):
             if self.side is not None:
-                self.side.wait_stream(self.stream)              # fork (inside a capture: a second branch of the graph)
-                hs = self.side_ctx.handle
+                # fork (inside a capture: a second branch of the graph).  Side stream: the target's envelope and DTW
+                # features, then both aperiodicities; main stream: the source's envelope and features, then the
+                # alignment as soon as the target's features are there.
+                self.side.wait_stream(self.stream)
+                with torch.cuda.stream(self.side):
+                    envelope(self.side_ctx, self.tgt)
+                    features(self.side_ctx, self.tgt)
+                    target_ready = torch.cuda.Event()
+                    target_ready.record(self.side)
+                    d4c(self.side_ctx, self.src)
+                    d4c(self.side_ctx, self.tgt)
+                envelope(self.ctx, self.src)
+                features(self.ctx, self.src)
+                self.stream.wait_event(target_ready)
+            else:
                 for s in (self.src, self.tgt):
-                    _lib.check(self.side_ctx, lib.kwy_d4c_dev(hs, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft,
-                                                              _p(s.ap)))
-            for s in (self.src, self.tgt):
-                self._chk(lib.kwy_cheaptrick_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, -0.15, 71.0,
-                                                 fft, float(fs), _p(s.sp)))
-                if self.side is None:
-                    self._chk(lib.kwy_d4c_dev(h, _p(s.x), s.N, fs, _p(s.t), _p(s.f0), s.T, 0.85, fft, _p(s.ap)))
-            for s in (self.src, self.tgt):
-                self._chk(lib.kwy_sp2mc_dev(h, _p(s.sp_pad), s.Tp, K, order, self.alpha, _p(s.mc_pad)))
-                self._chk(lib.kwy_align_features_dev(h, _p(s.mc_pad), s.Tp, order + 1, _p(s.f0_pad),
-                                                     POWER_WEIGHT, POWER_THRESHOLD, VUV_WEIGHT, _p(s.feat)))
+                    envelope(self.ctx, s)
+                    d4c(self.ctx, s)
+                for s in (self.src, self.tgt):
+                    features(self.ctx, s)
             self._chk(lib.kwy_fastdtw_dev(h, _p(self.src.feat), self.src.Tp, _p(self.tgt.feat), self.tgt.Tp,
                                           order + 2, self.radius, _p(self.dist), _p(self.path),
                                           _p(self.path_len)))
