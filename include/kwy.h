@@ -113,6 +113,15 @@ int kwy_synthesize(kwy_ctx *ctx, const double *f0, int64_t f0_length, const doub
 int kwy_synthesize_dev(kwy_ctx *ctx, const double *f0, int64_t f0_length, const double *sp,
                        const double *ap, int fft_size, double frame_period_ms, int fs,
                        double sp_mul, int64_t y_length, double *y);
+/* The same call in two steps, for pipelines: the pulse placement depends on f0 alone (WORLD's phase accumulation and
+ * zero-crossing search, synthesis.cpp GetTimeBase [RECALL]), so it can run on another context / stream while the
+ * spectral features are still being computed.  plan: kwy_synth_plan_bytes(y_length) bytes of device memory, written
+ * by kwy_synth_plan_dev and read by kwy_synth_render_dev (same f0-derived arguments in both calls). */
+int64_t kwy_synth_plan_bytes(int64_t y_length);
+int kwy_synth_plan_dev(kwy_ctx *ctx, const double *f0, int64_t f0_length, int fft_size, double frame_period_ms,
+                       int fs, int64_t y_length, void *plan);
+int kwy_synth_render_dev(kwy_ctx *ctx, const void *plan, int64_t f0_length, const double *sp, const double *ap,
+                         int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length, double *y);
 
 /* ---- mel-cepstrum ---------------------------------------------------------------- */
 /* pysptk.sp2mc(spec, order, alpha) row-wise          kwiiyatta/vocoder/mcep.py:71

@@ -82,6 +82,9 @@ SIGNATURES = {
                                c_vp]),
     'kwy_synthesize_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl,
                                    c_i64, c_vp]),
+    'kwy_synth_plan_bytes': (c_i64, [c_i64]),
+    'kwy_synth_plan_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_i64, c_vp]),
+    'kwy_synth_render_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_i64, c_vp]),
     'kwy_sp2mc': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_dbl, c_vp]),
     'kwy_sp2mc_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_dbl, c_vp]),
     'kwy_mc2sp': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_vp]),

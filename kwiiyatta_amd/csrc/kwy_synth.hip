@@ -808,54 +808,82 @@ static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const 
 
 static int syn_pulse_cap(int64_t y_length) { return (int)(y_length / 8 + 16); }
 
+static size_t syn_plan_bytes(int64_t y_length);
+static size_t syn_plan_scratch_bytes(int64_t y_length);
+static size_t syn_render_scratch_bytes(int64_t y_length, int fft_size, int fs) {
+  return kwy_pad(sizeof(double) * (size_t)SYN_SLOTS(y_length, fs) * fft_size) + kwy_pad(64);
+}
 static size_t syn_scratch_bytes(int64_t y_length, int fft_size, int fs) {
-  int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
-  int cap = syn_pulse_cap(y_length);
-  return kwy_pad(sizeof(int) * (nt + 1)) + 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) +
-         kwy_pad(y_length) + kwy_pad(sizeof(int32_t) * cap) + kwy_pad(sizeof(double) * cap) +
-         kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * (size_t)cap) + kwy_pad(64) +
-         kwy_pad(sizeof(double) * (size_t)SYN_SLOTS(y_length, fs) * fft_size);
+  return syn_plan_bytes(y_length) + syn_plan_scratch_bytes(y_length) + syn_render_scratch_bytes(y_length, fft_size, fs);
 }
 
-static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp, const double *ap,
-                      int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length,
-                      double *y) {
-  const int log2n = kwy_ilog2(fft_size);
-  if ((1 << log2n) != fft_size || log2n < 9 || log2n > 13) {
+// The pulse placement -- everything that depends on f0 only -- and the rendering of the pulses are separate steps, so
+// that a pipeline can place the pulses on another stream while the spectral features are still being computed
+// (kwy_synth_plan_dev / kwy_synth_render_dev); kwy_synthesize_dev runs both.
+struct syn_plan {
+  int *npulse;             // 16 ints
+  int *tile_cnt;           // nt + 1: pulses per output tile, then their offsets
+  unsigned char *vuv8;     // y_length
+  int32_t *pidx;           // cap
+  double *pshift;          // cap
+  uint32_t *ebase;         // cap x KWY_EBASE_WORDS
+};
+
+static size_t syn_plan_bytes(int64_t y_length) {
+  const int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
+  const int cap = syn_pulse_cap(y_length);
+  return kwy_pad(64) + kwy_pad(sizeof(int) * (nt + 1)) + kwy_pad(y_length) + kwy_pad(sizeof(int32_t) * cap) +
+         kwy_pad(sizeof(double) * cap) + kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * (size_t)cap);
+}
+
+static syn_plan syn_plan_carve(void *buffer, int64_t y_length) {
+  const int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
+  const int cap = syn_pulse_cap(y_length);
+  char *q = (char *)buffer;
+  syn_plan pl;
+  pl.npulse = (int *)q; q += kwy_pad(64);
+  pl.tile_cnt = (int *)q; q += kwy_pad(sizeof(int) * (nt + 1));
+  pl.vuv8 = (unsigned char *)q; q += kwy_pad(y_length);
+  pl.pidx = (int32_t *)q; q += kwy_pad(sizeof(int32_t) * cap);
+  pl.pshift = (double *)q; q += kwy_pad(sizeof(double) * cap);
+  pl.ebase = (uint32_t *)q;
+  return pl;
+}
+
+static int syn_make_params(kwy_ctx *ctx, int64_t T, int fft_size, double frame_period_ms, int fs, double sp_mul,
+                           int64_t y_length, syn_params *p, int *log2n) {
+  *log2n = kwy_ilog2(fft_size);
+  if ((1 << *log2n) != fft_size || *log2n < 9 || *log2n > 13) {
     ctx->err = "synthesize: fft_size must be a power of two in [512, 8192]";
     return KWY_EINVAL;
   }
-  KWY_HIP(hipMemsetAsync(y, 0, sizeof(double) * y_length, ctx->stream));
-  if (y_length < 2 || T < 2) return KWY_OK;
-  syn_params p;
-  p.T = T; p.y_length = y_length; p.fs = fs; p.fft_size = fft_size;
-  p.frame_period = frame_period_ms / 1000.0;
-  p.lowest_f0 = fs / fft_size + 1.0;  // integer division, as upstream
-  p.sp_mul = sp_mul;
+  p->T = T; p->y_length = y_length; p->fs = fs; p->fft_size = fft_size;
+  p->frame_period = frame_period_ms / 1000.0;
+  p->lowest_f0 = fs / fft_size + 1.0;  // integer division, as upstream
+  p->sp_mul = sp_mul;
+  return KWY_OK;
+}
+
+// scratch of the placement alone (phase scan): from the context's arena
+static size_t syn_plan_scratch_bytes(int64_t y_length) {
+  return 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) + kwy_pad(64);
+}
+
+static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const syn_plan &pl) {
+  const int64_t y_length = p.y_length;
   const int nt = (int)((y_length + SYN_TILE - 1) / SYN_TILE);
   const int cap = syn_pulse_cap(y_length);
   double *incr = kwy_arena<double>(ctx, y_length);
   const size_t npt_alloc = (size_t)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE) + 1;
   double *ph_tsum = kwy_arena<double>(ctx, npt_alloc), *ph_tin = kwy_arena<double>(ctx, npt_alloc);
   long long *ph_summ = kwy_arena<long long>(ctx, 3 * npt_alloc);
-  int *tile_cnt = kwy_arena<int>(ctx, nt + 1);
   double *wrap = kwy_arena<double>(ctx, y_length);
-  unsigned char *vuv8 = kwy_arena<unsigned char>(ctx, y_length);
-  int32_t *pidx = kwy_arena<int32_t>(ctx, cap);
-  double *pshift = kwy_arena<double>(ctx, cap);
-  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * cap);
-  int *npulse = kwy_arena<int>(ctx, 16);
-  const int slots = SYN_SLOTS(y_length, fs);
-  double *resp = kwy_arena<double>(ctx, (size_t)slots * fft_size);
-  if (!resp || !incr || !ph_tsum || !ph_tin || !ph_summ || !tile_cnt || !wrap || !vuv8 || !pidx || !pshift || !ebase || !npulse) {
+  if (!incr || !ph_tsum || !ph_tin || !ph_summ || !wrap) {
     ctx->err = "synthesize: scratch arena too small";
     return KWY_ENOMEM;
   }
-  const double *dcrem;
-  KWY_TRY(get_dc_remover(ctx, fft_size, &dcrem));
-
   hipLaunchKernelGGL(k_syn_inc, dim3((unsigned)((y_length + KWY_THREADS - 1) / KWY_THREADS)),
-                     dim3(KWY_THREADS), 0, ctx->stream, f0, p, incr, vuv8);
+                     dim3(KWY_THREADS), 0, ctx->stream, f0, p, incr, pl.vuv8);
   {
     const int npt = (int)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE);
     hipLaunchKernelGGL(k_syn_tile_sums, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum);
@@ -866,22 +894,52 @@ static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *s
     hipLaunchKernelGGL(k_syn_tile_apply, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tin,
                        wrap);
   }
-  hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, tile_cnt);
-  hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, tile_cnt, nt, npulse);
-  hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, fs,
-                     tile_cnt, cap, pidx, pshift);
-  hipLaunchKernelGGL(k_syn_ebase, dim3(512), dim3(KWY_THREADS), 0, ctx->stream, pidx, npulse, cap,
-                     ctx->d_pow2, ebase);
+  hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, pl.tile_cnt);
+  hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, pl.tile_cnt, nt, pl.npulse);
+  hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, p.fs,
+                     pl.tile_cnt, cap, pl.pidx, pl.pshift);
+  hipLaunchKernelGGL(k_syn_ebase, dim3(512), dim3(KWY_THREADS), 0, ctx->stream, pl.pidx, pl.npulse, cap,
+                     ctx->d_pow2, pl.ebase);
   KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static int synth_render(kwy_ctx *ctx, const syn_plan &pl, const double *sp, const double *ap, const syn_params &p,
+                        int log2n, double *y) {
+  const int64_t y_length = p.y_length;
+  const int nt = (int)((y_length + SYN_TILE - 1) / SYN_TILE);
+  const int cap = syn_pulse_cap(y_length);
+  const int slots = SYN_SLOTS(y_length, p.fs);
+  double *resp = kwy_arena<double>(ctx, (size_t)slots * p.fft_size);
+  if (!resp) { ctx->err = "synthesize: scratch arena too small"; return KWY_ENOMEM; }
+  const double *dcrem;
+  KWY_TRY(get_dc_remover(ctx, p.fft_size, &dcrem));
   switch (log2n) {
-    case 9: return launch_pulse<9>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
-    case 10: return launch_pulse<10>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
-    case 11: return launch_pulse<11>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
-    case 12: return launch_pulse<12>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
+    case 9: return launch_pulse<9>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 10: return launch_pulse<10>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 11: return launch_pulse<11>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 12: return launch_pulse<12>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
     // 8192: features resampled up to 96 kHz (3078 bins -> 4097, kwiiyatta/vocoder/world.py:71-78); rare, runs
     // with the 256-thread layout of the shorter transforms (register spills accepted)
-    default: return launch_pulse<13>(ctx, sp, ap, p, pidx, pshift, vuv8, npulse, cap, ebase, dcrem, tile_cnt, nt, slots, resp, y);
+    default: return launch_pulse<13>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
   }
+}
+
+static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp, const double *ap,
+                      int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length,
+                      double *y) {
+  syn_params p;
+  int log2n;
+  KWY_TRY(syn_make_params(ctx, T, fft_size, frame_period_ms, fs, sp_mul, y_length, &p, &log2n));
+  if (y_length < 2 || T < 2) {       // nothing to place: silence (otherwise the overlap-add writes every sample)
+    KWY_HIP(hipMemsetAsync(y, 0, sizeof(double) * y_length, ctx->stream));
+    return KWY_OK;
+  }
+  void *buffer = kwy_arena_alloc(ctx, syn_plan_bytes(y_length));
+  if (!buffer) { ctx->err = "synthesize: scratch arena too small"; return KWY_ENOMEM; }
+  const syn_plan pl = syn_plan_carve(buffer, y_length);
+  KWY_TRY(synth_plan(ctx, f0, p, pl));
+  return synth_render(ctx, pl, sp, ap, p, log2n, y);
 }
 
 static int syn_check(kwy_ctx *ctx, const void *f0, int64_t T, const void *sp, const void *ap,
@@ -903,6 +961,41 @@ extern "C" int kwy_synthesize_dev(kwy_ctx *ctx, const double *f0, int64_t T, con
   if (y_length == 0) return KWY_OK;
   KWY_TRY(kwy_arena_begin(ctx, syn_scratch_bytes(y_length, fft_size, fs)));
   return synth_core(ctx, f0, T, sp, ap, fft_size, frame_period_ms, fs, sp_mul, y_length, y);
+}
+
+extern "C" int64_t kwy_synth_plan_bytes(int64_t y_length) {
+  return y_length >= 0 && y_length <= 0x7fffffff ? (int64_t)syn_plan_bytes(y_length) : 0;
+}
+
+extern "C" int kwy_synth_plan_dev(kwy_ctx *ctx, const double *f0, int64_t T, int fft_size, double frame_period_ms,
+                                  int fs, int64_t y_length, void *plan) {
+  KWY_TRY(syn_check(ctx, f0, T, f0, f0, fft_size, frame_period_ms, fs, y_length, f0));
+  if (!plan) { ctx->err = "synth_plan: bad argument"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  syn_params p;
+  int log2n;
+  KWY_TRY(syn_make_params(ctx, T, fft_size, frame_period_ms, fs, 1.0, y_length, &p, &log2n));
+  if (y_length < 2 || T < 2) return KWY_OK;
+  KWY_TRY(kwy_arena_begin(ctx, syn_plan_scratch_bytes(y_length)));
+  return synth_plan(ctx, f0, p, syn_plan_carve(plan, y_length));
+}
+
+extern "C" int kwy_synth_render_dev(kwy_ctx *ctx, const void *plan, int64_t T, const double *sp, const double *ap,
+                                    int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length,
+                                    double *y) {
+  KWY_TRY(syn_check(ctx, sp, T, sp, ap, fft_size, frame_period_ms, fs, y_length, y));
+  if (!plan) { ctx->err = "synth_render: bad argument"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  if (y_length == 0) return KWY_OK;
+  syn_params p;
+  int log2n;
+  KWY_TRY(syn_make_params(ctx, T, fft_size, frame_period_ms, fs, sp_mul, y_length, &p, &log2n));
+  if (y_length < 2 || T < 2) {
+    KWY_HIP(hipMemsetAsync(y, 0, sizeof(double) * y_length, ctx->stream));
+    return KWY_OK;
+  }
+  KWY_TRY(kwy_arena_begin(ctx, syn_render_scratch_bytes(y_length, fft_size, fs)));
+  return synth_render(ctx, syn_plan_carve(const_cast<void *>(plan), y_length), sp, ap, p, log2n, y);
 }
 
 extern "C" int kwy_synthesize(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp,

@@ -157,7 +157,8 @@ class PairPipeline(_Graphed):
         utterances (which needs only waveform, f0 and frame times), while the first does the source's envelope and
         features and starts FastDTW as soon as the target's features are there; joined before the aligned
         aperiodicity is gathered.  The alignment is a chain of single-workgroup kernels, so D4C overlaps with it
-        almost completely.  A latency option (one pair alone: 3.5 -> 3.0 ms); with many pairs in flight the extra
+        almost completely; the synthesis' pulse placement (f0 only) runs there too.  A latency option (one pair alone:
+        3.3 -> 2.4 ms); with many pairs in flight the extra
         streams cost throughput (32 pairs: 1.49 M -> 1.30 M frames/s), hence off by default."""
         self.prepare_gmm_per_run = bool(prepare_gmm_per_run)
         self.keep_aligned_spectrum = bool(keep_aligned_spectrum)
@@ -194,6 +195,9 @@ class PairPipeline(_Graphed):
             self.sp_conv = torch.empty((Tt, self.K), **f64)
             self.ylen = lib.kwy_synth_length(Tt, self.frame_period, self.fs)
             self.wave = torch.empty(self.ylen, **f64)
+            # pulse placement of the synthesis (f0 only): computed on the side stream, ahead of the features
+            self.plan = torch.empty(lib.kwy_synth_plan_bytes(self.ylen), dtype=torch.uint8, device=self.dev) \
+                if self.side is not None else None
             # kwiiyatta.pad_silence: |N(0, EPS/fs)| spectra on the padding frames, host-drawn, uploaded once
             if silence is None:
                 silence = [draw_silence(self.fs, self.K) for _ in range(4)]
@@ -237,6 +241,9 @@ class PairPipeline(_Graphed):
                     target_ready.record(self.side)
                     d4c(self.side_ctx, self.src)
                     d4c(self.side_ctx, self.tgt)
+                    _lib.check(self.side_ctx, lib.kwy_synth_plan_dev(self.side_ctx.handle, _p(self.tgt.f0), self.tgt.T,
+                                                                     fft, self.frame_period, fs, self.ylen,
+                                                                     _p(self.plan)))
                 envelope(self.ctx, self.src)
                 features(self.ctx, self.src)
                 self.stream.wait_event(target_ready)
@@ -269,8 +276,12 @@ class PairPipeline(_Graphed):
                 self._chk(lib.kwy_convert_mcep_dev(h, _p(self.mc_al), Tt, order, g.M, _p(self.gmm_model),
                                                    _p(self.mc_conv)))
             self._chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), Tt, order, self.alpha, fft, _p(self.sp_conv)))
-            self._chk(lib.kwy_synthesize_dev(h, _p(self.tgt.f0), Tt, _p(self.sp_conv), _p(self.ap_al), fft,
-                                             self.frame_period, fs, float(fs), self.ylen, _p(self.wave)))
+            if self.side is not None:
+                self._chk(lib.kwy_synth_render_dev(h, _p(self.plan), Tt, _p(self.sp_conv), _p(self.ap_al), fft,
+                                                   self.frame_period, fs, float(fs), self.ylen, _p(self.wave)))
+            else:
+                self._chk(lib.kwy_synthesize_dev(h, _p(self.tgt.f0), Tt, _p(self.sp_conv), _p(self.ap_al), fft,
+                                                 self.frame_period, fs, float(fs), self.ylen, _p(self.wave)))
 
     def sync(self):
         self.ctx.sync()
