@@ -467,21 +467,30 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_ebase(const int32_t *__rest
                                                           const int *__restrict__ npulse, int cap,
                                                           const uint4 *__restrict__ pow2,
                                                           uint32_t *__restrict__ ebase) {
-  __shared__ uint32_t sh[KWY_WAVES][KWY_EBASE_WORDS];
+  // as k_rng_ebase (kwy_ctx.hip): the wavefronts jump SYN_EBASE_ITEMS pulses' states, 16 lanes emit them side by side
+  constexpr int ITEMS = 16, PER_WAVE = ITEMS / KWY_WAVES;
+  __shared__ uint32_t st[ITEMS][4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int P = min(npulse[0], cap);
-  for (int p = blockIdx.x * KWY_WAVES + wv; p < P; p += gridDim.x * KWY_WAVES) {
-    uint64_t steps = 12ull * (uint64_t)(pidx[p] - pidx[0]);
-    uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
-    kwy_wave_jump(s, steps, pow2);
-    if (lane == 0) {
-      kwy_rng r = {s[0], s[1], s[2], s[3]};
-      kwy_rng_ebase(r, sh[wv]);
+  const int first = pidx[0];
+  for (int p0 = blockIdx.x * ITEMS; p0 < P; p0 += gridDim.x * ITEMS) {
+    for (int f = 0; f < PER_WAVE; ++f) {
+      const int slot = wv * PER_WAVE + f;
+      if (p0 + slot < P) {
+        uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+        kwy_wave_jump(s, 12ull * (uint64_t)(pidx[p0 + slot] - first), pow2);
+        if (lane == 0) { st[slot][0] = s[0]; st[slot][1] = s[1]; st[slot][2] = s[2]; st[slot][3] = s[3]; }
+      }
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (int i = lane; i < KWY_EBASE_WORDS; i += 64) ebase[(int64_t)p * KWY_EBASE_WORDS + i] = sh[wv][i];
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if (threadIdx.x < ITEMS && p0 + (int)threadIdx.x < P) {
+      kwy_rng r = {st[threadIdx.x][0], st[threadIdx.x][1], st[threadIdx.x][2], st[threadIdx.x][3]};
+      uint32_t *e = ebase + (int64_t)(p0 + threadIdx.x) * KWY_EBASE_WORDS;
+      e[0] = r.x; e[1] = r.y; e[2] = r.z; e[3] = r.w;
+      for (int i = 4; i < 131; ++i) e[i] = kwy_rng_step(r);
+      e[131] = 0;
+    }
+    __syncthreads();
   }
 }
 
@@ -898,7 +907,7 @@ static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const
   hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, pl.tile_cnt, nt, pl.npulse);
   hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, p.fs,
                      pl.tile_cnt, cap, pl.pidx, pl.pshift);
-  hipLaunchKernelGGL(k_syn_ebase, dim3(512), dim3(KWY_THREADS), 0, ctx->stream, pl.pidx, pl.npulse, cap,
+  hipLaunchKernelGGL(k_syn_ebase, dim3(256), dim3(KWY_THREADS), 0, ctx->stream, pl.pidx, pl.npulse, cap,
                      ctx->d_pow2, pl.ebase);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
