@@ -108,6 +108,38 @@ def test_synthesis_leading_silence(ko, kw):
     assert t_sil < t_voiced + 0.1, (t_sil, t_voiced)
 
 
+def test_synthesis_plan_render_split(ko, kw):
+    """kwy_synth_plan_dev + kwy_synth_render_dev (pulse placement from f0 alone, then the rendering) give the
+    waveform of kwy_synthesize_dev bit for bit, also when the plan is made on another context / stream."""
+    import torch
+    from kwiiyatta_amd import _lib
+    lib = _lib.lib
+    fs, x = load(clb_variant('48'))
+    f0, t = f0_track(ko, x, fs)
+    sp, ap = kw.cheaptrick(x, f0, t, fs), kw.d4c(x, f0, t, fs)
+    dev = torch.device('cuda', 0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)    # noqa: E731
+    df0, dsp, dap = d(f0), d(sp), d(ap)
+    T, fft = len(f0), (sp.shape[1] - 1) * 2
+    ylen = lib.kwy_synth_length(T, 5.0, fs)
+    p = lambda a: _lib.c_vp(a.data_ptr())                              # noqa: E731
+    main = _lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    side_stream = torch.cuda.Stream(device=dev)
+    side = _lib.Context(0, stream=side_stream.cuda_stream)
+    whole = torch.empty(ylen, dtype=torch.float64, device=dev)
+    _lib.check(main, lib.kwy_synthesize_dev(main.handle, p(df0), T, p(dsp), p(dap), fft, 5.0, fs, 1.0, ylen, p(whole)))
+    plan = torch.empty(lib.kwy_synth_plan_bytes(ylen), dtype=torch.uint8, device=dev)
+    split = torch.empty(ylen, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    _lib.check(side, lib.kwy_synth_plan_dev(side.handle, p(df0), T, fft, 5.0, fs, ylen, p(plan)))
+    side_stream.synchronize()
+    _lib.check(main, lib.kwy_synth_render_dev(main.handle, p(plan), T, p(dsp), p(dap), fft, 5.0, fs, 1.0, ylen,
+                                              p(split)))
+    torch.cuda.synchronize()
+    assert torch.equal(whole, split)
+    assert np.array_equal(whole.cpu().numpy(), kw.synthesize(f0, sp, ap, fs, 5.0))
+
+
 def test_synthesis_is_deterministic(ko, kw):
     """Two runs give the same bits (ordered overlap-add, no floating-point atomics): what the reference asserts
     with `(analyzer_wav.data == feature_wav.data).all()`, tests/kwiiyatta/test_vocoder.py:171."""
