@@ -541,7 +541,7 @@ static size_t dtw_scratch_bytes(int64_t Tx, int64_t Ty, int dim, int radius, boo
   }
   uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
   tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD)) + kwy_pad(4 * (cap / 16 + 2 * Tx + 64));
-  tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1));
+  tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1));
   tot += kwy_pad(sizeof(double) * 4 * (Ty + 2));
   tot += 2 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + Tx / 64 + 8)) +
          kwy_pad(sizeof(int32_t) * 3 * (Tx / 64 + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
@@ -588,7 +588,6 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   double *dist = kwy_arena<double>(ctx, cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD);   // + the +inf cells of every row
   uint32_t *pred = kwy_arena<uint32_t>(ctx, cap / 16 + 2 * Tx + 64);
   int32_t *lo = kwy_arena<int32_t>(ctx, Tx), *hi = kwy_arena<int32_t>(ctx, Tx);
-  uint32_t *width = kwy_arena<uint32_t>(ctx, Tx);
   uint64_t *off = kwy_arena<uint64_t>(ctx, Tx + 1);
   double *bnd = kwy_arena<double>(ctx, DTW_WAVES * (Ty + 2));
   int32_t *pathA = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
@@ -597,7 +596,7 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   int32_t *sinfo = kwy_arena<int32_t>(ctx, 3 * (Tx / 64 + 2));
   int64_t *lenA = kwy_arena<int64_t>(ctx, 8), *lenB = kwy_arena<int64_t>(ctx, 8);
   int *status = kwy_arena<int>(ctx, 16);
-  if (!dist || !pred || !lo || !hi || !width || !off || !bnd || !pathA || !pathB || !rev || !sinfo || !lenA || !lenB || !status) {
+  if (!dist || !pred || !lo || !hi || !off || !bnd || !pathA || !pathB || !rev || !sinfo || !lenA || !lenB || !status) {
     ctx->err = "fastdtw: scratch arena too small";
     return KWY_ENOMEM;
   }
