@@ -216,6 +216,28 @@ __device__ __forceinline__ double kwy_wave_sum(double v) {
   return (kwy_readlane_f64(v, 0) + kwy_readlane_f64(v, 16)) + (kwy_readlane_f64(v, 32) + kwy_readlane_f64(v, 48));
 }
 
+// minimum / maximum over the wavefront (every lane gets the result); lanes without a DPP source keep their own value
+template <int CTRL>
+__device__ __forceinline__ double kwy_dpp_keep_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double kwy_wave_min_f64(double v) {
+  v = fmin(v, kwy_dpp_keep_f64<0x101>(v));
+  v = fmin(v, kwy_dpp_keep_f64<0x102>(v));
+  v = fmin(v, kwy_dpp_keep_f64<0x104>(v));
+  v = fmin(v, kwy_dpp_keep_f64<0x108>(v));  // lane 0 of every row now holds its row's minimum
+  return fmin(fmin(kwy_readlane_f64(v, 0), kwy_readlane_f64(v, 16)), fmin(kwy_readlane_f64(v, 32), kwy_readlane_f64(v, 48)));
+}
+__device__ __forceinline__ double kwy_wave_max_f64(double v) {
+  v = fmax(v, kwy_dpp_keep_f64<0x101>(v));
+  v = fmax(v, kwy_dpp_keep_f64<0x102>(v));
+  v = fmax(v, kwy_dpp_keep_f64<0x104>(v));
+  v = fmax(v, kwy_dpp_keep_f64<0x108>(v));
+  return fmax(fmax(kwy_readlane_f64(v, 0), kwy_readlane_f64(v, 16)), fmax(kwy_readlane_f64(v, 32), kwy_readlane_f64(v, 48)));
+}
+
 // inclusive prefix sums over the wavefront
 __device__ __forceinline__ uint32_t kwy_wave_scan_u32(uint32_t v) {
   v += kwy_dpp_u32<0x111>(v);
@@ -344,28 +366,51 @@ __device__ __forceinline__ void kwy_block_sum2(double a, double b, double *red, 
 #endif
 #define KWY_SELECT_BINS (1 << KWY_SELECT_BITS)
 #define KWY_SELECT_WORDS(NT) (2 * KWY_SELECT_BINS + 16)
+// The digits are taken from key - min(key), starting at the highest bit in which the block's keys differ: a power
+// spectrum spans a few dozen binades, so the sign and the leading exponent bits are the same in every key and a round
+// spent on them would select nothing (one round saved of typically three).  key[] is rewritten (relative keys).
 template <int RMAX, int NT = KWY_THREADS>
-__device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RMAX], int n, int m,
+__device__ inline void kwy_block_smallest_sum(unsigned long long (&key)[RMAX], int n, int m,
                                               uint32_t *hist, double *red, double *sum_small,
                                               double *sum_all) {
   constexpr int BITS = KWY_SELECT_BITS, BINS = 1 << BITS;
-  constexpr int ROUNDS = (63 + BITS - 1) / BITS;          // bit 63 (the sign) is never set
   constexpr int PERLANE = BINS / 64;                      // bins scanned per lane of wavefront 0
   static_assert(PERLANE % 4 == 0 && PERLANE >= 4, "bins per lane must be a multiple of 4");
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   uint32_t *ctlb = hist + 2 * BINS;  // 2 x {digit, new rank, population}, then one 64-bit key
+  // ---- the block's smallest and largest key (non-negative doubles order like their bit patterns)
+  double lo = INFINITY, hi = 0.0;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    if (tid + NT * r < n) {
+      const double x = __longlong_as_double((long long)key[r]);
+      lo = fmin(lo, x); hi = fmax(hi, x);
+    }
+  }
+  lo = kwy_wave_min_f64(lo);
+  hi = kwy_wave_max_f64(hi);
+  if (lane == 0) { red[wv] = lo; red[NT / 64 + wv] = hi; }
   for (int i = tid; i < BINS; i += NT) hist[i] = 0;
   __syncthreads();
+  lo = red[0]; hi = red[NT / 64];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) { lo = fmin(lo, red[i]); hi = fmax(hi, red[NT / 64 + i]); }
+  const unsigned long long kmin = (unsigned long long)__double_as_longlong(lo);
+  const unsigned long long range = (unsigned long long)__double_as_longlong(hi) - kmin;
+  const int top0 = range ? 64 - __clzll((long long)range) : 0;       // one past the highest differing bit
+  const int rounds = (top0 + BITS - 1) / BITS;                      // 0: all keys equal
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) key[r] -= kmin;                    // (slots beyond n are never looked at)
   unsigned long long prefix = 0ull;
   int kk = m;  // 1-based rank of the wanted element among the still-matching keys
   bool alive[RMAX];  // key still carries the prefix found so far
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) alive[r] = tid + NT * r < n;
-  for (int round = 0; round < ROUNDS; ++round) {
-    // digits are taken from bit 62 downwards; the last one may be narrower
-    const int top = 63 - BITS * round;                    // one past the digit's highest bit
+  for (int round = 0; round < rounds; ++round) {
+    // digits are taken from bit top0 - 1 downwards; the last one may be narrower
+    const int top = top0 - BITS * round;                  // one past the digit's highest bit
     const int shift = top - BITS > 0 ? top - BITS : 0;
-    const unsigned long long mask = (top - shift >= 64) ? ~0ull : ((1ull << (top - shift)) - 1ull);
+    const unsigned long long mask = (1ull << (top - shift)) - 1ull;
     uint32_t *h = hist + (round & 1) * BINS, *hn = hist + ((round + 1) & 1) * BINS;
     uint32_t *ctl = ctlb + (round & 1) * 4;
     for (int i = tid; i < BINS; i += NT) hn[i] = 0;
@@ -418,7 +463,7 @@ __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RM
     kk = (int)ctl[1];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) alive[r] = alive[r] && (int)((key[r] >> shift) & mask) == chosen;
-    if (ctl[2] == 1u && round < ROUNDS - 1) {
+    if (ctl[2] == 1u && round < rounds - 1) {
       // exactly one key carries this prefix: it IS the wanted element, skip the remaining rounds
       unsigned long long *k64 = (unsigned long long *)(ctlb + 8);
 #pragma unroll
@@ -430,13 +475,14 @@ __device__ inline void kwy_block_smallest_sum(const unsigned long long (&key)[RM
       break;
     }
   }
-  const double vstar = __longlong_as_double((long long)prefix);
+  // (all keys equal: no round ran, prefix = 0 = every relative key, kk = m of them)
+  const double vstar = __longlong_as_double((long long)(prefix + kmin));
   double s_less = 0.0, s_all = 0.0;
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
     int i = tid + NT * r;
     if (i < n) {
-      double x = __longlong_as_double((long long)key[r]);
+      double x = __longlong_as_double((long long)(key[r] + kmin));
       s_all += x;
       if (key[r] < prefix) s_less += x;
     }
