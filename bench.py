@@ -129,8 +129,8 @@ def main():
         return cpu_worker(sys.argv[2])
     ap_ = argparse.ArgumentParser()
     ap_.add_argument('--gpus', type=int, default=1)
-    ap_.add_argument('--steps', type=int, default=10)
-    ap_.add_argument('--warmup', type=int, default=2)
+    ap_.add_argument('--steps', type=int, default=20)
+    ap_.add_argument('--warmup', type=int, default=5)
     ap_.add_argument('--batch', type=int, default=32, help='utterance pairs per GPU per step (one stream each)')
     ap_.add_argument('--seconds', type=float, default=10.0, help='source utterance length')
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
