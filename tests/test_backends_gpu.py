@@ -109,6 +109,40 @@ def test_fastdtw_bit_exact(ko, Tx, Ty, dim, radius):
     assert ((dp >= 0) & (dp <= 1)).all() and (dp.sum(axis=1) >= 1).all()
 
 
+def test_fastdtw_fuzz(ko):
+    """Random shapes, radii and kinds of series (smooth, quantised with many exact ties, piecewise constant with long
+    plateaux, steep local slopes): path and distance bit-exact.  The kernels take different routes with the size
+    (number of levels, strips per level, windows computed by the previous level's DP kernel, back-trace tables and
+    predecessor words staged in LDS or read from memory)."""
+    from kwiiyatta_amd.backend import dtw
+    rng = np.random.default_rng(20261004)
+    kinds = ('smooth', 'ties', 'plateaux', 'steep')
+    for case in range(40):
+        Tx, Ty = (int(v) for v in rng.integers(1, 700, 2))
+        if case % 8 == 0:
+            Tx, Ty = int(rng.integers(900, 1500)), int(rng.integers(900, 1500))
+        dim = int(rng.integers(1, 4))
+        radius = int(rng.choice([1, 2, 5, 32]))
+        kind = kinds[case % len(kinds)]
+        if kind == 'smooth':
+            x, y = _series(rng, Tx, dim, 1.0), _series(rng, Ty, dim, 1.3)
+        elif kind == 'ties':
+            x = np.round(_series(rng, Tx, dim, 1.0) * 2.0) / 2.0
+            y = np.round(_series(rng, Ty, dim, 1.3) * 2.0) / 2.0
+        elif kind == 'plateaux':
+            x = np.repeat(rng.integers(0, 4, (Tx // 17 + 1, dim)).astype(np.float64), 17, axis=0)[:Tx]
+            y = np.repeat(rng.integers(0, 4, (Ty // 29 + 1, dim)).astype(np.float64), 29, axis=0)[:Ty]
+        else:       # the same curve traversed at very different local speeds
+            base = _series(rng, 2000, dim, 1.0)
+            ix = np.sort(rng.integers(0, 2000, Tx))
+            iy = np.sort((2000 * rng.random(Ty) ** 3).astype(int).clip(0, 1999))
+            x, y = np.ascontiguousarray(base[ix]), np.ascontiguousarray(base[iy])
+        ref = ko.fastdtw(x, y, radius=radius, dist=2)
+        got = dtw.fastdtw(x, y, radius=radius, dist=2)
+        assert got[1] == ref[1], (case, kind, Tx, Ty, dim, radius)
+        assert got[0] == ref[0], (case, kind, Tx, Ty, dim, radius)
+
+
 def test_fastdtw_ties_and_1d(ko):
     """Exact ties (integer-valued, repeated frames) exercise the predecessor order."""
     from kwiiyatta_amd.backend import dtw
