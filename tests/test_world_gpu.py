@@ -140,6 +140,36 @@ def test_synthesis_plan_render_split(ko, kw):
     assert np.array_equal(whole.cpu().numpy(), kw.synthesize(f0, sp, ap, fs, 5.0))
 
 
+def test_synthesis_voicing_patterns(ko, kw):
+    """Random voiced / unvoiced schedules -- silence at the start, in the middle, at the end, single voiced frames,
+    f0 jumps -- at two rates: the exact-rounding phase scan takes different routes through its tiles (fast tiles,
+    binade changes, runs of zero increments), the waveform must not notice."""
+    rng = np.random.default_rng(77)
+    for case, fs in enumerate((16000, 16000, 48000, 16000, 48000, 16000)):
+        T = int(rng.integers(40, 400))
+        K = kw.get_cheaptrick_fft_size(fs) // 2 + 1
+        f0 = np.zeros(T)
+        t = 0
+        while t < T:
+            run = int(rng.integers(1, 60))
+            if rng.random() < 0.55:
+                f0[t:t + run] = rng.uniform(60, 600) * np.exp(0.2 * np.sin(np.arange(min(run, T - t)) / 7.0))
+            t += run
+        if case == 0:
+            f0[:] = 0.0                                  # nothing voiced at all
+        if case == 1:
+            f0[:30] = 0.0; f0[-25:] = 0.0                 # silence at both ends
+        k = np.arange(K)
+        sp = np.exp(-k[None, :] / (K / 6.0)) * (1.0 + 0.3 * rng.random((T, 1))) * 1e-3 + 1e-9
+        ap = np.clip(0.1 + 0.8 * k[None, :] / K + 0.05 * rng.standard_normal((T, K)), 0.001, 0.999)
+        sp, ap = np.ascontiguousarray(sp), np.ascontiguousarray(ap)
+        got, ref = kw.synthesize(f0, sp, ap, fs, 5.0), ko.synthesize(f0, sp, ap, fs, 5.0)
+        assert got.shape == ref.shape
+        scale = max(np.sqrt(np.mean(ref ** 2)), 1e-12)
+        assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-9 * max(scale, 1.0) + 1e-12 * scale, (case, fs, T)
+        assert np.array_equal(got, kw.synthesize(f0, sp, ap, fs, 5.0))
+
+
 def test_synthesis_is_deterministic(ko, kw):
     """Two runs give the same bits (ordered overlap-add, no floating-point atomics): what the reference asserts
     with `(analyzer_wav.data == feature_wav.data).all()`, tests/kwiiyatta/test_vocoder.py:171."""
