@@ -499,13 +499,31 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
   }
   __syncthreads();
   if (dbg && threadIdx.x == 0) dbg[23] = clock64() - t_dp;
-  for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
-    const int c = cnt[k];
-    const int32_t *in = rev + 2 * (int64_t)sbase[k];
-    int32_t *out = path + 2 * (int64_t)exitc[k];
-    for (int m = 0; m < c; ++m) {
-      out[2 * (c - 1 - m)] = in[2 * m];
-      out[2 * (c - 1 - m) + 1] = in[2 * m + 1];
+  // every strip's segment, reversed, to its place: one thread per path cell (the strip of an output position by
+  // binary search over the segment offsets, staged in LDS) -- one lane per strip used to copy its ~130 cells one
+  // dependent load at a time
+  {
+    constexpr int MAXS = 256;
+    __shared__ int s_meta[3][MAXS];
+    if (nstrips <= MAXS) {
+      for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
+        s_meta[0][k] = cnt[k]; s_meta[1][k] = sbase[k]; s_meta[2][k] = exitc[k];
+      }
+      __syncthreads();
+      const int n = s_n;
+      for (int pos = threadIdx.x; pos < n; pos += 64 * DTW_WAVES) {
+        int a = 0, b = nstrips - 1;                  // last strip whose offset is <= pos
+        while (a < b) { const int mid = (a + b + 1) >> 1; if (s_meta[2][mid] <= pos) a = mid; else b = mid - 1; }
+        const int c = s_meta[0][a], q = pos - s_meta[2][a];
+        ((int2 *)path)[pos] = ((const int2 *)rev)[(int64_t)s_meta[1][a] + (c - 1 - q)];
+      }
+    } else {
+      for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
+        const int c = cnt[k];
+        const int2 *in = (const int2 *)rev + (int64_t)sbase[k];
+        int2 *out = (int2 *)path + (int64_t)exitc[k];
+        for (int m = 0; m < c; ++m) out[c - 1 - m] = in[m];
+      }
     }
   }
   if (dbg && threadIdx.x == 0) {
