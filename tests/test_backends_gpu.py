@@ -143,6 +143,16 @@ def test_fastdtw_fuzz(ko):
         assert got[0] == ref[0], (case, kind, Tx, Ty, dim, radius)
 
 
+@pytest.mark.parametrize('Tx,Ty,radius', [(5300, 5100, 1), (4900, 5600, 32)])
+def test_fastdtw_long_series(ko, Tx, Ty, radius):
+    """More than 4 798 target frames: the strips' boundary rows no longer fit the LDS and travel through global
+    memory (the kernel's other instantiation); 25 s and 28 s at a 5 ms hop."""
+    from kwiiyatta_amd.backend import dtw
+    rng = np.random.default_rng(Tx + Ty)
+    x, y = _series(rng, Tx, 3, 1.0), _series(rng, Ty, 3, 1.2)
+    assert dtw.fastdtw(x, y, radius=radius, dist=2) == ko.fastdtw(x, y, radius=radius, dist=2)
+
+
 def test_fastdtw_ties_and_1d(ko):
     """Exact ties (integer-valued, repeated frames) exercise the predecessor order."""
     from kwiiyatta_amd.backend import dtw
