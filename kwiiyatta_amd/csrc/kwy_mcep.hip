@@ -6,12 +6,21 @@
 //   sp2mc: c = irfft(log P); c[0] /= 2; mc = freqt(c, order, alpha)
 //   mc2sp: c = freqt(mc, fftlen/2, -alpha); c[0] *= 2; mirror; exp(real(rfft(c)))
 //
-// SPTK's freqt is a linear recursion, so it is applied as a small dense matrix
-// (built once per (alpha, sizes) on the host with the same recursion and cached
-// in HBM): one workgroup per frame does the FFT in LDS and the matrix product
-// from L2-resident coefficients.  Both kernels stream each frame once:
-// sp2mc reads K*8 B and writes (order+1)*8 B per frame; mc2sp the reverse.
+// SPTK's freqt is a linear recursion, so it is applied as a small dense matrix (built once per (alpha, sizes) on the
+// host with the same recursion and cached in HBM).
+//   sp2mc, power-of-two transforms: one workgroup per MC_FR frames does the inverse FFT of the log-spectrum in LDS
+//          and the matrix product from L2-resident coefficients; other lengths: the whole map as one dense K x 25
+//          matrix (k_sp2mc_dense).
+//   mc2sp, every length: the whole map as a dense 25 x K matrix applied on the matrix cores (k_mc2sp_mfma,
+//          v_mfma_f64_16x16x4_f64), exp on the accumulators.  It replaced the LDS-FFT form in round 2 (15 us against
+//          35 us for 2201 frames at K = 1025); the same formulation of sp2mc was measured slower than its FFT form
+//          (73 us against 37 us: 16-frame tiles give too few workgroups, and the log-spectra have to pass through LDS).
+// Both stream each frame once: sp2mc reads K*8 B and writes (order+1)*8 B per frame; mc2sp the reverse.
 #include <math.h>
+
+#include <map>
+#include <mutex>
+#include <string>
 
 #include <vector>
 
@@ -103,72 +112,6 @@ __global__ __launch_bounds__(KWY_THREADS) void k_sp2mc(const double *__restrict_
   }
 }
 
-// ---- mc2sp -----------------------------------------------------------------------
-#define MC2_FR 2
-// F2T: [order+1][H+1]: cepstrum index n <- mel-cepstral coefficient m.  MC2_FR frames per workgroup share
-// one walk over F2T (the cepstra stay in registers, bins tid + 256 r), then take turns in the FFT buffer.
-template <int LOG2N>
-__global__ __launch_bounds__(KWY_THREADS) void k_mc2sp(const double *__restrict__ mc, int64_t T, int order,
-                                                      const double *__restrict__ F2T,
-                                                      const kwy_c *__restrict__ twH,
-                                                      const kwy_c *__restrict__ twN,
-                                                      double *__restrict__ sp) {
-  constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
-  constexpr int TWL = (H / 8 > 1) ? H / 8 : 1;
-  constexpr int RK = (K + KWY_THREADS - 1) / KWY_THREADS;
-  extern __shared__ double smem[];
-  kwy_c *buf = (kwy_c *)smem;                 // H+1 complex
-  kwy_c *twl = buf + (H + 1);
-  double *m = (double *)(twl + TWL);          // MC2_FR x (order+1)
-  const int tid = threadIdx.x;
-  const int64_t f0 = (int64_t)blockIdx.x * MC2_FR;
-  for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
-  const kwy_c twb = twN[tid & (N - 1)];
-  for (int e = tid; e < MC2_FR * (order + 1); e += KWY_THREADS) {
-    const int fr = e / (order + 1), i = e - fr * (order + 1);
-    m[e] = (f0 + fr < T) ? mc[(f0 + fr) * (order + 1) + i] : 0.0;
-  }
-  __syncthreads();
-  double acc[MC2_FR][RK];
-#pragma unroll
-  for (int fr = 0; fr < MC2_FR; ++fr)
-#pragma unroll
-    for (int r = 0; r < RK; ++r) acc[fr][r] = 0.0;
-#pragma unroll 4
-  for (int i = 0; i <= order; ++i) {
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int n = tid + KWY_THREADS * r;
-      if (n <= H) {
-        const double f = F2T[(size_t)i * K + n];
-#pragma unroll
-        for (int fr = 0; fr < MC2_FR; ++fr) acc[fr][r] += f * m[fr * (order + 1) + i];
-      }
-    }
-  }
-  double *sym = (double *)buf;
-#pragma unroll
-  for (int fr = 0; fr < MC2_FR; ++fr) {
-    const int64_t frame = f0 + fr;
-    if (frame >= T) break;   // uniform
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int n = tid + KWY_THREADS * r;
-      if (n <= H) {
-        double v = acc[fr][r];
-        if (n == 0) v *= 2.0;
-        sym[n] = v;
-        if (n >= 1 && n < H) sym[N - n] = v;
-      }
-    }
-    __syncthreads();
-    kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
-    double *o = sp + frame * K;
-    for (int k = tid; k <= H; k += KWY_THREADS) o[k] = exp(buf[k].x);
-  }
-}
-
 // ---- any transform length: the dense form ---------------------------------------------------
 // The reference resamples features between sampling rates by cutting or padding the spectral axis
 // (kwiiyatta/vocoder/abc/synthesizer.py:77-113, vocoder/mcep.py:31-58), so pysptk.sp2mc / mc2sp also see
@@ -215,31 +158,43 @@ __global__ __launch_bounds__(KWY_THREADS) void k_sp2mc_dense(const double *__res
   }
 }
 
-// G2: [order+1][K].  One workgroup per MCD_FR frames, thread = bins tid, tid + 256, ...
-__global__ __launch_bounds__(KWY_THREADS) void k_mc2sp_dense(const double *__restrict__ mc, int64_t T, int order,
-                                                            int K, const double *__restrict__ G2,
-                                                            double *__restrict__ sp) {
-  extern __shared__ double smem[];
-  double *m = smem;                        // MCD_FR x (order+1)
-  const int tid = threadIdx.x;
-  const int64_t f0 = (int64_t)blockIdx.x * MCD_FR;
-  for (int e = tid; e < MCD_FR * (order + 1); e += KWY_THREADS) {
-    const int fr = e / (order + 1), i = e - fr * (order + 1);
-    m[e] = (f0 + fr < T) ? mc[(f0 + fr) * (order + 1) + i] : 0.0;
+typedef double mc_v4f64 __attribute__((ext_vector_type(4)));
+// mc2sp: G2 is [order+1][K].
+// The dense map as one f64 MFMA product per 16 frames x 16 bins (v_mfma_f64_16x16x4_f64: A = the frames'
+// coefficients, B = G2, order + 1 padded to a multiple of 4 in the k direction), exp applied to the accumulators.
+// Used for every length, power of two or not: at K = 1025 the product is 113 MFLOP and G2 (205 KB) stays in L2;
+// 15 us for 2201 frames against 35 us of the LDS-FFT form it replaced in round 2.  Lane map: A[row l&15][k l>>4], B[k l>>4][col l&15], D[row (l>>4)+4r][col l&15].
+#define MC2_KSTEPS ((MC_MAX_ORDER + 4) / 4)
+__global__ __launch_bounds__(KWY_THREADS) void k_mc2sp_mfma(const double *__restrict__ mc, int64_t T, int order,
+                                                           int K, const double *__restrict__ G2,
+                                                           double *__restrict__ sp) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ar = lane & 15, ak = lane >> 4;
+  const int64_t t0 = (int64_t)blockIdx.x * 16;
+  const int ksteps = (order + 4) / 4;
+  double a[MC2_KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < MC2_KSTEPS; ++ks) {
+    const int j = 4 * ks + ak;
+    a[ks] = (ks < ksteps && j <= order && t0 + ar < T) ? mc[(t0 + ar) * (order + 1) + j] : 0.0;
   }
-  __syncthreads();
-  for (int k = tid; k < K; k += KWY_THREADS) {
-    double acc[MCD_FR];
+  const int ntile = (K + 15) / 16;
+  for (int bt = blockIdx.y * KWY_WAVES + wv; bt < ntile; bt += gridDim.y * KWY_WAVES) {
+    const int b0 = bt * 16;
+    mc_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] = 0.0;
-    for (int i = 0; i <= order; ++i) {
-      const double g = G2[(size_t)i * K + k];
-#pragma unroll
-      for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] += g * m[fr * (order + 1) + i];
+    for (int ks = 0; ks < MC2_KSTEPS; ++ks) {
+      if (ks < ksteps) {
+        const int j = 4 * ks + ak;
+        const double b = (j <= order && b0 + ar < K) ? G2[(size_t)j * K + b0 + ar] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b, acc, 0, 0, 0);
+      }
     }
 #pragma unroll
-    for (int fr = 0; fr < MCD_FR; ++fr)
-      if (f0 + fr < T) sp[(f0 + fr) * K + k] = exp(acc[fr]);
+    for (int r = 0; r < 4; ++r) {
+      const int64_t t = t0 + ak + 4 * r;
+      if (t < T && b0 + ar < K) sp[t * K + b0 + ar] = exp(acc[r]);
+    }
   }
 }
 
@@ -274,23 +229,6 @@ static int get_sp2mc_matrix(kwy_ctx *ctx, int N, int order, double alpha, const 
   return KWY_OK;
 }
 
-static int get_mc2sp_matrix(kwy_ctx *ctx, int N, int order, double alpha, const double **out) {
-  char key[96];
-  snprintf(key, sizeof(key), "mc2sp:%d:%d:%.17g", N, order, alpha);
-  auto it = ctx->d_mats.find(key);
-  if (it == ctx->d_mats.end()) {
-    const int H = N / 2, K = H + 1;
-    std::vector<double> F;  // [order+1][H+1]: input index i -> outputs 0..H
-    freqt_matrix(order + 1, H, -alpha, F);
-    double *d = nullptr;
-    KWY_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)(order + 1) * K));
-    KWY_HIP(hipMemcpy(d, F.data(), sizeof(double) * (size_t)(order + 1) * K, hipMemcpyHostToDevice));
-    it = ctx->d_mats.emplace(key, d).first;
-  }
-  *out = it->second;
-  return KWY_OK;
-}
-
 template <int LOG2N>
 static int launch_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int order, const double *F, int ncut,
                         double *mc) {
@@ -307,20 +245,6 @@ static int launch_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int order, co
   return KWY_OK;
 }
 
-template <int LOG2N>
-static int launch_mc2sp(kwy_ctx *ctx, const double *mc, int64_t T, int order, const double *F2T, double *sp) {
-  constexpr int N = 1 << LOG2N, H = N / 2;
-  const kwy_c *twH, *twN;
-  KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
-  KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (size_t)MC2_FR * (order + 1);
-  KWY_HIP(hipFuncSetAttribute((const void *)k_mc2sp<LOG2N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_mc2sp", hipLaunchKernelGGL(k_mc2sp<LOG2N>, dim3((unsigned)((T + MC2_FR - 1) / MC2_FR)), dim3(KWY_THREADS), lds, ctx->stream, mc, T, order, F2T,
-                     twH, twN, sp));
-  KWY_HIP(hipGetLastError());
-  return KWY_OK;
-}
-
 // cos(2 pi m / N), m < N, in extended precision (first octant evaluated, the rest by symmetry of the index)
 static void cos_table(int N, std::vector<long double> &c) {
   c.resize(N);
@@ -329,35 +253,42 @@ static void cos_table(int N, std::vector<long double> &c) {
 }
 
 // G[k][j] (K x MC_STRIDE): mel-cepstral coefficient j per unit of log P[k], any even N = 2 (K - 1)
+static std::mutex g_dense_mutex;
+static std::map<std::string, std::vector<double>> g_dense_host;     // built once per process and (K, order, alpha):
+                                                                    // the batch drivers hold one context per stream
 static int get_sp2mc_dense(kwy_ctx *ctx, int K, int order, double alpha, const double **out) {
   char key[96];
   snprintf(key, sizeof(key), "sp2mc_dense:%d:%d:%.17g", K, order, alpha);
   auto it = ctx->d_mats.find(key);
   if (it == ctx->d_mats.end()) {
-    const int N = 2 * (K - 1), H = K - 1;
-    std::vector<double> F;
-    freqt_matrix(N, order, alpha, F);        // cepstral index n (< N) -> coefficient j
-    int nc = N;
-    while (nc > 1) {
-      double mx = 0.0;
-      for (int j = 0; j <= order; ++j) mx = fmax(mx, fabs(F[(size_t)(nc - 1) * (order + 1) + j]));
-      if (mx > 1e-40) break;
-      --nc;
-    }
-    std::vector<long double> cs;
-    cos_table(N, cs);
-    std::vector<double> G((size_t)K * MC_STRIDE, 0.0);
-    std::vector<long double> acc(order + 1);
-    for (int k = 0; k < K; ++k) {
-      // irfft: c[n] = (1/N) sum_k w_k L[k] cos(2 pi n k / N), w = 1 at k = 0 and k = H, else 2
-      const long double wk = ((k == 0 || k == H) ? 1.0L : 2.0L) / (long double)N;
-      for (int j = 0; j <= order; ++j) acc[j] = 0.0L;
-      for (int n = 0; n < nc; ++n) {
-        const long double cn = wk * cs[(int)(((int64_t)n * k) % N)] * (n == 0 ? 0.5L : 1.0L);
-        const double *f = &F[(size_t)n * (order + 1)];
-        for (int j = 0; j <= order; ++j) acc[j] += cn * (long double)f[j];
+    std::lock_guard<std::mutex> guard(g_dense_mutex);
+    std::vector<double> &G = g_dense_host[key];
+    if (G.empty()) {
+      const int N = 2 * (K - 1), H = K - 1;
+      std::vector<double> F;
+      freqt_matrix(N, order, alpha, F);        // cepstral index n (< N) -> coefficient j
+      int nc = N;
+      while (nc > 1) {
+        double mx = 0.0;
+        for (int j = 0; j <= order; ++j) mx = fmax(mx, fabs(F[(size_t)(nc - 1) * (order + 1) + j]));
+        if (mx > 1e-40) break;
+        --nc;
       }
-      for (int j = 0; j <= order; ++j) G[(size_t)k * MC_STRIDE + j] = (double)acc[j];
+      std::vector<long double> cs;
+      cos_table(N, cs);
+      G.assign((size_t)K * MC_STRIDE, 0.0);
+      std::vector<long double> acc(order + 1);
+      for (int k = 0; k < K; ++k) {
+        // irfft: c[n] = (1/N) sum_k w_k L[k] cos(2 pi n k / N), w = 1 at k = 0 and k = H, else 2
+        const long double wk = ((k == 0 || k == H) ? 1.0L : 2.0L) / (long double)N;
+        for (int j = 0; j <= order; ++j) acc[j] = 0.0L;
+        for (int n = 0; n < nc; ++n) {
+          const long double cn = wk * cs[(int)(((int64_t)n * k) % N)] * (n == 0 ? 0.5L : 1.0L);
+          const double *f = &F[(size_t)n * (order + 1)];
+          for (int j = 0; j <= order; ++j) acc[j] += cn * (long double)f[j];
+        }
+        for (int j = 0; j <= order; ++j) G[(size_t)k * MC_STRIDE + j] = (double)acc[j];
+      }
     }
     double *d = nullptr;
     KWY_HIP(hipMalloc((void **)&d, sizeof(double) * G.size()));
@@ -368,27 +299,31 @@ static int get_sp2mc_dense(kwy_ctx *ctx, int K, int order, double alpha, const d
   return KWY_OK;
 }
 
-// G2[j][k] ((order+1) x K): log P[k] per unit of mel-cepstral coefficient j
+
 static int get_mc2sp_dense(kwy_ctx *ctx, int K, int order, double alpha, const double **out) {
   char key[96];
   snprintf(key, sizeof(key), "mc2sp_dense:%d:%d:%.17g", K, order, alpha);
   auto it = ctx->d_mats.find(key);
   if (it == ctx->d_mats.end()) {
-    const int N = 2 * (K - 1), H = K - 1;
-    std::vector<double> F;                   // [order+1][H+1]: coefficient j -> cepstral index i
-    freqt_matrix(order + 1, H, -alpha, F);
-    std::vector<long double> cs;
-    cos_table(N, cs);
-    std::vector<double> G2((size_t)(order + 1) * K, 0.0);
-    std::vector<long double> acc(order + 1);
-    for (int k = 0; k < K; ++k) {
-      // rfft of the mirrored sequence: S[k] = 2 c0 + 2 sum_{0<i<H} c_i cos(2 pi i k / N) + c_H cos(pi k)
-      for (int j = 0; j <= order; ++j) acc[j] = 0.0L;
-      for (int i = 0; i <= H; ++i) {
-        const long double w = ((i == H) ? 1.0L : 2.0L) * cs[(int)(((int64_t)i * k) % N)];
-        for (int j = 0; j <= order; ++j) acc[j] += w * (long double)F[(size_t)j * (H + 1) + i];
+    std::lock_guard<std::mutex> guard(g_dense_mutex);
+    std::vector<double> &G2 = g_dense_host[key];
+    if (G2.empty()) {
+      const int N = 2 * (K - 1), H = K - 1;
+      std::vector<double> F;                   // [order+1][H+1]: coefficient j -> cepstral index i
+      freqt_matrix(order + 1, H, -alpha, F);
+      std::vector<long double> cs;
+      cos_table(N, cs);
+      G2.assign((size_t)(order + 1) * K, 0.0);
+      std::vector<long double> acc(order + 1);
+      for (int k = 0; k < K; ++k) {
+        // rfft of the mirrored sequence: S[k] = 2 c0 + 2 sum_{0<i<H} c_i cos(2 pi i k / N) + c_H cos(pi k)
+        for (int j = 0; j <= order; ++j) acc[j] = 0.0L;
+        for (int i = 0; i <= H; ++i) {
+          const long double w = ((i == H) ? 1.0L : 2.0L) * cs[(int)(((int64_t)i * k) % N)];
+          for (int j = 0; j <= order; ++j) acc[j] += w * (long double)F[(size_t)j * (H + 1) + i];
+        }
+        for (int j = 0; j <= order; ++j) G2[(size_t)j * K + k] = (double)acc[j];
       }
-      for (int j = 0; j <= order; ++j) G2[(size_t)j * K + k] = (double)acc[j];
     }
     double *d = nullptr;
     KWY_HIP(hipMalloc((void **)&d, sizeof(double) * G2.size()));
@@ -412,8 +347,9 @@ static int launch_sp2mc_dense(kwy_ctx *ctx, const double *sp, int64_t T, int K, 
 static int launch_mc2sp_dense(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, int K, double *sp) {
   const double *G2;
   KWY_TRY(get_mc2sp_dense(ctx, K, order, alpha, &G2));
-  const size_t lds = sizeof(double) * (size_t)MCD_FR * (order + 1);
-  KWY_PROF(ctx, "k_mc2sp_dense", hipLaunchKernelGGL(k_mc2sp_dense, dim3((unsigned)((T + MCD_FR - 1) / MCD_FR)), dim3(KWY_THREADS), lds, ctx->stream, mc, T, order, K, G2, sp));
+  const unsigned gx = (unsigned)((T + 15) / 16);
+  const unsigned gy = gx >= 512 ? 1 : (gx >= 256 ? 2 : 4);        // enough workgroups for the chip at short T too
+  KWY_PROF(ctx, "k_mc2sp", hipLaunchKernelGGL(k_mc2sp_mfma, dim3(gx, gy), dim3(KWY_THREADS), 0, ctx->stream, mc, T, order, K, G2, sp));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -456,16 +392,8 @@ extern "C" int kwy_mc2sp_dev(kwy_ctx *ctx, const double *mc, int64_t T, int orde
   int l;
   KWY_TRY(mcep_check(ctx, mc, sp, T, fftlen / 2 + 1, order, alpha, &l));
   KWY_HIP(hipSetDevice(ctx->device));
-  if (l == 0) return launch_mc2sp_dense(ctx, mc, T, order, alpha, fftlen / 2 + 1, sp);
-  const double *F2T;
-  KWY_TRY(get_mc2sp_matrix(ctx, 1 << l, order, alpha, &F2T));
-  switch (l) {
-    case 9: return launch_mc2sp<9>(ctx, mc, T, order, F2T, sp);
-    case 10: return launch_mc2sp<10>(ctx, mc, T, order, F2T, sp);
-    case 11: return launch_mc2sp<11>(ctx, mc, T, order, F2T, sp);
-    case 12: return launch_mc2sp<12>(ctx, mc, T, order, F2T, sp);
-    default: return launch_mc2sp<13>(ctx, mc, T, order, F2T, sp);
-  }
+  (void)l;      // one form for every length: the dense map on the matrix cores
+  return launch_mc2sp_dense(ctx, mc, T, order, alpha, fftlen / 2 + 1, sp);
 }
 
 extern "C" int kwy_sp2mc(kwy_ctx *ctx, const double *sp, int64_t T, int K, int order, double alpha,
