@@ -6,7 +6,7 @@ import glob
 import json
 import sys
 
-KERNELS = ('k_d4c_body', 'k_d4c_bands', 'k_cheaptrick', 'k_d4c_lovetrain', 'k_syn_pulse', 'k_sp2mc', 'k_mc2sp')
+KERNELS = ('k_d4c_body', 'k_d4c_bands', 'k_cheaptrick', 'k_d4c_lovetrain', 'k_syn_pulse', 'k_sp2mc', 'k_mc2sp_mfma')
 
 
 def main(root):
