@@ -14,7 +14,8 @@
 //   mc2sp, every length: the whole map as a dense 25 x K matrix applied on the matrix cores (k_mc2sp_mfma,
 //          v_mfma_f64_16x16x4_f64), exp on the accumulators.  It replaced the LDS-FFT form in round 2 (15 us against
 //          35 us for 2201 frames at K = 1025); the same formulation of sp2mc was measured slower than its FFT form
-//          (73 us against 37 us: 16-frame tiles give too few workgroups, and the log-spectra have to pass through LDS).
+//          twice (73 us with the log-spectra staged in LDS and a barrier pair per 256 bins, 46 us with eight
+//          independent wavefronts per 16 frames and no staging, against 37 us).
 // Both stream each frame once: sp2mc reads K*8 B and writes (order+1)*8 B per frame; mc2sp the reverse.
 #include <math.h>
 
