@@ -402,6 +402,15 @@ def main():
                                 'algorithmic_flop_per_frame': 10 * 5 * 4096 * 12,
                                 'note': 'FFT flop only (windows, RNG, smoothing, selects not counted); frames with '
                                         'work = frames with f0 > 0 (upper bound of the frames that pass the gate)'}
+            try:    # what the stage is bound by: vector-instruction issue (SQ counters, tools/pmc_sq.sh, one utterance alone)
+                with open(os.path.join(ROOT, 'profiles', 'r2_pmc_sq_summary.json')) as fh:
+                    sq = json.load(fh)
+                roofline_compute['valu_issue'] = {
+                    k: {'busy_share_of_launch_per_simd': sq[k]['VALU_busy_per_SIMD'],
+                        'valu_instructions_per_wavefront': sq[k]['VALU_insts_per_wave']}
+                    for k in ('k_d4c_body', 'k_d4c_bands') if k in sq}
+            except (OSError, KeyError, ValueError):
+                pass
         # the kernel with the largest SUMMED duration of all (what a rocprofv3 --stats table puts first)
         single = {k: v for k, v in kernel_ms.items() if '+' not in k}
         top = max(single, key=lambda k: single[k][0]) if single else None
