@@ -42,64 +42,40 @@ def make_pair(index, seconds):
     return src, tgt
 
 
-def cpu_pair_once(src, tgt, gmm_params, seconds=None):
-    """One pass of the config-3 path for one pair on the CPU oracle (C restatement of the reference's pyworld /
-    pysptk / fastdtw / nnmnkwii path), one thread.  seconds: use only the first `seconds` of the source
-    (and 1.1x that of the target).  Returns (source frames, wall seconds)."""
-    from oracle import oracle as ko
-    from kwiiyatta_amd.vocoder.align import project_path_iter
+def pair_silence(index, K=1025):
+    """The four pad spectra of pair `index` (source head, source tail, target head, target tail): what pad_silence
+    draws (kwiiyatta/vocoder/world.py:158-161), from a generator seeded per pair so that the pipeline and the CPU
+    chain see the same blocks."""
+    rng = np.random.RandomState(1000 + index)
+    return [np.abs(rng.normal(0, 2.220446049250313e-16 / FS, (100, K))) for _ in range(4)]
 
-    def cut(u, sec):
-        if sec is None:
-            return u
-        x, f0, t = u
-        n, T = int(FS * sec), int(sec * 1000 / FRAME_PERIOD) + 1
-        return np.ascontiguousarray(x[:n]), np.ascontiguousarray(f0[:T]), np.ascontiguousarray(t[:T])
 
-    (xs, f0s, ts), (xt, f0t, tt) = cut(src, seconds), cut(tgt, None if seconds is None else 1.1 * seconds)
-    weights, means, covs = gmm_params
-    alpha = ko.mcepalpha(FS)
-    P, K = 100, 1025
-    rng = np.random.RandomState(0)
-    t0 = time.perf_counter()
-    feats = []
-    for x, f0, t in ((xs, f0s, ts), (xt, f0t, tt)):
-        sp = ko.cheaptrick(x, f0, t, FS) / FS
-        ap = ko.d4c(x, f0, t, FS)
-        sil = lambda: np.abs(rng.normal(0, 2.220446049250313e-16 / FS, (P, K)))  # noqa: E731
-        sp_pad = np.ascontiguousarray(np.concatenate((sil(), sp, sil())))
-        ap_pad = np.concatenate((np.full((P, K), 1 - 1e-12), ap, np.full((P, K), 1 - 1e-12)))
-        f0_pad = np.r_[np.zeros(P), f0, np.zeros(P)]
-        mc = ko.sp2mc(sp_pad, 24, alpha)
-        feat = np.hstack((np.zeros((len(mc), 2)), mc[:, 1:]))
-        feat[:, 0][mc[:, 0] >= mc[:, 0].max() - 1.636] = 9.4
-        feat[:, 1][f0_pad > 0] = 9.0
-        feats.append((sp_pad, ap_pad, mc, feat))
-    _, path = ko.fastdtw(feats[0][3], feats[1][3], radius=32, dist=2)
-    idx = np.fromiter(project_path_iter(np.array(path), trim=True, trim_len=P), dtype=np.int64)
-    mc_al, ap_al = feats[0][2][idx], np.ascontiguousarray(feats[0][1][idx])
-    y = ko.gmm_mlpg(np.ascontiguousarray(mc_al[:, 1:]), weights, means, covs)
-    sp_conv = ko.mc2sp(np.hstack((mc_al[:, :1], y)), alpha, 2048)
-    ko.synthesize(f0t, np.ascontiguousarray(sp_conv * FS), ap_al, FS, FRAME_PERIOD)
-    return len(f0s), time.perf_counter() - t0
+def cpu_pair_once(src, tgt, gmm_params, silence):
+    """One pass of the config-3 path for one pair on the CPU oracle (oracle/chain.py: C restatement of the reference's
+    pyworld / pysptk / fastdtw / nnmnkwii path, every stage fed by the oracle's own previous output), one thread.
+    Returns the chain's result dict ('frames', 'seconds', 'wave', 'path', ...)."""
+    from oracle import chain
+    return chain.pair_chain(src, tgt, gmm_params, FS, silence)
 
 
 def cpu_worker(path):
     """`bench.py --cpu-worker FILE`: a fresh process (no torch, no GPU) that runs the pair stored in FILE once and
     prints its wall time; the all-core figure starts one of these per host core."""
     d = np.load(path)
-    frames, sec = cpu_pair_once((d['xs'], d['f0s'], d['ts']), (d['xt'], d['f0t'], d['tt']),
-                                (d['weights'], d['means'], d['covs']))
-    print(json.dumps({'frames': frames, 'seconds': sec}))
+    r = cpu_pair_once((d['xs'], d['f0s'], d['ts']), (d['xt'], d['f0t'], d['tt']),
+                      (d['weights'], d['means'], d['covs']), list(d['silence']))
+    print(json.dumps({'frames': r['frames'], 'seconds': r['seconds']}))
 
 
-def cpu_baseline_pair(src, tgt, gmm, budget_s=25.0):
+def cpu_baseline_pair(src, tgt, gmm, silence, budget_s=25.0):
     """The CPU oracle on the host cores of this box: the FULL 10 s + 11 s pair of the benchmark workload, once on
-    one core, then once per core on all cores at the same time (utterance-parallel, one process each)."""
+    one core, then once per core on all cores at the same time (utterance-parallel, one process each).
+    Returns (cpu_baseline object, the chain's result of the one-core pass)."""
     import subprocess
     import tempfile
     params = (gmm.weights_, gmm.means_, gmm.covariances_)
-    frames, sec1 = cpu_pair_once(src, tgt, params)
+    ref = cpu_pair_once(src, tgt, params, silence)
+    frames, sec1 = ref['frames'], ref['seconds']
     out = {'value': frames / sec1, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
            'sample': f'one full pair of the workload ({frames} source frames: 10 s source + 11 s target) through the same '
                      f'analyse->align->convert->synth path on oracle/liboracle.so (C restatement of pyworld 0.2.8 / '
@@ -110,7 +86,7 @@ def cpu_baseline_pair(src, tgt, gmm, budget_s=25.0):
         with tempfile.TemporaryDirectory() as tmp:
             f = os.path.join(tmp, 'pair.npz')
             np.savez(f, xs=src[0], f0s=src[1], ts=src[2], xt=tgt[0], f0t=tgt[1], tt=tgt[2], weights=params[0],
-                     means=params[1], covs=params[2])
+                     means=params[1], covs=params[2], silence=np.stack(silence))
             t0 = time.perf_counter()
             procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', f],
                                       stdout=subprocess.PIPE, env=dict(os.environ, OMP_NUM_THREADS='1'))
@@ -121,7 +97,143 @@ def cpu_baseline_pair(src, tgt, gmm, budget_s=25.0):
                             'processes': nproc, 'wall_seconds': wall,
                             'sample': f'{nproc} processes (os.cpu_count() = {os.cpu_count()}, CPU share of a one-GPU job: 16), the same full pair each, started '
                                       f'together; wall time includes process start-up'}
-    return out
+    return out, ref
+
+
+def _make_utterance_job(job):
+    """(seed, seconds) -> utterance; module-level so that a process pool can run it.  synthetic.py is loaded by path:
+    the workers need neither the package nor the HIP runtime."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('kwy_synthetic', os.path.join(ROOT, 'kwiiyatta_amd', 'synthetic.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seed, seconds = job
+    return mod.make_utterance(seed=seed, fs=FS, seconds=seconds, f0_base=110.0 + (seed % 7) * 15.0)
+
+
+def main_batch(args):
+    """BASELINE config 4: a batch of `--utterances` distinct synthetic 48 kHz utterances per GPU (256 on one GPU =
+    the configuration's whole batch; seeds = global utterance index), analysed and resynthesised through a fixed pool
+    of `--batch` streams -- many more utterances than streams, inputs resident in HBM, one frame = 5 ms of audio.
+    Reference flow: kwiiyatta/resynthesize_voice.py:46-79 per file."""
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    seeds = [rank + world * i for i in range(args.utterances)]
+    # host-side signal generation first, in worker processes, before this process touches the GPU
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    nproc = max(1, min(len(os.sched_getaffinity(0)), 16, len(seeds)))
+    with cf.ProcessPoolExecutor(nproc, mp_context=mp.get_context('spawn')) as ex:
+        utts = list(ex.map(_make_utterance_job, [(sd, args.seconds) for sd in seeds], chunksize=4))
+
+    import torch
+    import torch.distributed as dist
+    local_rank = local_rank % max(1, torch.cuda.device_count())
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    rdev = dev if args.backend == 'nccl' else torch.device('cpu')
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd import pipeline as pl
+
+    resident = [tuple(torch.from_numpy(a).to(dev) for a in u) for u in utts]
+    pool = cp.StreamPool(local_rank, args.batch)
+    ylen = [int(cp.lib.kwy_synth_length(len(u[1]), FRAME_PERIOD, FS)) for u in utts]
+    out = [torch.empty(n, dtype=torch.float64, device=dev) for n in ylen]
+
+    def step():
+        return cp.resynthesize_batch(resident, FS, device_index=local_rank, pool=pool, out=out)[1]
+
+    frames_step = 0
+    for _ in range(max(1, args.warmup)):
+        frames_step = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    frames_total = float(frames_step * args.steps)
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=rdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        ft = torch.tensor([frames_total], dtype=torch.float64, device=rdev)
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        frames_total = float(ft.item())
+    finite = all(bool(torch.isfinite(w).all().item()) for w in out)
+    first = [w.clone() for w in out]
+    step()
+    torch.cuda.synchronize()
+    identical = all(torch.equal(a, b) for a, b in zip(first, out))
+    if rank == 0:
+        # the D4C stage (dominant whole-chip kernels) of one utterance alone, HIP events on its stream
+        lone = pl.UtterancePipeline(local_rank, FS, utts[0])
+        lone.run(); lone.sync()
+        lone.profile(True)
+        per = {}
+        for _ in range(7):
+            lone.run(); lone.sync()
+            for nme in ('k_d4c_body', 'k_d4c_bands', 'k_cheaptrick', 'k_syn_pulse'):
+                ms, n = lone.profile_read(nme)
+                if n:
+                    per.setdefault(nme, []).append(ms / n)
+        lone.profile(False)
+        alone = {k: sorted(v)[len(v) // 2] for k, v in per.items()}
+        T, K = lone.T, lone.K
+        hop = FS * FRAME_PERIOD / 1000.0
+        d4c_ms = alone.get('k_d4c_body', float('nan')) + alone.get('k_d4c_bands', float('nan'))
+        bytes_per_launch = T * (hop * 8 + 16 + K * 8)
+        achieved = bytes_per_launch / (d4c_ms * 1e-3) / 1e9
+        value = frames_total / el
+        res = {
+            'metric': METRIC, 'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1000.0 * el / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'config4: batch of {args.utterances} distinct synthetic 48 kHz {args.seconds:g} s '
+                                   f'utterances per GPU (T={T}, K={K}; seeds = global utterance index): CheapTrick + D4C + '
+                                   f'WORLD synthesis each, through a fixed pool of streams',
+                       'utterances_per_gpu': args.utterances, 'streams_per_gpu': args.batch,
+                       'launch': 'per stream one pipeline per utterance shape; its pass is a captured HIP graph from the '
+                                 'second utterance of that shape on; inputs resident in HBM, copied device-to-device '
+                                 'into the pipeline\'s buffers; every waveform kept',
+                       'parallelism': f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective'},
+            'real_time_factor': value / 200.0,
+            'hbm_fraction_whole_path': value / world * 36664 / 8e12,
+            'kernel_ms_per_launch_alone': alone,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_d4c_body+k_d4c_bands', 'achieved': achieved, 'peak': 8000.0,
+                         'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': None, 'avg_launch_ms': d4c_ms,
+                         'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'note': 'one utterance alone, HIP events on its stream, median of 7 passes'},
+            'checks': {'all_outputs_finite': finite, 'second_pass_bit_identical': identical},
+            'cpu_baseline': None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle as ko
+            x, f0, t = utts[0]
+            t1 = time.perf_counter()
+            sp = ko.cheaptrick(x, f0, t, FS)
+            apv = ko.d4c(x, f0, t, FS)
+            ref = ko.synthesize(f0, sp, apv, FS, FRAME_PERIOD)
+            sec = time.perf_counter() - t1
+            res['cpu_baseline'] = {'value': len(f0) / sec, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+                                   'sample': f'utterance 0 of the batch ({len(f0)} frames): cheaptrick + d4c + synthesize on '
+                                             f'oracle/liboracle.so, 1 thread, {sec:.1f} s'}
+            res['parity'] = {'wave_rms_vs_cpu_chain': float(np.sqrt(np.mean((first[0].cpu().numpy() - ref) ** 2))),
+                             'tolerance': 1e-4, 'note': 'utterance 0 against the all-oracle analyse -> synthesise chain'}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -134,6 +246,11 @@ def main():
     ap_.add_argument('--batch', type=int, default=32, help='utterance pairs per GPU per step (one stream each)')
     ap_.add_argument('--seconds', type=float, default=10.0, help='source utterance length')
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
+    ap_.add_argument('--utterances', type=int, default=0,
+                     help='with --workload utterance: BASELINE config 4 -- this many DISTINCT utterances per GPU and step '
+                          '(seeds = global utterance index, 256 = the configuration\'s batch on one GPU) through a fixed '
+                          'pool of --batch streams (kwiiyatta_amd.corpus.resynthesize_batch); 0 = config 2 (one '
+                          'pipeline per stream)')
     ap_.add_argument('--components', type=int, default=64)
     ap_.add_argument('--no-cpu-baseline', action='store_true')
     ap_.add_argument('--distinct', type=int, default=8, help='distinct synthetic signal pairs per rank (cycled over the batch)')
@@ -154,6 +271,8 @@ def main():
     args = ap_.parse_args()
 
     args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.batch == 1)
+    if args.workload == 'utterance' and args.utterances > 0:
+        return main_batch(args)
 
     import torch
     import torch.distributed as dist
@@ -186,7 +305,7 @@ def main():
         src, tgt = base[i % nbase]
         if args.workload == 'pair':
             pipes.append(pl.PairPipeline(local_rank, FS, src, tgt, dgmm, prepare_gmm_per_run=args.gmm_prepare_per_pair,
-                                         side_stream=args.side_stream))
+                                         side_stream=args.side_stream, silence=pair_silence(mine[i % nbase])))
         else:
             pipes.append(pl.UtterancePipeline(local_rank, FS, src))
     torch.cuda.synchronize()
@@ -246,47 +365,77 @@ def main():
         for p in pipes:
             p.profile(False)
 
+    def timed_variant(step_fn, finish=None):
+        """the timing protocol of the main loop (one untimed step, barrier, K steps, barrier, MAX over ranks) around
+        another step function; returns seconds"""
+        step_fn()
+        sync_all()
+        if finish:
+            finish()
+        if world > 1:
+            dist.barrier()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        sync_all()
+        if finish:
+            finish()
+        if world > 1:
+            dist.barrier()
+        elp = time.perf_counter() - tp
+        if world > 1:
+            tt = torch.tensor([elp], dtype=torch.float64, device=rdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elp = float(tt.item())
+        return elp
+
+    def launch(p):
+        if args.graph:
+            p.replay()
+        else:
+            p.run()
+
     def run_pcie_variant():
-        pcie = None
-        if args.workload == 'pair' and not args.no_pcie_variant:
-            host = []
-            for p in pipes:
-                host.append((p.src.x.cpu().pin_memory(), p.tgt.x.cpu().pin_memory(),
-                             torch.empty(p.wave.shape, dtype=p.wave.dtype).pin_memory()))
-
-            def step_pcie():
-                for p, (hs, ht, hw) in zip(pipes, host):
-                    with torch.cuda.stream(p.stream):
-                        p.src.x.copy_(hs, non_blocking=True)
-                        p.tgt.x.copy_(ht, non_blocking=True)
-                    if args.graph:
-                        p.replay()
-                    else:
-                        p.run()
-                    with torch.cuda.stream(p.stream):
-                        hw.copy_(p.wave, non_blocking=True)
-            step_pcie()
-            sync_all()
-            if world > 1:
-                dist.barrier()
-            tp = time.perf_counter()
-            for _ in range(args.steps):
-                step_pcie()
-            sync_all()
-            if world > 1:
-                dist.barrier()
-            elp = time.perf_counter() - tp
-            if world > 1:
-                tt = torch.tensor([elp], dtype=torch.float64, device=rdev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                elp = float(tt.item())
-            pcie = {'ms_per_step': 1000.0 * elp / args.steps,
-                    'bytes_per_pair': int(sum(h.numel() * 8 for h in host[0])),
-                    'note': 'same steps with the two waveforms uploaded (pinned host memory) and the synthesised waveform '
-                            'downloaded on the pair\'s stream inside the timed region; never `value`'}
-            del host
-
+        if args.workload != 'pair' or args.no_pcie_variant:
+            return None
+        feeder = pl.HostFeeder(pipes)
+        elp = timed_variant(lambda: feeder.step(launch), feeder.sync)
+        pcie = {'ms_per_step': 1000.0 * elp / args.steps,
+                'bytes_per_pair': int(sum(h.numel() * 8 for h in feeder.host_in[0]) + feeder.host_out[0].numel() * 8),
+                'note': 'same steps with the two waveforms uploaded from pinned host memory and the synthesised waveform '
+                        'downloaded inside the timed region: one upload and one download stream for all pairs, two '
+                        'staging slots per pair, so the copies of neighbouring steps overlap with the kernels '
+                        '(kwiiyatta_amd.pipeline.HostFeeder); never `value`'}
+        del feeder
         return pcie
+
+    def run_pad_variant():
+        """`value` replays pad spectra that were drawn ONCE per pipeline, outside the timed region.  Here every pass
+        draws its four (100 x K) blocks afresh on the host, as kwiiyatta.pad_silence does per call (numpy's legacy
+        generator, serial), and uploads them."""
+        if args.workload != 'pair' or args.no_pcie_variant:
+            return None
+        K = pipes[0].K
+        stage = [[torch.empty((100, K), dtype=torch.float64).pin_memory() for _ in range(4)] for _ in pipes]
+        host_s = [0.0]
+
+        def step_pad():
+            for p, st in zip(pipes, stage):
+                p.sync()                 # the pinned blocks of this pair are about to be overwritten
+                t_ = time.perf_counter()
+                for blk in st:
+                    blk.copy_(torch.from_numpy(pl.draw_silence(FS, K)))
+                host_s[0] += time.perf_counter() - t_
+                rows = p.src.silence_rows() + p.tgt.silence_rows()
+                with torch.cuda.stream(p.stream):
+                    for dst, blk in zip(rows, st):
+                        dst.copy_(blk, non_blocking=True)
+                launch(p)
+        elp = timed_variant(step_pad)
+        return {'ms_per_step': 1000.0 * elp / args.steps,
+                'host_draw_ms_per_pair': 1000.0 * host_s[0] / ((args.steps + 1) * len(pipes)),
+                'note': 'same steps with the four pad blocks of every pair drawn on the host inside the timed region '
+                        '(np.random.normal from the global legacy generator, one thread) and uploaded; never `value`'}
 
     frames_rank = sum(p.frames for p in pipes) * args.steps
     if world > 1:
@@ -316,7 +465,7 @@ def main():
         alone_ms = {}
         if args.workload == 'pair':      # one kernel at a time: everything on one stream (no side stream for D4C)
             lone = pl.PairPipeline(local_rank, FS, *base[0], dgmm, prepare_gmm_per_run=args.gmm_prepare_per_pair,
-                                   side_stream=False)
+                                   side_stream=False, silence=pair_silence(mine[0]))
         else:
             lone = pipes[0]
         lone.profile(True)
@@ -444,6 +593,8 @@ def main():
                 'launch': ('one captured HIP graph per pass and stream; per-kernel HIP-event durations from the same '
                            'passes enqueued kernel by kernel right after the timed region') if args.graph else
                           'one host launch per kernel; per-kernel HIP events inside the timed region',
+                'pad_spectra': 'host-drawn once per pipeline, outside the timed region (see with_pad_draw)'
+                if args.workload == 'pair' else None,
                 'parallelism': f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective'},
             'real_time_factor': value / 200.0,
             'hbm_fraction_whole_path': value / world * path_bytes / 8e12,
@@ -452,18 +603,43 @@ def main():
             'roofline': roofline,
             'roofline_compute': roofline_compute,
             'with_pcie': None,
+            'with_pad_draw': None,
+            'parity': None,
             'distinct_pairs_per_gpu': nbase,
             'largest_summed_kernel': by_sum,
             'cpu_baseline': None,
         }
-    # the PCIe-inclusive variant comes last: every rank takes part, and the per-kernel measurements above are done
+    # the variants come last: every rank takes part, and the per-kernel measurements above are done
     pcie = run_pcie_variant()
+    pad = run_pad_variant()
+    if pad:                               # pass again with the original pads: pipes[0].wave is what the parity check reads
+        for p_, i_ in zip(pipes, range(len(pipes))):
+            rows = p_.src.silence_rows() + p_.tgt.silence_rows()
+            with torch.cuda.stream(p_.stream):
+                for dst, sil in zip(rows, pair_silence(mine[i_ % nbase])):
+                    dst.copy_(torch.from_numpy(np.ascontiguousarray(sil)))
+        step()
+        sync_all()
     if rank == 0:
         if pcie:
             out['with_pcie'] = {'value': frames_total / (pcie['ms_per_step'] * 1e-3 * args.steps), **pcie}
+        if pad:
+            out['with_pad_draw'] = {'value': frames_total / (pad['ms_per_step'] * 1e-3 * args.steps), **pad}
         if not args.no_cpu_baseline and world == 1:
             if args.workload == 'pair':
-                out['cpu_baseline'] = cpu_baseline_pair(base[0][0], base[0][1], gmm)
+                out['cpu_baseline'], ref = cpu_baseline_pair(base[0][0], base[0][1], gmm, pair_silence(mine[0]))
+                # the same pair, the same pads: the pipeline's final waveform against the all-CPU chain
+                p0 = pipes[0]
+                n = int(p0.path_len.item())
+                path = [tuple(r) for r in p0.path.cpu().numpy()[:n].tolist()]
+                wave = p0.wave.cpu().numpy()
+                out['parity'] = {
+                    'wave_rms_vs_cpu_chain': float(np.sqrt(np.mean((wave - ref['wave']) ** 2))),
+                    'wave_peak': float(np.abs(ref['wave']).max()),
+                    'dtw_path_equal': path == ref['path'], 'dtw_path_cells': len(ref['path']),
+                    'tolerance': 1e-4,
+                    'note': 'pair 0 of the timed batch after the last pass vs oracle/chain.py on the same waveforms, f0 '
+                            'tracks, GMM and pad blocks, every oracle stage fed by the oracle\'s own previous output'}
             else:
                 from oracle import oracle as ko
                 x, f0, t = base[0][0]

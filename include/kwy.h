@@ -47,6 +47,12 @@ int kwy_ctx_create(int device, void *stream, kwy_ctx **out);
 void kwy_ctx_destroy(kwy_ctx *ctx);
 int kwy_ctx_sync(kwy_ctx *ctx);
 void *kwy_ctx_stream(kwy_ctx *ctx);
+/* The context's scratch arena grows on demand, and growing RELOCATES it (the stream is synchronised first).  A HIP
+ * graph captured from calls on this context holds arena addresses: it is valid only while
+ * kwy_ctx_arena_generation() returns the value it had at capture time.  kwy_ctx_reserve() grows the arena to at
+ * least `bytes` ahead of time (e.g. for the longest utterance of a batch) so that later calls do not move it. */
+int64_t kwy_ctx_arena_generation(kwy_ctx *ctx);
+int kwy_ctx_reserve(kwy_ctx *ctx, int64_t bytes);
 /* Per-kernel timing: when enabled, the main kernels are bracketed by HIP events
  * on the context's stream.  kwy_ctx_profile_read synchronises the stream and
  * returns the summed duration [ms] and launch count of `kernel` since the last

@@ -61,6 +61,8 @@ SIGNATURES = {
     'kwy_ctx_destroy': (None, [c_vp]),
     'kwy_ctx_sync': (c_int, [c_vp]),
     'kwy_ctx_stream': (c_vp, [c_vp]),
+    'kwy_ctx_arena_generation': (c_i64, [c_vp]),
+    'kwy_ctx_reserve': (c_int, [c_vp, c_i64]),
     'kwy_ctx_profile': (c_int, [c_vp, c_int]),
     'kwy_ctx_debug_buffer': (c_int, [c_vp, c_vp]),
     'kwy_ctx_profile_read': (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
@@ -171,6 +173,10 @@ class Context:
 
     def profile(self, enable=True):
         check(self, lib.kwy_ctx_profile(self.handle, int(bool(enable))))
+
+    def arena_generation(self):
+        """changes whenever the scratch arena is relocated (captured HIP graphs of this context become invalid)"""
+        return int(lib.kwy_ctx_arena_generation(self.handle))
 
     def profile_read(self, kernel):
         """(total_ms, launches) of `kernel` since the last read; synchronises the stream."""

@@ -189,13 +189,15 @@ class ConvertPipeline(_Graphed):
         self.frames = self.T
 
     def load(self, utterance):
-        """another utterance of the same shape into the existing buffers (asynchronous on the pipeline's stream)"""
+        """another utterance of the same shape into the existing buffers (numpy arrays or device tensors;
+        asynchronous on the pipeline's stream)"""
         x, f0, t = utterance
         if len(x) != self.N or len(f0) != self.T:
             raise ValueError('ConvertPipeline.load: shape differs from the pipeline\'s')
         with torch.cuda.stream(self.stream):
             for dst, src in ((self.x, x), (self.f0, f0), (self.t, t)):
-                dst.copy_(torch.from_numpy(np.ascontiguousarray(src)), non_blocking=True)
+                dst.copy_(src if torch.is_tensor(src) else torch.from_numpy(np.ascontiguousarray(src)),
+                          non_blocking=True)
 
     def run(self):
         h, fs, fft, K, order, T = self.ctx.handle, self.fs, self.fft, self.K, self.order, self.T
@@ -286,7 +288,9 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
         torch.cuda.synchronize(dev)
     if not blocks:
         return torch.empty((0, 6 * order), dtype=torch.float64, device=dev), 0
-    return torch.cat(blocks).contiguous(), frames
+    X = torch.cat(blocks).contiguous()
+    torch.cuda.current_stream(dev).synchronize()      # the fit reads X on its own stream
+    return X, frames
 
 
 def fit_converter(X, components=64, seed=None, max_iter=100, device_index=0, verbose=0):
@@ -296,31 +300,77 @@ def fit_converter(X, components=64, seed=None, max_iter=100, device_index=0, ver
                               device_index=device_index).fit(X)
 
 
-def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16, pool=None):
-    """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors).  Every stream
-    keeps one pipeline per utterance shape, captured as a HIP graph: an utterance of a shape seen before costs an
-    upload, one graph launch and a device copy of the result, all enqueued on the pipeline's stream -- the streams
-    run independently of each other and the host waits once, at the end."""
-    dev = torch.device('cuda', device_index)
-    dg = DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
-    if pool is None:
-        pool = StreamPool(device_index, streams)
-    cache = [dict() for _ in range(len(pool))]
-    out = [None] * len(utterances)
+def _stream_batch(make_pipeline, utterances, pool, shapes_per_stream, keep):
+    """Utterance i on stream i % len(pool); a stream keeps the pipelines (buffers) of its `shapes_per_stream` most
+    recently used utterance shapes.  A shape seen for the first time just runs kernel by kernel; from its SECOND
+    appearance on the stream its pass is a captured HIP graph -- a corpus of files of all different lengths pays
+    neither the extra passes of a capture nor the memory of a graph per file.  All pipelines of a stream share the
+    stream's context and its scratch arena, which moves when a longer utterance needs more room: a graph captured
+    before such a move is discarded and captured again (`_Graphed.graph_valid`) instead of being replayed against
+    freed memory.  keep(i, pipeline): called with the pipeline's stream current right after utterance i was enqueued.
+    The streams run independently of each other and the host waits once, at the end."""
+    from collections import OrderedDict
+    cache = [OrderedDict() for _ in range(len(pool))]
     for i, u in enumerate(utterances):
         k = i % len(pool)
         shape = (len(u[0]), len(u[1]))
         p = cache[k].get(shape)
         if p is None:
-            p = ConvertPipeline(device_index, fs, u, dg, order=order, frame_period=frame_period,
-                                stream=pool.streams[k], ctx=pool.contexts[k])
-            p.capture()
+            while len(cache[k]) >= max(1, shapes_per_stream):
+                _, old = cache[k].popitem(last=False)
+                old.sync()                  # its buffers go back to the allocator: nothing of it may still be queued
+            p = make_pipeline(u, pool.streams[k], pool.contexts[k])
             cache[k][shape] = p
+            p.run()
         else:
+            cache[k].move_to_end(shape)
             p.load(u)
-        p.replay()
+            if not p.graph_valid():
+                p.capture()                 # a plain pass (sizes the arena for this shape), then the capture
+            p.replay()
         with torch.cuda.stream(p.stream):
-            out[i] = p.wave.clone()
+            keep(i, p)
     for s_ in pool.streams:
         s_.synchronize()
+
+
+def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16, pool=None,
+                  shapes_per_stream=4):
+    """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors);
+    see `_stream_batch` for the scheduling."""
+    dev = torch.device('cuda', device_index)
+    dg = DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
+    if pool is None:
+        pool = StreamPool(device_index, streams)
+    out = [None] * len(utterances)
+
+    def keep(i, p):
+        out[i] = p.wave.clone()
+    _stream_batch(lambda u, st, ctx: ConvertPipeline(device_index, fs, u, dg, order=order, frame_period=frame_period,
+                                                     stream=st, ctx=ctx), utterances, pool, shapes_per_stream, keep)
     return out
+
+
+def resynthesize_batch(utterances, fs, device_index=0, frame_period=5.0, streams=16, pool=None, shapes_per_stream=4,
+                       out=None):
+    """BASELINE config 4 on one rank: analyse + resynthesise every utterance ((x, f0, t) triples: numpy arrays or
+    device tensors) through a fixed pool of streams, more utterances than streams.  Returns the list of waveforms
+    (device tensors; written into `out[i]` instead when a list of preallocated tensors is given) and the number of
+    frames analysed."""
+    from .pipeline import UtterancePipeline
+    if pool is None:
+        pool = StreamPool(device_index, streams)
+    res = [None] * len(utterances)
+    frames = 0
+
+    def keep(i, p):
+        if out is not None:
+            out[i].copy_(p.wave)
+            res[i] = out[i]
+        else:
+            res[i] = p.wave.clone()
+    for u in utterances:
+        frames += len(u[1])
+    _stream_batch(lambda u, st, ctx: UtterancePipeline(device_index, fs, u, frame_period=frame_period, stream=st,
+                                                       ctx=ctx), utterances, pool, shapes_per_stream, keep)
+    return res, frames

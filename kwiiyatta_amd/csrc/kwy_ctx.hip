@@ -241,6 +241,7 @@ int kwy_arena_begin(kwy_ctx *ctx, size_t bytes) {
     size_t cap = bytes + bytes / 4;
     KWY_HIP(hipMalloc((void **)&ctx->arena, cap));
     ctx->arena_cap = cap;
+    ++ctx->arena_generation;
   }
   ctx->arena_off = 0;
   return KWY_OK;
@@ -384,6 +385,14 @@ int kwy_ctx_sync(kwy_ctx *ctx) {
   if (!ctx) return KWY_EINVAL;
   KWY_HIP(hipStreamSynchronize(ctx->stream));
   return KWY_OK;
+}
+
+int64_t kwy_ctx_arena_generation(kwy_ctx *ctx) { return ctx ? ctx->arena_generation : -1; }
+
+int kwy_ctx_reserve(kwy_ctx *ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return KWY_EINVAL;
+  KWY_HIP(hipSetDevice(ctx->device));
+  return kwy_arena_begin(ctx, (size_t)bytes);
 }
 
 int kwy_ctx_debug_buffer(kwy_ctx *ctx, void *device_buffer) {

@@ -21,6 +21,7 @@ struct kwy_ctx {
   // scratch arena (grow-only bump allocator, reset at the start of every call)
   char *arena = nullptr;
   size_t arena_cap = 0, arena_off = 0;
+  int64_t arena_generation = 0;            // counts (re)allocations: a captured HIP graph holds arena addresses
 
   // constant tables
   uint4 *d_pow2 = nullptr;                 // [64][128] columns of T^(2^k)

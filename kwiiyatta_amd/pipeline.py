@@ -111,9 +111,18 @@ class _Graphed:
         if profile:
             self.profile(False)
         self.graph = g
+        self._arena_gen = [c.arena_generation() for c in self.contexts()]
         self.sync()
 
+    def graph_valid(self):
+        """False once a context's scratch arena has been relocated since the capture (another, larger call on the same
+        context): the graph's kernel nodes then hold addresses of freed memory and it must be captured again."""
+        return self.graph is not None and self._arena_gen == [c.arena_generation() for c in self.contexts()]
+
     def replay(self):
+        if not self.graph_valid():
+            raise RuntimeError('the captured graph is stale: the context\'s scratch arena moved after the capture '
+                               '(capture() again, or give the pipeline a context of its own)')
         with torch.cuda.stream(self.stream):
             self.graph.replay()
 
@@ -288,38 +297,115 @@ class PairPipeline(_Graphed):
 
 
 class UtterancePipeline(_Graphed):
-    """analyse -> resynthesise of one utterance (BASELINE config 2), HBM-resident."""
+    """analyse -> resynthesise of one utterance (BASELINE config 2; resynthesize_voice.py without a carrier,
+    /root/reference/kwiiyatta/resynthesize_voice.py:46-79), HBM-resident."""
 
-    def __init__(self, device_index, fs, utterance, frame_period=5.0, stream=None):
+    def __init__(self, device_index, fs, utterance, frame_period=5.0, stream=None, ctx=None):
         self.dev = torch.device('cuda', device_index)
         self.fs, self.frame_period = int(fs), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
-        self.ctx = _lib.Context(device_index, stream=self.stream.cuda_stream)
+        self.ctx = ctx if ctx is not None else _lib.Context(device_index, stream=self.stream.cuda_stream)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
         self.K = self.fft // 2 + 1
         x, f0, t = utterance
         self.N, self.T = len(x), len(f0)
         f64 = dict(dtype=torch.float64, device=self.dev)
         with torch.cuda.stream(self.stream):
-            self.x, self.f0, self.t = (torch.from_numpy(a).to(self.dev) for a in (x, f0, t))
+            self.x, self.f0, self.t = (torch.empty(len(a), **f64) for a in (x, f0, t))
             self.sp = torch.empty((self.T, self.K), **f64)
             self.ap = torch.empty((self.T, self.K), **f64)
             self.ylen = lib.kwy_synth_length(self.T, self.frame_period, self.fs)
             self.wave = torch.empty(self.ylen, **f64)
+        self.load(utterance)
         self.stream.synchronize()
         self.frames = self.T
+
+    def load(self, utterance):
+        """another utterance of the same shape into the existing buffers (numpy arrays or device tensors;
+        asynchronous on the pipeline's stream)"""
+        x, f0, t = utterance
+        if len(x) != self.N or len(f0) != self.T:
+            raise ValueError('UtterancePipeline.load: shape differs from the pipeline\'s')
+        with torch.cuda.stream(self.stream):
+            for dst, src in ((self.x, x), (self.f0, f0), (self.t, t)):
+                dst.copy_(src if torch.is_tensor(src) else torch.from_numpy(np.ascontiguousarray(src)),
+                          non_blocking=True)
 
     def run(self):
         h, fs, fft = self.ctx.handle, self.fs, self.fft
         chk = lambda rc: _lib.check(self.ctx, rc)  # noqa: E731
-        chk(lib.kwy_cheaptrick_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), self.T, -0.15, 71.0, fft,
-                                   float(fs), _p(self.sp)))
-        chk(lib.kwy_d4c_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), self.T, 0.85, fft, _p(self.ap)))
-        chk(lib.kwy_synthesize_dev(h, _p(self.f0), self.T, _p(self.sp), _p(self.ap), fft, self.frame_period, fs,
-                                   float(fs), self.ylen, _p(self.wave)))
+        with torch.cuda.stream(self.stream):
+            chk(lib.kwy_cheaptrick_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), self.T, -0.15, 71.0, fft,
+                                       float(fs), _p(self.sp)))
+            chk(lib.kwy_d4c_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), self.T, 0.85, fft, _p(self.ap)))
+            chk(lib.kwy_synthesize_dev(h, _p(self.f0), self.T, _p(self.sp), _p(self.ap), fft, self.frame_period, fs,
+                                       float(fs), self.ylen, _p(self.wave)))
 
     def sync(self):
         self.ctx.sync()
+
+
+class HostFeeder:
+    """Waveforms from (pinned) host memory into a set of PairPipelines and the synthesised waveforms back, off the
+    pipelines' own streams: one upload stream and one download stream for the whole set (the link is shared anyway),
+    two staging slots per pipeline, events in between -- the upload of pass n+1 and the download of pass n-1 overlap
+    with the kernels of pass n.  The pipelines' input buffers keep their addresses (captured graphs stay valid): a
+    pass starts with a device-to-device copy out of the staging slot (3.8 MB: microseconds of HBM time).
+
+        feeder = HostFeeder(pipes)
+        feeder.step(lambda p: p.replay())      # per pass: upload, wait, copy in, pass, copy out, download
+        feeder.sync()                          # results of the last pass are in feeder.host_out[i]
+    """
+
+    def __init__(self, pipes, host_in=None):
+        self.pipes = list(pipes)
+        dev = self.pipes[0].dev
+        self.up, self.down = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        pin = lambda t: t.cpu().pin_memory()  # noqa: E731
+        self.host_in = host_in if host_in is not None else [(pin(p.src.x), pin(p.tgt.x)) for p in self.pipes]
+        self.host_out = [torch.empty(p.wave.shape, dtype=p.wave.dtype).pin_memory() for p in self.pipes]
+        self.slots = []
+        for p in self.pipes:
+            self.slots.append([dict(xs=torch.empty_like(p.src.x), xt=torch.empty_like(p.tgt.x),
+                                    y=torch.empty_like(p.wave), taken=None, drained=None) for _ in range(2)])
+        self.n = 0
+
+    def step(self, launch):
+        k = self.n & 1
+        self.n += 1
+        for p, slots, (hs, ht), ho in zip(self.pipes, self.slots, self.host_in, self.host_out):
+            sl = slots[k]
+            if sl['taken'] is not None:
+                self.up.wait_event(sl['taken'])           # the pass two steps ago has copied this slot in
+            with torch.cuda.stream(self.up):
+                sl['xs'].copy_(hs, non_blocking=True)
+                sl['xt'].copy_(ht, non_blocking=True)
+                arrived = torch.cuda.Event()
+                arrived.record(self.up)
+            p.stream.wait_event(arrived)
+            with torch.cuda.stream(p.stream):
+                p.src.x.copy_(sl['xs'], non_blocking=True)
+                p.tgt.x.copy_(sl['xt'], non_blocking=True)
+                sl['taken'] = torch.cuda.Event()
+                sl['taken'].record(p.stream)
+            launch(p)
+            if sl['drained'] is not None:
+                p.stream.wait_event(sl['drained'])        # the download of two steps ago has left this slot
+            with torch.cuda.stream(p.stream):
+                sl['y'].copy_(p.wave, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(p.stream)
+            self.down.wait_event(done)
+            with torch.cuda.stream(self.down):
+                ho.copy_(sl['y'], non_blocking=True)
+                sl['drained'] = torch.cuda.Event()
+                sl['drained'].record(self.down)
+
+    def sync(self):
+        for p in self.pipes:
+            p.sync()
+        self.up.synchronize()
+        self.down.synchronize()
 
 
 def synthetic_gmm(order=24, components=64, seed=0, n_frames=16000):

@@ -193,3 +193,45 @@ def test_fit_and_convert(corpus):
         got = w.cpu().numpy()
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+def test_convert_batch_shapes_share_one_arena(corpus):
+    """short, long, short again ... on ONE stream: the long utterance makes the stream's scratch arena grow (and
+    move) after the short shape's pass was captured as a HIP graph; the stale graph must be captured again, not
+    replayed against freed memory (round-2 review).  Also: the graphed passes equal the plain ones bit for bit, and
+    a stream keeps at most `shapes_per_stream` pipelines."""
+    import torch
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.synthetic import make_utterance
+    g = pl.synthetic_gmm(order=ORDER, components=4, seed=0, n_frames=3000)
+
+    def utt(seed, seconds):
+        x, f0, t = make_utterance(seed=seed, fs=FS, seconds=seconds)
+        return x, f0, t
+    short, long_, mid = utt(1, 0.6), utt(2, 3.0), utt(3, 1.3)
+    short2 = (np.ascontiguousarray(short[0][::-1]), short[1], short[2])      # same shape, other samples
+    order = [short, long_, short2, long_, short, mid, short2, mid, long_]
+    dev = torch.device('cuda', 0)
+    dg = pl.DeviceGMM(g.weights_, g.means_, g.covariances_, dev)
+    want = []
+    for u in order:                                                          # plain passes, a context each
+        p = cp.ConvertPipeline(0, FS, u, dg, order=ORDER)
+        p.run()
+        p.sync()
+        want.append(p.wave.cpu().numpy().copy())
+    pool = cp.StreamPool(0, 1)
+    gen0 = pool.contexts[0].arena_generation()
+    got = cp.convert_batch(order, FS, g, order=ORDER, pool=pool, shapes_per_stream=2)
+    assert pool.contexts[0].arena_generation() > gen0
+    for w, v in zip(want, got):
+        assert np.array_equal(w, v.cpu().numpy())
+    # a stale graph refuses to replay
+    p = cp.ConvertPipeline(0, FS, short, dg, order=ORDER, stream=pool.streams[0], ctx=pool.contexts[0])
+    p.capture()
+    assert p.graph_valid()
+    from kwiiyatta_amd._lib import lib, check
+    check(pool.contexts[0], lib.kwy_ctx_reserve(pool.contexts[0].handle, 1 << 30))
+    assert not p.graph_valid()
+    with pytest.raises(RuntimeError, match='stale'):
+        p.replay()

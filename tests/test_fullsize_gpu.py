@@ -90,3 +90,38 @@ def test_pair_pipeline_full_size(ko, gmm64):
     wave = p.wave.cpu().numpy()
     assert len(wave) == len(wave_ref) == 528240
     assert np.sqrt(np.mean((wave - wave_ref) ** 2)) <= 1e-9
+
+
+def test_pair_chained_against_all_oracle_chain(ko, gmm64):
+    """North star, config 3: the pipeline's FINAL waveform against an all-CPU chain in which every oracle stage is
+    fed by the oracle's own previous output (not by the GPU's), on the same waveforms, f0 tracks, GMM and the same
+    four pad blocks.  Equal FastDTW path, equal projection, waveform within 1e-4 RMS."""
+    import torch
+    from oracle import chain
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.synthetic import make_utterance
+    src = make_utterance(seed=1234, fs=FS, seconds=10.0)
+    tgt = make_utterance(seed=4321, fs=FS, seconds=10.0, time_warp=1.1, formant_scale=1.12)
+    rng = np.random.RandomState(7)
+    silence = [chain.draw_silence(rng, FS, 1025) for _ in range(4)]
+    ref = chain.pair_chain(src, tgt, (gmm64.weights_, gmm64.means_, gmm64.covariances_), FS, silence)
+    dg = pl.DeviceGMM(gmm64.weights_, gmm64.means_, gmm64.covariances_, torch.device('cuda', 0))
+    p = pl.PairPipeline(0, FS, src, tgt, dg, silence=silence)
+    p.run()
+    p.sync()
+    n = int(p.path_len.item())
+    path = [tuple(r) for r in p.path.cpu().numpy()[:n].tolist()]
+    differing = [(a, b) for a, b in zip(path, ref['path']) if a != b]
+    assert len(path) == len(ref['path']) and not differing, f'{len(differing)} path cells differ: {differing[:5]}'
+    assert p.dist.item() == pytest.approx(ref['dist'], rel=1e-9)
+    assert p.idx.cpu().numpy()[:p.tgt.T].tolist() == ref['idx'].tolist()
+    ap_err = np.abs(p.ap_al.cpu().numpy() - ref['ap_al']).max()
+    mc_err = np.abs(p.mc_conv.cpu().numpy() - ref['mc_conv']).max()
+    wave = p.wave.cpu().numpy()
+    assert len(wave) == len(ref['wave'])
+    rms = float(np.sqrt(np.mean((wave - ref['wave']) ** 2)))
+    peak = float(np.abs(ref['wave']).max())
+    print(f'chained config 3: wave rms {rms:.3e} (peak {peak:.3f}), aligned ap max err {ap_err:.3e}, '
+          f'converted mcep max err {mc_err:.3e}')
+    assert ap_err <= 1e-4 and mc_err <= 1e-8
+    assert rms <= 1e-4

@@ -120,3 +120,31 @@ def test_silence_synthesis_peak():
         y = ko.synthesize(f0, np.ascontiguousarray(sp * fs), ap, fs, 5.0)
         y = y - y.mean()
         assert 3.5e-8 < y.max() < 7e-8, y.max()
+
+
+def test_chain_projection_equals_package_projection():
+    """oracle/chain.py restates the reference's project_path_iter for the all-oracle config-3 chain; it must agree with
+    the package's host logic on DTW-shaped paths and on paths with jumps in y."""
+    import numpy as np
+    from oracle import chain
+    from kwiiyatta_amd.vocoder.align import project_path_iter
+    rng = np.random.default_rng(3)
+    for case in range(200):
+        nx, ny = rng.integers(5, 60, 2)
+        x = y = 0
+        path = [(0, 0)]
+        while x < nx - 1 or y < ny - 1:
+            step = rng.integers(0, 3)
+            jump = 1 if case % 3 else int(rng.integers(1, 4))
+            if step == 0 and x < nx - 1:
+                x += 1
+            elif step == 1 and y < ny - 1:
+                y = min(ny - 1, y + jump)
+            else:
+                x, y = min(nx - 1, x + 1), min(ny - 1, y + jump)
+            path.append((x, y))
+        for trim_len in (0, 1, 3):
+            if ny <= 2 * trim_len + 1:
+                continue
+            want = list(project_path_iter(np.array(path), trim=True, trim_len=trim_len))
+            assert chain.project_path(path, trim_len) == want

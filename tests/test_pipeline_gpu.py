@@ -225,3 +225,35 @@ def test_pipeline_matches_api_path_under_seed():
     assert np.array_equal(p.mc_al.cpu().numpy(), aligned.mel_cepstrum.data)
     assert np.array_equal(p.sp_al.cpu().numpy(), aligned.spectrum_envelope)
     assert np.array_equal(p.ap_al.cpu().numpy(), aligned.aperiodicity)
+
+
+def test_config4_batch_of_256_utterances():
+    """BASELINE config 4 on one GPU: 256 synthetic 48 kHz utterances (seeds 0 ... 255) analysed and resynthesised
+    through a fixed pool of 16 streams -- 16x more utterances than streams, every stream reusing one pipeline and,
+    from its second utterance on, one captured graph.  All outputs finite, a second pass bit-identical, and a sample
+    of utterances against the CPU oracle's own analyse -> synthesise chain (north star: 1e-4 RMS)."""
+    import torch
+    from oracle import oracle as ko
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd.synthetic import make_utterance
+    fs, n_utt = 48000, 256
+    utts = [make_utterance(seed=s, fs=fs, seconds=0.5, f0_base=110.0 + (s % 7) * 15.0) for s in range(n_utt)]
+    dev = torch.device('cuda', 0)
+    resident = [tuple(torch.from_numpy(a).to(dev) for a in u) for u in utts]     # inputs live in HBM
+    pool = cp.StreamPool(0, 16)
+    waves, frames = cp.resynthesize_batch(resident, fs, pool=pool)
+    assert frames == sum(len(u[1]) for u in utts) == 256 * 101
+    first = [w.cpu().numpy().copy() for w in waves]
+    assert all(np.isfinite(w).all() and np.abs(w).max() > 1e-3 for w in first)
+    waves2, _ = cp.resynthesize_batch(resident, fs, pool=pool)
+    assert all(np.array_equal(a, b.cpu().numpy()) for a, b in zip(first, waves2))
+    worst = 0.0
+    for i in (0, 17, 100, 255):
+        x, f0, t = utts[i]
+        sp = ko.cheaptrick(x, f0, t, fs)
+        ap = ko.d4c(x, f0, t, fs)
+        ref = ko.synthesize(f0, sp, ap, fs, 5.0)
+        assert ref.shape == first[i].shape
+        worst = max(worst, float(np.sqrt(np.mean((first[i] - ref) ** 2))))
+    print(f'config 4: 256 utterances on 16 streams, worst RMS against the all-oracle chain {worst:.3e}')
+    assert worst <= 1e-4
