@@ -53,6 +53,14 @@ void *kwy_ctx_stream(kwy_ctx *ctx);
  * least `bytes` ahead of time (e.g. for the longest utterance of a batch) so that later calls do not move it. */
 int64_t kwy_ctx_arena_generation(kwy_ctx *ctx);
 int kwy_ctx_reserve(kwy_ctx *ctx, int64_t bytes);
+/* WORLD's analysis / synthesis noise is ONE fixed pseudo-random sequence (the generator is reseeded at the entry of
+ * every pyworld call); the library keeps its first 2^KWY_RANDN_LOG2 draws (environment, default 25 = 128 MB, 0 = none)
+ * in a table per device and computes draws beyond it by jump-ahead -- the same numbers either way.  This call lowers
+ * the number of table draws THIS context uses (draws < 0: all of them); returns the length now in use.  For tests of
+ * the jump-ahead path. */
+int64_t kwy_ctx_set_randn_limit(kwy_ctx *ctx, int64_t draws);
+/* draws [first, first + count) of that sequence as WORLD's randn() returns them (host array), read from the table */
+int kwy_randn_stream(kwy_ctx *ctx, int64_t first, int64_t count, double *out);
 /* Per-kernel timing: when enabled, the main kernels are bracketed by HIP events
  * on the context's stream.  kwy_ctx_profile_read synchronises the stream and
  * returns the summed duration [ms] and launch count of `kernel` since the last
@@ -211,6 +219,15 @@ int kwy_decode_aperiodicity(kwy_ctx *ctx, const double *coded, int64_t T, int fs
                             double *ap);
 int kwy_decode_aperiodicity_dev(kwy_ctx *ctx, const double *coded, int64_t T, int fs, int fft_size, int bands,
                                 double *ap);
+
+/* ---- spectral-axis stretch (another number of bins at the same sampling rate) ------------------------
+ * Synthesizer._reshape_feature on log values, as reshape_spectrum_envelope / reshape_aperiodicity call it:
+ *   np.exp(scipy.signal.resample_poly(np.hstack((edge x pad, np.log(rows), edge x pad)), new_K, K, axis=1)[:, trim:-trim])
+ *                                        kwiiyatta/vocoder/abc/synthesizer.py:31-54
+ * rows: T x K (positive), out: T x new_K.  The FIR (scipy's firwin, Kaiser beta 5, 20 max(up, down) + 1 taps) is
+ * designed by the library per (K, new_K) and cached in the context. */
+int kwy_stretch_log(kwy_ctx *ctx, const double *rows, int64_t T, int K, int new_K, double *out);
+int kwy_stretch_log_dev(kwy_ctx *ctx, const double *rows, int64_t T, int K, int new_K, double *out);
 
 /* ---- MLSA differential-spectrum filter ---------------------------------------------------
  * pysptk.mc2b(mc, alpha)                                     kwiiyatta/filter/mlsa.py:28

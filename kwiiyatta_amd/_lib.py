@@ -63,6 +63,8 @@ SIGNATURES = {
     'kwy_ctx_stream': (c_vp, [c_vp]),
     'kwy_ctx_arena_generation': (c_i64, [c_vp]),
     'kwy_ctx_reserve': (c_int, [c_vp, c_i64]),
+    'kwy_ctx_set_randn_limit': (c_i64, [c_vp, c_i64]),
+    'kwy_randn_stream': (c_int, [c_vp, c_i64, c_i64, c_vp]),
     'kwy_ctx_profile': (c_int, [c_vp, c_int]),
     'kwy_ctx_debug_buffer': (c_int, [c_vp, c_vp]),
     'kwy_ctx_profile_read': (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
@@ -124,6 +126,8 @@ SIGNATURES = {
     'kwy_code_aperiodicity_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     'kwy_decode_aperiodicity': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
     'kwy_decode_aperiodicity_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
+    'kwy_stretch_log': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    'kwy_stretch_log_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     'kwy_mc2b': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_mc2b_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_mlsa_synthesis': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),
@@ -173,6 +177,10 @@ class Context:
 
     def profile(self, enable=True):
         check(self, lib.kwy_ctx_profile(self.handle, int(bool(enable))))
+
+    def set_randn_limit(self, draws=-1):
+        """use only the first `draws` entries of the device's randn table (beyond: jump-ahead); -1 = all"""
+        return int(lib.kwy_ctx_set_randn_limit(self.handle, int(draws)))
 
     def arena_generation(self):
         """changes whenever the scratch arena is relocated (captured HIP graphs of this context become invalid)"""

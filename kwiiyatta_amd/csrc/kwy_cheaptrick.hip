@@ -11,8 +11,9 @@
 //   -> exp -> HBM (coalesced, K doubles per frame)
 //
 // Algorithmic HBM bytes per frame: hop*8 (audio) + 16 (f0, t) in, K*8 out.
-// The serial xorshift "randn" stream of the CPU algorithm is reproduced with
-// per-frame jump-ahead (see kwy_ctx.hip).
+// The serial xorshift "randn" stream of the CPU algorithm is a constant: a frame
+// loads its draws from the device's table of it (jump-ahead beyond the table;
+// see kwy_device.hpp, kwy_ctx.hip).
 #include "kwy_internal.hpp"
 
 #define CT_EPS 0.00000000000000022204460492503131
@@ -43,13 +44,15 @@ template <int LOG2N>
 __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
     const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
     const double *__restrict__ f0, double q1, double f0_floor_eff,
-    const uint32_t *__restrict__ ebase, const uint4 *__restrict__ poly,
+    const uint64_t *__restrict__ offsets, kwy_randn_src rs, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN, double out_div,
     double *__restrict__ out) {
   constexpr int N = 1 << LOG2N;
   constexpr int H = N / 2;
   constexpr int K = H + 1;
-  constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;  // draws owned per thread
+  constexpr int E = N / KWY_THREADS;                           // window samples per thread: i = tid + 256 j
+  constexpr int RK = (K + KWY_THREADS - 1) / KWY_THREADS;      // spectrum bins per thread: k = tid + 256 r
+  constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;   // jump-ahead path: consecutive draws per thread
 
   // LDS: one FFT buffer (in-place radix-8 transforms; it also serves as the smoothing scratch and
   // the log-spectrum), the power spectrum, a small twiddle table: 29 KB at fft 2048
@@ -73,31 +76,53 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
 
   for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
   const kwy_c twb = twN[tid];
-  // ---- noise: this thread owns draws [C*tid, C*tid + C) of the frame's stream
-  for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
-  __syncthreads();
-  // the frame consumes wl + K draws; a thread owns c = ceil((wl + K) / 256) <= C consecutive ones
-  const int c = (wl + K + KWY_THREADS - 1) / KWY_THREADS;
-  kwy_rng rng;
-  if constexpr (sizeof(double) * (K + 1) >= 8192) {  // table-driven jump, table in the not yet used P array
-    kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)P);
-    __syncthreads();
-    rng = kwy_rng_combine_table((const uint4 *)P, poly[(c - 1) * KWY_THREADS + tid]);
-  } else {
-    rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
-  }
-  double nz[C];
+  // ---- noise: the frame consumes wl + K draws of the stream, from position offsets[frame]: draw i goes to window
+  //      sample i, draw wl + k to bin k.  They come from the table (coalesced dwords) ...
+  const uint64_t dpos = offsets[frame];
+  uint32_t rw[E], rb[RK];
+  if (dpos + (uint64_t)(wl + K) <= rs.n) {
+    const uint32_t *tp = rs.tab + dpos;
 #pragma unroll
-  for (int j = 0; j < C; ++j) nz[j] = (j < c) ? kwy_rng_randn(rng) : 0.0;
+    for (int j = 0; j < E; ++j) rw[j] = (tid + KWY_THREADS * j < wl) ? tp[tid + KWY_THREADS * j] : 0u;
+#pragma unroll
+    for (int r = 0; r < RK; ++r) rb[r] = (tid + KWY_THREADS * r <= H) ? tp[wl + tid + KWY_THREADS * r] : 0u;
+  } else {
+    // ... or, beyond it, from the generator itself: thread t jumps to draw c t and makes c consecutive ones, which
+    // travel through LDS (the still unused FFT buffer) to the threads that use them
+    kwy_rng_block_ebase(dpos, rs.pow2, e);
+    const int c = (wl + K + KWY_THREADS - 1) / KWY_THREADS;    // <= C
+    kwy_rng rng;
+    if constexpr (sizeof(double) * (K + 1) >= 8192) {  // table-driven jump, table in the not yet used P array
+      kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)P);
+      __syncthreads();
+      rng = kwy_rng_combine_table((const uint4 *)P, poly[(c - 1) * KWY_THREADS + tid]);
+    } else {
+      rng = kwy_rng_combine(e, poly[(c - 1) * KWY_THREADS + tid]);
+    }
+    uint32_t *D = (uint32_t *)bufA;                            // wl + K <= N + K words: fits (H+1) complex
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if (j < c) {
+        const uint32_t raw = kwy_rng_randn_raw(rng);
+        if (c * tid + j < wl + K) D[c * tid + j] = raw;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < E; ++j) rw[j] = (tid + KWY_THREADS * j < wl) ? D[tid + KWY_THREADS * j] : 0u;
+#pragma unroll
+    for (int r = 0; r < RK; ++r) rb[r] = (tid + KWY_THREADS * r <= H) ? D[wl + tid + KWY_THREADS * r] : 0u;
+    __syncthreads();
+  }
 
-  // ---- F0-adaptive window (thread owns samples i = c*tid + j < wl)
-  double wv[C];
+  // ---- F0-adaptive window (thread owns samples i = tid + 256 j < wl: coalesced reads of the framed audio)
+  double wv[E];
   double sumsq = 0.0;
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    int i = c * tid + j;
+  for (int j = 0; j < E; ++j) {
+    const int i = tid + KWY_THREADS * j;
     double w = 0.0;
-    if (j < c && i < wl) {
+    if (i < wl) {
       double position = (i - half) / 1.5 / fs;
       w = 0.5 * kwy_cos_pi_range(KWY_PI * position * cf0) + 0.5;   // |argument| <= pi inside the window
       sumsq += w * w;
@@ -108,14 +133,14 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   double *A = (double *)bufA;
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    int i = c * tid + j;
-    if (j < c && i < wl) {
+  for (int j = 0; j < E; ++j) {
+    const int i = tid + KWY_THREADS * j;
+    if (i < wl) {
       double wn = wv[j] / average;
       wv[j] = wn;
       int idx = min(x_length - 1, max(0, origin + i - half));
       double v = x[idx] * wn;
-      v = v + nz[j] * 0.000000000000001;
+      v = v + kwy_randn_from_raw(rw[j]) * 0.000000000000001;
       A[i] = v;
       s1 += v;
       s2 += wn;
@@ -125,9 +150,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   const double t2 = kwy_block_sum(s2, red);
   const double coef = t1 / t2;
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    int i = c * tid + j;
-    if (j < c && i < wl) A[i] -= wv[j] * coef;
+  for (int j = 0; j < E; ++j) {
+    const int i = tid + KWY_THREADS * j;
+    if (i < wl) A[i] -= wv[j] * coef;
   }
   for (int i = wl + tid; i < N; i += KWY_THREADS) A[i] = 0.0;
 
@@ -184,9 +209,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
 
   // ---- infinitesimal noise: draw wl + k belongs to bin k
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    int k = c * tid + j - wl;
-    if (j < c && k >= 0 && k <= H) P[k] = P[k] + fabs(nz[j]) * CT_EPS;
+  for (int r = 0; r < RK; ++r) {
+    const int k = tid + KWY_THREADS * r;
+    if (k <= H) P[k] = P[k] + fabs(kwy_randn_from_raw(rb[r])) * CT_EPS;
   }
   __syncthreads();
 
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
 template <int LOG2N>
 static int launch_ct(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
                      const double *f0, int64_t T, double q1, double floor_eff,
-                     const uint32_t *ebase, double out_div, double *out) {
+                     const uint64_t *offsets, double out_div, double *out) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;
   const kwy_c *twH, *twN;
@@ -243,14 +268,13 @@ static int launch_ct(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   KWY_HIP(hipFuncSetAttribute((const void *)k_cheaptrick<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_cheaptrick", hipLaunchKernelGGL(k_cheaptrick<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x,
-                     (int)x_length, fs, t, f0, q1, floor_eff, ebase, poly, twH, twN, out_div, out));
+                     (int)x_length, fs, t, f0, q1, floor_eff, offsets, kwy_randn(ctx), poly, twH, twN, out_div, out));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
 
 static size_t ct_scratch_bytes(int64_t T) {
-  return kwy_pad(sizeof(uint32_t) * T) + kwy_pad(sizeof(uint64_t) * (T + 1)) +
-         kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * T);
+  return kwy_pad(sizeof(uint64_t) * (T + 1));
 }
 
 // device-pointer core; the arena must already have room (ct_scratch_bytes)
@@ -265,16 +289,14 @@ static int cheaptrick_core(kwy_ctx *ctx, const double *x, int64_t x_length, int 
   const int K = fft_size / 2 + 1;
   const double floor_eff = 3.0 * fs / (fft_size - 3.0);
   uint64_t *offsets = kwy_arena<uint64_t>(ctx, T + 1);
-  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * T);
-  if (!offsets || !ebase) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
+  if (!offsets) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
   hipLaunchKernelGGL(k_ct_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, T, fs, floor_eff, K, offsets);
   KWY_HIP(hipGetLastError());
-  KWY_TRY(kwy_launch_ebase(ctx, offsets, nullptr, T, ebase));
   switch (log2n) {
-    case 9: return launch_ct<9>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
-    case 10: return launch_ct<10>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
-    case 11: return launch_ct<11>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
-    default: return launch_ct<12>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, ebase, out_div, out);
+    case 9: return launch_ct<9>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
+    case 10: return launch_ct<10>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
+    case 11: return launch_ct<11>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
+    default: return launch_ct<12>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
   }
 }
 

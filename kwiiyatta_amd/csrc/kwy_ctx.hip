@@ -12,7 +12,10 @@
 //     T^n S0 = sum_i c_i T^i S0, so the 256 threads of a block derive their own
 //     start states from 131 consecutive words of the block's stream.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "kwy_internal.hpp"
 
@@ -154,79 +157,73 @@ std::string g_create_err;
 
 }  // namespace
 
-// ================================================================ shared kernels
-// offsets[i] = exclusive prefix sum of counts (single block, chunk per thread)
-__global__ __launch_bounds__(KWY_THREADS) void k_scan_u32(const uint32_t *__restrict__ counts,
-                                                         uint64_t *__restrict__ offsets, int64_t n) {
-  __shared__ uint64_t tot[KWY_THREADS];
-  const int t = threadIdx.x;
-  const int64_t chunk = (n + KWY_THREADS - 1) / KWY_THREADS;
-  const int64_t b0 = t * chunk, b1 = min(n, b0 + chunk);
-  uint64_t run = 0;
-  for (int64_t i = b0; i < b1; ++i) run += counts[i];
-  tot[t] = run;
+// ================================================================ the randn table
+// The first 2^L raw draws of WORLD's stream, once per device and process (kwy_device.hpp: kwy_randn_src).  A
+// workgroup fills KWY_TABLE_CHUNK consecutive draws: it jumps to the chunk's stream position, every thread derives the
+// state of "its" 16 draws from the chunk's extended sequence (jump table in LDS) and steps through them.
+#define KWY_TABLE_PER_THREAD 16
+#define KWY_TABLE_CHUNK (KWY_THREADS * KWY_TABLE_PER_THREAD)
+__global__ __launch_bounds__(KWY_THREADS) void k_rng_table_fill(uint32_t *__restrict__ tab,
+                                                               const uint4 *__restrict__ pow2,
+                                                               const uint4 *__restrict__ poly) {
+  __shared__ uint32_t e[KWY_EBASE_WORDS];
+  __shared__ uint4 jtab[512];
+  const uint64_t first = (uint64_t)blockIdx.x * KWY_TABLE_CHUNK;
+  kwy_rng_block_ebase(first, pow2, e);
+  kwy_rng_build_table<KWY_THREADS>(e, jtab);
   __syncthreads();
-  if (t == 0) {
-    uint64_t acc = 0;
-    for (int i = 0; i < KWY_THREADS; ++i) { uint64_t v = tot[i]; tot[i] = acc; acc += v; }
-  }
-  __syncthreads();
-  run = tot[t];
-  for (int64_t i = b0; i < b1; ++i) { offsets[i] = run; run += counts[i]; }
-  if (b0 < n && b1 == n) offsets[n] = run;
-  if (n == 0 && t == 0) offsets[0] = 0;
+  kwy_rng rng = kwy_rng_combine_table(jtab, poly[threadIdx.x]);   // poly: x^(12 * 16 * t) mod P
+  uint32_t v[KWY_TABLE_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < KWY_TABLE_PER_THREAD; ++j) v[j] = kwy_rng_randn_raw(rng);
+  uint4 *o = (uint4 *)(tab + first + (uint64_t)threadIdx.x * KWY_TABLE_PER_THREAD);
+#pragma unroll
+  for (int q = 0; q < KWY_TABLE_PER_THREAD / 4; ++q) o[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-// Per item: jump the seed state by 12*(base+offsets[i]) steps, then emit the 131-word extended sequence of that
-// state.  The jump is wavefront-cooperative (128 matrix columns over 64 lanes), the emission is a serial recurrence
-// that one lane has to run: a workgroup takes KWY_EBASE_ITEMS items, every wavefront jumps a quarter of them one
-// after the other and leaves the states in LDS, then KWY_EBASE_ITEMS lanes of wavefront 0 emit all sequences side by
-// side (one lane per item used to emit alone while its 63 neighbours idled: 2.5x the instructions).
-#define KWY_EBASE_ITEMS 16
-__global__ __launch_bounds__(KWY_THREADS) void k_rng_ebase(const uint64_t *__restrict__ offsets,
-                                                          const uint64_t *__restrict__ base_ptr, int64_t n,
-                                                          const uint4 *__restrict__ pow2,
-                                                          uint32_t *__restrict__ ebase) {
-  __shared__ uint32_t st[KWY_EBASE_ITEMS][4];
-  __shared__ int live[KWY_EBASE_ITEMS];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t item0 = (int64_t)blockIdx.x * KWY_EBASE_ITEMS;
-  const uint64_t base_draws = base_ptr ? *base_ptr : 0ull;
-  constexpr int PER_WAVE = KWY_EBASE_ITEMS / KWY_WAVES;
-  for (int f = 0; f < PER_WAVE; ++f) {
-    const int slot = wv * PER_WAVE + f;
-    const int64_t item = item0 + slot;
-    const bool has = item < n && offsets[item] != ~0ull;   // ~0: item without draws
-    if (has) {
-      uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
-      kwy_wave_jump(s, 12ull * (base_draws + offsets[item]), pow2);
-      if (lane == 0) { st[slot][0] = s[0]; st[slot][1] = s[1]; st[slot][2] = s[2]; st[slot][3] = s[3]; }
+namespace {
+struct RandnTable { uint32_t *d = nullptr; uint64_t n = 0; bool tried = false; };
+std::mutex g_randn_mutex;
+std::map<int, RandnTable> g_randn;   // per device; lives as long as the process
+
+// log2 of the table length in draws: KWY_RANDN_LOG2 in the environment (12 ... 30; 0 = no table), default 25 =
+// 128 MB, which covers D4C of a 10 s utterance at 48 kHz down to a mean f0 of about 70 Hz (8 - 9 M draws at 140 Hz).
+int randn_table_log2() {
+  const char *v = getenv("KWY_RANDN_LOG2");
+  if (!v || !*v) return 25;
+  const int l = atoi(v);
+  if (l <= 0) return 0;
+  return l < 12 ? 12 : (l > 30 ? 30 : l);
+}
+}  // namespace
+
+static int kwy_attach_randn_table(kwy_ctx *ctx) {
+  std::lock_guard<std::mutex> lock(g_randn_mutex);
+  RandnTable &t = g_randn[ctx->device];
+  if (!t.tried) {
+    t.tried = true;
+    const int l = randn_table_log2();
+    if (l > 0) {
+      const uint64_t n = 1ull << l;
+      const uint4 *poly;
+      KWY_TRY(kwy_get_poly(ctx, 12ull * KWY_TABLE_PER_THREAD, &poly));
+      uint32_t *d = nullptr;
+      if (hipMalloc((void **)&d, sizeof(uint32_t) * n) != hipSuccess) {
+        (void)hipGetLastError();   // no room for the table: every draw comes from the jump-ahead path
+        ctx->d_randn = nullptr;
+        ctx->randn_n = 0;
+        return KWY_OK;
+      }
+      hipLaunchKernelGGL(k_rng_table_fill, dim3((unsigned)(n / KWY_TABLE_CHUNK)), dim3(KWY_THREADS), 0, ctx->stream, d,
+                         ctx->d_pow2, poly);
+      KWY_HIP(hipGetLastError());
+      KWY_HIP(hipStreamSynchronize(ctx->stream));
+      t.d = d;
+      t.n = n;
     }
-    if (lane == 0) live[slot] = has ? 1 : 0;
   }
-  __syncthreads();
-  if (threadIdx.x < KWY_EBASE_ITEMS && live[threadIdx.x]) {
-    kwy_rng r = {st[threadIdx.x][0], st[threadIdx.x][1], st[threadIdx.x][2], st[threadIdx.x][3]};
-    uint32_t *e = ebase + (item0 + threadIdx.x) * KWY_EBASE_WORDS;
-    e[0] = r.x; e[1] = r.y; e[2] = r.z; e[3] = r.w;
-    for (int i = 4; i < 131; ++i) e[i] = kwy_rng_step(r);
-    e[131] = 0;
-  }
-}
-
-int kwy_launch_scan(kwy_ctx *ctx, const uint32_t *counts, uint64_t *offsets, int64_t n) {
-  hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, counts, offsets, n);
-  KWY_HIP(hipGetLastError());
-  return KWY_OK;
-}
-
-int kwy_launch_ebase(kwy_ctx *ctx, const uint64_t *offsets, const uint64_t *base_draws, int64_t n,
-                     uint32_t *ebase) {
-  if (n <= 0) return KWY_OK;
-  int blocks = (int)((n + KWY_EBASE_ITEMS - 1) / KWY_EBASE_ITEMS);
-  hipLaunchKernelGGL(k_rng_ebase, dim3(blocks), dim3(KWY_THREADS), 0, ctx->stream, offsets,
-                     base_draws, n, ctx->d_pow2, ebase);
-  KWY_HIP(hipGetLastError());
+  ctx->d_randn = t.d;
+  ctx->randn_n = t.n;
   return KWY_OK;
 }
 
@@ -361,6 +358,11 @@ int kwy_ctx_create(int device, void *stream, kwy_ctx **out) {
     delete ctx;
     return KWY_EHIP;
   }
+  if (kwy_attach_randn_table(ctx) != KWY_OK) {
+    g_create_err = "randn table: " + ctx->err;
+    kwy_ctx_destroy(ctx);
+    return KWY_EHIP;
+  }
   *out = ctx;
   return KWY_OK;
 }
@@ -393,6 +395,24 @@ int kwy_ctx_reserve(kwy_ctx *ctx, int64_t bytes) {
   if (!ctx || bytes < 0) return KWY_EINVAL;
   KWY_HIP(hipSetDevice(ctx->device));
   return kwy_arena_begin(ctx, (size_t)bytes);
+}
+
+int64_t kwy_ctx_set_randn_limit(kwy_ctx *ctx, int64_t draws) {
+  if (!ctx) return -1;
+  std::lock_guard<std::mutex> lock(g_randn_mutex);
+  const uint64_t have = g_randn[ctx->device].n;
+  ctx->randn_n = draws < 0 ? have : ((uint64_t)draws < have ? (uint64_t)draws : have);
+  return (int64_t)ctx->randn_n;
+}
+
+int kwy_randn_stream(kwy_ctx *ctx, int64_t first, int64_t count, double *out) {
+  if (!ctx || !out || first < 0 || count < 0) return KWY_EINVAL;
+  if ((uint64_t)(first + count) > ctx->randn_n) { ctx->err = "randn_stream: beyond the table"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  std::vector<uint32_t> raw((size_t)count);
+  KWY_HIP(hipMemcpy(raw.data(), ctx->d_randn + first, sizeof(uint32_t) * (size_t)count, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < count; ++i) out[i] = raw[(size_t)i] / 268435456.0 - 6.0;
+  return KWY_OK;
 }
 
 int kwy_ctx_debug_buffer(kwy_ctx *ctx, void *device_buffer) {

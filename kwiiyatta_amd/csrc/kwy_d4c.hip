@@ -138,7 +138,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_body_scan(const double *__r
 template <int LOG2N, int NT>
 __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
     const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
-    const double *__restrict__ f0, const uint32_t *__restrict__ ebase,
+    const double *__restrict__ f0, const uint64_t *__restrict__ offsets, kwy_randn_src rs,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     double *__restrict__ ap0) {
   constexpr int N = 1 << LOG2N, H = N / 2;
@@ -166,24 +166,34 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
   kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
   const kwy_c twb = twN[tid];
 
-  for (int i = tid; i < KWY_EBASE_WORDS; i += NT) e[i] = ebase[frame * KWY_EBASE_WORDS + i];
-  __syncthreads();
-  // this thread draws the c noise values [c*tid, c*tid + c) of the frame (c adapts to the window)
-  const int c = (wl + NT - 1) / NT;
-  kwy_rng_build_table<NT>(e, (uint4 *)B);
-  __syncthreads();
-  kwy_rng rng = kwy_rng_combine_table((const uint4 *)B, poly[(c - 1) * NT + tid]);
-  __syncthreads();  // the table is consumed: the buffer takes the draws
+  // the frame's wl noise draws (stream position offsets[frame]): sample i = tid + NT r takes draw i
+  uint32_t raw[C];
+  const uint64_t dpos = offsets[frame];
+  if (dpos + (uint64_t)wl <= rs.n) {
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    if (j < c) {
-      int d = c * tid + j;
-      double nzv = kwy_rng_randn(rng);
-      if (d < wl) Bd[d] = nzv;
+    for (int r = 0; r < C; ++r) raw[r] = (tid + NT * r < wl) ? rs.tab[dpos + tid + NT * r] : 0u;
+  } else {
+    // beyond the table: thread t jumps to draw c t and makes c consecutive ones (c adapts to the window)
+    kwy_rng_block_ebase(dpos, rs.pow2, e);
+    const int c = (wl + NT - 1) / NT;
+    kwy_rng_build_table<NT>(e, (uint4 *)B);
+    __syncthreads();
+    kwy_rng rng = kwy_rng_combine_table((const uint4 *)B, poly[(c - 1) * NT + tid]);
+    __syncthreads();  // the table is consumed: the buffer takes the draws
+    uint32_t *D = (uint32_t *)B;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      if (j < c) {
+        const uint32_t v = kwy_rng_randn_raw(rng);
+        if (c * tid + j < wl) D[c * tid + j] = v;
+      }
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < C; ++r) raw[r] = (tid + NT * r < wl) ? D[tid + NT * r] : 0u;
+    __syncthreads();
   }
-  __syncthreads();
-  // sample i = tid + 256 r: the draw in Bd[i] is replaced by the window value, the sample waits in a register
+  // sample i = tid + NT r: the window value goes to Bd[i], the sample waits in a register
   double vv[C];
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
       double w = d4c_window(D4C_BLACKMAN, i, half, 3.0, fs, cf0);
       int idx = min(x_length - 1, max(0, origin + i - half));
       v = x[idx] * w;
-      v = v + Bd[i] * D4C_SAFE;
+      v = v + kwy_randn_from_raw(raw[r]) * D4C_SAFE;
       Bd[i] = w;
       s1 += v; s2 += w;
     }
@@ -239,13 +249,13 @@ struct d4c_params {
 // One WORLD window of the frame: x around `pos`, times the window function, plus the
 // safeguard noise, DC removed with the window as weight.  Element i = tid + NT*r
 // stays in av[r] (0 beyond the window).  The window's wl noise draws are a contiguous piece
-// of the serial stream; `eb` holds the generator's extended state sequence at the piece's
-// start, thread t jumps to draw c*t and produces c = ceil(wl/NT) draws, which travel through
+// of the serial stream starting at draw `dpos`: element i takes draw i, from the table; beyond the
+// table thread t jumps to draw c*t and produces c = ceil(wl/NT) draws, which travel through
 // Bd (N doubles of LDS, free on entry) to the threads that use them.  `normalise` scales to
 // unit power (GetCentroid).
 template <int N, int NT>
 __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
-                                                 double pos, int type, const uint32_t *__restrict__ eb,
+                                                 double pos, int type, uint64_t dpos, const kwy_randn_src &rs,
                                                  const uint4 *__restrict__ poly, uint32_t *e, uint4 *jtab,
                                                  double *Bd, bool normalise, double *red,
                                                  double (&av)[N / NT]) {
@@ -258,30 +268,36 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, c
   const int half = kwy_matlab_round(4.0 * p.fs / cf0 / 2.0);
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(pos * p.fs + 0.001);
-  // the samples are independent of the noise: get them on their way first
+  // samples and draws are independent loads: get both on their way first
   double xv[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = tid + NT * r;
     xv[r] = (i < wl) ? x[min(p.x_length - 1, max(0, origin + i - half))] : 0.0;
   }
-  for (int i = tid; i < KWY_EBASE_WORDS; i += NT) e[i] = eb[i];
-  __syncthreads();
-  kwy_rng_build_table<NT>(e, jtab);
-  __syncthreads();
-  {
+  uint32_t raw[E];
+  if (dpos + (uint64_t)wl <= rs.n) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) raw[r] = (tid + NT * r < wl) ? rs.tab[dpos + tid + NT * r] : 0u;
+  } else {
+    kwy_rng_block_ebase(dpos, rs.pow2, e);
+    kwy_rng_build_table<NT>(e, jtab);
+    __syncthreads();
     const int c = (wl + NT - 1) / NT;  // <= E
     kwy_rng rng = kwy_rng_combine_table(jtab, poly[(c - 1) * NT + tid]);
+    uint32_t *D = (uint32_t *)Bd;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
       if (j < c) {
-        const double nzv = kwy_rng_randn(rng);
-        const int d = c * tid + j;
-        if (d < wl) Bd[d] = nzv;
+        const uint32_t v = kwy_rng_randn_raw(rng);
+        if (c * tid + j < wl) D[c * tid + j] = v;
       }
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) raw[r] = (tid + NT * r < wl) ? D[tid + NT * r] : 0u;
+    __syncthreads();
   }
-  __syncthreads();
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -290,8 +306,8 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, c
     if (i < wl) {
       const double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
       v = xv[r] * w;
-      v = v + Bd[i] * D4C_SAFE;
-      Bd[i] = w;                       // the window value takes the place of the consumed draw
+      v = v + kwy_randn_from_raw(raw[r]) * D4C_SAFE;
+      Bd[i] = w;                       // kept for the DC removal below (only this thread reads it)
       s1 += v; s2 += w;
     }
     av[r] = v;
@@ -415,7 +431,8 @@ static constexpr size_t d4c_body_lds() {
 template <int LOG2N>
 __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d4c_body(
     const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
-    const double *__restrict__ ap0, d4c_params p, const uint32_t *__restrict__ ebase,
+    const double *__restrict__ ap0, d4c_params p, const uint64_t *__restrict__ offs3,
+    const uint64_t *__restrict__ draws_before, kwy_randn_src rs,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     double *__restrict__ dvbuf, double *__restrict__ out, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
@@ -454,7 +471,9 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
   // exp(-2 pi i k / N) of "my" spectrum bins k = tid + NT*r is this times a 16th root of unity
   const kwy_c twb = twN[tid];
-  const uint32_t *eb = ebase + (size_t)frame * 3 * KWY_EBASE_WORDS;  // one extended state per window
+  // stream positions of the frame's three windows: the body's noise continues where the LoveTrain pass stopped
+  const uint64_t dbase = *draws_before;
+  const uint64_t dpos0 = dbase + offs3[3 * frame], dpos1 = dbase + offs3[3 * frame + 1], dpos2 = dbase + offs3[3 * frame + 2];
 
   D4C_STAMP(1);
   // ---- static centroid: two temporal centroids at pos -+ 0.25/f0, each Re(X2 conj X1) of the
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     for (int which = 0; which < 2; ++which) {
       const int tid = kwy_tid_opaque();
       double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-      d4c_frame_window<N, NT>(x, p, cf0, cpos, D4C_BLACKMAN, eb + which * KWY_EBASE_WORDS, poly, e, jtab, Bd, true, red, av);
+      d4c_frame_window<N, NT>(x, p, cf0, cpos, D4C_BLACKMAN, which == 0 ? dpos0 : dpos1, rs, poly, e, jtab, Bd, true, red, av);
 #pragma unroll
       for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];   // each thread overwrites the draws it consumed
       __syncthreads();
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
 
     D4C_STAMP(6);
     // ---- smoothed power spectrum (the centroid sum waits in registers)
-    d4c_frame_window<N, NT>(x, p, cf0, pos, D4C_HANNING, eb + 2 * KWY_EBASE_WORDS, poly, e, jtab, Bd, false, red, av);
+    d4c_frame_window<N, NT>(x, p, cf0, pos, D4C_HANNING, dpos2, rs, poly, e, jtab, Bd, false, red, av);
 #pragma unroll
     for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];
     __syncthreads();
@@ -686,7 +705,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
 // ------------------------------------------------------------------ host side
 template <int LOG2N>
 static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
-                     const double *f0, int64_t T, const uint32_t *ebase, double *ap0) {
+                     const double *f0, int64_t T, const uint64_t *offsets, double *ap0) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   const kwy_c *twH, *twN;
   const uint4 *poly;
@@ -698,15 +717,15 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N, NT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_d4c_lovetrain", hipLaunchKernelGGL((k_d4c_lovetrain<LOG2N, NT>), dim3((unsigned)T), dim3(NT), lds, ctx->stream,
-                     x, (int)x_length, fs, t, f0, ebase, poly, twH, twN, ap0));
+                     x, (int)x_length, fs, t, f0, offsets, kwy_randn(ctx), poly, twH, twN, ap0));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
 
 template <int LOG2N>
 static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const double *f0,
-                       const double *ap0, const d4c_params &p, int64_t T, const uint32_t *ebase,
-                       const double *nuttall, double *dvbuf, double *out) {
+                       const double *ap0, const d4c_params &p, int64_t T, const uint64_t *offs3,
+                       const uint64_t *draws_before, const double *nuttall, double *dvbuf, double *out) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   const kwy_c *twH, *twN;
   const uint4 *poly;
@@ -718,7 +737,7 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(NT), lds, ctx->stream, x, t,
-                     f0, ap0, p, ebase, poly, twH, twN, dvbuf, out, (long long *)ctx->dbg));
+                     f0, ap0, p, offs3, draws_before, kwy_randn(ctx), poly, twH, twN, dvbuf, out, (long long *)ctx->dbg));
   const size_t lds_b = d4c_bands_lds<LOG2N>();
   if (p.window_length <= 2 * (H / 8) + 1) {
     KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_bands<LOG2N, true>,
@@ -760,9 +779,8 @@ static int d4c_fft_size(int fs) {
 
 static size_t d4c_scratch_bytes(int64_t T, int fs) {
   const size_t H = (size_t)d4c_fft_size(fs) / 2;
-  return kwy_pad(sizeof(double) * (size_t)T * (H + 1)) + 2 * (kwy_pad(sizeof(uint32_t) * T) + kwy_pad(sizeof(uint64_t) * (T + 1))) +
-         kwy_pad(sizeof(uint64_t) * 3 * T) + kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * 3 * T) +
-         kwy_pad(sizeof(double) * T);
+  return kwy_pad(sizeof(double) * (size_t)T * (H + 1)) + 2 * kwy_pad(sizeof(uint64_t) * (T + 1)) +
+         kwy_pad(sizeof(uint64_t) * 3 * T) + kwy_pad(sizeof(double) * T);
 }
 
 static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
@@ -790,33 +808,30 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   uint64_t *offs_lt = kwy_arena<uint64_t>(ctx, T + 1);
   uint64_t *offs_b = kwy_arena<uint64_t>(ctx, T + 1);
   uint64_t *offs3 = kwy_arena<uint64_t>(ctx, 3 * T);
-  uint32_t *ebase = kwy_arena<uint32_t>(ctx, (size_t)KWY_EBASE_WORDS * 3 * T);
   double *ap0 = kwy_arena<double>(ctx, T);
   double *dvbuf = kwy_arena<double>(ctx, (size_t)T * (n4 / 2 + 1));
-  if (!dvbuf || !offs_lt || !offs_b || !offs3 || !ebase || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
+  if (!dvbuf || !offs_lt || !offs_b || !offs3 || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
   const double *nuttall;
   KWY_TRY(get_nuttall(ctx, p.window_length, &nuttall));
 
   // LoveTrain pass
   hipLaunchKernelGGL(k_d4c_lt_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, T, fs, offs_lt);
   KWY_HIP(hipGetLastError());
-  KWY_TRY(kwy_launch_ebase(ctx, offs_lt, nullptr, T, ebase));
   switch (ll) {
-    case 10: KWY_TRY(launch_lt<10>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
-    case 11: KWY_TRY(launch_lt<11>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
-    case 12: KWY_TRY(launch_lt<12>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
-    default: KWY_TRY(launch_lt<13>(ctx, x, x_length, fs, t, f0, T, ebase, ap0)); break;
+    case 10: KWY_TRY(launch_lt<10>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
+    case 11: KWY_TRY(launch_lt<11>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
+    case 12: KWY_TRY(launch_lt<12>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
+    default: KWY_TRY(launch_lt<13>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
   }
-  // general body; its noise continues where the LoveTrain pass stopped (offs_lt[T])
+  // general body; its noise continues where the LoveTrain pass stopped (offs_lt[T], read by the kernel)
   hipLaunchKernelGGL(k_d4c_body_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, ap0, T, fs, threshold, offs_b,
                      offs3);
   KWY_HIP(hipGetLastError());
-  KWY_TRY(kwy_launch_ebase(ctx, offs3, offs_lt + T, 3 * T, ebase));
   switch (l4) {
-    case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
-    case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
-    case 12: return launch_body<12>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
-    default: return launch_body<13>(ctx, x, t, f0, ap0, p, T, ebase, nuttall, dvbuf, out);
+    case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
+    case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
+    case 12: return launch_body<12>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
+    default: return launch_body<13>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
   }
 }
 

@@ -106,6 +106,23 @@ __device__ __forceinline__ kwy_rng kwy_rng_combine(const uint32_t *e, uint4 c) {
   return r;
 }
 
+// ---------------------------------------------------------------- the randn stream as a table
+// WORLD reseeds its generator at the entry of CheapTrick, D4C and Synthesis, so draw i of the stream is the same
+// number in every call, for every utterance: the first `n` raw 12-step sums live in one process-wide table per
+// device (kwy_ctx.hip), and a consumer that knows the stream position of its piece loads the draws -- coalesced
+// dwords, shared by all streams through the 256 MiB Infinity Cache -- instead of jumping the generator and stepping
+// it (which was a quarter of the D4C stage's instructions).  Pieces that reach beyond the table fall back to the
+// GF(2) jump-ahead below, inside the consumer (kwy_rng_block_ebase + jump table + 12 steps per draw): same draws.
+struct kwy_randn_src {
+  const uint32_t *tab;   // raw sums of draws [0, n)
+  uint64_t n;
+  const uint4 *pow2;     // [64][128] columns of T^(2^k), for the positions beyond the table
+};
+
+__device__ __forceinline__ double kwy_randn_from_raw(uint32_t raw) {
+  return raw * 3.7252902984619140625e-09 - 6.0;   // raw / 2^28 - 6, exactly as the division
+}
+
 // threadIdx.x behind an optimisation barrier: address arithmetic derived from it is redone where it
 // is used instead of being computed once per kernel and carried (spilled) across every phase.
 __device__ __forceinline__ int kwy_tid_opaque() {
@@ -154,6 +171,22 @@ __device__ __forceinline__ kwy_rng kwy_rng_combine_table(const uint4 *tab, uint4
     }
   }
   return r;
+}
+
+// Fallback beyond the randn table: the extended word sequence e[0..131] (LDS) of the stream position `pos` (in draws),
+// made by the workgroup itself -- wavefront 0 jumps the seed state, its lane 0 runs the 127-step recurrence, the
+// others wait.  Slow (about 3 k instruction times), which is why the table should cover the utterance.
+// Ends with a barrier.
+__device__ inline void kwy_rng_block_ebase(uint64_t pos, const uint4 *__restrict__ pow2, uint32_t *e) {
+  if (threadIdx.x < 64) {
+    uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+    kwy_wave_jump(s, 12ull * pos, pow2);
+    if (threadIdx.x == 0) {
+      kwy_rng r = {s[0], s[1], s[2], s[3]};
+      kwy_rng_ebase(r, e);
+    }
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------ cos on [-pi, pi]

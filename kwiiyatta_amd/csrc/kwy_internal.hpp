@@ -25,6 +25,8 @@ struct kwy_ctx {
 
   // constant tables
   uint4 *d_pow2 = nullptr;                 // [64][128] columns of T^(2^k)
+  const uint32_t *d_randn = nullptr;       // the device's table of WORLD's randn stream (shared by all contexts)
+  uint64_t randn_n = 0;                    // draws of it this context uses (kwy_ctx_set_randn_limit lowers it)
   kwy_c *d_tw[20] = {nullptr};             // d_tw[l]: exp(-2 pi i k / 2^l), k < 2^l
   std::map<uint64_t, uint4 *> d_poly;      // stride(steps) -> x^(stride*t) mod P, t < 256
   std::map<std::string, double *> d_mats;  // cached host-built matrices (mcep etc.)
@@ -90,13 +92,10 @@ int kwy_get_poly(kwy_ctx *ctx, uint64_t stride_steps, const uint4 **out);
 // [max_c][nthreads] table: row c-1 holds x^(12*c*t) mod P, t < nthreads (chunk of c draws per thread)
 int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, int nthreads, const uint4 **out);
 
-// --- shared small kernels (kwy_ctx.hip) --------------------------------------
-// offsets[i] = sum_{j<i} counts[j] (u32 -> u64), single block
-int kwy_launch_scan(kwy_ctx *ctx, const uint32_t *counts, uint64_t *offsets, int64_t n);
-// ebase[i][0..131] for the generator state after 12*(*base + offsets[i]) steps
-// (base_draws: device pointer to a draw count, or NULL for 0)
-int kwy_launch_ebase(kwy_ctx *ctx, const uint64_t *offsets, const uint64_t *base_draws, int64_t n,
-                     uint32_t *ebase);
+// the context's view of the randn stream: table, usable length, jump matrices
+static inline kwy_randn_src kwy_randn(const kwy_ctx *ctx) {
+  return kwy_randn_src{ctx->d_randn, ctx->randn_n, ctx->d_pow2};
+}
 
 static inline int kwy_ilog2(int n) {
   int l = 0;

@@ -7,7 +7,8 @@
 //                 device-wide f64 scan (tile sums -> scan -> tile rescan),
 //                 pulse detection + ordered compaction          (5 tiny kernels)
 //   noise       : pulse p starts (idx[p]-idx[0]) draws into the serial randn
-//                 stream -> per-pulse jump-ahead                    (1 kernel)
+//                 stream -> read from the device's table of that stream
+//                 (jump-ahead inside the pulse kernel beyond the table)
 //   per pulse   : one 256-thread workgroup: interpolate the two neighbouring
 //                 spectral/aperiodicity frames (coalesced HBM reads), build the
 //                 minimum-phase periodic and aperiodic responses with LDS FFTs,
@@ -462,38 +463,6 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_emit(const double *__
   }
 }
 
-// per-pulse generator state: (idx[p] - idx[0]) draws into the stream
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_ebase(const int32_t *__restrict__ pidx,
-                                                          const int *__restrict__ npulse, int cap,
-                                                          const uint4 *__restrict__ pow2,
-                                                          uint32_t *__restrict__ ebase) {
-  // as k_rng_ebase (kwy_ctx.hip): the wavefronts jump SYN_EBASE_ITEMS pulses' states, 16 lanes emit them side by side
-  constexpr int ITEMS = 16, PER_WAVE = ITEMS / KWY_WAVES;
-  __shared__ uint32_t st[ITEMS][4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int P = min(npulse[0], cap);
-  const int first = pidx[0];
-  for (int p0 = blockIdx.x * ITEMS; p0 < P; p0 += gridDim.x * ITEMS) {
-    for (int f = 0; f < PER_WAVE; ++f) {
-      const int slot = wv * PER_WAVE + f;
-      if (p0 + slot < P) {
-        uint32_t s[4] = {123456789u, 362436069u, 521288629u, 88675123u};
-        kwy_wave_jump(s, 12ull * (uint64_t)(pidx[p0 + slot] - first), pow2);
-        if (lane == 0) { st[slot][0] = s[0]; st[slot][1] = s[1]; st[slot][2] = s[2]; st[slot][3] = s[3]; }
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < ITEMS && p0 + (int)threadIdx.x < P) {
-      kwy_rng r = {st[threadIdx.x][0], st[threadIdx.x][1], st[threadIdx.x][2], st[threadIdx.x][3]};
-      uint32_t *e = ebase + (int64_t)(p0 + threadIdx.x) * KWY_EBASE_WORDS;
-      e[0] = r.x; e[1] = r.y; e[2] = r.z; e[3] = r.w;
-      for (int i = 4; i < 131; ++i) e[i] = kwy_rng_step(r);
-      e[131] = 0;
-    }
-    __syncthreads();
-  }
-}
-
 // Minimum-phase spectrum (common.cpp GetMinimumPhaseSpectrum), in place: buf holds the half
 // log-spectrum L[0..H] as reals on entry and M[0..H] on return.  (The ~1e-17 imaginary rounding
 // residue of the real cepstrum that the CPU code carries along is dropped.)
@@ -554,7 +523,7 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
     const double *__restrict__ sp, const double *__restrict__ ap, syn_params p,
     const int32_t *__restrict__ pidx, const double *__restrict__ pshift,
     const unsigned char *__restrict__ vuv8, const int *__restrict__ npulse, int cap,
-    const uint32_t *__restrict__ ebase, const uint4 *__restrict__ poly,
+    kwy_randn_src rs, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     const double *__restrict__ dc_remover, int first_pulse, int slots, double *__restrict__ resp,
     double *__restrict__ y) {
@@ -586,8 +555,6 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
     const double current_vuv = vuv8[idx] ? 1.0 : 0.0;
     const double current_time = idx / (double)p.fs;
     const double shift = pshift[pp];
-
-    for (int i = tid; i < KWY_EBASE_WORDS; i += KWY_THREADS) e[i] = ebase[(int64_t)pp * KWY_EBASE_WORDS + i];
 
     // ---- spectral envelope / aperiodic ratio at the pulse time
     int fl = (int)floor(current_time / p.frame_period);
@@ -644,30 +611,47 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
     // ---- aperiodic response
     {
       const int tid = kwy_tid_opaque();
-      // jump table of this pulse's stream position (8 KB), built in the currently idle FFT buffer
-      // when that is large enough
-      kwy_rng rng;
-      if constexpr (sizeof(kwy_c) * (H + 1) >= 8192) {
-        kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)buf);
-        __syncthreads();
-        rng = kwy_rng_combine_table((const uint4 *)buf, poly[tid]);
+      // the pulse's noise: draws [dpos, dpos + noise_size) of the stream, dpos = idx - idx[0] (the serial code draws
+      // noise_size numbers per pulse); sample d = tid + 256 j takes draw d -- from the table, or beyond it from the
+      // generator (jump table of the pulse's stream position in the currently idle FFT buffer, thread t makes the C
+      // consecutive draws from C t on, which travel through LDS)
+      const uint64_t dpos = (uint64_t)(idx - pidx[0]);
+      uint32_t raw[C];
+      if (dpos + (uint64_t)ns_used <= rs.n) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) raw[j] = (tid + KWY_THREADS * j < ns_used) ? rs.tab[dpos + tid + KWY_THREADS * j] : 0u;
       } else {
-        rng = kwy_rng_combine(e, poly[tid]);
+        kwy_rng_block_ebase(dpos, rs.pow2, e);
+        kwy_rng rng;
+        if constexpr (sizeof(kwy_c) * (H + 1) >= 8192) {
+          kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)buf);
+          __syncthreads();
+          rng = kwy_rng_combine_table((const uint4 *)buf, poly[tid]);
+          __syncthreads();
+        } else {
+          rng = kwy_rng_combine(e, poly[tid]);
+        }
+        uint32_t *D = (uint32_t *)buf;
+#pragma unroll
+        for (int j = 0; j < C; ++j) D[C * tid + j] = kwy_rng_randn_raw(rng);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < C; ++j) raw[j] = D[tid + KWY_THREADS * j];
+        __syncthreads();
       }
       double *A = (double *)buf;
       double nv[C];
       double sum = 0.0;
 #pragma unroll
       for (int j = 0; j < C; ++j) {
-        int d = C * tid + j;
-        double v = kwy_rng_randn(rng);
-        nv[j] = v;
-        if (d < ns_used) sum += v;
+        const int d = tid + KWY_THREADS * j;
+        nv[j] = kwy_randn_from_raw(raw[j]);
+        if (d < ns_used) sum += nv[j];
       }
       const double average = kwy_block_sum(sum, red) / noise_size;
 #pragma unroll
       for (int j = 0; j < C; ++j) {
-        int d = C * tid + j;
+        const int d = tid + KWY_THREADS * j;
         A[d] = (d < ns_used) ? nv[j] - average : 0.0;
       }
       __syncthreads();
@@ -788,7 +772,7 @@ static int get_dc_remover(kwy_ctx *ctx, int fft_size, const double **out) {
 template <int LOG2N>
 static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const syn_params &p,
                         const int32_t *pidx, const double *pshift, const unsigned char *vuv8,
-                        const int *npulse, int cap, const uint32_t *ebase, const double *dcrem,
+                        const int *npulse, int cap, const double *dcrem,
                         const int *tile_off, int nt, int slots, double *resp, double *y) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   const kwy_c *twH, *twN;
@@ -805,12 +789,12 @@ static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const 
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL((k_syn_pulse<LOG2N, false>), dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
-                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, 0, slots, resp, y));
+                     pidx, pshift, vuv8, npulse, cap, kwy_randn(ctx), poly, twH, twN, dcrem, 0, slots, resp, y));
   KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, resp, pidx, tile_off,
                      npulse, cap, nt, N, 0, slots, p.y_length, y));
   // pulses beyond the slots (none for speech): one workgroup, serial, same order
   KWY_PROF(ctx, "k_syn_pulse_more", hipLaunchKernelGGL((k_syn_pulse<LOG2N, true>), dim3(1), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
-                     pidx, pshift, vuv8, npulse, cap, ebase, poly, twH, twN, dcrem, slots, cap, resp, y));
+                     pidx, pshift, vuv8, npulse, cap, kwy_randn(ctx), poly, twH, twN, dcrem, slots, cap, resp, y));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -835,14 +819,13 @@ struct syn_plan {
   unsigned char *vuv8;     // y_length
   int32_t *pidx;           // cap
   double *pshift;          // cap
-  uint32_t *ebase;         // cap x KWY_EBASE_WORDS
 };
 
 static size_t syn_plan_bytes(int64_t y_length) {
   const int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
   const int cap = syn_pulse_cap(y_length);
   return kwy_pad(64) + kwy_pad(sizeof(int) * (nt + 1)) + kwy_pad(y_length) + kwy_pad(sizeof(int32_t) * cap) +
-         kwy_pad(sizeof(double) * cap) + kwy_pad(sizeof(uint32_t) * KWY_EBASE_WORDS * (size_t)cap);
+         kwy_pad(sizeof(double) * cap);
 }
 
 static syn_plan syn_plan_carve(void *buffer, int64_t y_length) {
@@ -854,8 +837,7 @@ static syn_plan syn_plan_carve(void *buffer, int64_t y_length) {
   pl.tile_cnt = (int *)q; q += kwy_pad(sizeof(int) * (nt + 1));
   pl.vuv8 = (unsigned char *)q; q += kwy_pad(y_length);
   pl.pidx = (int32_t *)q; q += kwy_pad(sizeof(int32_t) * cap);
-  pl.pshift = (double *)q; q += kwy_pad(sizeof(double) * cap);
-  pl.ebase = (uint32_t *)q;
+  pl.pshift = (double *)q;
   return pl;
 }
 
@@ -907,8 +889,6 @@ static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const
   hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, pl.tile_cnt, nt, pl.npulse);
   hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, p.fs,
                      pl.tile_cnt, cap, pl.pidx, pl.pshift);
-  hipLaunchKernelGGL(k_syn_ebase, dim3(256), dim3(KWY_THREADS), 0, ctx->stream, pl.pidx, pl.npulse, cap,
-                     ctx->d_pow2, pl.ebase);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -924,13 +904,13 @@ static int synth_render(kwy_ctx *ctx, const syn_plan &pl, const double *sp, cons
   const double *dcrem;
   KWY_TRY(get_dc_remover(ctx, p.fft_size, &dcrem));
   switch (log2n) {
-    case 9: return launch_pulse<9>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
-    case 10: return launch_pulse<10>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
-    case 11: return launch_pulse<11>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
-    case 12: return launch_pulse<12>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 9: return launch_pulse<9>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 10: return launch_pulse<10>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 11: return launch_pulse<11>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 12: return launch_pulse<12>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
     // 8192: features resampled up to 96 kHz (3078 bins -> 4097, kwiiyatta/vocoder/world.py:71-78); rare, runs
     // with the 256-thread layout of the shorter transforms (register spills accepted)
-    default: return launch_pulse<13>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, pl.ebase, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    default: return launch_pulse<13>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
   }
 }
 

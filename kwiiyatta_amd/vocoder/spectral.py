@@ -1,16 +1,14 @@
 """Operations along the spectral axis of (frames, bins) feature matrices -- the host-side arithmetic behind
 `reshape` (another number of bins at the same sampling rate) and `resample` (another sampling rate at the same
-bin spacing).  Plain numpy / scipy functions, no state; the vocoder classes bind them to their features.
+bin spacing).  Pure functions, no state; the vocoder classes bind them to their features.  The stretch itself runs
+on the GPU (kwiiyatta_amd.backend.resample).
 
 Behaviour pinned by the reference (kwiiyatta/vocoder/abc/synthesizer.py:31-113) and by its tests
 (tests/kwiiyatta/test_vocoder.py:291-467): stretching is a polyphase resampling of the rows after replicating
 the edge bins (20 output periods on either side, cut off again afterwards), and it is applied to LOG values;
 lowering the sampling rate keeps the leading bins, raising it appends bins supplied by the vocoder.
 """
-import math
-
-import numpy as np
-import scipy.signal
+from ..backend import resample as _gpu
 
 EDGE_PERIODS = 20
 
@@ -20,20 +18,11 @@ def bins_at_rate(n_bins, fs, new_fs):
     return n_bins * new_fs // fs
 
 
-def stretch(rows, new_bins):
-    """(T, K) -> (T, new_bins): rational resampling of every row with replicated edges"""
-    bins = rows.shape[1]
-    unit = math.gcd(bins, new_bins)
-    lead_in, lead_out = bins // unit * EDGE_PERIODS, new_bins // unit * EDGE_PERIODS
-    left = np.repeat(rows[:, :1], lead_in, axis=1)
-    right = np.repeat(rows[:, -1:], lead_in, axis=1)
-    wide = scipy.signal.resample_poly(np.hstack((left, rows, right)), new_bins, bins, axis=1)
-    return wide[:, lead_out:wide.shape[1] - lead_out]
-
-
 def stretch_log(rows, new_bins):
-    """`stretch` in the log domain (power spectra, aperiodicity ratios)"""
-    return np.exp(stretch(np.log(rows), new_bins))
+    """(T, K) -> (T, new_bins) in the log domain (power spectra, aperiodicity ratios): rational resampling of the
+    logarithm of every row with replicated edges (EDGE_PERIODS filter periods on either side, cut off again
+    afterwards) -- kwy_stretch_log on the GPU"""
+    return _gpu.stretch_log(rows, new_bins)
 
 
 def keep_low_band(rows, new_bins):

@@ -375,3 +375,19 @@ def gmm_mlpg(x, weights, means, covs, windows=DELTA_WINDOWS, diff=False, return_
     if rc != 0:
         raise ValueError('oracle gmm_mlpg: covariance not positive definite')
     return (y, mix) if return_mix else y
+
+
+def stretch_log(rows, new_bins, edge_periods=20):
+    """Synthesizer._reshape_feature on log values (/root/reference/kwiiyatta/vocoder/abc/synthesizer.py:31-54) with the
+    reference's own third-party call, scipy.signal.resample_poly (scipy is installed here): the checker of
+    kwy_stretch_log."""
+    import math
+    import scipy.signal
+    rows = np.asarray(rows, dtype=np.float64)
+    bins = rows.shape[1]
+    unit = math.gcd(bins, int(new_bins))
+    lead_in, lead_out = bins // unit * edge_periods, int(new_bins) // unit * edge_periods
+    logs = np.log(rows)
+    wide = np.hstack((np.repeat(logs[:, :1], lead_in, axis=1), logs, np.repeat(logs[:, -1:], lead_in, axis=1)))
+    wide = scipy.signal.resample_poly(wide, int(new_bins), bins, axis=1)
+    return np.exp(wide[:, lead_out:wide.shape[1] - lead_out])

@@ -43,7 +43,7 @@ def _install_oracle_backend(monkeypatch):
     Test-only: the product never does this."""
     import numpy as np
     from oracle import oracle as ko
-    from kwiiyatta_amd.backend import dtw, mlpg, sptk, world
+    from kwiiyatta_amd.backend import dtw, mlpg, resample, sptk, world
 
     def cheaptrick(x, f0, t, fs, q1=-0.15, f0_floor=71.0, fft_size=None, ctx=None, out_div=1.0):
         sp = ko.cheaptrick(x, f0, t, fs, q1=q1, f0_floor=f0_floor, fft_size=fft_size)
@@ -79,6 +79,7 @@ def _install_oracle_backend(monkeypatch):
     monkeypatch.setattr(sptk.Synthesizer, 'synthesis',
                         lambda self, source, b: ko.mlsa_synthesis(source, b, self.filt.alpha, self.hopsize,
                                                                   self.filt.pd))
+    monkeypatch.setattr(resample, 'stretch_log', lambda rows, new_bins, ctx=None: ko.stretch_log(rows, new_bins))
     monkeypatch.setattr(dtw, 'fastdtw', lambda x, y, radius=1, dist=2, ctx=None: ko.fastdtw(x, y, radius, dist))
     monkeypatch.setattr(mlpg, 'MLPG', OracleMLPG)
     from kwiiyatta_amd.converter import gmm as gmm_mod

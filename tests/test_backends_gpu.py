@@ -256,3 +256,42 @@ def test_dio_short_and_silent(ko):
     f0r, tr = ko.dio(x, fs)
     assert np.array_equal(t, tr) and np.array_equal(f0, f0r)
     assert np.array_equal(world.stonemask(x, f0, t, fs), ko.stonemask(x, f0r, tr, fs))
+
+
+# ---------------------------------------------------------------- spectral-axis stretch (reshape), SURVEY 8f-3
+@pytest.mark.parametrize('bins,new_bins', [(513, 1025), (1025, 513), (1025, 2049), (2049, 1025), (2049, 513),
+                                           (372, 513), (1024, 1025), (3078, 4097), (513, 372), (65, 129), (129, 130),
+                                           (1025, 1025)])
+def test_stretch_log_matches_resample_poly(bins, new_bins):
+    """kwy_stretch_log against the reference's own call chain (np.log -> edge replication -> scipy.signal.resample_poly
+    -> trim -> np.exp) on spectra with a 120 dB range; relative 1e-12."""
+    from oracle import oracle as ko
+    from kwiiyatta_amd.backend import resample
+    rng = np.random.default_rng(bins * 7 + new_bins)
+    T = 37
+    rows = np.exp(np.cumsum(rng.standard_normal((T, bins)), axis=1) * 0.35 + rng.uniform(-8, 2, (T, 1)))
+    got = resample.stretch_log(rows, new_bins)
+    want = ko.stretch_log(rows, new_bins)
+    assert got.shape == want.shape == (T, new_bins)
+    assert np.abs(got / want - 1).max() <= 1e-12
+
+
+def test_stretch_log_device_rows_and_tiles():
+    """device-pointer entry on a row count that is not a multiple of the rows per workgroup, and aperiodicity-like
+    values in (0, 1)"""
+    import torch
+    from oracle import oracle as ko
+    from kwiiyatta_amd import _lib
+    from kwiiyatta_amd._lib import lib, c_vp
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(5)
+    for T, bins, new_bins in ((1, 1025, 513), (13, 513, 1025), (2201, 513, 1025)):
+        rows = 1.0 / (1.0 + np.exp(-np.cumsum(rng.standard_normal((T, bins)), axis=1) * 0.2))
+        d_in = torch.from_numpy(rows).cuda()
+        d_out = torch.empty((T, new_bins), dtype=torch.float64, device='cuda')
+        torch.cuda.synchronize()
+        _lib.check(ctx, lib.kwy_stretch_log_dev(ctx.handle, c_vp(d_in.data_ptr()), T, bins, new_bins,
+                                                c_vp(d_out.data_ptr())))
+        ctx.sync()
+        sel = slice(None) if T < 100 else slice(0, T, 97)
+        assert np.abs(d_out.cpu().numpy()[sel] / ko.stretch_log(rows[sel], new_bins) - 1).max() <= 1e-12

@@ -318,3 +318,44 @@ def test_synthesis_8192_points(ko, kw):
     got, ref = kw.synthesize(f0, sp8, ap8, fs, 5.0), ko.synthesize(f0, sp8, ap8, fs, 5.0)
     assert got.shape == ref.shape
     assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-9 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------- the randn table and the jump-ahead path beyond it
+def test_randn_table_equals_serial_stream(ko):
+    """WORLD's randn stream is a constant; the device keeps its first 2^L draws in a table.  Beginning, middle (across
+    the 4096-draw chunks the fill kernel works in) and end of the table against the oracle's serial generator."""
+    from kwiiyatta_amd import _lib
+    ctx = _lib.Context(0)
+    n = ctx.set_randn_limit(-1)
+    assert n >= 1 << 12
+    m = min(n, 3_000_000)
+    ref = ko.randn(m)
+    got = np.empty(m)
+    _lib.check(ctx, _lib.lib.kwy_randn_stream(ctx.handle, 0, m, _lib.ptr(got)))
+    assert np.array_equal(got, ref)
+    with pytest.raises(ValueError):
+        _lib.check(ctx, _lib.lib.kwy_randn_stream(ctx.handle, n - 4, 8, _lib.ptr(got)))
+
+
+@pytest.mark.parametrize('path,limit', [(clb_variant('48'), 0), (clb_variant('48'), 30_000), (clb_variant('48'), 150_000),
+                                        (clb_variant('48'), 400_000), (CLB_WAV, 77_777), (clb_variant('96'), 300_000)])
+def test_jump_ahead_beyond_the_table_gives_the_same_bits(ko, kw, path, limit):
+    """With the table cut short, the frames / pulses whose draws lie beyond it compute them by GF(2) jump-ahead inside
+    the kernels: every output must equal the all-table result bit for bit (limit 0: no table at all; the other limits
+    put the switch in the middle of CheapTrick, of the LoveTrain pass, of the D4C body and of the synthesis)."""
+    from kwiiyatta_amd import _lib
+    fs, x = load(path)
+    x = x[:int(1.2 * fs)]
+    f0, t = f0_track(ko, x, fs)
+    full, cut = _lib.Context(0), _lib.Context(0)
+    assert cut.set_randn_limit(limit) == limit
+    out = []
+    for ctx in (full, cut):
+        sp = kw.cheaptrick(x, f0, t, fs, ctx=ctx)
+        ap = kw.d4c(x, f0, t, fs, ctx=ctx)
+        y = kw.synthesize(f0, sp, ap, fs, 5.0, ctx=ctx)
+        out.append((sp, ap, y))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    check_spectrum(out[1][0], ko.cheaptrick(x, f0, t, fs))
+    assert np.abs(out[1][1] - ko.d4c(x, f0, t, fs)).max() <= 1e-4
