@@ -365,9 +365,10 @@ def main():
         for p in pipes:
             p.profile(False)
 
-    def timed_variant(step_fn, finish=None):
+    def timed_variant(step_fn, finish=None, steps=None):
         """the timing protocol of the main loop (one untimed step, barrier, K steps, barrier, MAX over ranks) around
         another step function; returns seconds"""
+        steps = args.steps if steps is None else steps
         step_fn()
         sync_all()
         if finish:
@@ -375,7 +376,7 @@ def main():
         if world > 1:
             dist.barrier()
         tp = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step_fn()
         sync_all()
         if finish:
@@ -411,13 +412,23 @@ def main():
 
     def run_pad_variant():
         """`value` replays pad spectra that were drawn ONCE per pipeline, outside the timed region.  Here every pass
-        draws its four (100 x K) blocks afresh on the host, as kwiiyatta.pad_silence does per call (numpy's legacy
-        generator, serial), and uploads them."""
+        gets fresh ones, as kwiiyatta.pad_silence draws them per call: (device) from numpy's legacy generator
+        reproduced on the GPU, one step ahead of the pipelines (kwiiyatta_amd.pipeline.SilenceFeeder); (host) with
+        np.random.normal itself, serial on one host thread, uploaded -- a few steps only, it is slow."""
         if args.workload != 'pair' or args.no_pcie_variant:
             return None
+        from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+        frames_step = sum(p.frames for p in pipes)
+        feeder = pl.SilenceFeeder(pipes, DeviceRandomState.from_seed(1000 + rank, device_index=local_rank))
+        eld = timed_variant(lambda: feeder.step(launch), feeder.sync)
+        res = {'device': {'ms_per_step': 1000.0 * eld / args.steps, 'frames_per_s_rank': frames_step * args.steps / eld,
+                          'note': 'same steps with the four pad blocks of every pair drawn inside the timed region by '
+                                  'k_np_normal (numpy\'s MT19937 + polar Box-Muller stream, draw for draw) on its own '
+                                  'stream, double-buffered; never `value`'}}
         K = pipes[0].K
         stage = [[torch.empty((100, K), dtype=torch.float64).pin_memory() for _ in range(4)] for _ in pipes]
         host_s = [0.0]
+        host_steps = 2
 
         def step_pad():
             for p, st in zip(pipes, stage):
@@ -431,11 +442,14 @@ def main():
                     for dst, blk in zip(rows, st):
                         dst.copy_(blk, non_blocking=True)
                 launch(p)
-        elp = timed_variant(step_pad)
-        return {'ms_per_step': 1000.0 * elp / args.steps,
-                'host_draw_ms_per_pair': 1000.0 * host_s[0] / ((args.steps + 1) * len(pipes)),
-                'note': 'same steps with the four pad blocks of every pair drawn on the host inside the timed region '
-                        '(np.random.normal from the global legacy generator, one thread) and uploaded; never `value`'}
+        elp = timed_variant(step_pad, steps=host_steps)
+        res['host'] = {'ms_per_step': 1000.0 * elp / host_steps, 'steps': host_steps,
+                       'frames_per_s_rank': frames_step * host_steps / elp,
+                       'host_draw_ms_per_pair': 1000.0 * host_s[0] / ((host_steps + 1) * len(pipes)),
+                       'note': 'same steps with the four pad blocks of every pair drawn on the host inside the timed '
+                               'region (np.random.normal from the global legacy generator, one thread) and uploaded; '
+                               'never `value`'}
+        return res
 
     frames_rank = sum(p.frames for p in pipes) * args.steps
     if world > 1:
@@ -593,7 +607,8 @@ def main():
                 'launch': ('one captured HIP graph per pass and stream; per-kernel HIP-event durations from the same '
                            'passes enqueued kernel by kernel right after the timed region') if args.graph else
                           'one host launch per kernel; per-kernel HIP events inside the timed region',
-                'pad_spectra': 'host-drawn once per pipeline, outside the timed region (see with_pad_draw)'
+                'pad_spectra': 'drawn once per pipeline, outside the timed region; with_pad_draw times the same steps '
+                               'with fresh pads per pass (device generator / host numpy)'
                 if args.workload == 'pair' else None,
                 'parallelism': f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective'},
             'real_time_factor': value / 200.0,
@@ -624,7 +639,7 @@ def main():
         if pcie:
             out['with_pcie'] = {'value': frames_total / (pcie['ms_per_step'] * 1e-3 * args.steps), **pcie}
         if pad:
-            out['with_pad_draw'] = {'value': frames_total / (pad['ms_per_step'] * 1e-3 * args.steps), **pad}
+            out['with_pad_draw'] = pad
         if not args.no_cpu_baseline and world == 1:
             if args.workload == 'pair':
                 out['cpu_baseline'], ref = cpu_baseline_pair(base[0][0], base[0][1], gmm, pair_silence(mine[0]))

@@ -67,9 +67,6 @@ int kwy_randn_stream(kwy_ctx *ctx, int64_t first, int64_t count, double *out);
  * read (kernel names as in rocprofv3, without template arguments, e.g.
  * "k_d4c_body"). */
 int kwy_ctx_profile(kwy_ctx *ctx, int enable);
-/* Diagnostic only: a device buffer of >= 64 int64 that instrumented kernels fill with
- * clock64() stamps for the workgroup whose index is stored in element 63 (NULL = off). */
-int kwy_ctx_debug_buffer(kwy_ctx *ctx, void *device_buffer);
 int kwy_ctx_profile_read(kwy_ctx *ctx, const char *kernel, double *total_ms, int64_t *count);
 const char *kwy_last_error(kwy_ctx *ctx);
 /* error text when kwy_ctx_create itself failed (no context to ask) */
@@ -188,6 +185,14 @@ int kwy_gmm_mlpg(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
 int kwy_gmm_mlpg_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int M,
                      const double *weights, const double *means, const double *covs, int diff,
                      double *y);
+/* MLPG(gmm, windows=DELTA_WINDOWS[0:1], diff).transform(X): GMMFeatureConverter.convert(feature, mlpg=False)
+ *                                                    kwiiyatta/converter/gmm.py:28-34
+ * frame-wise conversion without trajectory smoothing: y_t = sum_m p(m | x_t) E[y | x_t, m] (nnmnkwii MLPGBase).
+ * x, y: T x D rows of whatever the mixture was trained on (D <= 128); the mixture is over 2 D joint dimensions. */
+int kwy_gmm_convert_frames(kwy_ctx *ctx, const double *x, int64_t T, int D, int M, const double *weights,
+                           const double *means, const double *covs, int diff, double *y);
+int kwy_gmm_convert_frames_dev(kwy_ctx *ctx, const double *x, int64_t T, int D, int M, const double *weights,
+                               const double *means, const double *covs, int diff, double *y);
 /* The part of MLPG(gmm, windows, diff).__init__ that depends on the GMM only
  * (nnmnkwii computes it in the constructor, kwiiyatta/converter/gmm.py:32 builds one MLPG per
  * convert call): per mixture the Cholesky factor of Sxx, A = Syx Sxx^-1, b = mu_y - A mu_x, the
@@ -228,6 +233,19 @@ int kwy_decode_aperiodicity_dev(kwy_ctx *ctx, const double *coded, int64_t T, in
  * designed by the library per (K, new_K) and cached in the context. */
 int kwy_stretch_log(kwy_ctx *ctx, const double *rows, int64_t T, int K, int new_K, double *out);
 int kwy_stretch_log_dev(kwy_ctx *ctx, const double *rows, int64_t T, int K, int new_K, double *out);
+
+/* ---- numpy's legacy normal generator (the source of pad_silence's spectra) --------------------------------------
+ * np.abs(np.random.normal(0, EPS / fs, (frame_len, spectrum_len)))
+ *        WorldSynthesizer._silence_spectrum_envelope, kwiiyatta/vocoder/world.py:158-161 (via pad_silence,
+ *        vocoder/abc/feature.py:19-41, for both sides of every aligned pair)
+ * out[i] = loc + scale * g_i (its absolute value when take_abs), i < n, where g continues numpy's RandomState stream
+ * from `state`: MT19937 + polar Box-Muller with the same accept / reject decisions and the same use of the cached
+ * second value; `state` is advanced exactly as numpy advances it.  state: kwy_np_state_bytes() bytes laid out as
+ * { uint32 key[624]; int32 pos; int32 has_gauss; double cached_gaussian } = numpy's get_state() tuple.  Values agree
+ * with numpy's up to the rounding of log() (<= 1 ulp). */
+int64_t kwy_np_state_bytes(void);
+int kwy_np_normal(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n, double *out);
+int kwy_np_normal_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n, double *out);
 
 /* ---- MLSA differential-spectrum filter ---------------------------------------------------
  * pysptk.mc2b(mc, alpha)                                     kwiiyatta/filter/mlsa.py:28

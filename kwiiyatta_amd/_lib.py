@@ -66,7 +66,6 @@ SIGNATURES = {
     'kwy_ctx_set_randn_limit': (c_i64, [c_vp, c_i64]),
     'kwy_randn_stream': (c_int, [c_vp, c_i64, c_i64, c_vp]),
     'kwy_ctx_profile': (c_int, [c_vp, c_int]),
-    'kwy_ctx_debug_buffer': (c_int, [c_vp, c_vp]),
     'kwy_ctx_profile_read': (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_i64)]),
     'kwy_last_error': (ctypes.c_char_p, [c_vp]),
     'kwy_create_error': (ctypes.c_char_p, []),
@@ -120,6 +119,8 @@ SIGNATURES = {
     'kwy_km_update_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_mlpg_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'kwy_gmm_convert_frames': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    'kwy_gmm_convert_frames_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     'kwy_gmm_model_doubles': (c_i64, [c_int, c_int]),
     'kwy_aperiodicity_bands': (c_int, [c_int]),
     'kwy_code_aperiodicity': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
@@ -128,6 +129,9 @@ SIGNATURES = {
     'kwy_decode_aperiodicity_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]),
     'kwy_stretch_log': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     'kwy_stretch_log_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    'kwy_np_state_bytes': (c_i64, []),
+    'kwy_np_normal': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_i64, c_vp]),
+    'kwy_np_normal_dev': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_i64, c_vp]),
     'kwy_mc2b': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_mc2b_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_mlsa_synthesis': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),

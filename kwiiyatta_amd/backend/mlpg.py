@@ -20,6 +20,12 @@ def _is_delta_windows(windows):
                 for w, r in zip(windows, DELTA_WINDOWS)))
 
 
+def _is_static_window(windows):
+    w = DELTA_WINDOWS[0]
+    return len(windows) == 1 and windows[0][0] == w[0] and windows[0][1] == w[1] and \
+        np.array_equal(np.asarray(windows[0][2]), w[2])
+
+
 def delta_features(x, windows):
     """static -> static|delta|delta2 (np.correlate(..., 'same') per column).
     Host-side helper for dataset preparation (the fit path); the conversion
@@ -41,8 +47,10 @@ class MLPG:
     def __init__(self, gmm, windows=None, swap=False, diff=False, ctx=None):
         if windows is None:
             windows = DELTA_WINDOWS
-        if not _is_delta_windows(windows):
-            raise NotImplementedError('only the reference DELTA_WINDOWS are implemented on the GPU')
+        self.framewise = _is_static_window(windows)     # DELTA_WINDOWS[0:1]: conversion without trajectory smoothing
+        if not self.framewise and not _is_delta_windows(windows):
+            raise NotImplementedError('only the reference DELTA_WINDOWS (or their static part alone) are implemented '
+                                      'on the GPU')
         if swap:
             raise NotImplementedError('swap=True is not used by the reference and not implemented')
         assert gmm.covariance_type == 'full'
@@ -62,6 +70,18 @@ class MLPG:
         reference truncates to d either way: converter/delta.py:48-49)."""
         src = np.ascontiguousarray(src, dtype=np.float64)
         d = self.static_dim
+        if self.framewise:
+            # nnmnkwii: feature_dim == static_dim -> MLPGBase.transform, the posterior-weighted conditional mean of
+            # every frame on its own (all of the mixture's dimensions, dynamic features included, are "static" here)
+            if src.shape[1] != d:
+                raise ValueError(f'feature dimension {src.shape[1]} does not match the GMM ({d})')
+            ctx = self.ctx or _lib.default_context()
+            y = np.empty_like(src)
+            if len(src):
+                _lib.check(ctx, lib.kwy_gmm_convert_frames(ctx.handle, ptr(src), src.shape[0], d, self.num_mixtures,
+                                                           ptr(self.weights), ptr(self.means), ptr(self.covs),
+                                                           int(self.diff), ptr(y)))
+            return y
         if src.shape[1] not in (d, 3 * d):
             raise ValueError(f'feature dimension {src.shape[1]} does not match the GMM ({d})')
         x = np.ascontiguousarray(src[:, :d])

@@ -21,7 +21,6 @@ class GMMFeatureConverter(abc.FeatureConverter):
         self.gmm.fit(dataarray, **kwargs)
 
     def convert(self, feature, mlpg=True, diff=False):
-        if not mlpg:
-            raise NotImplementedError('frame-wise conversion (mlpg=False) is not used by the reference CLIs and '
-                                      'has no GPU implementation')
-        return MLPG(self.gmm, windows=delta.DELTA_WINDOWS, diff=diff).transform(feature)
+        # mlpg=False: the static window alone -- every frame converted on its own (posterior-weighted conditional mean)
+        windows = delta.DELTA_WINDOWS if mlpg else delta.DELTA_WINDOWS[0:1]
+        return MLPG(self.gmm, windows=windows, diff=diff).transform(feature)

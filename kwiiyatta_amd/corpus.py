@@ -68,7 +68,10 @@ class TrainPair:
     """
 
     def __init__(self, device_index, fs, source, target, order=24, radius=32, frame_period=5.0, stream=None,
-                 silence=None, ctx=None):
+                 silence=None, ctx=None, silence_ready=None):
+        """silence: the four (100, K) pad spectra (source head, source tail, target head, target tail) as numpy arrays
+        or device tensors (then `silence_ready`: an event after which they are valid); default: drawn here from
+        numpy's global generator in that order"""
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
@@ -82,7 +85,10 @@ class TrainPair:
         with torch.cuda.stream(self.stream):
             self.src = _TrainSide(*source, self.fs, self.K, order, self.dev)
             self.tgt = _TrainSide(*target, self.fs, self.K, order, self.dev)
-            self.silence = [torch.from_numpy(np.ascontiguousarray(s)).to(self.dev) for s in silence]
+            if silence_ready is not None:
+                self.stream.wait_event(silence_ready)
+            self.silence = [s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s)).to(self.dev)
+                            for s in silence]
         self.frames = self.src.T
         self.n_rows = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.joint = None
@@ -243,49 +249,93 @@ def shard_block(n_items, rank, world_size):
     return list(range(lo, hi))
 
 
-def _silence_ahead(n_pairs, fs, depth):
+class _silence_ahead:
     """The pad spectra of `n_pairs` pairs, drawn by a helper thread in pair order from numpy's global legacy generator
     (the reference's source, `draw_silence`) while the caller enqueues GPU work: the generator is serial (4.6 ms per
-    pair at 48 kHz) and numpy releases the GIL inside it.  The caller must not use `np.random` meanwhile."""
-    import queue
-    import threading
-    K = lib.kwy_cheaptrick_fft_size(int(fs), 71.0) // 2 + 1
-    q = queue.Queue(maxsize=max(1, depth))
+    pair at 48 kHz) and numpy releases the GIL inside it.  The caller must not use `np.random` between construction
+    and `stop()`; `stop()` (always called by build_training_matrix, also when a pair raises) ends the thread, so a
+    failed run does not leave a thread behind that keeps consuming global draws."""
 
-    def work():
-        for _ in range(n_pairs):
-            q.put([draw_silence(fs, K) for _ in range(4)])
+    def __init__(self, n_pairs, fs, depth):
+        import queue
+        import threading
+        K = lib.kwy_cheaptrick_fft_size(int(fs), 71.0) // 2 + 1
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.halt = threading.Event()
 
-    threading.Thread(target=work, daemon=True).start()
-    return q
+        def work():
+            for _ in range(n_pairs):
+                item = [draw_silence(fs, K) for _ in range(4)]
+                while not self.halt.is_set():
+                    try:
+                        self.q.put(item, timeout=0.05)
+                        break
+                    except queue.Full:
+                        continue
+                if self.halt.is_set():
+                    return
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+    def get(self):
+        return self.q.get()
+
+    def stop(self):
+        self.halt.set()
+        self.thread.join(timeout=5.0)
 
 
 def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_period=5.0, streams=16,
-                          silence_for=None, pool=None):
+                          silence_for=None, pool=None, rng=None, pairs_before=0):
     """pairs: list of ((x, f0, t), (x, f0, t)) numpy triples of THIS rank, in corpus order.  Returns the
     (n, 2*3*order) float64 device tensor of make_dataset_to_array and the number of source frames analysed.
     Pairs are processed `streams` at a time, each on its own stream (`pool`: a StreamPool to use instead of a new one).
-    silence_for(i): the four pad spectra of pair i; default: numpy's global generator in pair order, as the reference
-    draws them, one wave of pairs ahead of the GPU."""
+    The pad spectra of pair i come from
+      silence_for(i)   if given (four host arrays), else from
+      rng              a DeviceRandomState: drawn on the GPU, in the reference's order, from numpy's legacy stream;
+                       `pairs_before` pairs (those of the ranks before this one) are drawn and discarded first, so
+                       that every pair gets the pads it would get on one rank, whatever the number of ranks; else from
+      np.random        the global generator on the host, as the reference draws them, one wave of pairs ahead of the
+                       GPU on a helper thread (bit-equal to the Python API path under np.random.seed)."""
     dev = torch.device('cuda', device_index)
     if pool is None:
         pool = StreamPool(device_index, streams)
-    ahead = _silence_ahead(len(pairs), fs, 2 * len(pool)) if silence_for is None and pairs else None
+    K = lib.kwy_cheaptrick_fft_size(int(fs), 71.0) // 2 + 1
+    scale = 2.220446049250313e-16 / fs
+    if rng is not None and pairs_before:
+        sink = torch.empty((PAD_LEN, K), dtype=torch.float64, device=dev)
+        with torch.cuda.stream(rng.stream):
+            for _ in range(4 * pairs_before):
+                rng.abs_normal(scale, out=sink)
+    ahead = _silence_ahead(len(pairs), fs, 2 * len(pool)) if silence_for is None and rng is None and pairs else None
     blocks, frames = [], 0
-    for w0 in range(0, len(pairs), len(pool)):
-        wave = []
-        for k, (src, tgt) in enumerate(pairs[w0:w0 + len(pool)]):
-            sil = silence_for(w0 + k) if silence_for is not None else ahead.get()
-            wave.append(TrainPair(device_index, fs, src, tgt, order=order, radius=radius, frame_period=frame_period,
-                                  stream=pool.streams[k], ctx=pool.contexts[k], silence=sil))
-        for p in wave:
-            p.analyse()
-        for p in wave:
-            p.align()
-        for p in wave:
-            blocks.append(p.rows().clone())      # the clone is enqueued on the default stream after rows() has synchronised
-            frames += p.frames
-        torch.cuda.synchronize(dev)
+    try:
+        for w0 in range(0, len(pairs), len(pool)):
+            wave = []
+            for k, (src, tgt) in enumerate(pairs[w0:w0 + len(pool)]):
+                ready = None
+                if silence_for is not None:
+                    sil = silence_for(w0 + k)
+                elif rng is not None:
+                    with torch.cuda.stream(rng.stream):
+                        sil = [rng.abs_normal(scale, (PAD_LEN, K)) for _ in range(4)]
+                    ready = rng.record_event()
+                else:
+                    sil = ahead.get()
+                wave.append(TrainPair(device_index, fs, src, tgt, order=order, radius=radius,
+                                      frame_period=frame_period, stream=pool.streams[k], ctx=pool.contexts[k],
+                                      silence=sil, silence_ready=ready))
+            for p in wave:
+                p.analyse()
+            for p in wave:
+                p.align()
+            for p in wave:
+                blocks.append(p.rows().clone())  # enqueued on the default stream after rows() has synchronised
+                frames += p.frames
+            torch.cuda.synchronize(dev)
+    finally:
+        if ahead is not None:
+            ahead.stop()
     if not blocks:
         return torch.empty((0, 6 * order), dtype=torch.float64, device=dev), 0
     X = torch.cat(blocks).contiguous()

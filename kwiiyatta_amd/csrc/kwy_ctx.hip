@@ -415,6 +415,8 @@ int kwy_randn_stream(kwy_ctx *ctx, int64_t first, int64_t count, double *out) {
   return KWY_OK;
 }
 
+// Not part of the ABI (include/kwy.h): tools/d4c_stamps.py and tools/dtw_stamps.py hand instrumented kernels a device
+// buffer of >= 64 int64 for clock64() stamps of the workgroup whose index is stored in element 63 (NULL = off).
 int kwy_ctx_debug_buffer(kwy_ctx *ctx, void *device_buffer) {
   if (!ctx) return KWY_EINVAL;
   ctx->dbg = device_buffer;

@@ -276,6 +276,47 @@ __global__ __launch_bounds__(128) void k_gmm_cond(const double *__restrict__ X, 
   }
 }
 
+// ---- frame-wise conversion (MLPG switched off): posterior-weighted conditional mean ------------------------
+// nnmnkwii MLPGBase.transform, what GMMFeatureConverter.convert(mlpg=False) runs (kwiiyatta/converter/gmm.py:28-34
+// with windows[0:1]): y_t = sum_m p(m | x_t) (mu_y,m + A_m (x_t - mu_x,m)), the posterior being the softmax of the
+// weighted log-densities (sklearn predict_proba).  One workgroup per frame.
+__global__ __launch_bounds__(128) void k_gmm_soft(const double *__restrict__ X, ml_dims dm,
+                                                 const double *__restrict__ model,
+                                                 const double *__restrict__ logp, double *__restrict__ Y) {
+  __shared__ double post[256];
+  __shared__ double xs[192];
+  __shared__ double red[4];
+  const int64_t t = blockIdx.x;
+  const int tid = threadIdx.x, D = dm.D, M = dm.M;
+  double mx = -INFINITY;
+  for (int m = tid; m < M; m += 128) mx = fmax(mx, logp[t * M + m]);
+  mx = kwy_wave_max_f64(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  for (int i = tid; i < D; i += 128) xs[i] = X[t * D + i];
+  __syncthreads();
+  mx = fmax(red[0], red[1]);
+  double se = 0.0;
+  for (int m = tid; m < M; m += 128) { const double e = exp(logp[t * M + m] - mx); post[m] = e; se += e; }
+  se = kwy_wave_sum(se);
+  __syncthreads();
+  if ((tid & 63) == 0) red[2 + (tid >> 6)] = se;
+  __syncthreads();
+  const double inv = 1.0 / (red[2] + red[3]);
+  for (int i = tid; i < D; i += 128) {
+    double y = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const double pm = post[m] * inv;
+      if (pm == 0.0) continue;
+      const double *mod = model + (size_t)m * ml_model_stride(D);
+      const double *ar = mod + D * D + (size_t)i * D, *mux = mod + 2 * D * D, *muy = mux + D;
+      double v = muy[i];
+      for (int k = 0; k < D; ++k) v += ar[k] * (xs[k] - mux[k]);
+      y += pm * v;
+    }
+    Y[t * D + i] = y;
+  }
+}
+
 // ---- MLPG: normal equations ---------------------------------------------------------------------
 // rec[t][c][0..3] = P[t][t], P[t][t-1], P[t][t-2], rhs[t]: one 32-byte record per (row, dimension), so that the
 // solver moves it with two 16-byte accesses per lane (its sweeps are bound by the vector-memory instruction rate of
@@ -731,6 +772,82 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
                                                        band, Ysp, bnd, dm, pt, y, ldy, status, (long long *)ctx->dbg));
   }
   KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+// x, y: T x D device rows; weights / means / covs: the joint mixture over 2 D dimensions, on the device
+static int soft_core(kwy_ctx *ctx, const double *x, int64_t T, int D, int M, const double *weights,
+                     const double *means, const double *covs, int diff, double *y, int **status_out) {
+  ml_dims dm = {D, D, M, T};
+  double *model = kwy_arena<double>(ctx, ml_model_stride(D) * M);
+  double *logp = kwy_arena<double>(ctx, (size_t)T * M);
+  int *status = kwy_arena<int>(ctx, 16);
+  if (!model || !logp || !status) { ctx->err = "gmm_convert_frames: scratch arena too small"; return KWY_ENOMEM; }
+  *status_out = status;
+  KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
+  const size_t lds_prep = sizeof(double) * 3 * D * D;
+  const size_t lds_logp = sizeof(double) * (size_t)(ml_np(D) + ML_TILE) * (ml_kp(D) + 1);
+  if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024 || D > 192 || M > 256) {
+    ctx->err = "gmm_convert_frames: feature dimension (<= 128 per side) or mixture count (<= 256) too large";
+    return KWY_EINVAL;
+  }
+  KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
+  hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D, diff, model,
+                     status);
+  hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)ml_logp_splits(T, M), M), dim3(KWY_THREADS), lds_logp, ctx->stream, x, dm,
+                     model, logp);
+  hipLaunchKernelGGL(k_gmm_soft, dim3((unsigned)T), dim3(128), 0, ctx->stream, x, dm, model, logp, y);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+static size_t soft_scratch_bytes(int64_t T, int D, int M) {
+  return kwy_pad(sizeof(double) * ml_model_stride(D) * M) + kwy_pad(sizeof(double) * T * M) + kwy_pad(64);
+}
+
+static int soft_check(kwy_ctx *ctx, const void *x, int64_t T, int D, int M, const void *w, const void *mu,
+                      const void *cv, const void *y) {
+  if (!ctx) return KWY_EINVAL;
+  if (!x || !w || !mu || !cv || !y || T <= 0 || D <= 0 || M <= 0) {
+    ctx->err = "gmm_convert_frames: bad argument";
+    return KWY_EINVAL;
+  }
+  return KWY_OK;
+}
+
+extern "C" int kwy_gmm_convert_frames_dev(kwy_ctx *ctx, const double *x, int64_t T, int D, int M,
+                                          const double *weights, const double *means, const double *covs, int diff,
+                                          double *y) {
+  KWY_TRY(soft_check(ctx, x, T, D, M, weights, means, covs, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, soft_scratch_bytes(T, D, M)));
+  int *status;
+  return soft_core(ctx, x, T, D, M, weights, means, covs, diff, y, &status);
+}
+
+extern "C" int kwy_gmm_convert_frames(kwy_ctx *ctx, const double *x, int64_t T, int D, int M, const double *weights,
+                                      const double *means, const double *covs, int diff, double *y) {
+  KWY_TRY(soft_check(ctx, x, T, D, M, weights, means, covs, y));
+  KWY_HIP(hipSetDevice(ctx->device));
+  const int D2 = 2 * D;
+  const size_t bx = kwy_pad(sizeof(double) * T * D), bw = kwy_pad(sizeof(double) * M);
+  const size_t bm = kwy_pad(sizeof(double) * M * D2), bc = kwy_pad(sizeof(double) * (size_t)M * D2 * D2);
+  KWY_TRY(kwy_arena_begin(ctx, soft_scratch_bytes(T, D, M) + 2 * bx + bw + bm + bc));
+  double *dx = kwy_arena<double>(ctx, (size_t)T * D), *dy = kwy_arena<double>(ctx, (size_t)T * D);
+  double *dw = kwy_arena<double>(ctx, M), *dmu = kwy_arena<double>(ctx, (size_t)M * D2);
+  double *dcv = kwy_arena<double>(ctx, (size_t)M * D2 * D2);
+  KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * T * D, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dw, weights, sizeof(double) * M, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dmu, means, sizeof(double) * M * D2, hipMemcpyHostToDevice, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(dcv, covs, sizeof(double) * (size_t)M * D2 * D2, hipMemcpyHostToDevice, ctx->stream));
+  int *status;
+  KWY_TRY(soft_core(ctx, dx, T, D, M, dw, dmu, dcv, diff, dy, &status));
+  int hstatus = 0;
+  KWY_HIP(hipMemcpyAsync(y, dy, sizeof(double) * T * D, hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KWY_HIP(hipStreamSynchronize(ctx->stream));
+  if (hstatus != 0) { ctx->err = "gmm_convert_frames: source covariance is not positive definite"; return KWY_ENUMERIC; }
   return KWY_OK;
 }
 

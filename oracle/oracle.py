@@ -391,3 +391,30 @@ def stretch_log(rows, new_bins, edge_periods=20):
     wide = np.hstack((np.repeat(logs[:, :1], lead_in, axis=1), logs, np.repeat(logs[:, -1:], lead_in, axis=1)))
     wide = scipy.signal.resample_poly(wide, int(new_bins), bins, axis=1)
     return np.exp(wide[:, lead_out:wide.shape[1] - lead_out])
+
+
+def gmm_convert_frames(x, weights, means, covs, diff=False):
+    """nnmnkwii.baseline.gmm.MLPGBase.transform (0.0.17) -- what MLPG(gmm, windows=DELTA_WINDOWS[0:1], diff)
+    .transform(X) runs, i.e. GMMFeatureConverter.convert(mlpg=False) (/root/reference/kwiiyatta/converter/gmm.py:28-34):
+    per frame the posterior-weighted conditional mean, posteriors from scikit-learn's own predict_proba."""
+    import sklearn.mixture
+    from sklearn.mixture._gaussian_mixture import _compute_precision_cholesky
+    x = np.asarray(x, dtype=np.float64)
+    M, D = len(weights), x.shape[1]
+    src_means, tgt_means = means[:, :D], means[:, D:]
+    cxx, cxy, cyx = covs[:, :D, :D], covs[:, :D, D:], covs[:, D:, :D]
+    if diff:
+        tgt_means = tgt_means - src_means
+        cxy = cxy - cxx
+        cyx = np.transpose(cxy, (0, 2, 1))
+    px = sklearn.mixture.GaussianMixture(n_components=M, covariance_type='full')
+    px.weights_, px.means_, px.covariances_ = weights, src_means, cxx
+    px.precisions_cholesky_ = _compute_precision_cholesky(cxx, 'full')
+    post = px.predict_proba(x)
+    out = np.zeros_like(x)
+    for t in range(len(x)):
+        E = np.empty((M, D))
+        for m in range(M):
+            E[m] = tgt_means[m] + cyx[m].dot(np.linalg.solve(cxx[m], x[t] - src_means[m]))
+        out[t] = post[t].dot(E)
+    return out

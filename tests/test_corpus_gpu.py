@@ -235,3 +235,35 @@ def test_convert_batch_shapes_share_one_arena(corpus):
     assert not p.graph_valid()
     with pytest.raises(RuntimeError, match='stale'):
         p.replay()
+
+
+def test_training_matrix_with_device_drawn_pads(corpus):
+    """pad spectra from numpy's legacy stream reproduced on the GPU (backend.nprandom) instead of np.random on the
+    host: the same matrix as the host-drawn path under the same seed (the pads agree to an ulp of log(), the warping
+    paths are the same), and a rank that starts in the middle of the corpus (`pairs_before`) gets the pads -- hence
+    the rows -- it would get on one rank."""
+    import torch
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    np.random.seed(11)
+    want, _ = cp.build_training_matrix(corpus, FS, streams=2)
+    got, frames = cp.build_training_matrix(corpus, FS, streams=2, rng=DeviceRandomState.from_seed(11))
+    assert frames == sum(len(s[1]) for s, _ in corpus)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-9, atol=1e-12)
+    # "rank 1 of 2": the last two pairs, the generator advanced past the first two
+    tail, _ = cp.build_training_matrix(corpus[2:], FS, streams=2, rng=DeviceRandomState.from_seed(11), pairs_before=2)
+    head, _ = cp.build_training_matrix(corpus[:2], FS, streams=2, rng=DeviceRandomState.from_seed(11))
+    assert torch.equal(torch.cat((head, tail)), got)
+
+
+def test_silence_helper_thread_stops_on_error(corpus):
+    """a pair that raises must not leave the pad-drawing helper thread behind (it would keep consuming draws of the
+    global generator: a retry in the same process would no longer be reproducible)"""
+    import threading
+    from kwiiyatta_amd import corpus as cp
+    before = threading.active_count()
+    bad = list(corpus[:2]) + [((None, corpus[0][0][1], corpus[0][0][2]), corpus[0][1])]   # no waveform: raises on the host
+    with pytest.raises(Exception):
+        cp.build_training_matrix(bad, FS, streams=1)
+    assert threading.active_count() == before

@@ -8,6 +8,7 @@ p = pl.UtterancePipeline(0, 48000, u)
 dbg = torch.zeros(64, dtype=torch.int64, device='cuda')
 f0 = u[1]
 frame = int(np.where(f0>0)[0][200]); dbg[63] = frame
+lib.kwy_ctx_debug_buffer.argtypes = [c_vp, c_vp]   # diagnostic hook, not in include/kwy.h
 lib.kwy_ctx_debug_buffer(p.ctx.handle, c_vp(dbg.data_ptr()))
 p.run(); p.sync(); p.run(); p.sync()
 d = dbg.cpu().numpy()

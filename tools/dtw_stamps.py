@@ -12,6 +12,7 @@ x=series(2201,26,1.0); y=series(2401,26,1.3)
 ctx=_lib.default_context()
 dtw.fastdtw(x,y,radius=32)
 dbg=torch.zeros(256,dtype=torch.int64,device='cuda')
+lib.kwy_ctx_debug_buffer.argtypes = [c_vp, c_vp]   # diagnostic hook, not in include/kwy.h
 lib.kwy_ctx_debug_buffer(ctx.handle, c_vp(dbg.data_ptr()))
 dtw.fastdtw(x,y,radius=32)
 d=dbg.cpu().numpy()
