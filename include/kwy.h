@@ -246,6 +246,10 @@ int kwy_stretch_log_dev(kwy_ctx *ctx, const double *rows, int64_t T, int K, int 
 int64_t kwy_np_state_bytes(void);
 int kwy_np_normal(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n, double *out);
 int kwy_np_normal_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n, double *out);
+/* `count` (1 ... 4) consecutive requests of n_each values each in one call -- the four pad blocks of one aligned pair
+ * (source head, source tail, target head, target tail); outs: HOST array of `count` device pointers */
+int kwy_np_normal_blocks_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int count,
+                             int64_t n_each, double *const *outs);
 
 /* ---- MLSA differential-spectrum filter ---------------------------------------------------
  * pysptk.mc2b(mc, alpha)                                     kwiiyatta/filter/mlsa.py:28
@@ -299,13 +303,15 @@ int kwy_km_center_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, const dou
 int kwy_km_pp_dist_dev(kwy_ctx *ctx, const double *Xc, const double *xsq, int64_t n, int D, const double *cand,
                        int L, const double *closest, double *newd, double *pots);
 /* np.searchsorted(np.cumsum(closest), vals) over the global row order, shard by shard:
- * kwy_km_pp_total_dev fills csums (kwy_km_chunks(n) chunk totals) and total[0]; with lo = the totals of
- * the shards before this one, kwy_km_pp_pick_dev returns for each vals[c] the local row index of the hit,
- * or -1 if it lies in another shard (first / last: position of this shard; beyond the end -> last row). */
+ * kwy_km_pp_total_dev fills csums (kwy_km_chunks(n) chunk totals) and total[0]; with lo / hi = the cumulated totals
+ * of the shards before this one / including this one (the same cumulative sums of the all-gathered totals on every
+ * rank, so that a value on a shard boundary has exactly one owner; NULL: 0 / lo + this shard's total),
+ * kwy_km_pp_pick_dev returns for each vals[c] the local row index of the hit, or -1 if it lies in another shard
+ * (first / last: position of this shard; beyond the end -> last row). */
 int64_t kwy_km_chunks(int64_t n);
 int kwy_km_pp_total_dev(kwy_ctx *ctx, const double *v, int64_t n, double *csums, double *total);
 int kwy_km_pp_pick_dev(kwy_ctx *ctx, const double *v, int64_t n, const double *csums, const double *lo,
-                       const double *vals, int L, int first, int last, int64_t *idx);
+                       const double *hi, const double *vals, int L, int first, int last, int64_t *idx);
 /* Lloyd: labels[t] = argmin_j |c_j|^2 - 2 <Xc[t], c_j> (int32; in: previous labels), resp = one-hot rows
  * (n x M, may be NULL), changed[0] = number of rows whose label changed (uint64).  The centroid sums are
  * kwy_gmm_em_sums_dev(Xc, resp); kwy_km_update_dev turns the reduced [count, sums] into the new centres

@@ -114,7 +114,7 @@ SIGNATURES = {
     'kwy_km_pp_dist_dev': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     'kwy_km_chunks': (c_i64, [c_i64]),
     'kwy_km_pp_total_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
-    'kwy_km_pp_pick_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    'kwy_km_pp_pick_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_km_assign_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     'kwy_km_update_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -132,6 +132,7 @@ SIGNATURES = {
     'kwy_np_state_bytes': (c_i64, []),
     'kwy_np_normal': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_i64, c_vp]),
     'kwy_np_normal_dev': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_i64, c_vp]),
+    'kwy_np_normal_blocks_dev': (c_int, [c_vp, c_vp, c_dbl, c_dbl, c_int, c_int, c_i64, ctypes.POINTER(c_vp)]),
     'kwy_mc2b': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_mc2b_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_mlsa_synthesis': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),

@@ -89,6 +89,22 @@ class DeviceRandomState:
     def abs_normal(self, scale, size=None, out=None):
         return self.normal(0.0, scale, size=size, out=out, absolute=True)
 
+    def abs_normal_blocks(self, scale, outs):
+        """np.abs(np.random.normal(0, scale, shape)) for up to four equally sized tensors in a row, one library call
+        (the pad blocks of one aligned pair: source head, source tail, target head, target tail)"""
+        n_each = outs[0].numel()
+        for t in outs:
+            if t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.dev or t.numel() != n_each:
+                raise ValueError('outs must be equally sized contiguous float64 tensors on the generator\'s device')
+        ptrs = (c_vp * len(outs))(*[t.data_ptr() for t in outs])
+        _lib.check(self.ctx, lib.kwy_np_normal_blocks_dev(self.ctx.handle, c_vp(self.state.data_ptr()), 0.0, float(scale),
+                                                          1, len(outs), n_each, ptrs))
+        return outs
+
+    def sync(self):
+        """wait for everything enqueued on the generator's stream (results are written asynchronously on it)"""
+        self.stream.synchronize()
+
     def record_event(self):
         ev = torch.cuda.Event()
         ev.record(self.stream)

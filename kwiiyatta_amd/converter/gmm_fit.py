@@ -213,11 +213,12 @@ class HipStats:
                                                     self._p(self.csums), self._p(self.total)))
         return self.total
 
-    def km_pick(self, lo, vals, first, last):
-        """local row indices (int64 device tensor, -1: not in this shard) of searchsorted(lo + cumsum(closest), vals)"""
+    def km_pick(self, lo, hi, vals, first, last):
+        """local row indices (int64 device tensor, -1: not in this shard) of searchsorted(lo + cumsum(closest), vals);
+        this shard owns the values in (lo, hi] (first / last shard: also those below / beyond)"""
         L = len(vals)
         self._chk(self._lib.lib.kwy_km_pp_pick_dev(self.ctx.handle, self._p(self.closest), self.n, self._p(self.csums),
-                                                   self._p(lo), self._p(vals), L, int(first), int(last),
+                                                   self._p(lo), self._p(hi), self._p(vals), L, int(first), int(last),
                                                    self._p(self.pick)))
         return self.pick[:L]
 
@@ -320,10 +321,13 @@ def _kmeans_init(stats, n_components, random_state, max_iter, tol, verbose):
     stats.km_accept(torch.zeros(1, dtype=torch.int64, device=dev))
     current_pot = pot[0]
     for c in range(1, M):
+        # shard r owns the values in (bounds[r], bounds[r + 1]]: one cumulative sum of the gathered totals, the same
+        # numbers on every rank, so that a value on a boundary has exactly one owner
         totals = comm.all_gather_scalar(stats.km_closest_total())
-        lo = totals[:comm.rank].sum().reshape(1)
+        bounds = torch.cat((torch.zeros(1, **f64), torch.cumsum(totals, 0)))
+        lo, hi = bounds[comm.rank:comm.rank + 1].contiguous(), bounds[comm.rank + 1:comm.rank + 2].contiguous()
         vals = (u[c - 1] * current_pot).contiguous()
-        idx = stats.km_pick(lo, vals, first=comm.rank == 0, last=comm.rank == comm.world - 1)
+        idx = stats.km_pick(lo, hi, vals, first=comm.rank == 0, last=comm.rank == comm.world - 1)
         cand = fetch_rows(idx)
         pots = comm.all_reduce(stats.km_candidates(cand, use_closest=True).clone())
         best = torch.argmin(pots).reshape(1)

@@ -303,10 +303,10 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
     K = lib.kwy_cheaptrick_fft_size(int(fs), 71.0) // 2 + 1
     scale = 2.220446049250313e-16 / fs
     if rng is not None and pairs_before:
-        sink = torch.empty((PAD_LEN, K), dtype=torch.float64, device=dev)
         with torch.cuda.stream(rng.stream):
-            for _ in range(4 * pairs_before):
-                rng.abs_normal(scale, out=sink)
+            sink = [torch.empty((PAD_LEN, K), dtype=torch.float64, device=dev) for _ in range(4)]
+            for _ in range(pairs_before):
+                rng.abs_normal_blocks(scale, sink)
     ahead = _silence_ahead(len(pairs), fs, 2 * len(pool)) if silence_for is None and rng is None and pairs else None
     blocks, frames = [], 0
     try:
@@ -318,7 +318,8 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
                     sil = silence_for(w0 + k)
                 elif rng is not None:
                     with torch.cuda.stream(rng.stream):
-                        sil = [rng.abs_normal(scale, (PAD_LEN, K)) for _ in range(4)]
+                        sil = rng.abs_normal_blocks(scale, [torch.empty((PAD_LEN, K), dtype=torch.float64, device=dev)
+                                                            for _ in range(4)])
                     ready = rng.record_event()
                 else:
                     sil = ahead.get()

@@ -199,10 +199,14 @@ __global__ __launch_bounds__(KWY_THREADS) void k_km_total(const double *__restri
 
 // np.searchsorted(lo + cumsum(v), vals[c]) restricted to this shard (single workgroup).
 // idx[c] = local index, or -1 when the hit lies in another rank's shard:
-//   mine  <=>  (first || vals[c] > lo) && (vals[c] <= lo + total || last);  beyond the end (last rank): n - 1
+//   mine  <=>  (first || vals[c] > lo) && (vals[c] <= hi || last);  beyond the end (last rank): n - 1
+// lo / hi are the driver's cumulative sums of the all-gathered shard totals -- the SAME two numbers bound
+// neighbouring shards on every rank, so a value on a boundary is owned by exactly one rank (with hi taken from this
+// shard's own block sums, whose rounding differs from the gathered totals', two ranks or none could claim it).
 __global__ __launch_bounds__(KWY_THREADS) void k_km_pick(const double *__restrict__ v, int64_t n, int64_t chunk,
                                                         const double *__restrict__ csums, int nchunks,
                                                         const double *__restrict__ lo_p,
+                                                        const double *__restrict__ hi_p,
                                                         const double *__restrict__ vals, int L, int first, int last,
                                                         int64_t *__restrict__ idx) {
   extern __shared__ double sm[];
@@ -215,10 +219,10 @@ __global__ __launch_bounds__(KWY_THREADS) void k_km_pick(const double *__restric
   __syncthreads();
   kwy_block_cumsum(pre, nchunks, tot);
   const double lo = lo_p ? lo_p[0] : 0.0;
-  const double total = pre[nchunks - 1];
+  const double hi = hi_p ? hi_p[0] : lo + pre[nchunks - 1];
   for (int c = 0; c < L; ++c) {
     const double val = vals[c] - lo;
-    const bool mine = (first || val > 0.0) && (val <= total || last);
+    const bool mine = (first || vals[c] > lo) && (vals[c] <= hi || last);
     if (!mine) { if (tid == 0) idx[c] = -1; continue; }   // uniform
     if (tid == 0) best = (long long)nchunks;
     __syncthreads();
@@ -496,9 +500,10 @@ extern "C" int kwy_km_pp_total_dev(kwy_ctx *ctx, const double *v, int64_t n, dou
 }
 
 // idx[c] (int64, c < L): np.searchsorted(lo + cumsum(v), vals[c]) as a local index, -1 if it lies in another
-// shard (first / last: this is the first / last shard in the global row order).  lo: device scalar or NULL.
+// shard (first / last: this is the first / last shard in the global row order).  lo / hi: device scalars, the
+// cumulated totals of the shards before this one / up to and including this one (NULL: 0 / lo + this shard's total).
 extern "C" int kwy_km_pp_pick_dev(kwy_ctx *ctx, const double *v, int64_t n, const double *csums, const double *lo,
-                                  const double *vals, int L, int first, int last, int64_t *idx) {
+                                  const double *hi, const double *vals, int L, int first, int last, int64_t *idx) {
   if (!ctx) return KWY_EINVAL;
   if (!v || !csums || !vals || !idx || n <= 0 || L < 1 || L > KM_MAXL) {
     ctx->err = "km_pp_pick: null pointer or more than 8 values";
@@ -509,7 +514,7 @@ extern "C" int kwy_km_pp_pick_dev(kwy_ctx *ctx, const double *v, int64_t n, cons
   const size_t lds = sizeof(double) * ((size_t)nchunks + KM_CHUNK + KWY_THREADS);
   KWY_HIP(hipFuncSetAttribute((const void *)k_km_pick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_km_pick, dim3(1), dim3(KWY_THREADS), lds, ctx->stream, v, n, km_chunk(n), csums, nchunks, lo,
-                     vals, L, first, last, idx);
+                     hi, vals, L, first, last, idx);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

@@ -158,6 +158,160 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_normal(np_state *__restrict_
   }
 }
 
+// ------------------------------------------------------------------ large requests: five launches
+// The single-workgroup kernel above spends most of its time on the Box-Muller arithmetic of 156 attempts per round with
+// one wavefront per SIMD.  For large requests only the MT19937 recurrence stays serial (one workgroup writes the raw
+// state words of as many 624-word blocks as the request can possibly consume); the attempts are then judged by the
+// whole chip: count the accepted ones per tile, scan the tile counts, write the outputs of the first `need` accepted
+// attempts in order, and move the generator state to the word after the last one used.
+//   kbuf[b][624]  block 0 = the state's current key, block b its b-th successor; attempt a takes the words
+//                 pos + 4a .. pos + 4a + 3 of that stream (tempered on the fly)
+struct np_job {
+  int64_t n;            // outputs wanted
+  int64_t attempts;     // attempts laid out (an upper bound of those needed)
+  int64_t n_each;       // outputs per destination block (outs[i / n_each][i % n_each])
+  double loc, scale;
+  int take_abs;
+  double *outs[4];
+};
+#define NP_TILE (KWY_THREADS * 4)     // attempts per workgroup of the counting / writing kernels
+
+__global__ __launch_bounds__(KWY_THREADS) void k_np_words(const np_state *__restrict__ st, int nblocks,
+                                                         uint32_t *__restrict__ kbuf) {
+  __shared__ uint32_t mt[2][MT_N];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < MT_N; i += KWY_THREADS) { const uint32_t v = st->key[i]; mt[0][i] = v; kbuf[i] = v; }
+  __syncthreads();
+  int cur = 0;
+  for (int b = 1; b < nblocks; ++b) {
+    const uint32_t *o = mt[cur];
+    uint32_t *w = mt[cur ^ 1];
+    uint32_t *dst = kbuf + (size_t)b * MT_N;
+    if (tid < MT_N - MT_M) { const uint32_t v = mt_twist(o[tid], o[tid + 1], o[tid + MT_M]); w[tid] = v; dst[tid] = v; }
+    __syncthreads();
+    if (tid < MT_N - MT_M) {
+      const int k = (MT_N - MT_M) + tid;
+      const uint32_t v = mt_twist(o[k], o[k + 1], w[k - (MT_N - MT_M)]);
+      w[k] = v; dst[k] = v;
+    }
+    __syncthreads();
+    {
+      const int k = 2 * (MT_N - MT_M) + tid;
+      if (k < MT_N) {
+        const uint32_t v = k < MT_N - 1 ? mt_twist(o[k], o[k + 1], w[k - (MT_N - MT_M)]) : mt_twist(o[k], w[0], w[MT_M - 1]);
+        w[k] = v; dst[k] = v;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+__device__ __forceinline__ bool np_attempt(const uint32_t *__restrict__ kbuf, int pos, int64_t a, double *x1, double *x2,
+                                           double *r2) {
+  const int64_t g = (int64_t)pos + 4 * a;
+  const uint32_t wa = mt_temper(kbuf[g]), wb = mt_temper(kbuf[g + 1]), wc = mt_temper(kbuf[g + 2]), wd = mt_temper(kbuf[g + 3]);
+  *x1 = 2.0 * np_uniform53(wa, wb) - 1.0;
+  *x2 = 2.0 * np_uniform53(wc, wd) - 1.0;
+  *r2 = *x1 * *x1 + *x2 * *x2;
+  return !(*r2 >= 1.0 || *r2 == 0.0);
+}
+
+__global__ __launch_bounds__(KWY_THREADS) void k_np_count(const np_state *__restrict__ st, const uint32_t *__restrict__ kbuf,
+                                                         np_job job, int *__restrict__ counts) {
+  __shared__ int red[KWY_WAVES];
+  const int pos = st->pos;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t a = (int64_t)blockIdx.x * NP_TILE + j * KWY_THREADS + threadIdx.x;
+    double x1, x2, r2;
+    if (a < job.attempts && np_attempt(kbuf, pos, a, &x1, &x2, &r2)) ++c;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of the tile counts; emits the cached Gaussian of the previous call first; flags a shortage
+__global__ __launch_bounds__(KWY_THREADS) void k_np_scan(np_state *__restrict__ st, np_job job, int ntiles,
+                                                        int *__restrict__ counts, int64_t *__restrict__ info) {
+  __shared__ uint64_t tot[KWY_THREADS];
+  __shared__ int64_t s_total;
+  const int had = st->has_gauss;
+  kwy_block_count_scan<KWY_THREADS>([&](int64_t i) -> uint64_t { return (uint64_t)counts[i]; }, ntiles,
+                                    (uint64_t *)(info + 8), tot);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int64_t first = had ? 1 : 0;                 // outputs served by the cached value
+    if (had) {
+      const double v = job.loc + job.scale * st->gauss;
+      job.outs[0][0] = job.take_abs ? fabs(v) : v;
+      st->has_gauss = 0;
+      st->gauss = 0.0;
+    }
+    const int64_t need = (job.n - first + 1) / 2;      // accepted attempts wanted
+    info[0] = first;
+    info[1] = need;
+    info[2] = -1;                                      // the last attempt used (set by k_np_emit)
+    info[3] = (int64_t)(info + 8)[ntiles] < need ? 1 : 0;   // shortage: cannot happen with the margin laid out
+  }
+}
+
+__global__ __launch_bounds__(KWY_THREADS) void k_np_emit(np_state *__restrict__ st, const uint32_t *__restrict__ kbuf,
+                                                        np_job job, int64_t *__restrict__ info) {
+  __shared__ int wsum[4][KWY_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pos = st->pos;
+  const int64_t first = info[0], need = info[1];
+  const int64_t tile_base = (int64_t)((const uint64_t *)(info + 8))[blockIdx.x];
+  if (tile_base >= need) return;
+  double x1[4], x2[4], r2[4];
+  bool ok[4];
+  unsigned long long bal[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t a = (int64_t)blockIdx.x * NP_TILE + j * KWY_THREADS + tid;
+    ok[j] = a < job.attempts && np_attempt(kbuf, pos, a, &x1[j], &x2[j], &r2[j]);
+    bal[j] = __ballot(ok[j]);
+    if (lane == 0) wsum[j][wv] = __popcll(bal[j]);
+  }
+  __syncthreads();
+  int64_t before = tile_base;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int64_t rank = before + __popcll(bal[j] & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int w = 0; w < KWY_WAVES; ++w) {
+      if (w < wv) rank += wsum[j][w];
+      before += wsum[j][w];
+    }
+    if (ok[j] && rank < need) {
+      const double f = sqrt(-2.0 * log(r2[j]) / r2[j]);
+      const int64_t o = first + 2 * rank;
+      const double va = job.loc + job.scale * (f * x2[j]), vb = job.loc + job.scale * (f * x1[j]);
+      job.outs[o / job.n_each][o % job.n_each] = job.take_abs ? fabs(va) : va;
+      if (o + 1 < job.n) job.outs[(o + 1) / job.n_each][(o + 1) % job.n_each] = job.take_abs ? fabs(vb) : vb;
+      else { st->gauss = f * x1[j]; st->has_gauss = 1; }
+      if (rank == need - 1) info[2] = (int64_t)blockIdx.x * NP_TILE + j * KWY_THREADS + tid;
+    }
+  }
+}
+
+// the state moves to the word after the last attempt used
+__global__ __launch_bounds__(KWY_THREADS) void k_np_advance(np_state *__restrict__ st, const uint32_t *__restrict__ kbuf,
+                                                           const int64_t *__restrict__ info, int *__restrict__ status) {
+  if (info[3] != 0) { if (threadIdx.x == 0) atomicExch(status, 1); return; }
+  const int64_t last = info[2];
+  if (last < 0) return;                                  // nothing but the cached value was needed
+  const int64_t g_last = (int64_t)st->pos + 4 * last + 3;    // stream index of the last word consumed
+  const int64_t b = g_last / MT_N;
+  __syncthreads();
+  for (int i = threadIdx.x; i < MT_N; i += KWY_THREADS) st->key[i] = kbuf[(size_t)b * MT_N + i];
+  if (threadIdx.x == 0) st->pos = (int)(g_last - b * MT_N) + 1;
+}
+
 // ------------------------------------------------------------------ C ABI
 extern "C" int64_t kwy_np_state_bytes(void) { return (int64_t)sizeof(np_state); }
 
@@ -167,15 +321,71 @@ static int np_check(kwy_ctx *ctx, const void *state, int64_t n, const void *out)
   return KWY_OK;
 }
 
+#define NP_SMALL 4096     // up to here the single-workgroup kernel (no scratch, exact for any acceptance pattern)
+
+static int64_t np_attempts_cap(int64_t n) { return (int64_t)((n / 2 + 1) * 1.35) + 256; }
+
+static size_t np_scratch_bytes(int64_t n) {
+  if (n <= NP_SMALL) return 256;
+  const int64_t attempts = np_attempts_cap(n);
+  const int64_t nblocks = 2 + (MT_N + 4 * attempts) / MT_N;
+  const int64_t ntiles = (attempts + NP_TILE - 1) / NP_TILE;
+  return kwy_pad(sizeof(uint32_t) * (size_t)nblocks * MT_N) + kwy_pad(sizeof(int) * ntiles) +
+         kwy_pad(sizeof(int64_t) * (size_t)(ntiles + 16)) + kwy_pad(64);
+}
+
+// outs: `count` destination blocks of n_each doubles each (device), filled in order from one continuous stream
+static int np_core(kwy_ctx *ctx, np_state *state, double loc, double scale, int take_abs, int count, int64_t n_each,
+                   double *const *outs) {
+  const int64_t n = (int64_t)count * n_each;
+  if (n <= NP_SMALL || count > 4) {
+    for (int c = 0; c < count; ++c)
+      KWY_PROF(ctx, "k_np_normal", hipLaunchKernelGGL(k_np_normal, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, loc,
+                                                      scale, take_abs, n_each, outs[c]));
+    KWY_HIP(hipGetLastError());
+    return KWY_OK;
+  }
+  np_job job;
+  job.n = n; job.n_each = n_each; job.loc = loc; job.scale = scale; job.take_abs = take_abs;
+  job.attempts = np_attempts_cap(n);
+  for (int c = 0; c < 4; ++c) job.outs[c] = c < count ? outs[c] : nullptr;
+  const int nblocks = (int)(2 + (MT_N + 4 * job.attempts) / MT_N);
+  const int ntiles = (int)((job.attempts + NP_TILE - 1) / NP_TILE);
+  uint32_t *kbuf = kwy_arena<uint32_t>(ctx, (size_t)nblocks * MT_N);
+  int *counts = kwy_arena<int>(ctx, ntiles);
+  int64_t *info = kwy_arena<int64_t>(ctx, (size_t)ntiles + 16);
+  int *status = kwy_arena<int>(ctx, 16);
+  if (!kbuf || !counts || !info || !status) { ctx->err = "np_normal: scratch arena too small"; return KWY_ENOMEM; }
+  KWY_HIP(hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+  KWY_PROF(ctx, "k_np_words", hipLaunchKernelGGL(k_np_words, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, nblocks, kbuf));
+  hipLaunchKernelGGL(k_np_count, dim3(ntiles), dim3(KWY_THREADS), 0, ctx->stream, state, kbuf, job, counts);
+  hipLaunchKernelGGL(k_np_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, job, ntiles, counts, info);
+  KWY_PROF(ctx, "k_np_emit", hipLaunchKernelGGL(k_np_emit, dim3(ntiles), dim3(KWY_THREADS), 0, ctx->stream, state, kbuf, job, info));
+  hipLaunchKernelGGL(k_np_advance, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, kbuf, info, status);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
 extern "C" int kwy_np_normal_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n,
                                  double *out) {
   KWY_TRY(np_check(ctx, state, n, out));
   if (n == 0) return KWY_OK;
   KWY_HIP(hipSetDevice(ctx->device));
-  KWY_PROF(ctx, "k_np_normal", hipLaunchKernelGGL(k_np_normal, dim3(1), dim3(KWY_THREADS), 0, ctx->stream,
-                                                  (np_state *)state, loc, scale, take_abs, n, out));
-  KWY_HIP(hipGetLastError());
-  return KWY_OK;
+  KWY_TRY(kwy_arena_begin(ctx, np_scratch_bytes(n)));
+  double *outs[1] = {out};
+  return np_core(ctx, (np_state *)state, loc, scale, take_abs, 1, n, outs);
+}
+
+// `count` (<= 4) blocks of n_each values each from one continuous stream: what pad_silence draws for one aligned pair
+extern "C" int kwy_np_normal_blocks_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int count,
+                                        int64_t n_each, double *const *outs) {
+  if (!ctx) return KWY_EINVAL;
+  if (!state || !outs || count < 1 || count > 4 || n_each < 1) { ctx->err = "np_normal_blocks: bad argument"; return KWY_EINVAL; }
+  for (int c = 0; c < count; ++c)
+    if (!outs[c]) { ctx->err = "np_normal_blocks: null destination"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, np_scratch_bytes((int64_t)count * n_each)));
+  return np_core(ctx, (np_state *)state, loc, scale, take_abs, count, n_each, outs);
 }
 
 extern "C" int kwy_np_normal(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n,
@@ -183,11 +393,12 @@ extern "C" int kwy_np_normal(kwy_ctx *ctx, void *state, double loc, double scale
   KWY_TRY(np_check(ctx, state, n, out));
   if (n == 0) return KWY_OK;
   KWY_HIP(hipSetDevice(ctx->device));
-  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(np_state)) + kwy_pad(sizeof(double) * (size_t)n)));
+  KWY_TRY(kwy_arena_begin(ctx, np_scratch_bytes(n) + kwy_pad(sizeof(np_state)) + kwy_pad(sizeof(double) * (size_t)n)));
   np_state *ds = (np_state *)kwy_arena_alloc(ctx, sizeof(np_state));
   double *dout = kwy_arena<double>(ctx, (size_t)n);
   KWY_HIP(hipMemcpyAsync(ds, state, sizeof(np_state), hipMemcpyHostToDevice, ctx->stream));
-  KWY_TRY(kwy_np_normal_dev(ctx, ds, loc, scale, take_abs, n, dout));
+  double *outs[1] = {dout};
+  KWY_TRY(np_core(ctx, ds, loc, scale, take_abs, 1, n, outs));
   KWY_HIP(hipMemcpyAsync(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipMemcpyAsync(state, ds, sizeof(np_state), hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipStreamSynchronize(ctx->stream));

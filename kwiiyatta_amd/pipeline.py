@@ -436,8 +436,7 @@ class SilenceFeeder:
             sl = slots[k]
             if sl['taken'] is not None:
                 self.rng.stream.wait_event(sl['taken'])
-            for blk in sl['blocks']:
-                self.rng.abs_normal(self.scale, out=blk)
+            self.rng.abs_normal_blocks(self.scale, sl['blocks'])
             p.stream.wait_event(self.rng.record_event())
             rows = p.src.silence_rows() + p.tgt.silence_rows()
             with torch.cuda.stream(p.stream):

@@ -102,12 +102,12 @@ class NumpyStats:
     def km_closest_total(self):
         return _t(np.array([self.closest.sum()]))
 
-    def km_pick(self, lo, vals, first, last):
+    def km_pick(self, lo, hi, vals, first, last):
         cum = np.cumsum(self.closest)
         out = np.empty(len(vals), dtype=np.int64)
-        for c, val in enumerate(vals.numpy() - float(lo)):
-            mine = (first or val > 0.0) and (val <= cum[-1] or last)
-            out[c] = min(int(np.searchsorted(cum, val)), self.n - 1) if mine else -1
+        for c, v in enumerate(vals.numpy()):
+            mine = (first or v > float(lo)) and (v <= float(hi) or last)
+            out[c] = min(int(np.searchsorted(cum, v - float(lo))), self.n - 1) if mine else -1
         return _t(out)
 
     def km_candidates(self, cand, use_closest):

@@ -150,6 +150,61 @@ def test_fit_two_ranks_gloo():
     assert np.allclose(ref.means_, m0, rtol=1e-7, atol=1e-9)
 
 
+def _hip_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    c = TWO_RANK_HIP
+    X = make_data(c['n'], c['D'], 6, seed=c['seed'])
+    cut = [0, c['cut'], c['n']]
+    g = GaussianMixtureHIP(n_components=c['M'], random_state=c['seed'], max_iter=c['max_iter'], device_index=0)
+    g.fit(np.ascontiguousarray(X[cut[rank]:cut[rank + 1]]))      # the product's statistics class: HipStats
+    q.put((rank, g.n_iter_, g.lower_bound_, g.weights_, g.means_, g.covariances_, g.kmeans_n_iter_, g.kmeans_centers_))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+TWO_RANK_HIP = dict(n=9000, D=144, M=16, seed=3, max_iter=12, cut=3700)
+
+
+@pytest.mark.gpu
+def test_hip_fit_two_ranks_share_one_gpu():
+    """The N-rank fit with the PRODUCT's statistics class: two processes (gloo for the collectives, both on cuda:0)
+    fit uneven shards with HipStats -- foreign (-1) rows in the seeding, the external-stream ordering around the
+    collectives, the device-side all-gathers -- and end with the same model as one process on all rows, and as
+    scikit-learn."""
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, it0, lb0, w0, m0, c0, kit0, kc0), (_, it1, lb1, w1, m1, c1, kit1, kc1) = res
+    assert it0 == it1 and kit0 == kit1 and abs(lb0 - lb1) <= 1e-12 * abs(lb0)
+    assert np.allclose(w0, w1, rtol=1e-12) and np.allclose(m0, m1, rtol=1e-12, atol=1e-14)
+    c = TWO_RANK_HIP
+    X = make_data(c['n'], c['D'], 6, seed=c['seed'])
+    one = GaussianMixtureHIP(n_components=c['M'], random_state=c['seed'], max_iter=c['max_iter']).fit(X)
+    assert one.kmeans_n_iter_ == kit0
+    assert np.abs(one.kmeans_centers_ - kc0).max() <= 1e-11 * np.abs(kc0).max()
+    assert one.n_iter_ == it0 and abs(one.lower_bound_ - lb0) <= 1e-9 * abs(lb0)
+    assert np.allclose(one.weights_, w0, rtol=1e-9) and np.allclose(one.means_, m0, rtol=1e-8, atol=1e-11)
+    assert np.allclose(one.covariances_, c0, rtol=1e-7, atol=1e-10)
+    ref = sklearn_fit(X, c['M'], seed=c['seed'], max_iter=c['max_iter'])
+    assert ref.n_iter_ == it0 and np.allclose(ref.means_, m0, rtol=1e-6, atol=1e-8)
+
+
 def test_rccl_path_reduces_device_tensors_only():
     """Under backend 'nccl' a host tensor must never reach all_reduce (RCCL has no CPU backend): the
     communicator refuses it instead of letting torch.distributed raise half-way through a fit."""
@@ -251,9 +306,23 @@ def test_hip_kmeans_blocks_match_numpy():
         cum = np.cumsum(ns.closest)
         vals = np.array([0.0, cum[0] * 0.5, cum[10] * (1 - 1e-9), cum[3333] * (1 + 1e-12), cum[-1] * 0.999999, cum[-1] * 1.01])
         for lo, first, last in ((0.0, True, True), (0.0, True, False), (cum[-1] * 0.25, False, False), (cum[-1] * 0.25, False, True)):
-            want = ns.km_pick(torch.tensor([lo]), torch.from_numpy(vals), first, last).numpy()
-            got = hs.km_pick(torch.tensor([lo]).cuda(), torch.from_numpy(vals).cuda(), first, last).cpu().numpy()
+            hi = lo + tot_h
+            want = ns.km_pick(torch.tensor([lo]), torch.tensor([hi]), torch.from_numpy(vals), first, last).numpy()
+            got = hs.km_pick(torch.tensor([lo]).cuda(), torch.tensor([hi]).cuda(), torch.from_numpy(vals).cuda(), first,
+                             last).cpu().numpy()
             assert np.array_equal(got, want), (lo, first, last, got, want)
+        # the edges of the search (the k-means++ seeding once aborted in a torch gather on an out-of-range row,
+        # DESIGN.md section 6): a draw at or beyond the total potential -> the LAST row, never row n; a value owned
+        # by another shard -> -1, which the driver must not use as an index; a value exactly on the upper bound
+        # belongs to this shard and not to the next one
+        lo, hi = 3.0 * tot_h, 4.0 * tot_h
+        edge = np.array([hi, hi * (1 + 1e-15) + 1e-300, lo, lo * (1 - 1e-15), 10 * hi, np.nextafter(lo, np.inf)])
+        t = lambda v: torch.tensor([v]).cuda()     # noqa: E731
+        mid = hs.km_pick(t(lo), t(hi), torch.from_numpy(edge).cuda(), False, False).cpu().numpy()
+        assert mid[0] == n - 1 and mid[1] == -1 and mid[2] == -1 and mid[3] == -1 and mid[4] == -1 and mid[5] == 0
+        nxt = hs.km_pick(t(hi), t(hi + tot_h), torch.from_numpy(edge).cuda(), False, True).cpu().numpy()
+        assert nxt[0] == -1 and nxt[1] == 0 and nxt[4] == n - 1          # the boundary value has exactly one owner
+        assert ((mid >= -1) & (mid < n)).all() and ((nxt >= -1) & (nxt < n)).all()
         p_h = hs.km_candidates(torch.from_numpy(cand[:3].copy()).cuda(), use_closest=True).cpu().numpy()
         p_n = ns.km_candidates(torch.from_numpy(cand[:3].copy()), use_closest=True).numpy()
         assert np.allclose(p_h, p_n, rtol=1e-12)

@@ -21,7 +21,9 @@ def test_pad_block_equals_numpy(seed):
     rs = DeviceRandomState.from_seed(seed)
     ref = np.random.RandomState(seed)
     for block in range(4):
-        got = rs.abs_normal(EPS / 48000, (100, 1025)).cpu().numpy()
+        got = rs.abs_normal(EPS / 48000, (100, 1025))
+        rs.sync()
+        got = got.cpu().numpy()
         want = np.abs(ref.normal(0, EPS / 48000, (100, 1025)))
         assert got.shape == want.shape
         assert np.abs(got / want - 1).max() <= 1e-15, block
@@ -38,7 +40,9 @@ def test_odd_counts_and_cached_gaussian():
     ref.randint(0, 10, 3)             # and a few single words
     rs = DeviceRandomState(ref.get_state())
     for n in (1, 1, 2, 3, 0, 7, 155, 156, 157, 311, 312, 313, 1000, 1, 4097, 12345):
-        got = rs.normal(0.25, 3.0, (n,)).cpu().numpy()
+        got = rs.normal(0.25, 3.0, (n,))
+        rs.sync()
+        got = got.cpu().numpy()
         want = ref.normal(0.25, 3.0, n)
         assert got.shape == want.shape
         if n:
@@ -58,7 +62,30 @@ def test_global_generator_round_trip():
     b = np.random.normal(size=5)
     np.random.seed(7)
     rs = DeviceRandomState.from_global()
-    a_dev = rs.abs_normal(1e-20, (100, 513)).cpu().numpy()
-    rs.to_global()
+    a_dev = rs.abs_normal(1e-20, (100, 513))
+    rs.to_global()                    # (synchronises the generator's stream)
+    a_dev = a_dev.cpu().numpy()
     assert np.abs(a_dev / a - 1).max() <= 1e-15
     assert np.allclose(np.random.normal(size=5), b, rtol=1e-15, atol=0)
+
+
+def test_pair_blocks_in_one_call_and_both_code_paths():
+    """the four pad blocks of a pair in one call (the five-launch path: serial MT19937 words, chip-wide accept / scan /
+    emit) equal four separate numpy calls, the single-workgroup kernel (small requests) continues the same stream, and
+    the states agree after every mix of the two"""
+    import torch
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    ref = np.random.RandomState(5)
+    rs = DeviceRandomState.from_seed(5)
+    for shape in ((100, 1025), (100, 513), (3, 7), (100, 1025), (41, 101)):
+        outs = [torch.empty(shape, dtype=torch.float64, device='cuda') for _ in range(4)]
+        rs.abs_normal_blocks(EPS / 48000, outs)
+        rs.sync()
+        for t in outs:
+            want = np.abs(ref.normal(0, EPS / 48000, shape))
+            assert np.abs(t.cpu().numpy() / want - 1).max() <= 1e-15
+        assert _same_state(rs.get_state(), ref.get_state())
+        odd = rs.normal(1.0, 2.0, (4099,))        # large and odd: the cached twin crosses into the next call
+        rs.sync()
+        assert np.abs(odd.cpu().numpy() - ref.normal(1.0, 2.0, 4099)).max() <= 1e-14
+        assert _same_state(rs.get_state(), ref.get_state())
