@@ -32,6 +32,8 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '64')
 
 FS = 48000
 FRAME_PERIOD = 5.0
+# counter summaries of the current kernels (tools/final_measure.sh + tools/collect_profiles.sh)
+PMC_TRAFFIC, PMC_SQ = 'r3_pmc_traffic.json', 'r3_pmc_sq_summary.json'
 METRIC = 'frames/sec end-to-end analyse->align->convert->synth, 48 kHz 5 ms hop'
 
 
@@ -396,12 +398,25 @@ def main():
         else:
             p.run()
 
+    # The variants below add service streams (copies, the pad generator) to the pair streams.  The chip runs 32 hardware
+    # queues side by side; with more live streams than that the queue scheduler time-slices them at ~12 ms a turn, and
+    # a chain of cross-stream events then pays a turn per link (measured: HostFeeder on 32 + 2 streams 411 ms per
+    # step).  So the variants run on the first 30 pair streams and say so.
+    vpipes = pipes[:30] if len(pipes) > 30 else pipes
+    vframes = sum(p.frames for p in vpipes)
+
+    def sync_v():
+        for p in vpipes:
+            p.sync()
+        torch.cuda.synchronize()
+
     def run_pcie_variant():
         if args.workload != 'pair' or args.no_pcie_variant:
             return None
-        feeder = pl.HostFeeder(pipes)
+        feeder = pl.HostFeeder(vpipes)
         elp = timed_variant(lambda: feeder.step(launch), feeder.sync)
-        pcie = {'ms_per_step': 1000.0 * elp / args.steps,
+        pcie = {'ms_per_step': 1000.0 * elp / args.steps, 'pairs_per_step': len(vpipes),
+                'frames_per_s_rank': vframes * args.steps / elp,
                 'bytes_per_pair': int(sum(h.numel() * 8 for h in feeder.host_in[0]) + feeder.host_out[0].numel() * 8),
                 'note': 'same steps with the two waveforms uploaded from pinned host memory and the synthesised waveform '
                         'downloaded inside the timed region: one upload and one download stream for all pairs, two '
@@ -418,20 +433,21 @@ def main():
         if args.workload != 'pair' or args.no_pcie_variant:
             return None
         from kwiiyatta_amd.backend.nprandom import DeviceRandomState
-        frames_step = sum(p.frames for p in pipes)
-        feeder = pl.SilenceFeeder(pipes, DeviceRandomState.from_seed(1000 + rank, device_index=local_rank))
+        frames_step = vframes
+        feeder = pl.SilenceFeeder(vpipes, DeviceRandomState.from_seed(1000 + rank, device_index=local_rank))
         eld = timed_variant(lambda: feeder.step(launch), feeder.sync)
-        res = {'device': {'ms_per_step': 1000.0 * eld / args.steps, 'frames_per_s_rank': frames_step * args.steps / eld,
+        res = {'device': {'ms_per_step': 1000.0 * eld / args.steps, 'pairs_per_step': len(vpipes),
+                          'frames_per_s_rank': frames_step * args.steps / eld,
                           'note': 'same steps with the four pad blocks of every pair drawn inside the timed region by '
                                   'k_np_normal (numpy\'s MT19937 + polar Box-Muller stream, draw for draw) on its own '
                                   'stream, double-buffered; never `value`'}}
         K = pipes[0].K
-        stage = [[torch.empty((100, K), dtype=torch.float64).pin_memory() for _ in range(4)] for _ in pipes]
+        stage = [[torch.empty((100, K), dtype=torch.float64).pin_memory() for _ in range(4)] for _ in vpipes]
         host_s = [0.0]
         host_steps = 2
 
         def step_pad():
-            for p, st in zip(pipes, stage):
+            for p, st in zip(vpipes, stage):
                 p.sync()                 # the pinned blocks of this pair are about to be overwritten
                 t_ = time.perf_counter()
                 drawn = [pl.draw_silence(FS, K) for _ in st]
@@ -444,9 +460,9 @@ def main():
                         dst.copy_(blk, non_blocking=True)
                 launch(p)
         elp = timed_variant(step_pad, steps=host_steps)
-        res['host'] = {'ms_per_step': 1000.0 * elp / host_steps, 'steps': host_steps,
+        res['host'] = {'ms_per_step': 1000.0 * elp / host_steps, 'steps': host_steps, 'pairs_per_step': len(vpipes),
                        'frames_per_s_rank': frames_step * host_steps / elp,
-                       'host_draw_ms_per_pair': 1000.0 * host_s[0] / ((host_steps + 1) * len(pipes)),
+                       'host_draw_ms_per_pair': 1000.0 * host_s[0] / ((host_steps + 1) * len(vpipes)),
                        'note': 'same steps with the four pad blocks of every pair drawn on the host inside the timed '
                                'region (np.random.normal from the global legacy generator, one thread) and uploaded; '
                                'never `value`'}
@@ -510,13 +526,20 @@ def main():
                 tbl[D4C] = [a[0] + b[0], min(a[1], b[1])] if isinstance(a, list) else a + b
         if D4C in alone_ms:
             alone_n[D4C] = alone_n['k_d4c_body']
-        # Frames one launch of a per-frame kernel processes (pair: source and target utterances alternate).
-        fpl = float(T) if args.workload == 'utterance' else (pipes[0].src.T + pipes[0].tgt.T) / 2.0
+        # Frames one launch of a per-frame kernel processes.  Pair workload: the analysis kernels take BOTH utterances
+        # of the pair in one grid (kwy_*_batch_dev: source + target frames per launch) unless D4C runs on the side
+        # stream (--batch 1 in the timed region: one utterance per launch); the lone pipeline measured for the
+        # roofline always batches.  The synthesis renders the target's frames.
+        if args.workload == 'utterance':
+            fpl = fpl_syn = float(T)
+        else:
+            fpl = float(pipes[0].src.T + pipes[0].tgt.T)
+            fpl_syn = float(pipes[0].tgt.T)
         hop = FS * FRAME_PERIOD / 1000.0
         # ALGORITHMIC HBM bytes per launch of the whole-chip kernels:
         # hop new samples + (f0, t) in, one K-bin f64 row out per frame; synthesis reads sp+ap rows, writes hop samples.
         algo = {D4C: fpl * (hop * 8 + 16 + K * 8), 'k_cheaptrick': fpl * (hop * 8 + 16 + K * 8),
-                'k_d4c_lovetrain': fpl * (hop * 8 + 16 + 8), 'k_syn_pulse': fpl * (2 * K * 8 + hop * 8)}
+                'k_d4c_lovetrain': fpl * (hop * 8 + 16 + 8), 'k_syn_pulse': fpl_syn * (2 * K * 8 + hop * 8)}
         # The dominant kernel = the whole-chip kernel with the largest summed duration.  The single-workgroup
         # serial kernels (k_dtw_dp, k_syn_phase, ...) occupy one CU each and overlap with other streams;
         # they bound latency, not throughput, and are listed in kernel_ms_per_launch.
@@ -525,24 +548,27 @@ def main():
         tot_ms, launches = kernel_ms.get(dom, (0.0, 0))
         bytes_per_launch = algo[dom]
         avg_s = (tot_ms / launches) * 1e-3 if launches else float('nan')
-        achieved = bytes_per_launch / avg_s / 1e9 if launches else None
+        # (with D4C on the side stream the timed passes launch the analysis per utterance: half the bytes per launch)
+        shared_bytes = bytes_per_launch / 2 if (args.workload == 'pair' and args.side_stream and dom != 'k_syn_pulse') \
+            else bytes_per_launch
+        achieved = shared_bytes / avg_s / 1e9 if launches else None
         traffic = None
         try:        # PMC-measured HBM bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) per launch
-            with open(os.path.join(ROOT, 'profiles', 'r2_pmc_traffic.json')) as fh:
+            with open(os.path.join(ROOT, 'profiles', PMC_TRAFFIC)) as fh:
                 pmc = json.load(fh)
             traffic = sum(pmc['kernels'][k]['hbm_bytes_per_launch_raw'] for k in dom.split('+')) \
                 * fpl / pmc['frames_per_launch']
         except (OSError, KeyError, ValueError):
             pass
         # The roofline line is priced on the kernel's own duration: HIP events around launches of one stream with
-        # the GPU to itself (they agree with rocprofv3's per-dispatch durations, profiles/r2_pair_b1_kernel_stats.csv).
+        # the GPU to itself (they agree with rocprofv3's per-dispatch durations, profiles/r3_pair_b1_kernel_stats.csv).
         # Events around a launch that competes with 31 other streams also span the time the dispatch waits in its
         # hardware queue -- about 3x what rocprofv3 reports for the same dispatches -- and are kept in `shared`.
         alone_achieved = (bytes_per_launch / (alone_ms[dom] * 1e-3) / 1e9) if dom in alone_ms else None
         roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': alone_achieved, 'peak': 8000.0, 'unit': 'GB/s',
                     'frac': (alone_achieved / 8000.0) if alone_achieved else None, 'traffic': traffic,
                     'avg_launch_ms': alone_ms.get(dom), 'launches': alone_n.get(dom, 0),
-                    'algorithmic_bytes_per_launch': bytes_per_launch,
+                    'algorithmic_bytes_per_launch': bytes_per_launch, 'frames_per_launch': fpl if dom != 'k_syn_pulse' else fpl_syn,
                     'shared': {'avg_launch_ms': tot_ms / launches if launches else None, 'launches': launches,
                                'achieved': achieved,
                                'measured': ('passes enqueued kernel by kernel on the same streams right after the '
@@ -550,14 +576,14 @@ def main():
                                             'the timed region replays)') if args.graph else 'inside the timed region'},
                     'note': 'kernel is bound by f64 FFT arithmetic and barrier latency in LDS, not by HBM; the HBM '
                             'fraction is reported as asked (DESIGN.md section 5).  traffic = FETCH_SIZE+WRITE_SIZE of '
-                            'profiles/r2_pmc_traffic.json scaled to the frames of one launch.  avg_launch_ms: HIP events '
+                            'profiles/r3_pmc_traffic.json scaled to the frames of one launch.  avg_launch_ms: HIP events '
                             'on the launching stream, one stream running, right after the timed region'}
         # Compute roofline of the same kernel family: algorithmic f64 flop (5 N log2 N per real FFT of
         # size N; the D4C stage runs 10 transforms of 4096 per frame that passes the voicing gate) / kernel time /
         # the f64 vector peak (1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s).
         roofline_compute = None
         if args.workload == 'pair' and D4C in alone_ms:
-            voiced = (float((pipes[0].src.f0 > 0).sum().item()) + float((pipes[0].tgt.f0 > 0).sum().item())) / 2.0
+            voiced = float((pipes[0].src.f0 > 0).sum().item()) + float((pipes[0].tgt.f0 > 0).sum().item())
             flop = voiced * 10 * 5 * 4096 * 12
             tf = flop / (alone_ms[D4C] * 1e-3) / 1e12
             roofline_compute = {'bound': 'f64 vector', 'kernel': D4C, 'achieved': tf, 'peak': 78.6,
@@ -567,7 +593,7 @@ def main():
                                 'note': 'FFT flop only (windows, RNG, smoothing, selects not counted); frames with '
                                         'work = frames with f0 > 0 (upper bound of the frames that pass the gate)'}
             try:    # what the stage is bound by: vector-instruction issue (SQ counters, tools/pmc_sq.sh, one utterance alone)
-                with open(os.path.join(ROOT, 'profiles', 'r2_pmc_sq_summary.json')) as fh:
+                with open(os.path.join(ROOT, 'profiles', PMC_SQ)) as fh:
                     sq = json.load(fh)
                 roofline_compute['valu_issue'] = {
                     k: {'busy_share_of_launch_per_simd': sq[k]['VALU_busy_per_SIMD'],
@@ -638,7 +664,7 @@ def main():
         sync_all()
     if rank == 0:
         if pcie:
-            out['with_pcie'] = {'value': frames_total / (pcie['ms_per_step'] * 1e-3 * args.steps), **pcie}
+            out['with_pcie'] = pcie
         if pad:
             out['with_pad_draw'] = pad
         if not args.no_cpu_baseline and world == 1:

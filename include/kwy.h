@@ -93,6 +93,20 @@ int kwy_cheaptrick_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
                        const double *temporal_positions, const double *f0, int64_t f0_length,
                        double q1, double f0_floor, int fft_size, double out_div, double *out);
 
+/* The same call for a batch of utterances of one sampling rate (device pointers), one grid over all their frames:
+ * what Analyzer.extract_spectrum_envelope does file after file (kwiiyatta/vocoder/world.py:43-52) for both sides of a
+ * pair, or for every file of a corpus.  A lone utterance's ~2 000 workgroups are 2.2 rounds of what the chip holds. */
+typedef struct kwy_utterance {
+  const double *x;                   /* waveform, x_length samples */
+  int64_t x_length;
+  const double *temporal_positions;  /* f0_length frame times [s] */
+  const double *f0;                  /* f0_length */
+  int64_t f0_length;
+  double *out;                       /* f0_length x (fft_size/2+1) */
+} kwy_utterance;
+int kwy_cheaptrick_batch_dev(kwy_ctx *ctx, const kwy_utterance *utterances, int count, int fs, double q1,
+                             double f0_floor, int fft_size, double out_div);
+
 /* pyworld.d4c(x, f0, t, fs, threshold, fft_size)     kwiiyatta/vocoder/world.py:55
  * out: T x (fft_size/2+1). */
 int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
@@ -101,6 +115,9 @@ int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
 int kwy_d4c_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
                 const double *temporal_positions, const double *f0, int64_t f0_length,
                 double threshold, int fft_size, double *out);
+/* ... for a batch of utterances (see kwy_cheaptrick_batch_dev) */
+int kwy_d4c_batch_dev(kwy_ctx *ctx, const kwy_utterance *utterances, int count, int fs, double threshold,
+                      int fft_size);
 
 /* pyworld.dio(x, fs, f0_floor, f0_ceil, channels_in_octave, frame_period, speed,
  *             allowed_range) -> (f0, t)              kwiiyatta/vocoder/world.py:35

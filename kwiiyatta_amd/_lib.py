@@ -76,6 +76,8 @@ SIGNATURES = {
                                c_dbl, c_vp]),
     'kwy_cheaptrick_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl,
                                    c_int, c_dbl, c_vp]),
+    'kwy_cheaptrick_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl]),
+    'kwy_d4c_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_int]),
     'kwy_d4c': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_int, c_vp]),
     'kwy_d4c_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_int, c_vp]),
     'kwy_dio': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_dbl,
@@ -151,6 +153,22 @@ for _name, (_res, _args) in SIGNATURES.items():
         continue
     _f.restype = _res
     _f.argtypes = _args
+
+
+class Utterance(ctypes.Structure):
+    """kwy_utterance (include/kwy.h): device pointers of one utterance for the batched analysis calls"""
+    _fields_ = [('x', c_vp), ('x_length', c_i64), ('temporal_positions', c_vp), ('f0', c_vp), ('f0_length', c_i64),
+                ('out', c_vp)]
+
+
+def utterance_array(items):
+    """items: (x, t, f0, out) device tensors per utterance -> a ctypes array of kwy_utterance"""
+    arr = (Utterance * len(items))()
+    for q, (x, t, f0, out) in zip(arr, items):
+        q.x, q.x_length = x.data_ptr(), x.numel()
+        q.temporal_positions, q.f0, q.f0_length = t.data_ptr(), f0.data_ptr(), f0.numel()
+        q.out = out.data_ptr()
+    return arr
 
 
 class Context:

@@ -19,14 +19,24 @@
 #define CT_EPS 0.00000000000000022204460492503131
 #define CT_DEFAULT_F0 500.0
 
-// per-frame draw counts (window length + K) and their exclusive prefix sums, in one single-workgroup launch
-__global__ __launch_bounds__(KWY_THREADS) void k_ct_scan(const double *__restrict__ f0, int64_t T, int fs,
-                                                        double f0_floor_eff, int K, uint64_t *__restrict__ offsets) {
+// one utterance of a launch
+struct ct_view {
+  const double *x, *tpos, *f0;
+  double *out;
+  uint64_t *offsets;     // T + 1: stream position of every frame's first draw (WORLD reseeds per call: 0 for frame 0)
+  int x_length, T;
+};
+typedef kwy_batch<ct_view> ct_batch;
+
+// per-frame draw counts (window length + K) and their exclusive prefix sums; one workgroup per utterance
+__global__ __launch_bounds__(KWY_THREADS) void k_ct_scan(ct_batch b, int fs, double f0_floor_eff, int K) {
   __shared__ uint64_t tot[KWY_THREADS];
+  const ct_view v = b.u[blockIdx.x];
+  const double *f0 = v.f0;
   kwy_block_count_scan<KWY_THREADS>([&](int64_t i) -> uint64_t {
     const double cf0 = f0[i] <= f0_floor_eff ? CT_DEFAULT_F0 : f0[i];
     return (uint64_t)(2 * kwy_matlab_round(1.5 * fs / cf0) + 1 + K);
-  }, T, offsets, tot);
+  }, v.T, v.offsets, tot);
 }
 
 // y(x) on the regular grid x0 + shift*j (WORLD interp1Q); delta of the last node is 0
@@ -42,11 +52,8 @@ __device__ __forceinline__ double ct_interp1q(double x0, double shift, const dou
 
 template <int LOG2N>
 __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
-    const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
-    const double *__restrict__ f0, double q1, double f0_floor_eff,
-    const uint64_t *__restrict__ offsets, kwy_randn_src rs, const uint4 *__restrict__ poly,
-    const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN, double out_div,
-    double *__restrict__ out) {
+    ct_batch batch, int fs, double q1, double f0_floor_eff, kwy_randn_src rs, const uint4 *__restrict__ poly,
+    const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN, double out_div) {
   constexpr int N = 1 << LOG2N;
   constexpr int H = N / 2;
   constexpr int K = H + 1;
@@ -66,10 +73,15 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   uint32_t *e = (uint32_t *)(tot + KWY_THREADS);  // KWY_EBASE_WORDS
 
   const int tid = threadIdx.x;
-  const int64_t frame = blockIdx.x;
-  const double f0v = f0[frame];
+  const int utt = batch.find(blockIdx.x);
+  const int64_t frame = (int)blockIdx.x - batch.start[utt];
+  const double *__restrict__ x = batch.u[utt].x;
+  const int x_length = batch.u[utt].x_length;
+  const uint64_t *__restrict__ offsets = batch.u[utt].offsets;
+  double *__restrict__ out = batch.u[utt].out;
+  const double f0v = batch.u[utt].f0[frame];
   const double cf0 = f0v <= f0_floor_eff ? CT_DEFAULT_F0 : f0v;
-  const double pos = tpos[frame];
+  const double pos = batch.u[utt].tpos[frame];
   const int half = kwy_matlab_round(1.5 * fs / cf0);
   const int wl = 2 * half + 1;
   const int origin = kwy_matlab_round(pos * fs + 0.001);
@@ -116,15 +128,20 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   }
 
   // ---- F0-adaptive window (thread owns samples i = tid + 256 j < wl: coalesced reads of the framed audio)
+  // The Hanning window's argument advances by a constant from one j to the next: cos and sin of the first element,
+  // then rotations by the step angle (kwy_device.hpp) instead of a trigonometric polynomial per element.
   double wv[E];
   double sumsq = 0.0;
+  double wc, ws, wcd, wsd;
+  kwy_sincos_pi_range(KWY_PI * ((tid - half) / 1.5 / fs) * cf0, &ws, &wc);   // |argument| <= pi inside the window
+  sincos(KWY_PI * (KWY_THREADS / 1.5 / fs) * cf0, &wsd, &wcd);
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int i = tid + KWY_THREADS * j;
     double w = 0.0;
+    if (j > 0) kwy_rotate(wc, ws, wcd, wsd);
     if (i < wl) {
-      double position = (i - half) / 1.5 / fs;
-      w = 0.5 * kwy_cos_pi_range(KWY_PI * position * cf0) + 0.5;   // |argument| <= pi inside the window
+      w = 0.5 * wc + 0.5;
       sumsq += w * w;
     }
     wv[j] = w;
@@ -253,9 +270,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
 }
 
 template <int LOG2N>
-static int launch_ct(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
-                     const double *f0, int64_t T, double q1, double floor_eff,
-                     const uint64_t *offsets, double out_div, double *out) {
+static int launch_ct(kwy_ctx *ctx, const ct_batch &b, int fs, double q1, double floor_eff, double out_div) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;
   const kwy_c *twH, *twN;
@@ -267,8 +282,8 @@ static int launch_ct(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
                sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_cheaptrick<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_cheaptrick", hipLaunchKernelGGL(k_cheaptrick<LOG2N>, dim3((unsigned)T), dim3(KWY_THREADS), lds, ctx->stream, x,
-                     (int)x_length, fs, t, f0, q1, floor_eff, offsets, kwy_randn(ctx), poly, twH, twN, out_div, out));
+  KWY_PROF(ctx, "k_cheaptrick", hipLaunchKernelGGL(k_cheaptrick<LOG2N>, dim3((unsigned)b.start[b.n]), dim3(KWY_THREADS), lds,
+                     ctx->stream, b, fs, q1, floor_eff, kwy_randn(ctx), poly, twH, twN, out_div));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -277,10 +292,9 @@ static size_t ct_scratch_bytes(int64_t T) {
   return kwy_pad(sizeof(uint64_t) * (T + 1));
 }
 
-// device-pointer core; the arena must already have room (ct_scratch_bytes)
-static int cheaptrick_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
-                           const double *f0, int64_t T, double q1, int fft_size, double out_div,
-                           double *out) {
+// device-pointer core for up to KWY_BATCH_MAX utterances (b.u[].offsets are filled in here from the arena, which must
+// already have room: ct_scratch_bytes per utterance)
+static int cheaptrick_core(kwy_ctx *ctx, ct_batch &b, int fs, double q1, int fft_size, double out_div) {
   const int log2n = kwy_ilog2(fft_size);
   if ((1 << log2n) != fft_size || log2n < 9 || log2n > 12) {
     ctx->err = "cheaptrick: fft_size must be a power of two in [512, 4096]";
@@ -288,16 +302,28 @@ static int cheaptrick_core(kwy_ctx *ctx, const double *x, int64_t x_length, int 
   }
   const int K = fft_size / 2 + 1;
   const double floor_eff = 3.0 * fs / (fft_size - 3.0);
-  uint64_t *offsets = kwy_arena<uint64_t>(ctx, T + 1);
-  if (!offsets) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
-  hipLaunchKernelGGL(k_ct_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, T, fs, floor_eff, K, offsets);
+  b.start[0] = 0;
+  for (int u = 0; u < b.n; ++u) {
+    b.u[u].offsets = kwy_arena<uint64_t>(ctx, (size_t)b.u[u].T + 1);
+    if (!b.u[u].offsets) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
+    b.start[u + 1] = b.start[u] + b.u[u].T;
+  }
+  hipLaunchKernelGGL(k_ct_scan, dim3(b.n), dim3(KWY_THREADS), 0, ctx->stream, b, fs, floor_eff, K);
   KWY_HIP(hipGetLastError());
   switch (log2n) {
-    case 9: return launch_ct<9>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
-    case 10: return launch_ct<10>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
-    case 11: return launch_ct<11>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
-    default: return launch_ct<12>(ctx, x, x_length, fs, t, f0, T, q1, floor_eff, offsets, out_div, out);
+    case 9: return launch_ct<9>(ctx, b, fs, q1, floor_eff, out_div);
+    case 10: return launch_ct<10>(ctx, b, fs, q1, floor_eff, out_div);
+    case 11: return launch_ct<11>(ctx, b, fs, q1, floor_eff, out_div);
+    default: return launch_ct<12>(ctx, b, fs, q1, floor_eff, out_div);
   }
+}
+
+static int cheaptrick_one(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                          const double *f0, int64_t T, double q1, int fft_size, double out_div, double *out) {
+  ct_batch b;
+  b.n = 1;
+  b.u[0] = ct_view{x, t, f0, out, nullptr, (int)x_length, (int)T};
+  return cheaptrick_core(ctx, b, fs, q1, fft_size, out_div);
 }
 
 static int ct_check(kwy_ctx *ctx, const void *x, int64_t x_length, int fs, const void *t,
@@ -320,7 +346,36 @@ extern "C" int kwy_cheaptrick_dev(kwy_ctx *ctx, const double *x, int64_t x_lengt
   KWY_TRY(ct_check(ctx, x, x_length, fs, t, f0, T, out, &fft_size, f0_floor));
   KWY_HIP(hipSetDevice(ctx->device));
   KWY_TRY(kwy_arena_begin(ctx, ct_scratch_bytes(T)));
-  return cheaptrick_core(ctx, x, x_length, fs, t, f0, T, q1, fft_size, out_div, out);
+  return cheaptrick_one(ctx, x, x_length, fs, t, f0, T, q1, fft_size, out_div, out);
+}
+
+// pyworld.cheaptrick for `count` utterances of one sampling rate in as few launches as possible (KWY_BATCH_MAX
+// utterances each): one grid over all frames
+extern "C" int kwy_cheaptrick_batch_dev(kwy_ctx *ctx, const kwy_utterance *utts, int count, int fs, double q1,
+                                        double f0_floor, int fft_size, double out_div) {
+  if (!ctx) return KWY_EINVAL;
+  if (!utts || count < 1) { ctx->err = "cheaptrick_batch: bad argument"; return KWY_EINVAL; }
+  size_t scratch = 0;
+  int64_t frames = 0;
+  for (int i = 0; i < count; ++i) {
+    const kwy_utterance &q = utts[i];
+    KWY_TRY(ct_check(ctx, q.x, q.x_length, fs, q.temporal_positions, q.f0, q.f0_length, q.out, &fft_size, f0_floor));
+    scratch += ct_scratch_bytes(q.f0_length);
+    frames += q.f0_length;
+  }
+  if (frames > 0x7fffffff) { ctx->err = "cheaptrick_batch: too many frames"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, scratch));
+  for (int i0 = 0; i0 < count; i0 += KWY_BATCH_MAX) {
+    ct_batch b;
+    b.n = count - i0 < KWY_BATCH_MAX ? count - i0 : KWY_BATCH_MAX;
+    for (int u = 0; u < b.n; ++u) {
+      const kwy_utterance &q = utts[i0 + u];
+      b.u[u] = ct_view{q.x, q.temporal_positions, q.f0, q.out, nullptr, (int)q.x_length, (int)q.f0_length};
+    }
+    KWY_TRY(cheaptrick_core(ctx, b, fs, q1, fft_size, out_div));
+  }
+  return KWY_OK;
 }
 
 extern "C" int kwy_cheaptrick(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
@@ -339,7 +394,7 @@ extern "C" int kwy_cheaptrick(kwy_ctx *ctx, const double *x, int64_t x_length, i
   KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * x_length, hipMemcpyHostToDevice, ctx->stream));
   KWY_HIP(hipMemcpyAsync(dt, t, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
   KWY_HIP(hipMemcpyAsync(df0, f0, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
-  KWY_TRY(cheaptrick_core(ctx, dx, x_length, fs, dt, df0, T, q1, fft_size, out_div, dout));
+  KWY_TRY(cheaptrick_one(ctx, dx, x_length, fs, dt, df0, T, q1, fft_size, out_div, dout));
   KWY_HIP(hipMemcpyAsync(out, dout, sizeof(double) * T * K, hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipStreamSynchronize(ctx->stream));
   return KWY_OK;

@@ -27,14 +27,27 @@
 
 enum { D4C_HANNING = 1, D4C_BLACKMAN = 2 };
 
+// WORLD's F0-adaptive windows sampled at i = tid + NT r: value = g(cos(theta_i)), theta_i = pi cf0 (2 (i - half) /
+// ratio) / fs.  theta advances by a constant from one r to the next, so only the first element evaluates the
+// trigonometric polynomials; the others rotate (cos, sin) by the step angle (kwy_rotate: 6 instructions instead of
+// ~40, error growth ~1 ulp per step over at most 16 steps -- far below the FFT rounding that follows).
 __device__ __forceinline__ double d4c_window(int type, int i, int half, double ratio, int fs, double cf0) {
-  double position = (2.0 * (i - half) / ratio) / fs;
-  if (type == D4C_HANNING) return 0.5 * kwy_cos_pi_range(KWY_PI * position * cf0) + 0.5;
-  // Blackman: the second harmonic through the double-angle identity (one cos instead of two;
-  // differs from cos(2x) by <= 2 ulp of the window value)
-  const double c1 = kwy_cos_pi_range(KWY_PI * position * cf0);
-  return 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
+  const double c1 = kwy_cos_pi_range(KWY_PI * ((2.0 * (i - half) / ratio) / fs) * cf0);
+  return type == D4C_HANNING ? 0.5 * c1 + 0.5 : 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
 }
+
+struct d4c_window_walk {
+  double c, s, cd, sd;
+  __device__ __forceinline__ d4c_window_walk(int i0, int step, int half, double ratio, int fs, double cf0) {
+    kwy_sincos_pi_range(KWY_PI * ((2.0 * (i0 - half) / ratio) / fs) * cf0, &s, &c);   // |theta| <= pi inside the window
+    sincos(KWY_PI * ((2.0 * step / ratio) / fs) * cf0, &sd, &cd);
+  }
+  __device__ __forceinline__ void next() { kwy_rotate(c, s, cd, sd); }
+  // Blackman: the second harmonic through the double-angle identity
+  __device__ __forceinline__ double value(int type) const {
+    return type == D4C_HANNING ? 0.5 * c + 0.5 : 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0);
+  }
+};
 
 // interp1Q with the grid step given as its reciprocal (two divisions per output bin saved;
 // the position differs from (xi - x0) / shift by an ulp, the interpolant is continuous)
@@ -100,24 +113,39 @@ __device__ inline void d4c_linear_smoothing(const double *in, double *out, doubl
   __syncthreads();
 }
 
-// LoveTrain pass: per-frame draw counts and their exclusive prefix sums, one single-workgroup launch
-__global__ __launch_bounds__(KWY_THREADS) void k_d4c_lt_scan(const double *__restrict__ f0, int64_t T, int fs,
-                                                            uint64_t *__restrict__ offsets) {
+// one utterance of a launch (kwy_internal.hpp: kwy_batch)
+struct d4c_view {
+  const double *x, *tpos, *f0;
+  double *out;
+  uint64_t *offs_lt;    // T + 1: stream positions of the LoveTrain windows; [T] = the draws of the whole pass
+  uint64_t *offs_b;     // T + 1: scratch of the body scan
+  uint64_t *offs3;      // 3 T: stream positions of the body's three windows per frame, relative to offs_lt[T]
+  double *ap0;          // T: LoveTrain's voicing measure
+  double *dvbuf;        // T x (H + 1): static group delay, body -> bands
+  int x_length, T;
+};
+typedef kwy_batch<d4c_view> d4c_batch;
+
+// LoveTrain pass: per-frame draw counts and their exclusive prefix sums, one workgroup per utterance
+__global__ __launch_bounds__(KWY_THREADS) void k_d4c_lt_scan(d4c_batch b, int fs) {
   __shared__ uint64_t tot[KWY_THREADS];
+  const d4c_view v = b.u[blockIdx.x];
+  const double *f0 = v.f0;
   kwy_block_count_scan<KWY_THREADS>([&](int64_t i) -> uint64_t {
     const double f = f0[i];
     if (f == 0.0) return 0;
     return (uint64_t)(kwy_matlab_round(1.5 * fs / (f > 40.0 ? f : 40.0)) * 2 + 1);
-  }, T, offsets, tot);
+  }, v.T, v.offs_lt, tot);
 }
 
 // General body: per-frame draw counts (three windows; none for ungated frames), their prefix sums, and the draw
-// offsets of the three windows of every frame (~0 = no work), one single-workgroup launch
-__global__ __launch_bounds__(KWY_THREADS) void k_d4c_body_scan(const double *__restrict__ f0,
-                                                              const double *__restrict__ ap0, int64_t T, int fs,
-                                                              double threshold, uint64_t *__restrict__ offs,
-                                                              uint64_t *__restrict__ offs3) {
+// offsets of the three windows of every frame (~0 = no work), one workgroup per utterance
+__global__ __launch_bounds__(KWY_THREADS) void k_d4c_body_scan(d4c_batch b, int fs, double threshold) {
   __shared__ uint64_t tot[KWY_THREADS];
+  const d4c_view v = b.u[blockIdx.x];
+  const double *f0 = v.f0, *ap0 = v.ap0;
+  uint64_t *offs = v.offs_b, *offs3 = v.offs3;
+  const int64_t T = v.T;
   auto window = [&](int64_t i) -> uint64_t {      // draws of ONE window of frame i
     const double f = f0[i];
     if (f == 0.0 || ap0[i] <= threshold) return 0;
@@ -137,10 +165,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_d4c_body_scan(const double *__r
 // NT threads: 256, or 512 for the 8192-point transform of 96 kHz (one radix-8 butterfly per thread and pass).
 template <int LOG2N, int NT>
 __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
-    const double *__restrict__ x, int x_length, int fs, const double *__restrict__ tpos,
-    const double *__restrict__ f0, const uint64_t *__restrict__ offsets, kwy_randn_src rs,
-    const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    double *__restrict__ ap0) {
+    d4c_batch batch, int fs, kwy_randn_src rs,
+    const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int C = N / NT;
   constexpr int HEX = 16 * NT / N;
@@ -152,8 +178,13 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
   double *Bd = (double *)B;
 
   const int tid = threadIdx.x;
-  const int64_t frame = blockIdx.x;
-  const double f0v = f0[frame];
+  const int utt = batch.find(blockIdx.x);
+  const int64_t frame = (int)blockIdx.x - batch.start[utt];
+  const double *__restrict__ x = batch.u[utt].x;
+  const int x_length = batch.u[utt].x_length;
+  const uint64_t *__restrict__ offsets = batch.u[utt].offs_lt;
+  double *__restrict__ ap0 = batch.u[utt].ap0;
+  const double f0v = batch.u[utt].f0[frame];
   if (f0v == 0.0) {
     if (tid == 0) ap0[frame] = 0.0;
     return;
@@ -161,7 +192,7 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
   const double cf0 = f0v > 40.0 ? f0v : 40.0;
   const int half = kwy_matlab_round(3.0 * fs / cf0 / 2.0);
   const int wl = 2 * half + 1;
-  const int origin = kwy_matlab_round(tpos[frame] * fs + 0.001);
+  const int origin = kwy_matlab_round(batch.u[utt].tpos[frame] * fs + 0.001);
   kwy_c tw4[4];
   kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
   const kwy_c twb = twN[tid];
@@ -196,12 +227,14 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
   // sample i = tid + NT r: the window value goes to Bd[i], the sample waits in a register
   double vv[C];
   double s1 = 0.0, s2 = 0.0;
+  d4c_window_walk walk(tid, NT, half, 3.0, fs, cf0);
 #pragma unroll
   for (int r = 0; r < C; ++r) {
     const int i = tid + NT * r;
     double v = 0.0;
+    if (r > 0) walk.next();
     if (i < wl) {
-      double w = d4c_window(D4C_BLACKMAN, i, half, 3.0, fs, cf0);
+      double w = walk.value(D4C_BLACKMAN);
       int idx = min(x_length - 1, max(0, origin + i - half));
       v = x[idx] * w;
       v = v + kwy_randn_from_raw(raw[r]) * D4C_SAFE;
@@ -242,7 +275,7 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
 
 // ------------------------------------------------------------------ general body
 struct d4c_params {
-  int x_length, fs, K, fft_size, nbands, window_length;
+  int fs, K, fft_size, nbands, window_length;
   double threshold;
 };
 
@@ -254,7 +287,7 @@ struct d4c_params {
 // Bd (N doubles of LDS, free on entry) to the threads that use them.  `normalise` scales to
 // unit power (GetCentroid).
 template <int N, int NT>
-__device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, const d4c_params &p, double cf0,
+__device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, int x_length, const d4c_params &p, double cf0,
                                                  double pos, int type, uint64_t dpos, const kwy_randn_src &rs,
                                                  const uint4 *__restrict__ poly, uint32_t *e, uint4 *jtab,
                                                  double *Bd, bool normalise, double *red,
@@ -273,7 +306,7 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, c
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = tid + NT * r;
-    xv[r] = (i < wl) ? x[min(p.x_length - 1, max(0, origin + i - half))] : 0.0;
+    xv[r] = (i < wl) ? x[min(x_length - 1, max(0, origin + i - half))] : 0.0;
   }
   uint32_t raw[E];
   if (dpos + (uint64_t)wl <= rs.n) {
@@ -298,6 +331,8 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, c
     for (int r = 0; r < E; ++r) raw[r] = (tid + NT * r < wl) ? D[tid + NT * r] : 0u;
     __syncthreads();
   }
+  // (the rotation walk of the LoveTrain window was measured here too: no gain -- 0.185 ms either way -- and the
+  // walk's four doubles push the kernel into scratch; one polynomial per element stays)
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -430,11 +465,9 @@ static constexpr size_t d4c_body_lds() {
 
 template <int LOG2N>
 __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d4c_body(
-    const double *__restrict__ x, const double *__restrict__ tpos, const double *__restrict__ f0,
-    const double *__restrict__ ap0, d4c_params p, const uint64_t *__restrict__ offs3,
-    const uint64_t *__restrict__ draws_before, kwy_randn_src rs,
+    d4c_batch batch, d4c_params p, kwy_randn_src rs,
     const uint4 *__restrict__ poly, const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    double *__restrict__ dvbuf, double *__restrict__ out, long long *__restrict__ dbg) {
+    long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int NT = d4c_nt<LOG2N>::value;
   constexpr int E = N / NT;                  // window elements per thread
@@ -456,15 +489,21 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   uint4 *jtab = (uint4 *)((LOG2N >= 12) ? A0 : jt_own);
 
   const int tid = threadIdx.x;
-  const int64_t frame = blockIdx.x;
-  const double f0v = kwy_uniform(f0[frame]);
-  double *o = out + frame * p.K;
-  if (f0v == 0.0 || kwy_uniform(ap0[frame]) <= p.threshold) {
+  const int utt = batch.find(blockIdx.x);
+  const int64_t frame = (int)blockIdx.x - batch.start[utt];
+  const double *__restrict__ x = batch.u[utt].x;
+  const int x_length = batch.u[utt].x_length;
+  const uint64_t *__restrict__ offs3 = batch.u[utt].offs3;
+  const uint64_t *__restrict__ draws_before = batch.u[utt].offs_lt + batch.u[utt].T;
+  double *__restrict__ dvbuf = batch.u[utt].dvbuf;
+  const double f0v = kwy_uniform(batch.u[utt].f0[frame]);
+  double *o = batch.u[utt].out + frame * p.K;
+  if (f0v == 0.0 || kwy_uniform(batch.u[utt].ap0[frame]) <= p.threshold) {
     for (int k = tid; k < p.K; k += NT) o[k] = 1.0 - D4C_SAFE;
     return;
   }
   const double cf0 = kwy_uniform(f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0);
-  const double pos = kwy_uniform(tpos[frame]);
+  const double pos = kwy_uniform(batch.u[utt].tpos[frame]);
 
   D4C_STAMP(0);
   kwy_c tw4[4];   // this thread's factor of every radix-8 pass
@@ -484,7 +523,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     for (int which = 0; which < 2; ++which) {
       const int tid = kwy_tid_opaque();
       double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-      d4c_frame_window<N, NT>(x, p, cf0, cpos, D4C_BLACKMAN, which == 0 ? dpos0 : dpos1, rs, poly, e, jtab, Bd, true, red, av);
+      d4c_frame_window<N, NT>(x, x_length, p, cf0, cpos, D4C_BLACKMAN, which == 0 ? dpos0 : dpos1, rs, poly, e, jtab, Bd, true, red, av);
 #pragma unroll
       for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];   // each thread overwrites the draws it consumed
       __syncthreads();
@@ -516,7 +555,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
 
     D4C_STAMP(6);
     // ---- smoothed power spectrum (the centroid sum waits in registers)
-    d4c_frame_window<N, NT>(x, p, cf0, pos, D4C_HANNING, dpos2, rs, poly, e, jtab, Bd, false, red, av);
+    d4c_frame_window<N, NT>(x, x_length, p, cf0, pos, D4C_HANNING, dpos2, rs, poly, e, jtab, Bd, false, red, av);
 #pragma unroll
     for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];
     __syncthreads();
@@ -584,9 +623,8 @@ static constexpr size_t d4c_bands_lds() {
 // one register budget)
 template <int LOG2N, bool SPARSE>
 __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d4c_bands(
-    const double *__restrict__ f0, const double *__restrict__ ap0, d4c_params p, const kwy_c *__restrict__ twH,
-    const kwy_c *__restrict__ twN, const double *__restrict__ nuttall, const double *__restrict__ dvbuf,
-    double *__restrict__ out) {
+    d4c_batch batch, d4c_params p, const kwy_c *__restrict__ twH,
+    const kwy_c *__restrict__ twN, const double *__restrict__ nuttall) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int NT = d4c_nt<LOG2N>::value;
   constexpr int E = N / NT;
@@ -600,9 +638,12 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   uint32_t *hist = (uint32_t *)B;
 
   const int tid = threadIdx.x;
-  const int64_t frame = blockIdx.x;
-  const double f0v = kwy_uniform(f0[frame]);
-  if (f0v == 0.0 || kwy_uniform(ap0[frame]) <= p.threshold) return;   // the body wrote the frame's row
+  const int utt = batch.find(blockIdx.x);
+  const int64_t frame = (int)blockIdx.x - batch.start[utt];
+  const double *__restrict__ dvbuf = batch.u[utt].dvbuf;
+  double *__restrict__ out = batch.u[utt].out;
+  const double f0v = kwy_uniform(batch.u[utt].f0[frame]);
+  if (f0v == 0.0 || kwy_uniform(batch.u[utt].ap0[frame]) <= p.threshold) return;   // the body wrote the frame's row
   const double cf0 = kwy_uniform(f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0);
   kwy_c tw4[4];
   kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
@@ -704,8 +745,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
 
 // ------------------------------------------------------------------ host side
 template <int LOG2N>
-static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
-                     const double *f0, int64_t T, const uint64_t *offsets, double *ap0) {
+static int launch_lt(kwy_ctx *ctx, const d4c_batch &b, int fs) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   const kwy_c *twH, *twN;
   const uint4 *poly;
@@ -716,16 +756,14 @@ static int launch_lt(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, co
   size_t lds = sizeof(kwy_c) * (H + 1) + sizeof(double) * 8 + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_lovetrain<LOG2N, NT>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_d4c_lovetrain", hipLaunchKernelGGL((k_d4c_lovetrain<LOG2N, NT>), dim3((unsigned)T), dim3(NT), lds, ctx->stream,
-                     x, (int)x_length, fs, t, f0, offsets, kwy_randn(ctx), poly, twH, twN, ap0));
+  KWY_PROF(ctx, "k_d4c_lovetrain", hipLaunchKernelGGL((k_d4c_lovetrain<LOG2N, NT>), dim3((unsigned)b.start[b.n]), dim3(NT), lds,
+                     ctx->stream, b, fs, kwy_randn(ctx), poly, twH, twN));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
 
 template <int LOG2N>
-static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const double *f0,
-                       const double *ap0, const d4c_params &p, int64_t T, const uint64_t *offs3,
-                       const uint64_t *draws_before, const double *nuttall, double *dvbuf, double *out) {
+static int launch_body(kwy_ctx *ctx, const d4c_batch &b, const d4c_params &p, const double *nuttall) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   const kwy_c *twH, *twN;
   const uint4 *poly;
@@ -733,22 +771,23 @@ static int launch_body(kwy_ctx *ctx, const double *x, const double *t, const dou
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   constexpr int NT = d4c_nt<LOG2N>::value;
   KWY_TRY(kwy_get_poly_multi(ctx, N / NT, NT, &poly));
+  const unsigned grid = (unsigned)b.start[b.n];
   size_t lds = d4c_body_lds<LOG2N>();
   KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_body<LOG2N>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3((unsigned)T), dim3(NT), lds, ctx->stream, x, t,
-                     f0, ap0, p, offs3, draws_before, kwy_randn(ctx), poly, twH, twN, dvbuf, out, (long long *)ctx->dbg));
+  KWY_PROF(ctx, "k_d4c_body", hipLaunchKernelGGL(k_d4c_body<LOG2N>, dim3(grid), dim3(NT), lds, ctx->stream, b, p,
+                     kwy_randn(ctx), poly, twH, twN, (long long *)ctx->dbg));
   const size_t lds_b = d4c_bands_lds<LOG2N>();
   if (p.window_length <= 2 * (H / 8) + 1) {
     KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_bands<LOG2N, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-    KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, true>), dim3((unsigned)T), dim3(NT), lds_b, ctx->stream,
-                       f0, ap0, p, twH, twN, nuttall, dvbuf, out));
+    KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, true>), dim3(grid), dim3(NT), lds_b, ctx->stream,
+                       b, p, twH, twN, nuttall));
   } else {
     KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_bands<LOG2N, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-    KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, false>), dim3((unsigned)T), dim3(NT), lds_b, ctx->stream,
-                       f0, ap0, p, twH, twN, nuttall, dvbuf, out));
+    KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, false>), dim3(grid), dim3(NT), lds_b, ctx->stream,
+                       b, p, twH, twN, nuttall));
   }
   KWY_HIP(hipGetLastError());
   return KWY_OK;
@@ -783,8 +822,9 @@ static size_t d4c_scratch_bytes(int64_t T, int fs) {
          kwy_pad(sizeof(uint64_t) * 3 * T) + kwy_pad(sizeof(double) * T);
 }
 
-static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
-                    const double *f0, int64_t T, double threshold, int fft_size, double *out) {
+// device-pointer core for up to KWY_BATCH_MAX utterances; the per-utterance scratch comes from the arena
+// (d4c_scratch_bytes each)
+static int d4c_core(kwy_ctx *ctx, d4c_batch &b, int fs, double threshold, int fft_size) {
   const int n4 = d4c_fft_size(fs);
   const int nl = (int)pow(2.0, 1.0 + (int)(log(3.0 * fs / 40.0 + 1) / 0.69314718055994529));
   const int l4 = kwy_ilog2(n4), ll = kwy_ilog2(nl);
@@ -793,7 +833,6 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
     return KWY_EINVAL;
   }
   d4c_params p;
-  p.x_length = (int)x_length;
   p.fs = fs;
   p.fft_size = fft_size;
   p.K = fft_size / 2 + 1;
@@ -805,34 +844,47 @@ static int d4c_core(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, con
   p.window_length = (int)(D4C_FREQ_INTERVAL * n4 / fs) * 2 + 1;
   p.threshold = threshold;
 
-  uint64_t *offs_lt = kwy_arena<uint64_t>(ctx, T + 1);
-  uint64_t *offs_b = kwy_arena<uint64_t>(ctx, T + 1);
-  uint64_t *offs3 = kwy_arena<uint64_t>(ctx, 3 * T);
-  double *ap0 = kwy_arena<double>(ctx, T);
-  double *dvbuf = kwy_arena<double>(ctx, (size_t)T * (n4 / 2 + 1));
-  if (!dvbuf || !offs_lt || !offs_b || !offs3 || !ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
+  b.start[0] = 0;
+  for (int u = 0; u < b.n; ++u) {
+    d4c_view &v = b.u[u];
+    const size_t T = (size_t)v.T;
+    v.offs_lt = kwy_arena<uint64_t>(ctx, T + 1);
+    v.offs_b = kwy_arena<uint64_t>(ctx, T + 1);
+    v.offs3 = kwy_arena<uint64_t>(ctx, 3 * T);
+    v.ap0 = kwy_arena<double>(ctx, T);
+    v.dvbuf = kwy_arena<double>(ctx, T * (n4 / 2 + 1));
+    if (!v.dvbuf || !v.offs_lt || !v.offs_b || !v.offs3 || !v.ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
+    b.start[u + 1] = b.start[u] + v.T;
+  }
   const double *nuttall;
   KWY_TRY(get_nuttall(ctx, p.window_length, &nuttall));
 
   // LoveTrain pass
-  hipLaunchKernelGGL(k_d4c_lt_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, T, fs, offs_lt);
+  hipLaunchKernelGGL(k_d4c_lt_scan, dim3(b.n), dim3(KWY_THREADS), 0, ctx->stream, b, fs);
   KWY_HIP(hipGetLastError());
   switch (ll) {
-    case 10: KWY_TRY(launch_lt<10>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
-    case 11: KWY_TRY(launch_lt<11>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
-    case 12: KWY_TRY(launch_lt<12>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
-    default: KWY_TRY(launch_lt<13>(ctx, x, x_length, fs, t, f0, T, offs_lt, ap0)); break;
+    case 10: KWY_TRY(launch_lt<10>(ctx, b, fs)); break;
+    case 11: KWY_TRY(launch_lt<11>(ctx, b, fs)); break;
+    case 12: KWY_TRY(launch_lt<12>(ctx, b, fs)); break;
+    default: KWY_TRY(launch_lt<13>(ctx, b, fs)); break;
   }
   // general body; its noise continues where the LoveTrain pass stopped (offs_lt[T], read by the kernel)
-  hipLaunchKernelGGL(k_d4c_body_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, f0, ap0, T, fs, threshold, offs_b,
-                     offs3);
+  hipLaunchKernelGGL(k_d4c_body_scan, dim3(b.n), dim3(KWY_THREADS), 0, ctx->stream, b, fs, threshold);
   KWY_HIP(hipGetLastError());
   switch (l4) {
-    case 10: return launch_body<10>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
-    case 11: return launch_body<11>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
-    case 12: return launch_body<12>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
-    default: return launch_body<13>(ctx, x, t, f0, ap0, p, T, offs3, offs_lt + T, nuttall, dvbuf, out);
+    case 10: return launch_body<10>(ctx, b, p, nuttall);
+    case 11: return launch_body<11>(ctx, b, p, nuttall);
+    case 12: return launch_body<12>(ctx, b, p, nuttall);
+    default: return launch_body<13>(ctx, b, p, nuttall);
   }
+}
+
+static int d4c_one(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t, const double *f0, int64_t T,
+                   double threshold, int fft_size, double *out) {
+  d4c_batch b;
+  b.n = 1;
+  b.u[0] = d4c_view{x, t, f0, out, nullptr, nullptr, nullptr, nullptr, nullptr, (int)x_length, (int)T};
+  return d4c_core(ctx, b, fs, threshold, fft_size);
 }
 
 static int d4c_check(kwy_ctx *ctx, const void *x, int64_t x_length, int fs, const void *t,
@@ -852,7 +904,37 @@ extern "C" int kwy_d4c_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int 
   KWY_TRY(d4c_check(ctx, x, x_length, fs, t, f0, T, out, &fft_size));
   KWY_HIP(hipSetDevice(ctx->device));
   KWY_TRY(kwy_arena_begin(ctx, d4c_scratch_bytes(T, fs)));
-  return d4c_core(ctx, x, x_length, fs, t, f0, T, threshold, fft_size, out);
+  return d4c_one(ctx, x, x_length, fs, t, f0, T, threshold, fft_size, out);
+}
+
+// pyworld.d4c for `count` utterances of one sampling rate, one grid over all their frames per kernel
+// (kwy_cheaptrick_batch_dev's descriptors; out: T x (fft_size / 2 + 1) each)
+extern "C" int kwy_d4c_batch_dev(kwy_ctx *ctx, const kwy_utterance *utts, int count, int fs, double threshold,
+                                 int fft_size) {
+  if (!ctx) return KWY_EINVAL;
+  if (!utts || count < 1) { ctx->err = "d4c_batch: bad argument"; return KWY_EINVAL; }
+  size_t scratch = 0;
+  int64_t frames = 0;
+  for (int i = 0; i < count; ++i) {
+    const kwy_utterance &q = utts[i];
+    KWY_TRY(d4c_check(ctx, q.x, q.x_length, fs, q.temporal_positions, q.f0, q.f0_length, q.out, &fft_size));
+    scratch += d4c_scratch_bytes(q.f0_length, fs);
+    frames += q.f0_length;
+  }
+  if (frames > 0x7fffffff) { ctx->err = "d4c_batch: too many frames"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, scratch));
+  for (int i0 = 0; i0 < count; i0 += KWY_BATCH_MAX) {
+    d4c_batch b;
+    b.n = count - i0 < KWY_BATCH_MAX ? count - i0 : KWY_BATCH_MAX;
+    for (int u = 0; u < b.n; ++u) {
+      const kwy_utterance &q = utts[i0 + u];
+      b.u[u] = d4c_view{q.x, q.temporal_positions, q.f0, q.out, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        (int)q.x_length, (int)q.f0_length};
+    }
+    KWY_TRY(d4c_core(ctx, b, fs, threshold, fft_size));
+  }
+  return KWY_OK;
 }
 
 extern "C" int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
@@ -870,7 +952,7 @@ extern "C" int kwy_d4c(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, 
   KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * x_length, hipMemcpyHostToDevice, ctx->stream));
   KWY_HIP(hipMemcpyAsync(dt, t, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
   KWY_HIP(hipMemcpyAsync(df0, f0, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
-  KWY_TRY(d4c_core(ctx, dx, x_length, fs, dt, df0, T, threshold, fft_size, dout));
+  KWY_TRY(d4c_one(ctx, dx, x_length, fs, dt, df0, T, threshold, fft_size, dout));
   KWY_HIP(hipMemcpyAsync(out, dout, sizeof(double) * T * K, hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipStreamSynchronize(ctx->stream));
   return KWY_OK;

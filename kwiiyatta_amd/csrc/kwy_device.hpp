@@ -106,6 +106,14 @@ __device__ __forceinline__ kwy_rng kwy_rng_combine(const uint32_t *e, uint4 c) {
   return r;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores
+// (it is a workgroup-scope fence: s_waitcnt vmcnt(0) before s_barrier) -- a microsecond per barrier in a loop that
+// streams results out while it exchanges through LDS.  Use where no thread reads global data another thread of the
+// workgroup wrote.
+__device__ __forceinline__ void kwy_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------- the randn stream as a table
 // WORLD reseeds its generator at the entry of CheapTrick, D4C and Synthesis, so draw i of the stream is the same
 // number in every call, for every utterance: the first `n` raw 12-step sums live in one process-wide table per
@@ -216,6 +224,42 @@ __device__ __forceinline__ double kwy_cos_pi_range(double x) {
   // cos(ax) = cos(y + k pi/2)
   const double v = (k & 1) ? sn : cs;
   return ((k + 1) & 2) ? -v : v;
+}
+
+// sin and cos on [-pi, pi] from the same reduction (the two kernel polynomials are evaluated by the routine above
+// anyway).  A window function sampled at i = tid + NT r advances its argument by a constant per r: one call for
+// r = 0, then the rotation kwy_rotate() per further element (6 instead of ~40 instructions; the error grows by about
+// an ulp per step, 16 steps at most).
+__device__ __forceinline__ void kwy_sincos_pi_range(double x, double *sn_out, double *cs_out) {
+  const double ax = fabs(x);
+  const double kf = rint(ax * 6.36619772367581382433e-01);
+  const int k = (int)kf;
+  double y = ax - kf * 1.57079632673412561417e+00;
+  y = y - kf * 6.07710050650619224932e-11;
+  const double z = y * y;
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sn = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
+  const double rc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 +
+                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cs = w + (((1.0 - w) - hz) + z * rc);
+  // (cos, sin)(y + k pi/2)
+  const double c = (k & 1) ? sn : cs, s_ = (k & 1) ? cs : sn;
+  *cs_out = ((k + 1) & 2) ? -c : c;
+  const double sa = (k & 2) ? -s_ : s_;
+  *sn_out = x < 0.0 ? -sa : sa;
+}
+
+// (c, s) <- the same angle advanced by the angle whose cosine / sine are (cd, sd)
+__device__ __forceinline__ void kwy_rotate(double &c, double &s, double cd, double sd) {
+  const double c2 = c * cd - s * sd;
+  s = s * cd + c * sd;
+  c = c2;
 }
 
 // ------------------------------------------------------------ block reductions

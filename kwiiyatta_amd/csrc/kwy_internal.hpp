@@ -97,6 +97,26 @@ static inline kwy_randn_src kwy_randn(const kwy_ctx *ctx) {
   return kwy_randn_src{ctx->d_randn, ctx->randn_n, ctx->d_pow2};
 }
 
+// --- utterance batches -------------------------------------------------------------
+// The frame-parallel analysis kernels take up to KWY_BATCH_MAX utterances per launch: workgroup g belongs to the
+// utterance u with start[u] <= g < start[u + 1] and handles its frame g - start[u].  The per-utterance pointers travel
+// BY VALUE in the kernel arguments (scalar loads, no descriptor table in device memory, capturable in HIP graphs);
+// one launch over both utterances of a pair -- or over all pairs of a step -- fills the chip where a single
+// utterance's 2 000 frames are 2.2 rounds of resident workgroups.
+#define KWY_BATCH_MAX 16
+template <class VIEW>
+struct kwy_batch {
+  int n;
+  int start[KWY_BATCH_MAX + 1];
+  VIEW u[KWY_BATCH_MAX];
+  // utterance of workgroup g (uniform: scalar loop)
+  __device__ __forceinline__ int find(int g) const {
+    int k = 0;
+    while (k + 1 < n && g >= start[k + 1]) ++k;
+    return k;
+  }
+};
+
 static inline int kwy_ilog2(int n) {
   int l = 0;
   while ((1 << l) < n) ++l;

@@ -188,13 +188,13 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_words(const np_state *__rest
     uint32_t *w = mt[cur ^ 1];
     uint32_t *dst = kbuf + (size_t)b * MT_N;
     if (tid < MT_N - MT_M) { const uint32_t v = mt_twist(o[tid], o[tid + 1], o[tid + MT_M]); w[tid] = v; dst[tid] = v; }
-    __syncthreads();
+    kwy_lds_barrier();      // (the block's words stream out to global memory meanwhile: nothing here reads them)
     if (tid < MT_N - MT_M) {
       const int k = (MT_N - MT_M) + tid;
       const uint32_t v = mt_twist(o[k], o[k + 1], w[k - (MT_N - MT_M)]);
       w[k] = v; dst[k] = v;
     }
-    __syncthreads();
+    kwy_lds_barrier();
     {
       const int k = 2 * (MT_N - MT_M) + tid;
       if (k < MT_N) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_words(const np_state *__rest
         w[k] = v; dst[k] = v;
       }
     }
-    __syncthreads();
+    kwy_lds_barrier();
     cur ^= 1;
   }
 }

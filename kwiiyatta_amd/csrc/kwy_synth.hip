@@ -514,7 +514,7 @@ __device__ __forceinline__ double syn_safe_ap(double x) {
 }
 
 // One pulse per workgroup iteration; its response goes to slot (pulse - first_pulse) of `resp`.  LDS: one FFT buffer (in-place transforms), the
-// interpolated envelope / aperiodic ratio rows, a small twiddle table -- 35 KB at 48 kHz, four
+// interpolated envelope / aperiodic ratio rows, the periodic response, a small twiddle table -- 51 KB at 48 kHz, three
 // workgroups per CU.  The noise spectrum waits in registers (bins tid + 256 r) while the
 // buffer computes the aperiodic minimum-phase response.
 // (workgroups per CU by LDS: three up to 2048 points, two at 4096, one at 8192 -- the register budget follows)
@@ -538,6 +538,11 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
   kwy_c *buf = twl + TWL;                  // H+1 complex
   double *env = (double *)(buf + (H + 1)); // K
   double *ratio = env + K + 1;             // K
+  // Up to 2048 points the periodic response waits in LDS (N doubles) rather than in 2 C registers per thread while the
+  // FFT buffer computes the aperiodic one: the kernel is at its register cap there (3 workgroups per CU either way);
+  // the longer transforms have registers to spare and no LDS for it.
+  constexpr bool PER_LDS = LOG2N <= 11;
+  double *perl = ratio + K + 1;            // N (PER_LDS)
 
   const int tid = threadIdx.x;
   for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
@@ -578,11 +583,12 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
     }
     __syncthreads();
 
-    // ---- periodic response (kept in registers: sample i = tid + 256*m)
-    double per[C];
+    // ---- periodic response (sample i = tid + 256*m, parked in LDS; only this thread touches its elements)
+    const bool has_periodic = current_vuv > 0.5 && !(ratio[0] > 0.999);
+    double per[PER_LDS ? 1 : C];
 #pragma unroll
-    for (int m = 0; m < C; ++m) per[m] = 0.0;
-    if (current_vuv > 0.5 && !(ratio[0] > 0.999)) {
+    for (int m = 0; m < (PER_LDS ? 1 : C); ++m) per[m] = 0.0;
+    if (has_periodic) {
       double *L = (double *)buf;
       for (int k = tid; k <= H; k += KWY_THREADS)
         L[k] = log(env[k] * (1.0 - ratio[k]) + SYN_SAFE) / 2.0;
@@ -603,7 +609,8 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
       for (int m = 0; m < C; ++m) {
         int i = tid + KWY_THREADS * m;
         double v = (i < H) ? -dc_component * dc_remover[i] : w[i - H] - dc_component * dc_remover[i];
-        per[m] = v;
+        if constexpr (PER_LDS) perl[i] = v;
+        else per[PER_LDS ? 0 : m] = v;
       }
       __syncthreads();
     }
@@ -689,7 +696,8 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
       for (int m = 0; m < C; ++m) {
         int i = tid + KWY_THREADS * m;
         double aper = (i < H) ? w[i + H] : w[i - H];
-        const double r = (per[m] * sqrt_noise_size + aper) / N;
+        const double pv = PER_LDS ? (has_periodic ? perl[i] : 0.0) : per[PER_LDS ? 0 : m];
+        const double r = (pv * sqrt_noise_size + aper) / N;
         if constexpr (DIRECT) {
           const int64_t n = offset + i;
           if (n >= 0 && n < p.y_length) y[n] += r;
@@ -780,8 +788,8 @@ static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const 
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
-  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (2 * (K + 1) + 8) +
-               sizeof(uint32_t) * KWY_EBASE_WORDS;
+  size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) +
+               sizeof(double) * (2 * (K + 1) + (LOG2N <= 11 ? N : 0) + 8) + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int grid = slots < 2048 ? slots : 2048;

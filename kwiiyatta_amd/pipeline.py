@@ -257,10 +257,14 @@ class PairPipeline(_Graphed):
                 features(self.ctx, self.src)
                 self.stream.wait_event(target_ready)
             else:
-                for s in (self.src, self.tgt):
-                    envelope(self.ctx, s)
-                    d4c(self.ctx, s)
-                for s in (self.src, self.tgt):
+                # both utterances of the pair in one grid per kernel (kwy_*_batch_dev): 4 202 frames fill the chip
+                # better than 2 001 + 2 201 one after the other, and half the launches
+                both = (self.src, self.tgt)
+                _lib.check(self.ctx, lib.kwy_cheaptrick_batch_dev(
+                    h, _lib.utterance_array([(s.x, s.t, s.f0, s.sp) for s in both]), 2, fs, -0.15, 71.0, fft, float(fs)))
+                _lib.check(self.ctx, lib.kwy_d4c_batch_dev(
+                    h, _lib.utterance_array([(s.x, s.t, s.f0, s.ap) for s in both]), 2, fs, 0.85, fft))
+                for s in both:
                     features(self.ctx, s)
             self._chk(lib.kwy_fastdtw_dev(h, _p(self.src.feat), self.src.Tp, _p(self.tgt.feat), self.tgt.Tp,
                                           order + 2, self.radius, _p(self.dist), _p(self.path),

@@ -307,9 +307,9 @@ def test_hip_kmeans_blocks_match_numpy():
         vals = np.array([0.0, cum[0] * 0.5, cum[10] * (1 - 1e-9), cum[3333] * (1 + 1e-12), cum[-1] * 0.999999, cum[-1] * 1.01])
         for lo, first, last in ((0.0, True, True), (0.0, True, False), (cum[-1] * 0.25, False, False), (cum[-1] * 0.25, False, True)):
             hi = lo + tot_h
-            want = ns.km_pick(torch.tensor([lo]), torch.tensor([hi]), torch.from_numpy(vals), first, last).numpy()
-            got = hs.km_pick(torch.tensor([lo]).cuda(), torch.tensor([hi]).cuda(), torch.from_numpy(vals).cuda(), first,
-                             last).cpu().numpy()
+            t64 = lambda v: torch.tensor([v], dtype=torch.float64)     # noqa: E731
+            want = ns.km_pick(t64(lo), t64(hi), torch.from_numpy(vals), first, last).numpy()
+            got = hs.km_pick(t64(lo).cuda(), t64(hi).cuda(), torch.from_numpy(vals).cuda(), first, last).cpu().numpy()
             assert np.array_equal(got, want), (lo, first, last, got, want)
         # the edges of the search (the k-means++ seeding once aborted in a torch gather on an out-of-range row,
         # DESIGN.md section 6): a draw at or beyond the total potential -> the LAST row, never row n; a value owned
@@ -317,7 +317,7 @@ def test_hip_kmeans_blocks_match_numpy():
         # belongs to this shard and not to the next one
         lo, hi = 3.0 * tot_h, 4.0 * tot_h
         edge = np.array([hi, hi * (1 + 1e-15) + 1e-300, lo, lo * (1 - 1e-15), 10 * hi, np.nextafter(lo, np.inf)])
-        t = lambda v: torch.tensor([v]).cuda()     # noqa: E731
+        t = lambda v: torch.tensor([v], dtype=torch.float64).cuda()     # noqa: E731
         mid = hs.km_pick(t(lo), t(hi), torch.from_numpy(edge).cuda(), False, False).cpu().numpy()
         assert mid[0] == n - 1 and mid[1] == -1 and mid[2] == -1 and mid[3] == -1 and mid[4] == -1 and mid[5] == 0
         nxt = hs.km_pick(t(hi), t(hi + tot_h), torch.from_numpy(edge).cuda(), False, True).cpu().numpy()

@@ -359,3 +359,33 @@ def test_jump_ahead_beyond_the_table_gives_the_same_bits(ko, kw, path, limit):
         assert np.array_equal(a, b)
     check_spectrum(out[1][0], ko.cheaptrick(x, f0, t, fs))
     assert np.abs(out[1][1] - ko.d4c(x, f0, t, fs)).max() <= 1e-4
+
+
+def test_batched_analysis_equals_single_calls(ko, kw):
+    """kwy_cheaptrick_batch_dev / kwy_d4c_batch_dev: utterances of different lengths in one grid per kernel (more of
+    them than one launch takes: 19 > KWY_BATCH_MAX = 16) give bit for bit what the single-utterance calls give --
+    every utterance's noise stream starts at draw 0, as every pyworld call reseeds."""
+    import torch
+    from kwiiyatta_amd import _lib
+    from kwiiyatta_amd._lib import lib
+    fs, x = load(clb_variant('48'))
+    ctx = _lib.Context(0)
+    utts = []
+    for k in range(19):
+        xs = np.ascontiguousarray(x[int(0.03 * k * fs):int((0.45 + 0.05 * (k % 5)) * fs) + int(0.03 * k * fs)])
+        f0, t = f0_track(ko, xs, fs)
+        utts.append((xs, f0, t))
+    fft = lib.kwy_cheaptrick_fft_size(fs, 71.0)
+    K = fft // 2 + 1
+    dev = [tuple(torch.from_numpy(a).cuda() for a in u) for u in utts]
+    sp = [torch.empty((len(u[1]), K), dtype=torch.float64, device='cuda') for u in utts]
+    ap = [torch.empty((len(u[1]), K), dtype=torch.float64, device='cuda') for u in utts]
+    torch.cuda.synchronize()
+    arr = _lib.utterance_array([(d[0], d[2], d[1], o) for d, o in zip(dev, sp)])
+    _lib.check(ctx, lib.kwy_cheaptrick_batch_dev(ctx.handle, arr, len(utts), fs, -0.15, 71.0, fft, 1.0))
+    arr = _lib.utterance_array([(d[0], d[2], d[1], o) for d, o in zip(dev, ap)])
+    _lib.check(ctx, lib.kwy_d4c_batch_dev(ctx.handle, arr, len(utts), fs, 0.85, fft))
+    ctx.sync()
+    for (xs, f0, t), s_, a_ in zip(utts, sp, ap):
+        assert np.array_equal(s_.cpu().numpy(), kw.cheaptrick(xs, f0, t, fs))
+        assert np.array_equal(a_.cpu().numpy(), kw.d4c(xs, f0, t, fs))
