@@ -399,10 +399,12 @@ def main():
             p.run()
 
     # The variants below add service streams (copies, the pad generator) to the pair streams.  The chip runs 32 hardware
-    # queues side by side; with more live streams than that the queue scheduler time-slices them at ~12 ms a turn, and
-    # a chain of cross-stream events then pays a turn per link (measured: HostFeeder on 32 + 2 streams 411 ms per
-    # step).  So the variants run on the first 30 pair streams and say so.
+    # queues; with more live streams than that, streams share queues, and a copy that sits behind another pair's pass
+    # in a shared queue while a third pair waits for it serialises the step (measured: HostFeeder with two extra
+    # streams beside 32 pair streams 180 - 410 ms per step instead of 35).  So the variants run 30 pairs and use the
+    # streams of the two idle pairs as service streams, and say so.
     vpipes = pipes[:30] if len(pipes) > 30 else pipes
+    spare = [p.stream for p in pipes[30:32]] if len(pipes) >= 32 else [None, None]
     vframes = sum(p.frames for p in vpipes)
 
     def sync_v():
@@ -413,15 +415,15 @@ def main():
     def run_pcie_variant():
         if args.workload != 'pair' or args.no_pcie_variant:
             return None
-        feeder = pl.HostFeeder(vpipes)
+        feeder = pl.HostFeeder(vpipes, up=spare[0], down=spare[1])
         elp = timed_variant(lambda: feeder.step(launch), feeder.sync)
         pcie = {'ms_per_step': 1000.0 * elp / args.steps, 'pairs_per_step': len(vpipes),
                 'frames_per_s_rank': vframes * args.steps / elp,
-                'bytes_per_pair': int(sum(h.numel() * 8 for h in feeder.host_in[0]) + feeder.host_out[0].numel() * 8),
+                'bytes_per_pair': int((feeder.host_in.numel() + feeder.host_out[0].numel()) * 8 // len(vpipes)),
                 'note': 'same steps with the two waveforms uploaded from pinned host memory and the synthesised waveform '
-                        'downloaded inside the timed region: one upload and one download stream for all pairs, two '
-                        'staging slots per pair, so the copies of neighbouring steps overlap with the kernels '
-                        '(kwiiyatta_amd.pipeline.HostFeeder); never `value`'}
+                        'downloaded inside the timed region: one upload and one download per step (all pairs in one '
+                        'block each way) on two service streams, two staging slots, so the transfers of neighbouring '
+                        'steps overlap with the kernels (kwiiyatta_amd.pipeline.HostFeeder); never `value`'}
         del feeder
         return pcie
 
@@ -434,7 +436,8 @@ def main():
             return None
         from kwiiyatta_amd.backend.nprandom import DeviceRandomState
         frames_step = vframes
-        feeder = pl.SilenceFeeder(vpipes, DeviceRandomState.from_seed(1000 + rank, device_index=local_rank))
+        feeder = pl.SilenceFeeder(vpipes, DeviceRandomState.from_seed(1000 + rank, device_index=local_rank,
+                                                                      stream=spare[0]))
         eld = timed_variant(lambda: feeder.step(launch), feeder.sync)
         res = {'device': {'ms_per_step': 1000.0 * eld / args.steps, 'pairs_per_step': len(vpipes),
                           'frames_per_s_rank': frames_step * args.steps / eld,

@@ -263,8 +263,9 @@ int kwy_stretch_log_dev(kwy_ctx *ctx, const double *rows, int64_t T, int K, int 
 int64_t kwy_np_state_bytes(void);
 int kwy_np_normal(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n, double *out);
 int kwy_np_normal_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int64_t n, double *out);
-/* `count` (1 ... 4) consecutive requests of n_each values each in one call -- the four pad blocks of one aligned pair
- * (source head, source tail, target head, target tail); outs: HOST array of `count` device pointers */
+/* `count` consecutive requests of n_each values each in one call -- the four pad blocks of one aligned pair (source
+ * head, source tail, target head, target tail), or those of all pairs of a batch in pair order; outs: HOST array of
+ * `count` device pointers */
 int kwy_np_normal_blocks_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int count,
                              int64_t n_each, double *const *outs);
 

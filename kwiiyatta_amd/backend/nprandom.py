@@ -90,8 +90,9 @@ class DeviceRandomState:
         return self.normal(0.0, scale, size=size, out=out, absolute=True)
 
     def abs_normal_blocks(self, scale, outs):
-        """np.abs(np.random.normal(0, scale, shape)) for up to four equally sized tensors in a row, one library call
-        (the pad blocks of one aligned pair: source head, source tail, target head, target tail)"""
+        """np.abs(np.random.normal(0, scale, shape)) for equally sized tensors in a row, one library call (the four pad
+        blocks of an aligned pair: source head, source tail, target head, target tail -- or those of all pairs of a
+        batch in pair order: the serial part of the generator then runs as ONE kernel)"""
         n_each = outs[0].numel()
         for t in outs:
             if t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.dev or t.numel() != n_each:

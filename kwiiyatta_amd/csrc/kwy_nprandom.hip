@@ -172,7 +172,7 @@ struct np_job {
   int64_t n_each;       // outputs per destination block (outs[i / n_each][i % n_each])
   double loc, scale;
   int take_abs;
-  double *outs[4];
+  double *const *outs;  // device array of the destination blocks
 };
 #define NP_TILE (KWY_THREADS * 4)     // attempts per workgroup of the counting / writing kernels
 
@@ -325,20 +325,21 @@ static int np_check(kwy_ctx *ctx, const void *state, int64_t n, const void *out)
 
 static int64_t np_attempts_cap(int64_t n) { return (int64_t)((n / 2 + 1) * 1.35) + 256; }
 
-static size_t np_scratch_bytes(int64_t n) {
+static size_t np_scratch_bytes(int64_t n, int count = 1) {
   if (n <= NP_SMALL) return 256;
   const int64_t attempts = np_attempts_cap(n);
   const int64_t nblocks = 2 + (MT_N + 4 * attempts) / MT_N;
   const int64_t ntiles = (attempts + NP_TILE - 1) / NP_TILE;
   return kwy_pad(sizeof(uint32_t) * (size_t)nblocks * MT_N) + kwy_pad(sizeof(int) * ntiles) +
-         kwy_pad(sizeof(int64_t) * (size_t)(ntiles + 16)) + kwy_pad(64);
+         kwy_pad(sizeof(int64_t) * (size_t)(ntiles + 16)) + kwy_pad(64) + kwy_pad(sizeof(double *) * (size_t)count);
 }
 
-// outs: `count` destination blocks of n_each doubles each (device), filled in order from one continuous stream
+// outs: HOST array of `count` device pointers to blocks of n_each doubles each, filled in order from one continuous
+// stream
 static int np_core(kwy_ctx *ctx, np_state *state, double loc, double scale, int take_abs, int count, int64_t n_each,
                    double *const *outs) {
   const int64_t n = (int64_t)count * n_each;
-  if (n <= NP_SMALL || count > 4) {
+  if (n <= NP_SMALL) {
     for (int c = 0; c < count; ++c)
       KWY_PROF(ctx, "k_np_normal", hipLaunchKernelGGL(k_np_normal, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, loc,
                                                       scale, take_abs, n_each, outs[c]));
@@ -348,14 +349,18 @@ static int np_core(kwy_ctx *ctx, np_state *state, double loc, double scale, int 
   np_job job;
   job.n = n; job.n_each = n_each; job.loc = loc; job.scale = scale; job.take_abs = take_abs;
   job.attempts = np_attempts_cap(n);
-  for (int c = 0; c < 4; ++c) job.outs[c] = c < count ? outs[c] : nullptr;
+  if (2 + (MT_N + 4 * job.attempts) / MT_N > 0x7fffffff) { ctx->err = "np_normal: request too large"; return KWY_EINVAL; }
   const int nblocks = (int)(2 + (MT_N + 4 * job.attempts) / MT_N);
   const int ntiles = (int)((job.attempts + NP_TILE - 1) / NP_TILE);
   uint32_t *kbuf = kwy_arena<uint32_t>(ctx, (size_t)nblocks * MT_N);
   int *counts = kwy_arena<int>(ctx, ntiles);
   int64_t *info = kwy_arena<int64_t>(ctx, (size_t)ntiles + 16);
   int *status = kwy_arena<int>(ctx, 16);
-  if (!kbuf || !counts || !info || !status) { ctx->err = "np_normal: scratch arena too small"; return KWY_ENOMEM; }
+  double **douts = kwy_arena<double *>(ctx, (size_t)count);
+  if (!kbuf || !counts || !info || !status || !douts) { ctx->err = "np_normal: scratch arena too small"; return KWY_ENOMEM; }
+  // (the pointer list is small and comes from pageable host memory: the copy is done when the call returns)
+  KWY_HIP(hipMemcpyAsync(douts, outs, sizeof(double *) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  job.outs = douts;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
   KWY_PROF(ctx, "k_np_words", hipLaunchKernelGGL(k_np_words, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, nblocks, kbuf));
   hipLaunchKernelGGL(k_np_count, dim3(ntiles), dim3(KWY_THREADS), 0, ctx->stream, state, kbuf, job, counts);
@@ -376,15 +381,16 @@ extern "C" int kwy_np_normal_dev(kwy_ctx *ctx, void *state, double loc, double s
   return np_core(ctx, (np_state *)state, loc, scale, take_abs, 1, n, outs);
 }
 
-// `count` (<= 4) blocks of n_each values each from one continuous stream: what pad_silence draws for one aligned pair
+// `count` blocks of n_each values each from one continuous stream: what pad_silence draws for one aligned pair
+// (count = 4), or for all pairs of a batch in pair order (one serial word kernel instead of one per pair)
 extern "C" int kwy_np_normal_blocks_dev(kwy_ctx *ctx, void *state, double loc, double scale, int take_abs, int count,
                                         int64_t n_each, double *const *outs) {
   if (!ctx) return KWY_EINVAL;
-  if (!state || !outs || count < 1 || count > 4 || n_each < 1) { ctx->err = "np_normal_blocks: bad argument"; return KWY_EINVAL; }
+  if (!state || !outs || count < 1 || n_each < 1) { ctx->err = "np_normal_blocks: bad argument"; return KWY_EINVAL; }
   for (int c = 0; c < count; ++c)
     if (!outs[c]) { ctx->err = "np_normal_blocks: null destination"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
-  KWY_TRY(kwy_arena_begin(ctx, np_scratch_bytes((int64_t)count * n_each)));
+  KWY_TRY(kwy_arena_begin(ctx, np_scratch_bytes((int64_t)count * n_each, count)));
   return np_core(ctx, (np_state *)state, loc, scale, take_abs, count, n_each, outs);
 }
 

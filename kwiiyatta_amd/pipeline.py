@@ -350,63 +350,86 @@ class UtterancePipeline(_Graphed):
 
 
 class HostFeeder:
-    """Waveforms from (pinned) host memory into a set of PairPipelines and the synthesised waveforms back, off the
-    pipelines' own streams: one upload stream and one download stream for the whole set (the link is shared anyway),
-    two staging slots per pipeline, events in between -- the upload of pass n+1 and the download of pass n-1 overlap
-    with the kernels of pass n.  The pipelines' input buffers keep their addresses (captured graphs stay valid): a
-    pass starts with a device-to-device copy (a kernel) out of the staging slot (3.8 MB: microseconds of HBM time).
+    """Waveforms from pinned host memory into a set of PairPipelines and the synthesised waveforms back, off the
+    pipelines' own streams and in TWO transfers per step: all inputs of the step travel as one contiguous block on an
+    upload stream, all outputs as one block on a download stream, through two staging slots -- the upload of step n+1
+    and the download of step n-1 overlap with the kernels of step n.  The pipelines' input buffers keep their addresses
+    (captured graphs stay valid): a pass starts with a device-to-device copy KERNEL out of the staging block (3.8 MB:
+    microseconds of HBM time; copy-engine transfers in both directions spread over dozens of streams collapse to
+    ~4 GB/s here, and a chain of per-pipeline copies and events pays the dispatch latency of a busy chip per link).
 
         feeder = HostFeeder(pipes)
-        feeder.step(lambda p: p.replay())      # per pass: upload, wait, copy in, pass, copy out, download
-        feeder.sync()                          # results of the last pass are in feeder.host_out[i]
-    """
+        feeder.step(lambda p: p.replay())      # per step: upload, passes, download
+        feeder.sync()                          # results of the last step: feeder.result(i)
 
-    def __init__(self, pipes, host_in=None):
+    up / down: the streams that carry the transfers (default: new ones).  The chip has 32 hardware queues; a process
+    with more live streams than that has some of them SHARE a queue, and a copy queued behind another pipeline's pass
+    in the shared queue serialises the step.  With 30 or more pipeline streams pass two streams that carry nothing
+    else."""
+
+    def __init__(self, pipes, up=None, down=None):
         self.pipes = list(pipes)
         dev = self.pipes[0].dev
-        self.up, self.down = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        pin = lambda t: t.cpu().pin_memory()  # noqa: E731
-        self.host_in = host_in if host_in is not None else [(pin(p.src.x), pin(p.tgt.x)) for p in self.pipes]
-        self.host_out = [torch.empty(p.wave.shape, dtype=p.wave.dtype).pin_memory() for p in self.pipes]
-        self.slots = []
-        for p in self.pipes:
-            self.slots.append([dict(xs=torch.empty_like(p.src.x), xt=torch.empty_like(p.tgt.x),
-                                    y=torch.empty_like(p.wave), taken=None, drained=None) for _ in range(2)])
+        self.up = up if up is not None else torch.cuda.Stream(device=dev)
+        self.down = down if down is not None else torch.cuda.Stream(device=dev)
+        n_in = [(p.src.x.numel(), p.tgt.x.numel()) for p in self.pipes]
+        n_out = [p.wave.numel() for p in self.pipes]
+        self.in_off = np.concatenate(([0], np.cumsum([a + b for a, b in n_in]))).astype(np.int64)
+        self.out_off = np.concatenate(([0], np.cumsum(n_out))).astype(np.int64)
+        f64 = dict(dtype=torch.float64)
+        self.host_in = torch.empty(int(self.in_off[-1]), **f64).pin_memory()
+        self.host_out = [torch.empty(int(self.out_off[-1]), **f64).pin_memory() for _ in range(2)]
+        for i, p in enumerate(self.pipes):
+            a = int(self.in_off[i])
+            self.host_in[a:a + n_in[i][0]].copy_(p.src.x)
+            self.host_in[a + n_in[i][0]:a + n_in[i][0] + n_in[i][1]].copy_(p.tgt.x)
+        self.n_in = n_in
+        self.slots = [dict(dev_in=torch.empty(int(self.in_off[-1]), device=dev, **f64),
+                           dev_out=torch.empty(int(self.out_off[-1]), device=dev, **f64),
+                           taken=[], drained=None) for _ in range(2)]
         self.n = 0
 
     def step(self, launch):
         k = self.n & 1
         self.n += 1
-        for p, slots, (hs, ht), ho in zip(self.pipes, self.slots, self.host_in, self.host_out):
-            sl = slots[k]
-            if sl['taken'] is not None:
-                self.up.wait_event(sl['taken'])           # the pass two steps ago has copied this slot in
-            with torch.cuda.stream(self.up):
-                sl['xs'].copy_(hs, non_blocking=True)
-                sl['xt'].copy_(ht, non_blocking=True)
-                arrived = torch.cuda.Event()
-                arrived.record(self.up)
+        sl = self.slots[k]
+        for ev in sl['taken']:                   # the passes of two steps ago have copied this slot in
+            self.up.wait_event(ev)
+        with torch.cuda.stream(self.up):
+            sl['dev_in'].copy_(self.host_in, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record(self.up)
+        sl['taken'] = []
+        done = []
+        for i, p in enumerate(self.pipes):
+            a, (ns, nt) = int(self.in_off[i]), self.n_in[i]
+            o = int(self.out_off[i])
             p.stream.wait_event(arrived)
             with torch.cuda.stream(p.stream):
-                # device-to-device by a KERNEL, not a memcpy: copy-engine transfers in both directions spread over
-                # dozens of streams collapse to ~4 GB/s here (measured: 32 streams, H2D and D2H interleaved), while
-                # two copy streams beside kernel streams run at 30-50 GB/s
-                torch.mul(sl['xs'], 1.0, out=p.src.x)
-                torch.mul(sl['xt'], 1.0, out=p.tgt.x)
-                sl['taken'] = torch.cuda.Event()
-                sl['taken'].record(p.stream)
+                torch.mul(sl['dev_in'][a:a + ns], 1.0, out=p.src.x)
+                torch.mul(sl['dev_in'][a + ns:a + ns + nt], 1.0, out=p.tgt.x)
+                ev = torch.cuda.Event()
+                ev.record(p.stream)
+                sl['taken'].append(ev)
             launch(p)
             if sl['drained'] is not None:
                 p.stream.wait_event(sl['drained'])        # the download of two steps ago has left this slot
             with torch.cuda.stream(p.stream):
-                torch.mul(p.wave, 1.0, out=sl['y'])
-                done = torch.cuda.Event()
-                done.record(p.stream)
-            self.down.wait_event(done)
-            with torch.cuda.stream(self.down):
-                ho.copy_(sl['y'], non_blocking=True)
-                sl['drained'] = torch.cuda.Event()
-                sl['drained'].record(self.down)
+                torch.mul(p.wave, 1.0, out=sl['dev_out'][o:o + p.wave.numel()])
+                ev = torch.cuda.Event()
+                ev.record(p.stream)
+                done.append(ev)
+        for ev in done:
+            self.down.wait_event(ev)
+        with torch.cuda.stream(self.down):
+            self.host_out[k].copy_(sl['dev_out'], non_blocking=True)
+            sl['drained'] = torch.cuda.Event()
+            sl['drained'].record(self.down)
+
+    def result(self, i):
+        """pipeline i's waveform of the last step (pinned host memory; call sync() first)"""
+        k = (self.n - 1) & 1
+        return self.host_out[k][int(self.out_off[i]):int(self.out_off[i + 1])]
 
     def sync(self):
         for p in self.pipes:
@@ -419,8 +442,9 @@ class SilenceFeeder:
     """Fresh pad spectra for every pass of a set of PairPipelines, drawn ON THE DEVICE from numpy's legacy generator
     (kwiiyatta_amd.backend.nprandom.DeviceRandomState: the same draws `pad_silence` would take from np.random, in the
     same order -- source head, source tail, target head, target tail, pair after pair), one step ahead of the
-    pipelines: the generator has its own stream and two staging slots per pipeline; a pass starts by copying its four
-    blocks into the pad rows.
+    pipelines: the generator has its own stream and two staging slots; ONE call draws the pads of all pipelines of a
+    step (the serial MT19937 part is then one kernel: a chain of per-pair launches pays the dispatch latency of a busy
+    chip per link), and a pass starts by copying its four blocks into the pad rows.
 
         feeder = SilenceFeeder(pipes, DeviceRandomState.from_global())
         feeder.step(lambda p: p.replay())
@@ -429,25 +453,28 @@ class SilenceFeeder:
     def __init__(self, pipes, rng):
         self.pipes, self.rng = list(pipes), rng
         self.scale = EPS / self.pipes[0].fs
-        self.slots = [[dict(blocks=[torch.empty((PAD_LEN, p.K), dtype=torch.float64, device=p.dev) for _ in range(4)],
-                            taken=None) for _ in range(2)] for p in self.pipes]
+        self.slots = [dict(blocks=[[torch.empty((PAD_LEN, p.K), dtype=torch.float64, device=p.dev) for _ in range(4)]
+                                   for p in self.pipes], taken=[]) for _ in range(2)]
         self.n = 0
 
     def step(self, launch):
         k = self.n & 1
         self.n += 1
-        for p, slots in zip(self.pipes, self.slots):
-            sl = slots[k]
-            if sl['taken'] is not None:
-                self.rng.stream.wait_event(sl['taken'])
-            self.rng.abs_normal_blocks(self.scale, sl['blocks'])
-            p.stream.wait_event(self.rng.record_event())
+        sl = self.slots[k]
+        for ev in sl['taken']:
+            self.rng.stream.wait_event(ev)
+        self.rng.abs_normal_blocks(self.scale, [b for blocks in sl['blocks'] for b in blocks])
+        ready = self.rng.record_event()
+        sl['taken'] = []
+        for p, blocks in zip(self.pipes, sl['blocks']):
+            p.stream.wait_event(ready)
             rows = p.src.silence_rows() + p.tgt.silence_rows()
             with torch.cuda.stream(p.stream):
-                for dst, blk in zip(rows, sl['blocks']):
+                for dst, blk in zip(rows, blocks):
                     torch.mul(blk, 1.0, out=dst)
-                sl['taken'] = torch.cuda.Event()
-                sl['taken'].record(p.stream)
+                ev = torch.cuda.Event()
+                ev.record(p.stream)
+                sl['taken'].append(ev)
             launch(p)
 
     def sync(self):

@@ -257,3 +257,41 @@ def test_config4_batch_of_256_utterances():
         worst = max(worst, float(np.sqrt(np.mean((first[i] - ref) ** 2))))
     print(f'config 4: 256 utterances on 16 streams, worst RMS against the all-oracle chain {worst:.3e}')
     assert worst <= 1e-4
+
+
+def test_host_and_silence_feeders(pair):
+    """HostFeeder (waveforms through pinned memory, one block each way per step, double-buffered) returns the
+    waveforms of plain passes; SilenceFeeder fills the pad rows with numpy's own draws in the reference's order
+    (pair after pair: source head, source tail, target head, target tail), a step ahead of the passes."""
+    import torch
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    fs, src, tgt = pair
+    gmm = pl.synthetic_gmm(order=24, components=4, seed=0, n_frames=3000)
+    dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
+    sil = [[pl.draw_silence(fs, 1025) for _ in range(4)] for _ in range(3)]
+    pipes = [pl.PairPipeline(0, fs, src if i != 1 else tgt, tgt if i != 1 else src, dg, silence=sil[i]) for i in range(3)]
+    want = []
+    for p in pipes:
+        p.run()
+        p.sync()
+        want.append(p.wave.cpu().numpy().copy())
+        p.capture()
+    feeder = pl.HostFeeder(pipes)
+    for _ in range(3):
+        feeder.step(lambda p: p.replay())
+    feeder.sync()
+    for i, w in enumerate(want):
+        assert np.array_equal(feeder.result(i).numpy(), w)
+    # pads drawn on the device, three steps: the rows of the last step are numpy's draws number 2 * 12 ... 3 * 12 - 1
+    ref = np.random.RandomState(123)
+    sf = pl.SilenceFeeder(pipes, DeviceRandomState.from_seed(123))
+    for _ in range(3):
+        sf.step(lambda p: p.replay())
+        blocks = [np.abs(ref.normal(0, pl.EPS / fs, (pl.PAD_LEN, 1025))) for _ in range(12)]
+    sf.sync()
+    for i, p in enumerate(pipes):
+        rows = p.src.silence_rows() + p.tgt.silence_rows()
+        for r, b in zip(rows, blocks[4 * i:4 * i + 4]):
+            assert np.abs(r.cpu().numpy() / b - 1).max() <= 1e-15
+        assert np.isfinite(p.wave.cpu().numpy()).all()
