@@ -195,53 +195,31 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
     __syncthreads();
   }
 
-  // ---- linear smoothing, width 2 f0 / 3 (loops unrolled to their compile-time maxima: the LDS reads of the mirrored
-  //      fill, of the prefix sum's chunk and of the two interpolations per bin are issued together)
+  // ---- linear smoothing, width 2 f0 / 3
   {
-    constexpr int QF = (2 * H + 1 + KWY_THREADS - 1) / KWY_THREADS;   // boundary <= H / 2: L <= 2 H + 1
     const double width = cf0 * 2.0 / 3.0;
     int boundary = (int)(width * N / fs) + 1;
     if (boundary > H / 2) boundary = H / 2;  // guards LDS only; f0 > 3fs/8 is outside WORLD's domain
     const int L = H + boundary * 2 + 1;
-    {
-      double m[QF];
-#pragma unroll
-      for (int q = 0; q < QF; ++q) {
-        const int i = tid + KWY_THREADS * q;
-        int j = i - boundary;                  // mirrored at both ends
-        j = j < 0 ? -j : j;
-        j = j > H ? 2 * H - j : j;
-        m[q] = i < L ? P[j] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < QF; ++q) {
-        const int i = tid + KWY_THREADS * q;
-        if (i < L) S[i] = m[q] * fs / N;
-      }
+    for (int i = tid; i < L; i += KWY_THREADS) {
+      double m;
+      if (i < boundary) m = P[boundary - i];
+      else if (i < H + boundary) m = P[i - boundary];
+      else m = P[H - (i - (H + boundary))];
+      S[i] = m * fs / N;
     }
     __syncthreads();
-    kwy_block_cumsum_regs<KWY_THREADS, QF>(S, L, tot);
+    kwy_block_cumsum(S, L, tot);
     const double origin_of_mirroring_axis = -(boundary - 0.5) * fs / N;
     const double dfi = (double)fs / N;
-    double sm[RK];
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + KWY_THREADS * r;
-      sm[r] = 0.0;
-      if (k <= H) {
-        double fa = (double)k / N * fs - width / 2.0;
-        double low = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
-        fa += width;
-        double high = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
-        // the serial CPU cumulative sum is monotone, so its differences are >= 0; the block-parallel one can
-        // come out an ulp of the running total below zero in bins that carry no energy at all
-        sm[r] = fmax((high - low) / width, 0.0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + KWY_THREADS * r;
-      if (k <= H) P[k] = sm[r];
+    for (int k = tid; k <= H; k += KWY_THREADS) {
+      double fa = (double)k / N * fs - width / 2.0;
+      double low = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
+      fa += width;
+      double high = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
+      // the serial CPU cumulative sum is monotone, so its differences are >= 0; the block-parallel one can
+      // come out an ulp of the running total below zero in bins that carry no energy at all
+      P[k] = fmax((high - low) / width, 0.0);
     }
     __syncthreads();
   }

@@ -84,63 +84,36 @@ __device__ inline void d4c_dc_correction(double *P, double *S, double cf0, int f
   __syncthreads();
 }
 
-// WORLD LinearSmoothing of in[0..H] (LDS) with the loops unrolled to their compile-time maxima: the mirrored fill,
-// the prefix sum (chunk in registers) and the two interpolated reads per bin each issue their LDS reads together
-// instead of one dependent read per loop iteration.  S: scratch of >= H + 2 boundary + 1 doubles.
-//   MODE 0: out[k] = smoothed (out may alias in)   MODE 1: out[k] = in[k] - smoothed (out == in)
-//   MODE 2: outv[r] = max(smoothed, 0) for the thread's bins k = tid + NT r (a smoothed POWER spectrum)
-template <int NT, int LOG2N, int MODE, int RK>
-__device__ __forceinline__ void d4c_smooth(const double *in, double *out, double (&outv)[RK], double *S, double *tot,
-                                           double width, int fs) {
-  constexpr int N = 1 << LOG2N, H = N / 2;
-  constexpr int QF = (2 * H + 1 + NT - 1) / NT;     // boundary <= H / 2: L <= 2 H + 1
+// WORLD LinearSmoothing: in[0..H] -> out[0..H] (out may alias in); S: scratch of >= H+2b+1
+// (Measured in round 3 and dropped: the same three passes -- mirrored fill, prefix sum, two interpolated reads per
+// bin -- unrolled to their compile-time maxima with the prefix sum's chunk in registers, so that the LDS reads of a
+// pass are issued together: k_d4c_body 0.343 ms against 0.333 ms per launch of two utterances.  The kernel is bound
+// by instruction issue, the other resident workgroups already cover the LDS latency of these loops, and the
+// predicated unrolled forms issue more instructions.)
+template <int NT>
+__device__ inline void d4c_linear_smoothing(const double *in, double *out, double *S, double *tot,
+                                            double width, int fs, int N) {
+  const int H = N / 2;
   int boundary = (int)(width * N / fs) + 1;
   if (boundary > H / 2) boundary = H / 2;  // LDS guard; outside WORLD's domain anyway
   const int L = H + boundary * 2 + 1;
-  const int tid = kwy_tid_opaque();
-  {
-    double m[QF];
-#pragma unroll
-    for (int q = 0; q < QF; ++q) {
-      const int i = tid + NT * q;
-      int j = i - boundary;                         // mirrored at both ends
-      j = j < 0 ? -j : j;
-      j = j > H ? 2 * H - j : j;
-      m[q] = i < L ? in[j] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < QF; ++q) {
-      const int i = tid + NT * q;
-      if (i < L) S[i] = m[q] * fs / N;
-    }
+  for (int i = threadIdx.x; i < L; i += NT) {
+    double m;
+    if (i < boundary) m = in[boundary - i];
+    else if (i < H + boundary) m = in[i - boundary];
+    else m = in[H - (i - (H + boundary))];
+    S[i] = m * fs / N;
   }
   __syncthreads();
-  kwy_block_cumsum_regs<NT, QF>(S, L, tot);
+  kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
   const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
-  double sm[RK];
-#pragma unroll
-  for (int r = 0; r < RK; ++r) {
-    const int k = tid + NT * r;
-    sm[r] = 0.0;
-    if (k <= H) {
-      double fa = (double)k / N * fs - width / 2.0;
-      const double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
-      fa += width;
-      const double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
-      sm[r] = (high - low) * inv_width;
-    }
-  }
-  if constexpr (MODE == 2) {
-#pragma unroll
-    for (int r = 0; r < RK; ++r) outv[r] = fmax(sm[r], 0.0);
-  } else {
-    // (out may alias in: every read of `in` by the fill lies before the barriers of the prefix sum)
-#pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + NT * r;
-      if (k <= H) out[k] = MODE == 1 ? in[k] - sm[r] : sm[r];
-    }
+  for (int k = threadIdx.x; k <= H; k += NT) {
+    double fa = (double)k / N * fs - width / 2.0;
+    double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+    fa += width;
+    double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+    out[k] = (high - low) * inv_width;
   }
   __syncthreads();
 }
@@ -400,6 +373,68 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, i
   }
 }
 
+// WORLD LinearSmoothing as above, but out[k] = in[k] - smoothed[k] (the last step of the static group delay)
+template <int NT>
+__device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot, double width, int fs, int N) {
+  const int H = N / 2;
+  int boundary = (int)(width * N / fs) + 1;
+  if (boundary > H / 2) boundary = H / 2;
+  const int L = H + boundary * 2 + 1;
+  for (int i = threadIdx.x; i < L; i += NT) {
+    double m;
+    if (i < boundary) m = io[boundary - i];
+    else if (i < H + boundary) m = io[i - boundary];
+    else m = io[H - (i - (H + boundary))];
+    S[i] = m * fs / N;
+  }
+  __syncthreads();
+  kwy_block_cumsum<NT>(S, L, tot);
+  const double origin = -(boundary - 0.5) * fs / N;
+  const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
+  for (int k = threadIdx.x; k <= H; k += NT) {
+    double fa = (double)k / N * fs - width / 2.0;
+    double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+    fa += width;
+    double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+    io[k] = io[k] - (high - low) * inv_width;
+  }
+  __syncthreads();
+}
+
+// WORLD LinearSmoothing with the result left in registers: outv[r] = smoothed[tid + NT*r]
+template <int NT, int RK>
+__device__ inline void d4c_linear_smoothing_regs(const double *in, double (&outv)[RK], double *S, double *tot,
+                                                 double width, int fs, int N) {
+  const int H = N / 2;
+  int boundary = (int)(width * N / fs) + 1;
+  if (boundary > H / 2) boundary = H / 2;
+  const int L = H + boundary * 2 + 1;
+  for (int i = threadIdx.x; i < L; i += NT) {
+    double m;
+    if (i < boundary) m = in[boundary - i];
+    else if (i < H + boundary) m = in[i - boundary];
+    else m = in[H - (i - (H + boundary))];
+    S[i] = m * fs / N;
+  }
+  __syncthreads();
+  kwy_block_cumsum<NT>(S, L, tot);
+  const double origin = -(boundary - 0.5) * fs / N;
+  const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
+#pragma unroll
+  for (int r = 0; r < RK; ++r) {
+    const int k = threadIdx.x + NT * r;
+    outv[r] = 0.0;
+    if (k <= H) {
+      double fa = (double)k / N * fs - width / 2.0;
+      double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+      fa += width;
+      double high = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
+      outv[r] = fmax((high - low) * inv_width, 0.0);   // a smoothed POWER spectrum (see kwy_cheaptrick.hip)
+    }
+  }
+  __syncthreads();
+}
+
 // a per-thread constant behind an optimisation barrier: what is derived from it (the nine bin
 // twiddles, a few multiplications each) is recomputed at every use instead of living in -- at this
 // register budget, being spilled from -- 36 registers for the whole kernel
@@ -549,7 +584,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     if (tid + NT * r <= H) P[tid + NT * r] = pv[r];
   __syncthreads();
   d4c_dc_correction<NT>(P, S, cf0, p.fs, N);
-  d4c_smooth<NT, LOG2N, 2, RK>(P, nullptr, pv, S, tot, cf0, p.fs);   // P is dead from here on
+  d4c_linear_smoothing_regs<NT, RK>(P, pv, S, tot, cf0, p.fs, N);   // P is dead from here on
 
   D4C_STAMP(9);
   // ---- static group delay: the centroid sum moves into A0
@@ -562,11 +597,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   for (int r = 0; r < RK; ++r)
     if (tid + NT * r <= H) Dv[tid + NT * r] = Dv[tid + NT * r] / pv[r];
   __syncthreads();
-  {
-    double none[RK];
-    d4c_smooth<NT, LOG2N, 0, RK>(Dv, Dv, none, S, tot, cf0 / 2.0, p.fs);
-    d4c_smooth<NT, LOG2N, 1, RK>(Dv, Dv, none, S, tot, cf0, p.fs);
-  }
+  d4c_linear_smoothing<NT>(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N);
+  d4c_subtract_smoothed<NT>(Dv, S, tot, cf0, p.fs, N);
 
   D4C_STAMP(10);
   // ---- hand the static group delay to the band items (k_d4c_bands): one row of H+1 doubles per frame

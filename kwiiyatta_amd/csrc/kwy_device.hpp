@@ -379,43 +379,6 @@ __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
   __syncthreads();
 }
 
-// The same prefix sum with the thread's chunk held in registers: all LDS reads of the chunk are issued together, the
-// running sum is formed in registers, and one pass writes offset + running sum (kwy_block_cumsum walks its chunk twice
-// with a dependent LDS read per element: ~2 x chunk LDS latencies).  Same additions in the same order.  CH >= the
-// largest chunk ceil(L / NT) the caller can have.
-template <int NT, int CH>
-__device__ __forceinline__ void kwy_block_cumsum_regs(double *buf, int L, double *tot) {
-  constexpr int PER = NT / 64;
-  const int t = threadIdx.x;
-  const int chunk = (L + NT - 1) / NT;
-  const int b0 = t * chunk;
-  double v[CH];
-#pragma unroll
-  for (int q = 0; q < CH; ++q) v[q] = (q < chunk && b0 + q < L) ? buf[b0 + q] : 0.0;
-  double run = 0.0;
-#pragma unroll
-  for (int q = 0; q < CH; ++q) { run += v[q]; v[q] = run; }
-  tot[t] = run;
-  __syncthreads();
-  if (t < 64) {
-    double a[PER];
-    double acc = 0.0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) { acc += tot[PER * t + q]; a[q] = acc; }
-    const double inc = kwy_wave_scan_f64(acc);
-    const double excl = inc - acc;
-    tot[PER * t] = excl;
-#pragma unroll
-    for (int q = 1; q < PER; ++q) tot[PER * t + q] = excl + a[q - 1];
-  }
-  __syncthreads();
-  const double off = tot[t];
-#pragma unroll
-  for (int q = 0; q < CH; ++q)
-    if (q < chunk && b0 + q < L) buf[b0 + q] = t > 0 ? v[q] + off : v[q];
-  __syncthreads();
-}
-
 // offsets[i] = sum_{j<i} count(j) for i <= n, the counts given by a function of the index (evaluated twice: once for
 // the chunk totals, once for the offsets) -- counting and scanning in ONE single-workgroup launch.  tot: NT uint64 of LDS.
 template <int NT, class F>

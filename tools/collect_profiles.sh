@@ -1,9 +1,9 @@
 #!/bin/bash
 # Copy the summaries of tools/final_measure.sh (merged back into gpurun_out/final by gpurun) into profiles/<round>_*:
-#   tools/collect_profiles.sh [round, default r2] [source dir, default gpurun_out/final]
+#   tools/collect_profiles.sh [round, default r3] [source dir, default gpurun_out/final]
 set -e
 cd "$(dirname "$0")/.."
-RND=${1:-r2}
+RND=${1:-r3}
 S=${2:-gpurun_out/final}
 P=profiles
 newest() { ls -t $1 2>/dev/null | head -1; }
@@ -12,6 +12,9 @@ cp $S/bench_b1.json $P/${RND}_pair_b1_bench.json
 cp $S/bench_utt_b1.json $P/${RND}_utterance_b1_bench.json
 cp $S/bench_fit.json $P/${RND}_fit_bench.json
 cp $S/bench_corpus.json $P/${RND}_corpus_bench.json
+for f in config4 corpus_ref_em corpus_hostpads fit_2rank_gloo corpus_2rank_gloo corpus_1rank_64 2rank_gloo; do
+  [ -s $S/bench_$f.json ] && cp $S/bench_$f.json $P/${RND}_${f}_bench.json
+done
 cp "$(newest "$S/stats_pair_b32/*/*kernel_stats.csv")" $P/${RND}_pair_b32_kernel_stats.csv
 cp "$(newest "$S/stats_pair_b1/*/*kernel_stats.csv")" $P/${RND}_pair_b1_kernel_stats.csv
 F=$(newest "$S/pmc_fetch/*/*counter_collection.csv"); W=$(newest "$S/pmc_write/*/*counter_collection.csv")
