@@ -303,6 +303,17 @@ int kwy_gmm_em_finalize_dev(kwy_ctx *ctx, const double *stats, const double *sxx
                             double reg_covar, double *weights, double *covs);
 int kwy_gmm_em_scratch_bytes(int64_t n, int D, int M, int64_t *bytes);
 
+/* The whole fit of ONE rank's rows as one call: GaussianMixture(n_components=M, covariance_type='full', max_iter, tol,
+ * reg_covar, random_state=seed).fit(X)                kwiiyatta/converter/gmm.py:14-26
+ * -- the k-means initialisation below (numpy's RandomState(seed) draws, scikit-learn's seeding and Lloyd loop) and the
+ * EM loop above, run by the library.  X: n x D on the device; weights (M), means (M x D), covs (M x D x D): HOST outputs;
+ * n_iter / lower_bound / converged / kmeans_iter: scikit-learn's n_iter_, lower_bound_, converged_ and the number of
+ * Lloyd iterations (may be NULL).  Synchronous.  The multi-rank fit is driven from kwiiyatta_amd/converter/gmm_fit.py,
+ * which owns the communicator. */
+int kwy_gmm_fit_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, int max_iter, double tol, double reg_covar,
+                    uint32_t seed, double *weights, double *means, double *covs, int *n_iter, double *lower_bound,
+                    int *converged, int *kmeans_iter);
+
 /* ---- converter fit: k-means initialisation ------------------------------------------------------
  * The `init_params='kmeans'` step of the same GaussianMixture.fit (kwiiyatta/converter/gmm.py:14-23):
  * sklearn.cluster.KMeans(n_clusters=M, n_init=1) -- centred input, k-means++ seeding with 2 + ln M

@@ -427,6 +427,31 @@ def _em_fit(stats, n_total, max_iter, tol, reg_covar, verbose):
     return lower_bound, converged, n_iter
 
 
+def fit_one_call(X, n_components, max_iter=100, tol=1e-3, reg_covar=1e-6, random_state=0, device_index=0, ctx=None):
+    """The fit of one rank's rows through the library's single entry point `kwy_gmm_fit_dev` (the control flow of this
+    module in C++, for binders without a Python driver).  X: (n, D) numpy array or float64 device tensor; an integer
+    `random_state`.  Returns a GaussianMixtureHIP carrying the fitted attributes."""
+    import ctypes
+    import torch
+    from .. import _lib
+    dev = torch.device('cuda', device_index)
+    Xd = X if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(dev)
+    n, D = Xd.shape
+    M = int(n_components)
+    ctx = ctx or _lib.Context(device_index)
+    g = GaussianMixtureHIP(n_components=M, max_iter=max_iter, tol=tol, reg_covar=reg_covar, random_state=random_state,
+                           device_index=device_index)
+    g.weights_, g.means_, g.covariances_ = np.empty(M), np.empty((M, D)), np.empty((M, D, D))
+    it, conv, kit, lb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
+    torch.cuda.synchronize(dev)
+    _lib.check(ctx, _lib.lib.kwy_gmm_fit_dev(ctx.handle, _lib.c_vp(Xd.data_ptr()), n, D, M, int(max_iter), float(tol),
+                                             float(reg_covar), int(random_state), _lib.ptr(g.weights_),
+                                             _lib.ptr(g.means_), _lib.ptr(g.covariances_), ctypes.byref(it),
+                                             ctypes.byref(lb), ctypes.byref(conv), ctypes.byref(kit)))
+    g.n_iter_, g.lower_bound_, g.converged_, g.kmeans_n_iter_ = it.value, lb.value, bool(conv.value), kit.value
+    return g
+
+
 class GaussianMixtureHIP:
     """Drop-in for the sklearn GaussianMixture object held by GMMFeatureConverter
     (full covariance, one initialisation)."""

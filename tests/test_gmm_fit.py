@@ -375,3 +375,22 @@ def test_hip_fit_rejects_degenerate_covariance():
     X[:, 0] = np.arange(100)
     with pytest.raises(ValueError):
         GaussianMixtureHIP(n_components=2, random_state=0, reg_covar=0.0).fit(X)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,D,M,seed', [(6000, 24, 8, 0), (20000, 144, 64, 1), (900, 12, 3, 7)])
+def test_single_call_fit_matches_driver_and_sklearn(n, D, M, seed):
+    """kwy_gmm_fit_dev -- initialisation and EM as ONE C call (numpy's RandomState draws reproduced in the library) --
+    against the Python driver over the same kernels and against scikit-learn: same iteration counts, same model."""
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP, fit_one_call
+    X = make_data(n, D, min(M, 8), seed=seed + 10)
+    one = fit_one_call(X, M, max_iter=10, random_state=seed)
+    drv = GaussianMixtureHIP(n_components=M, random_state=seed, max_iter=10).fit(X)
+    ref = sklearn_fit(X, M, seed=seed, max_iter=10)
+    assert one.kmeans_n_iter_ == drv.kmeans_n_iter_
+    assert one.n_iter_ == drv.n_iter_ == ref.n_iter_ and one.converged_ == drv.converged_
+    assert abs(one.lower_bound_ - drv.lower_bound_) <= 1e-10 * abs(drv.lower_bound_)
+    assert np.allclose(one.weights_, drv.weights_, rtol=1e-10) and np.allclose(one.means_, drv.means_, rtol=1e-9, atol=1e-12)
+    assert np.allclose(one.covariances_, drv.covariances_, rtol=1e-8, atol=1e-12)
+    assert np.allclose(one.means_, ref.means_, rtol=1e-6, atol=1e-8)
+    assert np.allclose(one.covariances_, ref.covariances_, rtol=1e-5, atol=1e-8)
