@@ -13,7 +13,7 @@ cp $S/bench_utt_b1.json $P/${RND}_utterance_b1_bench.json
 cp $S/bench_fit.json $P/${RND}_fit_bench.json
 cp $S/bench_corpus.json $P/${RND}_corpus_bench.json
 for f in config4 corpus_ref_em corpus_hostpads fit_2rank_gloo corpus_2rank_gloo corpus_1rank_64 2rank_gloo; do
-  [ -s $S/bench_$f.json ] && cp $S/bench_$f.json $P/${RND}_${f}_bench.json
+  [ -s $S/bench_$f.json ] && tail -n 1 $S/bench_$f.json > $P/${RND}_${f}_bench.json   # (gloo prints a line of its own first)
 done
 cp "$(newest "$S/stats_pair_b32/*/*kernel_stats.csv")" $P/${RND}_pair_b32_kernel_stats.csv
 cp "$(newest "$S/stats_pair_b1/*/*kernel_stats.csv")" $P/${RND}_pair_b1_kernel_stats.csv
