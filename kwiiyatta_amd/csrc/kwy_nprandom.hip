@@ -180,6 +180,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_words(const np_state *__rest
                                                          uint32_t *__restrict__ kbuf) {
   __shared__ uint32_t mt[2][MT_N];
   const int tid = threadIdx.x;
+  // (This one serial workgroup shares its CU with workgroups of whatever else the chip is running and runs ~2.7x
+  // slower beside a full load than alone; raising its wave priority with s_setprio was measured: no effect.)
   for (int i = tid; i < MT_N; i += KWY_THREADS) { const uint32_t v = st->key[i]; mt[0][i] = v; kbuf[i] = v; }
   __syncthreads();
   int cur = 0;
