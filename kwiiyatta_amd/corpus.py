@@ -162,9 +162,19 @@ class TrainPair:
 
 class ConvertPipeline(_Graphed):
     """convert_voice.convert(diffvc=False) of one utterance, HBM-resident: analyse -> mel-cepstrum -> GMM/MLPG
-    conversion (c0 kept) -> spectrum -> synthesis with the utterance's own f0 and aperiodicity."""
+    conversion (c0 kept) -> spectrum -> synthesis with the utterance's own f0 and aperiodicity.
 
-    def __init__(self, device_index, fs, utterance, gmm, order=24, frame_period=5.0, stream=None, ctx=None):
+    mcep_fs: the sampling rate the converter was trained at, when it differs from the utterance's
+    (`--mcep-fs`; MelCepstrumFeatureConverter.convert and the `feature.mel_cepstrum = ...` that follows it,
+    /root/reference/kwiiyatta/converter/mcep.py:47-61, vocoder/mcep.py:31-45, vocoder/abc/feature.py): the
+    mel-cepstrum travels to the converter's rate and back through its spectrum -- mc2sp on the vocoder's grid of
+    the old rate, the bins cut at the new Nyquist frequency or extended by "silent" bins |N(0, EPS / old_fs)|, sp2mc
+    with the new rate's alpha (any bin count: the dense form).  The silent bins are one numpy draw of (T, missing)
+    values per call; `rng` (a backend.nprandom.DeviceRandomState) draws them on the device in the reference's
+    order, so a seeded run equals the Python API path."""
+
+    def __init__(self, device_index, fs, utterance, gmm, order=24, frame_period=5.0, stream=None, ctx=None,
+                 mcep_fs=None, rng=None):
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.frame_period = int(fs), int(order), float(frame_period)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
@@ -180,6 +190,8 @@ class ConvertPipeline(_Graphed):
         x, f0, t = utterance
         self.N, self.T = len(x), len(f0)
         f64 = dict(dtype=torch.float64, device=self.dev)
+        self.mcep_fs = int(mcep_fs) if mcep_fs is not None and int(mcep_fs) != self.fs else None
+        self.rng = rng
         with torch.cuda.stream(self.stream):
             self.x, self.f0, self.t = (torch.from_numpy(np.ascontiguousarray(a)).to(self.dev) for a in (x, f0, t))
             self.sp = torch.empty((self.T, self.K), **f64)
@@ -191,6 +203,24 @@ class ConvertPipeline(_Graphed):
             self.sp_conv = torch.empty((self.T, self.K), **f64)
             self.ylen = lib.kwy_synth_length(self.T, self.frame_period, self.fs)
             self.wave = torch.empty(self.ylen, **f64)
+            if self.mcep_fs is not None:
+                if rng is None:
+                    raise ValueError('ConvertPipeline(mcep_fs=...) needs rng: the silent bins of the wider spectrum '
+                                     'are random draws')
+                fc = self.mcep_fs
+                self.alpha_c = sptk.mcepalpha(fc)
+                self.Kc = lib.kwy_cheaptrick_fft_size(fc, 71.0) // 2 + 1         # the vocoder's grid at the other rate
+                self.n_there = self.K * fc // self.fs                            # our grid carried to the converter's rate
+                self.n_back = self.Kc * self.fs // fc                            # its grid carried back to ours
+                self.spec_u = torch.empty((self.T, self.K), **f64)
+                self.there = torch.empty((self.T, self.n_there), **f64)
+                self.mc_c = torch.empty((self.T, order + 1), **f64)
+                self.mc_c2 = torch.empty((self.T, order + 1), **f64)
+                self.spec_c = torch.empty((self.T, self.Kc), **f64)
+                self.back = torch.empty((self.T, self.n_back), **f64)
+                # the one "up" direction of the round trip appends random silent bins (drawn per run)
+                miss = self.n_there - self.K if fc > self.fs else self.n_back - self.Kc
+                self.silent = torch.empty((self.T, miss), **f64)
         self.stream.synchronize()
         self.frames = self.T
 
@@ -205,6 +235,37 @@ class ConvertPipeline(_Graphed):
                 dst.copy_(src if torch.is_tensor(src) else torch.from_numpy(np.ascontiguousarray(src)),
                           non_blocking=True)
 
+    def _convert_across_rates(self, chk, h):
+        """self.mc (utterance rate) -> self.mc_conv (utterance rate) through the converter's rate"""
+        T, order, fs, fc = self.T, self.order, self.fs, self.mcep_fs
+        EPS = 2.220446049250313e-16
+        up_first = fc > fs
+        if True:                    # (one block: the order below IS the order of the reference's calls)
+            # MelCepstrum.resample_data(fc): spectrum on our grid, cut / extended, coefficients with the new alpha
+            chk(lib.kwy_mc2sp_dev(h, _p(self.mc), T, order, self.alpha, self.fft, _p(self.spec_u)))
+            if up_first:
+                self.rng.stream.wait_stream(self.stream)
+                self.rng.abs_normal(EPS / fs, out=self.silent)
+                self.stream.wait_event(self.rng.record_event())
+                self.there[:, :self.K].copy_(self.spec_u)
+                self.there[:, self.K:].copy_(self.silent)
+            else:
+                self.there.copy_(self.spec_u[:, :self.n_there])
+            chk(lib.kwy_sp2mc_dev(h, _p(self.there), T, self.n_there, order, self.alpha_c, _p(self.mc_c)))
+            # the conversion itself, at the converter's rate (c0 kept)
+            chk(lib.kwy_convert_mcep_dev(h, _p(self.mc_c), T, order, self.gmm.M, _p(self.gmm_model), _p(self.mc_c2)))
+            # `feature.mel_cepstrum = converted` -> resample_data(fs): back through the converter rate's grid
+            chk(lib.kwy_mc2sp_dev(h, _p(self.mc_c2), T, order, self.alpha_c, 2 * (self.Kc - 1), _p(self.spec_c)))
+            if not up_first:
+                self.rng.stream.wait_stream(self.stream)
+                self.rng.abs_normal(EPS / fc, out=self.silent)
+                self.stream.wait_event(self.rng.record_event())
+                self.back[:, :self.Kc].copy_(self.spec_c)
+                self.back[:, self.Kc:].copy_(self.silent)
+            else:
+                self.back.copy_(self.spec_c[:, :self.n_back])
+            chk(lib.kwy_sp2mc_dev(h, _p(self.back), T, self.n_back, order, self.alpha, _p(self.mc_conv)))
+
     def run(self):
         h, fs, fft, K, order, T = self.ctx.handle, self.fs, self.fft, self.K, self.order, self.T
         chk = lambda rc: _lib.check(self.ctx, rc)  # noqa: E731
@@ -213,7 +274,10 @@ class ConvertPipeline(_Graphed):
                                        float(fs), _p(self.sp)))
             chk(lib.kwy_d4c_dev(h, _p(self.x), self.N, fs, _p(self.t), _p(self.f0), T, 0.85, fft, _p(self.ap)))
             chk(lib.kwy_sp2mc_dev(h, _p(self.sp), T, K, order, self.alpha, _p(self.mc)))
-            chk(lib.kwy_convert_mcep_dev(h, _p(self.mc), T, order, self.gmm.M, _p(self.gmm_model), _p(self.mc_conv)))
+            if self.mcep_fs is None:
+                chk(lib.kwy_convert_mcep_dev(h, _p(self.mc), T, order, self.gmm.M, _p(self.gmm_model), _p(self.mc_conv)))
+            else:
+                self._convert_across_rates(chk, h)
             chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), T, order, self.alpha, fft, _p(self.sp_conv)))
             chk(lib.kwy_synthesize_dev(h, _p(self.f0), T, _p(self.sp_conv), _p(self.ap), fft, self.frame_period, fs,
                                        float(fs), self.ylen, _p(self.wave)))

@@ -267,3 +267,43 @@ def test_silence_helper_thread_stops_on_error(corpus):
     with pytest.raises(Exception):
         cp.build_training_matrix(bad, FS, streams=1)
     assert threading.active_count() == before
+
+
+@pytest.mark.parametrize('fs_u,fs_c', [(48000, 16000), (16000, 48000), (22050, 16000)])
+def test_convert_pipeline_with_converter_at_another_rate(fs_u, fs_c):
+    """--mcep-fs: a converter trained at another sampling rate than the utterance's.  ConvertPipeline(mcep_fs=...)
+    against the package's Python API path (MelCepstrumFeatureConverter.convert, then `feature.mel_cepstrum = ...` and
+    the synthesis: kwiiyatta/convert_voice.py:35-46), the silent bins of the widening step drawn from the same seeded
+    numpy stream -- on the host there, on the device here."""
+    import torch
+    import kwiiyatta_amd as kw
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.backend import world
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    from kwiiyatta_amd.synthetic import make_utterance
+    x, _, _ = make_utterance(seed=21, fs=fs_u, seconds=0.8)
+    g = pl.synthetic_gmm(order=ORDER, components=4, seed=0, n_frames=3000)
+    conv = kw.MelCepstrumConverter(use_delta=True, components=4)
+    conv.gmm.weights_, conv.gmm.means_, conv.gmm.covariances_ = g.weights_, g.means_, g.covariances_
+    conv.order, conv.fs = ORDER, fs_c
+    conv.base.frame_period = 5
+    # the API path
+    np.random.seed(77)
+    src = kw.Analyzer(kw.Wavdata(fs_u, x), mcep_order=ORDER)
+    mcep = conv.convert(src.mel_cepstrum, diff=False)
+    assert mcep.fs == fs_c
+    feat = kw.feature(src)
+    feat.mel_cepstrum = mcep
+    want = kw.Synthesizer._synthesize(feat).data
+    # the device path on the same f0 track
+    f0, t = np.ascontiguousarray(src.f0), np.ascontiguousarray(src._timeaxis)
+    np.random.seed(77)
+    dg = pl.DeviceGMM(g.weights_, g.means_, g.covariances_, torch.device('cuda', 0))
+    p = cp.ConvertPipeline(0, fs_u, (x, f0, t), dg, order=ORDER, mcep_fs=fs_c, rng=DeviceRandomState.from_global())
+    p.run()
+    p.sync()
+    got = p.wave.cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
+    assert np.abs(p.mc_c2.cpu().numpy() - mcep.data).max() <= 1e-9 * np.abs(mcep.data).max()
