@@ -243,21 +243,31 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(bufA, twl, twb, twN);
   kwy_c *Cx = bufA;
 
-  // ---- smoothing + recovery lifter
-  for (int k = tid; k <= H; k += KWY_THREADS) {
-    double sl, cl;
-    if (k == 0) {
-      sl = 1.0;
-      cl = (1.0 - 2.0 * q1) + 2.0 * q1;
-    } else {
-      // one sine serves both factors: cos(2 th) = 1 - 2 sin^2(th) (differs from cos() by ~2 ulp of a factor near 1)
-      double quefrency = (double)k / fs;
-      const double th = KWY_PI * cf0 * quefrency;
-      const double sn = sin(th);
-      sl = sn / th;
-      cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * sn * sn);
+  // ---- smoothing + recovery lifter.  The lifters' argument pi cf0 k / fs advances by a constant from one of the
+  //      thread's bins k = tid + 256 r to the next: one sincos for r = 0 and one for the step, then rotations
+  //      (kwy_rotate) -- the general-range sin() per bin was 5 % of the kernel's instructions.
+  {
+    double ls, lc, lsd, lcd;
+    sincos(KWY_PI * cf0 * ((double)tid / fs), &ls, &lc);
+    sincos(KWY_PI * cf0 * ((double)KWY_THREADS / fs), &lsd, &lcd);
+#pragma unroll
+    for (int r = 0; r < RK; ++r) {
+      const int k = tid + KWY_THREADS * r;
+      if (r > 0) kwy_rotate(lc, ls, lcd, lsd);
+      if (k <= H) {
+        double sl, cl;
+        if (k == 0) {
+          sl = 1.0;
+          cl = (1.0 - 2.0 * q1) + 2.0 * q1;
+        } else {
+          // one sine serves both factors: cos(2 th) = 1 - 2 sin^2(th) (differs from cos() by ~2 ulp of a factor near 1)
+          const double th = KWY_PI * cf0 * ((double)k / fs);
+          sl = ls / th;
+          cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * ls * ls);
+        }
+        Cx[k] = {Cx[k].x * sl * cl / N, 0.0};
+      }
     }
-    Cx[k] = {Cx[k].x * sl * cl / N, 0.0};
   }
   kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(bufA, twl, twb, twN);
   const double *wr = (const double *)bufA;

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
   for (int r = 0; r < RK; ++r) {
     const int k = tid + NT * r;
     if (k > boundary0 && k <= boundary2 && k <= H) {
-      const kwy_c v = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(twb, HEX * r));
+      const kwy_c v = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(twb, HEX * r));
       double pw = v.x * v.x + v.y * v.y;
       c2 += pw;
       if (k <= boundary1) c1 += pw;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
 #pragma unroll
       for (int r = 0; r < RK; ++r) {
         const int k = tid + NT * r;
-        X1[r] = k <= H ? kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r)) : kwy_c{0.0, 0.0};
+        X1[r] = k <= H ? kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r)) : kwy_c{0.0, 0.0};
       }
       __syncthreads();
 #pragma unroll
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
       for (int r = 0; r < RK; ++r) {
         const int k = tid + NT * r;
         if (k <= H) {
-          const kwy_c X2 = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
+          const kwy_c X2 = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
           const double v = X2.x * X1[r].x + X1[r].y * X2.y;
           cen[r] = which == 0 ? v : cen[r] + v;
         }
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     const int k = tid + NT * r;
     pv[r] = 0.0;
     if (k <= H) {
-      const kwy_c v = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
+      const kwy_c v = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
       pv[r] = v.x * v.x + v.y * v.y;
     }
   }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
       const int k = tid + NT * r;
       key[r] = ~0ull;
       if (k <= H) {
-        const kwy_c cc = kwy_rfft_bin_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
+        const kwy_c cc = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
         key[r] = (unsigned long long)__double_as_longlong(cc.x * cc.x + cc.y * cc.y);
       }
     }
