@@ -12,6 +12,7 @@ if [ "$PART" = a ]; then
   python -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
   python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
   python $R/bench.py --batch 16 --no-cpu-baseline --no-pcie-variant > $O/bench_b16.json 2>/dev/null
+  python $R/bench.py --batch 64 --steps 5 --no-cpu-baseline --no-pcie-variant > $O/bench_b64.json 2>/dev/null
   python $R/bench.py --batch 1 --steps 5 --no-cpu-baseline --no-pcie-variant > $O/bench_b1.json 2>/dev/null
   python $R/bench.py --workload utterance --batch 1 > $O/bench_utt_b1.json 2>/dev/null
   python $R/bench.py --workload utterance --batch 16 --no-cpu-baseline > $O/bench_utt_b16.json 2>/dev/null
