@@ -47,7 +47,7 @@ __device__ __forceinline__ double ct_interp1q(double x0, double shift, const dou
   double frac = r - base;
   double y0 = y[base];
   double dy = (base >= x_length - 1) ? 0.0 : y[base + 1] - y0;
-  return y0 + dy * frac;
+  return __builtin_fma(dy, frac, y0);
 }
 
 template <int LOG2N>

@@ -58,7 +58,7 @@ __device__ __forceinline__ double d4c_interp1q_inv(double x0, double inv_shift, 
   double frac = r - base;
   double y0 = y[base];
   double dy = (base >= x_length - 1) ? 0.0 : y[base + 1] - y0;
-  return y0 + dy * frac;
+  return __builtin_fma(dy, frac, y0);
 }
 
 __device__ __forceinline__ double d4c_interp1q(double x0, double shift, const double *y, int x_length,
@@ -68,7 +68,7 @@ __device__ __forceinline__ double d4c_interp1q(double x0, double shift, const do
   double frac = r - base;
   double y0 = y[base];
   double dy = (base >= x_length - 1) ? 0.0 : y[base + 1] - y0;
-  return y0 + dy * frac;
+  return __builtin_fma(dy, frac, y0);
 }
 
 // WORLD DCCorrection in place on P[0..H]; S: scratch
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
     const int k = tid + NT * r;
     if (k > boundary0 && k <= boundary2 && k <= H) {
       const kwy_c v = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(twb, HEX * r));
-      double pw = v.x * v.x + v.y * v.y;
+      double pw = __builtin_fma(v.x, v.x, v.y * v.y);
       c2 += pw;
       if (k <= boundary1) c1 += pw;
     }
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
         const int k = tid + NT * r;
         if (k <= H) {
           const kwy_c X2 = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
-          const double v = X2.x * X1[r].x + X1[r].y * X2.y;
+          const double v = __builtin_fma(X2.x, X1[r].x, X1[r].y * X2.y);
           cen[r] = which == 0 ? v : cen[r] + v;
         }
       }
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     pv[r] = 0.0;
     if (k <= H) {
       const kwy_c v = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
-      pv[r] = v.x * v.x + v.y * v.y;
+      pv[r] = __builtin_fma(v.x, v.x, v.y * v.y);
     }
   }
   __syncthreads();
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
       key[r] = ~0ull;
       if (k <= H) {
         const kwy_c cc = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
-        key[r] = (unsigned long long)__double_as_longlong(cc.x * cc.x + cc.y * cc.y);
+        key[r] = (unsigned long long)__double_as_longlong(__builtin_fma(cc.x, cc.x, cc.y * cc.y));
       }
     }
     __syncthreads();

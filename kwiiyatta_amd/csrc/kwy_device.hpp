@@ -205,22 +205,22 @@ __device__ __forceinline__ double kwy_cos_pi_range(double x) {
   const double ax = fabs(x);
   const double kf = rint(ax * 6.36619772367581382433e-01);  // 0, 1 or 2 (3 if x is a hair beyond pi... )
   const int k = (int)kf;
-  double y = ax - kf * 1.57079632673412561417e+00;
-  y = y - kf * 6.07710050650619224932e-11;
+  double y = __builtin_fma(-kf, 1.57079632673412561417e+00, ax);
+  y = __builtin_fma(-kf, 6.07710050650619224932e-11, y);
   const double z = y * y;
   // sin kernel
-  const double rs = 8.33333333332248946124e-03 +
-                    z * (-1.98412698298579493134e-04 +
-                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-  const double sn = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
+  // (Horner steps as explicit fused multiply-adds: half the instructions, and the library's -ffp-contract=off is meant
+  // for the kernels that reproduce serial CPU roundings, not for this polynomial)
+  const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
+                                  -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                  -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+  const double sn = __builtin_fma(z * y, __builtin_fma(z, rs, -1.66666666666666324348e-01), y);
   // cos kernel
-  const double rc = z * (4.16666666666666019037e-02 +
-                         z * (-1.38888888888741095749e-03 +
-                              z * (2.48015872894767294178e-05 +
-                                   z * (-2.75573143513906633035e-07 +
-                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
+                        -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
   const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cs = w + (((1.0 - w) - hz) + z * rc);
+  const double cs = w + __builtin_fma(z, rc, (1.0 - w) - hz);
   // cos(ax) = cos(y + k pi/2)
   const double v = (k & 1) ? sn : cs;
   return ((k + 1) & 2) ? -v : v;
@@ -234,20 +234,20 @@ __device__ __forceinline__ void kwy_sincos_pi_range(double x, double *sn_out, do
   const double ax = fabs(x);
   const double kf = rint(ax * 6.36619772367581382433e-01);
   const int k = (int)kf;
-  double y = ax - kf * 1.57079632673412561417e+00;
-  y = y - kf * 6.07710050650619224932e-11;
+  double y = __builtin_fma(-kf, 1.57079632673412561417e+00, ax);
+  y = __builtin_fma(-kf, 6.07710050650619224932e-11, y);
   const double z = y * y;
-  const double rs = 8.33333333332248946124e-03 +
-                    z * (-1.98412698298579493134e-04 +
-                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-  const double sn = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
-  const double rc = z * (4.16666666666666019037e-02 +
-                         z * (-1.38888888888741095749e-03 +
-                              z * (2.48015872894767294178e-05 +
-                                   z * (-2.75573143513906633035e-07 +
-                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  // (Horner steps as explicit fused multiply-adds: half the instructions, and the library's -ffp-contract=off is meant
+  // for the kernels that reproduce serial CPU roundings, not for this polynomial)
+  const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
+                                  -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                  -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+  const double sn = __builtin_fma(z * y, __builtin_fma(z, rs, -1.66666666666666324348e-01), y);
+  const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
+                        -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
   const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cs = w + (((1.0 - w) - hz) + z * rc);
+  const double cs = w + __builtin_fma(z, rc, (1.0 - w) - hz);
   // (cos, sin)(y + k pi/2)
   const double c = (k & 1) ? sn : cs, s_ = (k & 1) ? cs : sn;
   *cs_out = ((k + 1) & 2) ? -c : c;
@@ -867,7 +867,7 @@ __device__ inline void kwy_rfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw, 
       const double er = 0.5 * (A.x + Bc.x), ei = 0.5 * (A.y - Bc.y);
       const double dr = 0.5 * (A.x - Bc.x), di = 0.5 * (A.y + Bc.y);
       const double orr = di, oi = -dr;
-      const double pr = orr * w.x - oi * w.y, pi = orr * w.y + oi * w.x;
+      const double pr = __builtin_fma(orr, w.x, -(oi * w.y)), pi = __builtin_fma(orr, w.y, oi * w.x);
       z[k] = {er + pr, ei + pi};
       if (k != H - k) z[H - k] = {er - pr, -(ei - pi)};
     }
@@ -899,7 +899,7 @@ __device__ inline void kwy_irfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw,
       const double er = A.x + Bc.x, ei = A.y - Bc.y;
       const double dr = A.x - Bc.x, di = A.y + Bc.y;
       const double wr = w.x, wi = -w.y;
-      const double orr = dr * wr - di * wi, oi = dr * wi + di * wr;
+      const double orr = __builtin_fma(dr, wr, -(di * wi)), oi = __builtin_fma(dr, wi, di * wr);
       z[k] = {er - oi, ei + orr};
       if (k != H - k) z[H - k] = {er + oi, -(ei - orr)};
     }

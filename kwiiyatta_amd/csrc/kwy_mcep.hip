@@ -99,7 +99,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_sp2mc(const double *__restrict_
     for (int n = q; n < ncut; n += 4) {   // unrolled: eight matrix loads in flight, not one L2 round trip per step
       const double f = F[(size_t)n * MC_STRIDE + j];
 #pragma unroll
-      for (int fr = 0; fr < MC_FR; ++fr) acc[fr] += f * cep[fr * ncut + n];
+      for (int fr = 0; fr < MC_FR; ++fr) acc[fr] = __builtin_fma(f, cep[fr * ncut + n], acc[fr]);   // (explicit: the
+      // library is built with -ffp-contract=off for the kernels that reproduce serial roundings; this sum is not one)
     }
   }
 #pragma unroll
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_sp2mc_dense(const double *__res
     for (int k = q; k < K; k += 4) {
       const double g = G[(size_t)k * MC_STRIDE + j];
 #pragma unroll
-      for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] += g * lg[(size_t)fr * K + k];
+      for (int fr = 0; fr < MCD_FR; ++fr) acc[fr] = __builtin_fma(g, lg[(size_t)fr * K + k], acc[fr]);
     }
   }
 #pragma unroll

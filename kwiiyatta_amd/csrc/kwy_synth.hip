@@ -598,7 +598,7 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
         const double re = buf[k].x, im = buf[k].y;
         const double re2 = kwy_cos_pi_range(coefficient * k);   // shift * fs < 1: the argument stays in [0, pi]
         const double im2 = sqrt(1.0 - re2 * re2);
-        buf[k] = {re * re2 + im * im2, im * re2 - re * im2};
+        buf[k] = {__builtin_fma(re, re2, im * im2), __builtin_fma(im, re2, -(re * im2))};
       }
       kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
       const double *w = (const double *)buf;
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
         const int k = tid + KWY_THREADS * r;
         if (k <= H) {
           const kwy_c a = buf[k], b = nz[r];
-          buf[k] = {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+          buf[k] = cmulf(a, b);
         }
       }
       kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
