@@ -198,6 +198,9 @@ __device__ inline void kwy_rng_block_ebase(uint64_t pos, const uint4 *__restrict
 }
 
 // ------------------------------------------------------------------ cos on [-pi, pi]
+// (Its Horner steps as explicit fused multiply-adds were measured in round 3 and dropped: half the instructions of the
+// polynomial, but the different schedule pushes k_d4c_body and k_syn_pulse, both at their register cap, from 12 / 96
+// to 92 / 224 bytes of scratch per lane: k_d4c_body 0.315 -> 0.334 ms.)
 // The analysis windows evaluate cos() a few thousand times per frame with arguments that never
 // leave [-pi, pi] (up to rounding).  Two-constant Cody-Waite reduction by pi/2 and the fdlibm
 // kernel polynomials: < 1 ulp, a quarter of the instructions of the general-range routine.
@@ -205,22 +208,22 @@ __device__ __forceinline__ double kwy_cos_pi_range(double x) {
   const double ax = fabs(x);
   const double kf = rint(ax * 6.36619772367581382433e-01);  // 0, 1 or 2 (3 if x is a hair beyond pi... )
   const int k = (int)kf;
-  double y = __builtin_fma(-kf, 1.57079632673412561417e+00, ax);
-  y = __builtin_fma(-kf, 6.07710050650619224932e-11, y);
+  double y = ax - kf * 1.57079632673412561417e+00;
+  y = y - kf * 6.07710050650619224932e-11;
   const double z = y * y;
   // sin kernel
-  // (Horner steps as explicit fused multiply-adds: half the instructions, and the library's -ffp-contract=off is meant
-  // for the kernels that reproduce serial CPU roundings, not for this polynomial)
-  const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
-                                  -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                  -1.98412698298579493134e-04), 8.33333333332248946124e-03);
-  const double sn = __builtin_fma(z * y, __builtin_fma(z, rs, -1.66666666666666324348e-01), y);
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sn = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
   // cos kernel
-  const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
-                        -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double rc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 +
+                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
   const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cs = w + __builtin_fma(z, rc, (1.0 - w) - hz);
+  const double cs = w + (((1.0 - w) - hz) + z * rc);
   // cos(ax) = cos(y + k pi/2)
   const double v = (k & 1) ? sn : cs;
   return ((k + 1) & 2) ? -v : v;
@@ -234,20 +237,20 @@ __device__ __forceinline__ void kwy_sincos_pi_range(double x, double *sn_out, do
   const double ax = fabs(x);
   const double kf = rint(ax * 6.36619772367581382433e-01);
   const int k = (int)kf;
-  double y = __builtin_fma(-kf, 1.57079632673412561417e+00, ax);
-  y = __builtin_fma(-kf, 6.07710050650619224932e-11, y);
+  double y = ax - kf * 1.57079632673412561417e+00;
+  y = y - kf * 6.07710050650619224932e-11;
   const double z = y * y;
-  // (Horner steps as explicit fused multiply-adds: half the instructions, and the library's -ffp-contract=off is meant
-  // for the kernels that reproduce serial CPU roundings, not for this polynomial)
-  const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
-                                  -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                  -1.98412698298579493134e-04), 8.33333333332248946124e-03);
-  const double sn = __builtin_fma(z * y, __builtin_fma(z, rs, -1.66666666666666324348e-01), y);
-  const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
-                        -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                        2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sn = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
+  const double rc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 +
+                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
   const double hz = 0.5 * z, w = 1.0 - hz;
-  const double cs = w + __builtin_fma(z, rc, (1.0 - w) - hz);
+  const double cs = w + (((1.0 - w) - hz) + z * rc);
   // (cos, sin)(y + k pi/2)
   const double c = (k & 1) ? sn : cs, s_ = (k & 1) ? cs : sn;
   *cs_out = ((k + 1) & 2) ? -c : c;
