@@ -241,8 +241,7 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
     if (i < wl) {
       double w = walk.value(D4C_BLACKMAN);
       int idx = min(x_length - 1, max(0, origin + i - half));
-      v = x[idx] * w;
-      v = v + kwy_randn_from_raw(raw[r]) * D4C_SAFE;
+      v = __builtin_fma(kwy_randn_from_raw(raw[r]), D4C_SAFE, x[idx] * w);
       Bd[i] = w;
       s1 += v; s2 += w;
     }
@@ -345,8 +344,7 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, i
     double v = 0.0;
     if (i < wl) {
       const double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
-      v = xv[r] * w;
-      v = v + kwy_randn_from_raw(raw[r]) * D4C_SAFE;
+      v = __builtin_fma(kwy_randn_from_raw(raw[r]), D4C_SAFE, xv[r] * w);
       Bd[i] = w;                       // kept for the DC removal below (only this thread reads it)
       s1 += v; s2 += w;
     }
@@ -359,9 +357,9 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, i
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     if (tid + NT * r < wl) {
-      double v = av[r] - Bd[tid + NT * r] * coef;
+      double v = __builtin_fma(-Bd[tid + NT * r], coef, av[r]);
       av[r] = v;
-      pw += v * v;
+      pw = __builtin_fma(v, v, pw);
     }
   }
   if (normalise) {

@@ -128,7 +128,8 @@ struct kwy_randn_src {
 };
 
 __device__ __forceinline__ double kwy_randn_from_raw(uint32_t raw) {
-  return raw * 3.7252902984619140625e-09 - 6.0;   // raw / 2^28 - 6, exactly as the division
+  return __builtin_fma((double)raw, 3.7252902984619140625e-09, -6.0);   // raw / 2^28 - 6: the product is exact, so the
+                                                                       // fused form rounds like the division
 }
 
 // threadIdx.x behind an optimisation barrier: address arithmetic derived from it is redone where it
