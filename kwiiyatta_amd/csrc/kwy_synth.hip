@@ -618,6 +618,25 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
     // ---- aperiodic response
     {
       const int tid = kwy_tid_opaque();
+      // The minimum-phase spectrum first, pulled into registers (bins tid + 256 r); the noise spectrum is formed in the
+      // buffer afterwards and multiplied in place -- so the RK complex registers are alive across one transform (the
+      // noise's), not across the two of the minimum-phase construction.
+      {
+        double *L = (double *)buf;
+        if (current_vuv != 0.0) {
+          for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k] * ratio[k]) / 2.0;
+        } else {
+          for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k]) / 2.0;
+        }
+      }
+      syn_min_phase<LOG2N>(buf, twl, twb, twN);
+      kwy_c mp[RK];
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const int k = tid + KWY_THREADS * r;
+        mp[r] = k <= H ? buf[k] : kwy_c{0.0, 0.0};
+      }
+      __syncthreads();
       // the pulse's noise: draws [dpos, dpos + noise_size) of the stream, dpos = idx - idx[0] (the serial code draws
       // noise_size numbers per pulse); sample d = tid + 256 j takes draw d -- from the table, or beyond it from the
       // generator (jump table of the pulse's stream position in the currently idle FFT buffer, thread t makes the C
@@ -663,27 +682,10 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
       }
       __syncthreads();
       kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
-      kwy_c nz[RK];
 #pragma unroll
       for (int r = 0; r < RK; ++r) {
         const int k = tid + KWY_THREADS * r;
-        nz[r] = k <= H ? buf[k] : kwy_c{0.0, 0.0};
-      }
-      __syncthreads();
-      double *L = (double *)buf;
-      if (current_vuv != 0.0) {
-        for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k] * ratio[k]) / 2.0;
-      } else {
-        for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k]) / 2.0;
-      }
-      syn_min_phase<LOG2N>(buf, twl, twb, twN);
-#pragma unroll
-      for (int r = 0; r < RK; ++r) {
-        const int k = tid + KWY_THREADS * r;
-        if (k <= H) {
-          const kwy_c a = buf[k], b = nz[r];
-          buf[k] = cmulf(a, b);
-        }
+        if (k <= H) buf[k] = cmulf(mp[r], buf[k]);
       }
       kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
       const double *w = (const double *)buf;

@@ -125,3 +125,48 @@ def test_pair_chained_against_all_oracle_chain(ko, gmm64):
           f'converted mcep max err {mc_err:.3e}')
     assert ap_err <= 1e-4 and mc_err <= 1e-8
     assert rms <= 1e-4
+
+
+@pytest.mark.parametrize('which', ['16k', '48k'])
+def test_pair_chained_on_recorded_speech(ko, which):
+    """The same chained comparison on RECORDED speech (two CMU ARCTIC speakers saying the same sentence; the 48 kHz
+    variant of the reference's own fixtures for the second case): f0 by the library's DIO + StoneMask, an 8-component
+    GMM, the pipeline's final waveform against the all-oracle chain.  Real recordings have frames near the voicing
+    gates (D4C's LoveTrain threshold, aperiodicity 0.999) that the synthetic signals lack."""
+    import torch
+    from scipy.io import wavfile
+    from conftest import CLB_WAV, SLT_WAV, clb_variant
+    from oracle import chain
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.backend import world
+
+    def load(path):
+        fs, d = wavfile.read(path)
+        return fs, np.ascontiguousarray(d.astype(np.float64) / 2 ** 15)
+    if which == '16k':
+        (fs, xs), (_, xt) = load(CLB_WAV), load(SLT_WAV)
+    else:
+        fs, xs = load(clb_variant('48'))
+        xt = np.ascontiguousarray(xs[int(0.05 * fs):] * 0.8)      # the same recording, shifted and scaled: a second "speaker"
+    utts = []
+    for x in (xs, xt):
+        f0, t = world.dio(x, fs, frame_period=5.0)
+        utts.append((x, world.stonemask(x, f0, t, fs), t))
+    g = pl.synthetic_gmm(order=24, components=8, seed=0, n_frames=4000)
+    K = ko.get_cheaptrick_fft_size(fs) // 2 + 1
+    rng = np.random.RandomState(3)
+    silence = [chain.draw_silence(rng, fs, K) for _ in range(4)]
+    ref = chain.pair_chain(utts[0], utts[1], (g.weights_, g.means_, g.covariances_), fs, silence)
+    dg = pl.DeviceGMM(g.weights_, g.means_, g.covariances_, torch.device('cuda', 0))
+    p = pl.PairPipeline(0, fs, utts[0], utts[1], dg, silence=silence)
+    p.run()
+    p.sync()
+    n = int(p.path_len.item())
+    path = [tuple(r) for r in p.path.cpu().numpy()[:n].tolist()]
+    assert path == ref['path'], f'{sum(a != b for a, b in zip(path, ref["path"]))} of {len(ref["path"])} path cells differ'
+    wave = p.wave.cpu().numpy()
+    rms = float(np.sqrt(np.mean((wave - ref['wave']) ** 2)))
+    ap_err = float(np.abs(p.ap_al.cpu().numpy() - ref['ap_al']).max())
+    print(f'chained, recorded speech at {fs} Hz: wave rms {rms:.3e} (peak {np.abs(ref["wave"]).max():.3f}), '
+          f'aligned aperiodicity max err {ap_err:.3e}')
+    assert rms <= 1e-4

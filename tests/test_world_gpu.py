@@ -361,14 +361,15 @@ def test_jump_ahead_beyond_the_table_gives_the_same_bits(ko, kw, path, limit):
     assert np.abs(out[1][1] - ko.d4c(x, f0, t, fs)).max() <= 1e-4
 
 
-def test_batched_analysis_equals_single_calls(ko, kw):
+@pytest.mark.parametrize('path', [clb_variant('48'), CLB_WAV, clb_variant('96')])
+def test_batched_analysis_equals_single_calls(ko, kw, path):
     """kwy_cheaptrick_batch_dev / kwy_d4c_batch_dev: utterances of different lengths in one grid per kernel (more of
     them than one launch takes: 19 > KWY_BATCH_MAX = 16) give bit for bit what the single-utterance calls give --
     every utterance's noise stream starts at draw 0, as every pyworld call reseeds."""
     import torch
     from kwiiyatta_amd import _lib
     from kwiiyatta_amd._lib import lib
-    fs, x = load(clb_variant('48'))
+    fs, x = load(path)
     ctx = _lib.Context(0)
     utts = []
     for k in range(19):
