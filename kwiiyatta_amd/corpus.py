@@ -381,7 +381,22 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
                 rng.abs_normal_blocks(scale, sink)
     ahead = _silence_ahead(len(pairs), fs, 2 * len(pool)) if silence_for is None and rng is None and pairs else None
     blocks, frames = [], 0
+
+    def finish(wave):
+        """the host-dependent half of a wave: trim lengths back, alignment and row extraction enqueued, rows collected"""
+        nonlocal frames
+        for p in wave:
+            p.align()
+        for p in wave:
+            blocks.append(p.rows().clone())  # enqueued on the default stream after rows() has synchronised
+            frames += p.frames
+        torch.cuda.current_stream(dev).synchronize()     # the copies are done before the wave's buffers are released
+
     try:
+        # Waves of len(pool) pairs, software-pipelined: the analysis of wave w + 1 is enqueued (same streams, behind
+        # wave w's analysis) BEFORE the host turns to wave w's alignment, whose two read-backs per pair (trim lengths,
+        # row count) would otherwise leave the GPU idle.
+        prev = None
         for w0 in range(0, len(pairs), len(pool)):
             wave = []
             for k, (src, tgt) in enumerate(pairs[w0:w0 + len(pool)]):
@@ -400,12 +415,12 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
                                       silence=sil, silence_ready=ready))
             for p in wave:
                 p.analyse()
-            for p in wave:
-                p.align()
-            for p in wave:
-                blocks.append(p.rows().clone())  # enqueued on the default stream after rows() has synchronised
-                frames += p.frames
-            torch.cuda.synchronize(dev)
+            if prev is not None:
+                finish(prev)
+            prev = wave
+        if prev is not None:
+            finish(prev)
+        torch.cuda.synchronize(dev)
     finally:
         if ahead is not None:
             ahead.stop()
