@@ -484,7 +484,7 @@ def main():
         T = pipes[0].frames
         K = pipes[0].K
         names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_d4c_bands', 'k_syn_phase', 'k_syn_pulse', 'k_syn_ola', 'k_sp2mc',
-                 'k_mc2sp', 'k_dtw_dist', 'k_dtw_dp', 'k_gmm_prep', 'k_gmm_logp', 'k_mlpg_chunks', 'k_mlpg_finish', 'k_align_project']
+                 'k_mc2sp', 'k_dtw_dist', 'k_dtw_values', 'k_dtw_codes', 'k_dtw_trace', 'k_dtw_small', 'k_gmm_prep', 'k_gmm_logp', 'k_mlpg_chunks', 'k_mlpg_finish', 'k_align_project']
         kernel_ms = {}
         for p in pipes:
             for nme in names:
@@ -544,7 +544,7 @@ def main():
         algo = {D4C: fpl * (hop * 8 + 16 + K * 8), 'k_cheaptrick': fpl * (hop * 8 + 16 + K * 8),
                 'k_d4c_lovetrain': fpl * (hop * 8 + 16 + 8), 'k_syn_pulse': fpl_syn * (2 * K * 8 + hop * 8)}
         # The dominant kernel = the whole-chip kernel with the largest summed duration.  The single-workgroup
-        # serial kernels (k_dtw_dp, k_syn_phase, ...) occupy one CU each and overlap with other streams;
+        # serial kernels (k_dtw_values, k_syn_phase, ...) occupy one CU each and overlap with other streams;
         # they bound latency, not throughput, and are listed in kernel_ms_per_launch.
         cand = [k for k in algo if k in kernel_ms]
         dom = max(cand, key=lambda k: kernel_ms[k][0]) if cand else D4C
@@ -612,10 +612,10 @@ def main():
             by_sum = {'kernel': top, 'avg_launch_ms': kernel_ms[top][0] / kernel_ms[top][1],
                       'launches': kernel_ms[top][1], 'alone_avg_launch_ms': alone_ms.get(top),
                       'share_of_tracked_kernel_time': kernel_ms[top][0] / sum(v[0] for v in single.values()),
-                      'note': ('one workgroup per launch: a serial recurrence (FastDTW DP + back-trace, critical path '
+                      'note': ('one workgroup per launch: a serial recurrence (FastDTW recurrence / back-trace, critical path '
                                'Tx+Ty steps) that holds 1 of 256 CUs and overlaps with the other streams; it bounds the '
                                'latency of one pair, not the throughput, and has no HBM or MFMA roofline')
-                              if top in ('k_dtw_dp', 'k_syn_phase', 'k_align_project') else
+                              if top in ('k_dtw_values', 'k_dtw_trace', 'k_syn_phase', 'k_align_project') else
                               'whole-chip kernel'}
         # whole-path algorithmic bytes per source frame
         path_bytes = 36664 if args.workload == 'utterance' else 81000

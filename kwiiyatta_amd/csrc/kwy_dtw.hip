@@ -20,11 +20,11 @@
 // Tie-breaking follows fastdtw's pure-Python min(): (i-1,j), (i,j-1), (i-1,j-1).
 #include <math.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "kwy_internal.hpp"
 
-#define DTW_PAD 128          // slack cells before/after the band storage
 
 __global__ void k_dtw_halve(const double *__restrict__ in, int n_out, int dim, double *__restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,16 +75,56 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dtw_halve_all(dtw_halve_desc d)
 // Window rows.  cpath == nullptr: full window (the coarsest level).  Otherwise cpath is the coarser level's path (cn
 // cells, both coordinates non-decreasing): row i takes the columns of the path cells within +-radius rows of i / 2,
 // widened by the radius and doubled.
-// The same windows for all rows, and the rows' offsets in the band storage (exclusive prefix sums of the widths), in
-// one single-workgroup launch.
-// cpath: the coarser level's path (cn cells), or null for the full window of the coarsest level.  tot: NT uint64 of LDS.
+// The same windows for all rows, the rows' offsets in the predecessor planes (exclusive prefix sums of the widths) and
+// the strips' offsets in the skewed bands, in one single-workgroup launch.
+//
+// Skewed band (distances, D values): strip k = rows 64 k .. 64 k + 63.  Cell (i, j) of the strip is handled by lane
+// i - 64 k at step s = j - lo[64 k] + (i - 64 k) of the recurrence and lives at
+//     soff[k] + ((s >> 1) * 64 + lane) * 2 + (s & 1):
+// what the 64 lanes of a wavefront need for two consecutive steps is 1 KB of consecutive memory.  (With one row per
+// lane in a row-major band every lane of a load touched its own cache line: 64 tag look-ups per instruction, and
+// those look-ups, not the arithmetic, set the 170-200 cycles a step took until round 3.)  A strip holds
+// steps16 = ceil16(hi[last row] - lo[first row] + 1 + 63) steps; the cells of the rectangle outside the rows' windows
+// hold +inf distances.
+__device__ __forceinline__ int dtw_strip_steps16(const int32_t *lo, const int32_t *hi, int len_x, int k) {
+  const int il = min(64 * k + 63, len_x - 1);
+  return ((hi[il] - lo[64 * k] + 1 + 63) + 15) & ~15;
+}
+__device__ __forceinline__ uint64_t dtw_skew_index(uint64_t sbase, int s, int lane) {
+  return sbase + ((uint64_t)(s >> 1) * 64 + (uint64_t)lane) * 2 + (uint64_t)(s & 1);
+}
+// cpath: the coarser level's path (cn cells), or null for the full window of the coarsest level.
+// lds: lds_bytes of LDS, at least NT uint64.  With room for two ints per coarse row the path is first turned into a
+// table {column of the row's first cell, column of its last cell} (a monotone path visits every row: a cell is the
+// first of its row if the cell before it lies in another one), and a window is two look-ups; otherwise two binary
+// searches over the path in memory per row (12 dependent loads each at the finest level).
 template <int NT>
 __device__ __forceinline__ void dtw_window_scan_body(const int32_t *__restrict__ cpath, int cn, int radius, int len_x,
-                                                     int len_y, int32_t *__restrict__ lo, int32_t *__restrict__ hi,
-                                                     uint64_t *__restrict__ off, uint64_t *tot) {
+                                                     int len_y, int32_t *lo, int32_t *hi, uint64_t *off,
+                                                     uint64_t *soff, uint64_t cap_rows, uint64_t cap_skew,
+                                                     int *status, unsigned char *lds, size_t lds_bytes) {
+  uint64_t *tot = (uint64_t *)lds;
+  const int crows = (cpath && cn > 0) ? cpath[2 * (cn - 1)] + 1 : 0;       // rows of the coarser level
+  const bool table = crows > 0 && sizeof(uint64_t) * NT + 8ull * (size_t)crows <= lds_bytes;
+  int32_t *firstj = (int32_t *)(tot + NT), *lastj = firstj + crows;
+  if (table) {
+    for (int p = threadIdx.x; p < cn; p += NT) {
+      const int r = cpath[2 * p], j = cpath[2 * p + 1];
+      if (p == 0 || cpath[2 * (p - 1)] != r) firstj[r] = j;
+      if (p == cn - 1 || cpath[2 * (p + 1)] != r) lastj[r] = j;
+    }
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < len_x; i += NT) {
     int l = 0, h = len_y - 1;
-    if (cpath && cn > 0) {
+    if (table) {
+      const int a = i / 2;
+      const int fr = a - radius;             // first cell in a row >= fr (none: the path's last cell)
+      const int jf = fr < crows ? firstj[max(fr, 0)] : lastj[crows - 1];
+      const int jl = lastj[min(a + radius, crows - 1)];                  // last cell in a row <= a + radius
+      l = max(0, 2 * (jf - radius));
+      h = min(len_y - 1, 2 * (jl + radius) + 1);
+    } else if (cpath && cn > 0) {
       const int a = i / 2;
       int b0 = 0, b1 = cn;
       while (b0 < b1) { int mid = (b0 + b1) >> 1; if (cpath[2 * mid] >= a - radius) b1 = mid; else b0 = mid + 1; }
@@ -100,52 +140,100 @@ __device__ __forceinline__ void dtw_window_scan_body(const int32_t *__restrict__
   }
   __syncthreads();
   kwy_block_count_scan<NT>([&](int64_t i) -> uint64_t { return (uint64_t)(hi[i] - lo[i] + 1); }, len_x, off, tot);
+  const int nstrips = (len_x + 63) / 64;
+  kwy_block_count_scan<NT>([&](int64_t k) -> uint64_t { return 64ull * (uint64_t)dtw_strip_steps16(lo, hi, len_x, (int)k); },
+                           nstrips, soff, tot);
+  __syncthreads();
+  if (threadIdx.x == 0 && (off[len_x] > cap_rows || soff[nstrips] > cap_skew)) atomicExch(status, 1);
 }
 
 // The coarsest level (full window) has its own launch, which also clears the status words of the call; every other
-// level's windows are computed by the tail of the previous level's k_dtw_dp (same workgroup, path still hot).
+// level's windows are computed by the tail of the previous level's k_dtw_trace (same workgroup, path still hot).
 #define DTW_WS_NT 1024
-__global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(const int32_t *__restrict__ cpath,
-                                                              const int64_t *__restrict__ cpath_len, int radius,
-                                                              int len_x, int len_y, int32_t *__restrict__ lo,
-                                                              int32_t *__restrict__ hi, uint64_t *__restrict__ off,
-                                                              int *__restrict__ status_clear) {
+__global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(int radius, int len_x, int len_y, int32_t *lo, int32_t *hi,
+                                                              uint64_t *off, uint64_t *soff, uint64_t cap_rows,
+                                                              uint64_t cap_skew, int *status) {
   __shared__ uint64_t tot[DTW_WS_NT];
-  if (status_clear && threadIdx.x < 16) status_clear[threadIdx.x] = 0;
-  const int cn = cpath ? (int)*cpath_len : 0;
-  dtw_window_scan_body<DTW_WS_NT>(cpath, cn, radius, len_x, len_y, lo, hi, off, tot);
-}
-
-// Band storage: row i holds width[i] distances at dist[DTW_PAD + off[i] + 16 i + 8 ...], with DTW_ROWPAD +inf
-// cells before and after them.  The DP fetches 8 consecutive cells per lane at a time from a clamped
-// start: a lane that is outside its row (wholly or partly) reads pad cells, so a cell outside the window
-// costs +inf by itself and the DP step needs no activity mask.
-#define DTW_ROWPAD 8
-__device__ __forceinline__ uint64_t dtw_row_base(const uint64_t *__restrict__ off, int i) {
-  return (uint64_t)DTW_PAD + off[i] + (uint64_t)(2 * DTW_ROWPAD) * (uint64_t)i + DTW_ROWPAD;
-}
-
-// dist[row_base(i) + j - lo[i]] = || x_i - y_j ||_2   (sequential sum over the dimensions)
-__global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(const double *__restrict__ x,
-                                                         const double *__restrict__ y, int dim,
-                                                         const int32_t *__restrict__ lo,
-                                                         const int32_t *__restrict__ hi,
-                                                         const uint64_t *__restrict__ off, uint64_t cap,
-                                                         double *__restrict__ dist, int *__restrict__ status) {
-  extern __shared__ double xs[];
-  const int i = blockIdx.x;
-  if (off[i] + (uint64_t)(hi[i] - lo[i] + 1) > cap) { if (threadIdx.x == 0) atomicExch(status, 1); return; }
-  for (int k = threadIdx.x; k < dim; k += KWY_THREADS) xs[k] = x[(int64_t)i * dim + k];
+  if (threadIdx.x < 16) status[threadIdx.x] = 0;
   __syncthreads();
-  double *row = dist + dtw_row_base(off, i);
-  const int l = lo[i], h = hi[i];
-  if (threadIdx.x < DTW_ROWPAD) { row[-1 - (int)threadIdx.x] = INFINITY; row[h - l + 1 + threadIdx.x] = INFINITY; }
-  for (int j = l + threadIdx.x; j <= h; j += KWY_THREADS) {
-    const double *yr = y + (int64_t)j * dim;
-    double s = 0.0;
-    for (int k = 0; k < dim; ++k) { double d = xs[k] - yr[k]; s += d * d; }
-    row[j - l] = sqrt(s);
+  dtw_window_scan_body<DTW_WS_NT>((const int32_t *)nullptr, 0, radius, len_x, len_y, lo, hi, off, soff, cap_rows,
+                                  cap_skew, status, (unsigned char *)tot, sizeof(tot));
+}
+
+// dist(i, j) = || x_i - y_j ||_2 (sequential sum over the dimensions) for every cell of the strips' rectangles that
+// lies in its row's window, +inf for the others.  A workgroup = 16 steps x 64 lanes of one strip: 64 frames of x and
+// the 79 frames of y its cells pair them with, staged in LDS 32 dimensions at a time (the sum keeps its order).
+#define DTW_DT 32                       // dimensions per tile
+#define DTW_DTP (DTW_DT + 1)            // padded row (lane l reads row l, row s - l: 33 doubles apart, no bank conflict)
+#define DTW_DIST_LDS (sizeof(double) * (64 + 80) * DTW_DTP)
+// (unit_first, unit_stride: the units of 1024 cells this workgroup takes; lds: DTW_DIST_LDS bytes)
+__device__ __forceinline__ void dtw_dist_body(const double *x, const double *y, int dim, int len_x, int len_y,
+                                              const int32_t *lo, const int32_t *hi, const uint64_t *soff,
+                                              double *dist, const int *status, unsigned unit_first,
+                                              unsigned unit_stride, unsigned char *lds) {
+  double *xs = (double *)lds, *ys = xs + 64 * DTW_DTP;
+  if (status[0] != 0) return;
+  const int nstrips = (len_x + 63) / 64;
+  const uint64_t total = soff[nstrips];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  constexpr int PER = 16 / (KWY_THREADS / 64);          // steps per wavefront
+  for (uint64_t cell0 = (uint64_t)unit_first * 1024ull; cell0 < total; cell0 += (uint64_t)unit_stride * 1024ull) {
+    int a = 0, b = nstrips - 1;                   // the strip of this unit: the last one that starts at or before it
+    while (a < b) { const int mid = (a + b + 1) >> 1; if (soff[mid] <= cell0) a = mid; else b = mid - 1; }
+    const int k = a;
+    const uint64_t sb = soff[k];
+    const int s0 = (int)((cell0 - sb) >> 6);
+    const int i = 64 * k + lane;
+    const bool valid = i < len_x;
+    const int jmin = lo[64 * k], l = valid ? lo[i] : 0, h = valid ? hi[i] : -1;
+    const int jbase = jmin + s0 - 63;             // y frame of ys row 0; the cell (lane, step s) uses row s - s0 + 63 - lane
+    bool in[PER];
+    double acc[PER];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int j = jmin + s0 + PER * sub + q - lane;
+      in[q] = j >= l && j <= h;
+      any = any || in[q];
+      acc[q] = 0.0;
+    }
+    if (__syncthreads_or(any)) {
+      for (int c0 = 0; c0 < dim; c0 += DTW_DT) {
+        const int cw = min(DTW_DT, dim - c0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * cw; e += KWY_THREADS) {
+          const int r = e / cw, c = e - r * cw, ii = 64 * k + r;
+          xs[r * DTW_DTP + c] = ii < len_x ? x[(int64_t)ii * dim + c0 + c] : 0.0;
+        }
+        for (int e = threadIdx.x; e < 79 * cw; e += KWY_THREADS) {
+          const int r = e / cw, c = e - r * cw, jj = jbase + r;
+          ys[r * DTW_DTP + c] = (jj >= 0 && jj < len_y) ? y[(int64_t)jj * dim + c0 + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          if (in[q]) {
+            const double *xr = xs + lane * DTW_DTP, *yr = ys + (PER * sub + q + 63 - lane) * DTW_DTP;
+            double t = acc[q];
+            for (int c = 0; c < cw; ++c) { const double df = xr[c] - yr[c]; t += df * df; }
+            acc[q] = t;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      dist[dtw_skew_index(sb, s0 + PER * sub + q, lane)] = in[q] ? sqrt(acc[q]) : INFINITY;
+    __syncthreads();        // (the tiles are rewritten by the next unit)
   }
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(const double *__restrict__ x, const double *__restrict__ y,
+                                                         int dim, int len_x, int len_y, const int32_t *__restrict__ lo,
+                                                         const int32_t *__restrict__ hi,
+                                                         const uint64_t *__restrict__ soff,
+                                                         double *__restrict__ dist, const int *__restrict__ status) {
+  __shared__ double tiles[(64 + 80) * DTW_DTP];
+  dtw_dist_body(x, y, dim, len_x, len_y, lo, hi, soff, dist, status, blockIdx.x, gridDim.x, (unsigned char *)tiles);
 }
 
 // lane l <- lane l-1 across the whole wavefront (DPP wave_shr:1, no LDS round trip);
@@ -165,52 +253,68 @@ __device__ __forceinline__ double dtw_wave_rol1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// Predecessor codes: 2 bits per cell, 16 cells per 32-bit word.
-// Words are cut at multiples of 16 of the STEP index s (cell (i, j) of strip i0 is handled at
-// step s = j - lo[i0] + (i - i0)), so that all lanes of a wavefront flush their word at the same
-// step: one store instruction per 16 steps instead of a trickle that the in-order memory counter
-// would make every distance prefetch wait for.  A row therefore owns up to width/16 + 2 words.
-__device__ __forceinline__ uint64_t dtw_word_base(const uint64_t *__restrict__ off, int i) {
-  return (off[i] >> 4) + 2ull * (uint64_t)i;
-}
-__device__ __forceinline__ int dtw_row_shift(const int32_t *__restrict__ lo, int i) {
-  const int i0 = i & ~63;
-  return (i - i0) + lo[i] - lo[i0];  // step at which the row's first cell is handled
-}
-__device__ __forceinline__ uint64_t dtw_row_words_end(const uint64_t *__restrict__ off,
-                                                      const int32_t *__restrict__ lo,
-                                                      const int32_t *__restrict__ hi, int i) {
-  const int sh = dtw_row_shift(lo, i);
-  return dtw_word_base(off, i) + (uint64_t)(((sh + hi[i] - lo[i]) >> 4) - (sh >> 4)) + 1;
+// v_min_f64 as is: fmin() puts a canonicalising v_max_f64 x, x in front of every operand that comes out of a load or
+// a lane shift (its contract for signalling NaNs), on the recurrence's dependence chain.  No NaN arises from finite
+// distances and +inf.
+__device__ __forceinline__ double dtw_min_raw(double a, double b) {
+  return fmin(a, b);
 }
 
-// The DP + back-trace of one level: ONE workgroup of DTW_WAVES wavefronts.  Strip k (64 rows) is
-// processed by wave k % DTW_WAVES; strip k+1 trails strip k by one 64-step block, synchronised
-// through a progress word in LDS (the boundary row written by strip k is read by strip k+1).
+// Predecessor codes: two bit planes per (row, group of 64 columns of the row's window): bit c of m0 says "the first
+// candidate (i-1, j) attains the minimum", bit c of m1 the same for (i, j-1); neither: the diagonal.  Group g of row i
+// is predm[2 (gbase(i) + g)], predm[2 (gbase(i) + g) + 1].
+__device__ __forceinline__ uint64_t dtw_group_base(const uint64_t *__restrict__ off, int i) {
+  return (off[i] >> 6) + (uint64_t)i;
+}
+
+// One level = three launches.
+//   k_dtw_values  ONE workgroup, four wavefronts: the serial recurrence and nothing else.  Rows in lanes, strips of 64
+//                 rows, lane l works on column j - l; per step two DPP shifts, three additions, two minima.  The values
+//                 D[i][j] go to a band with the distances' layout (one 8-cell store per lane and 8 steps).
+//   k_dtw_codes   one workgroup per strip, all at once: the predecessor of every cell from D and the distances (the
+//                 first of the candidates (i-1,j), (i,j-1), (i-1,j-1) whose sum equals D[i][j]: fastdtw's order), and
+//                 for the cells of the strip's last row the column at which the best path entered the strip.
+//   k_dtw_trace   ONE workgroup: one thread hops from strip to strip over the entry columns, every strip is then
+//                 walked by its own lane, the segments are copied to their places; its tail computes the next
+//                 (finer) level's windows.
+// Until round 3 the recurrence kernel also produced the codes and carried the entry columns along: ~32 instructions
+// per step on the wavefront that owns a strip, 170-200 cycles per step.  Neither is on the dependence chain.
+struct dtw_level_args {
+  int len_x, len_y;
+  const int32_t *lo, *hi;       // (lo_w, hi_w, off_w alias them: the trace's tail rewrites the tables)
+  const uint64_t *off;          // rows' offsets (cells of the windows): where a row's predecessor planes are
+  const uint64_t *soff;         // strips' offsets in the skewed bands
+  uint64_t cap_rows, cap_skew;
+  double *dist;                 // skewed band of distances; the strips' last rows get their cells' entry columns
+  double *dval;                 // skewed band of D values
+  uint64_t *predm;
+  double *bnd_global;           // DTW_WAVES x (len_y + 2), or null: boundary rows in LDS
+  int32_t *path, *rev, *sinfo;  // sinfo: 3 x strips
+  int64_t *path_len;
+  double *out_dist;
+  int *status;                  // [0] band overflow (k_dtw_dist), [1] this level has no entry columns
+  long long *dbg;
+  int lds_bytes;
+  int next_len_x, next_len_y, radius;
+  int32_t *lo_w, *hi_w;
+  uint64_t *off_w, *soff_w;
+};
+
 #define DTW_WAVES 4
 // Steps between two looks at the previous strip's progress.  Strip k+1 trails strip k by the 63
-// steps of the row skew plus one chunk; with 4 wavefronts a wavefront's next strip is ready when it
-// finishes the current one only if 4 x (63 + chunk) stays below the strip length (~300 steps).
+// steps of the row skew plus one chunk.
 #define DTW_CHUNK 16
-#define DTW_RING 4           // chunks of distances held in registers (three of them in flight)
-typedef double dtw_d2 __attribute__((ext_vector_type(2), aligned(8)));
-typedef int dtw_i4 __attribute__((ext_vector_type(4), aligned(4)));
+#ifndef DTW_RING
+#define DTW_RING 5           // chunks of distances held in registers (all but one of them in flight)
+#endif
+#ifndef DTW_BLK
+#define DTW_BLK 16           // steps between two rounds of bookkeeping (stores of D, boundary row, progress word)
+#endif
+typedef double dtw_d2 __attribute__((ext_vector_type(2), aligned(16)));
+
 template <bool BND_LDS>
-__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y, const int32_t *lo, const int32_t *hi,
-                                              const uint64_t *off /* = lo_w, hi_w, off_w: rewritten by the tail */,
-                                              uint64_t cap,
-                                              double *dist /* the strips' last rows get their cells' entry columns */,
-                                              uint32_t *__restrict__ predw,
-                                              double *__restrict__ bnd_global /* DTW_WAVES x (len_y+2) or null */,
-                                              int32_t *__restrict__ path, int32_t *__restrict__ rev,
-                                              int32_t *__restrict__ sinfo /* 3 x strips */,
-                                              int64_t *__restrict__ path_len, double *__restrict__ out_dist,
-                                              const int *__restrict__ status, long long *__restrict__ dbg,
-                                              int lds_bytes, int next_len_x, int next_len_y, int radius,
-                                              int32_t *lo_w, int32_t *hi_w, uint64_t *off_w) {
-  extern __shared__ unsigned char bt[];  // boundary rows (BND_LDS); the back-trace's tables afterwards
-  const long long t_start = dbg ? clock64() : 0;
-  __shared__ int s_n;
+__device__ __forceinline__ void dtw_values_body(const dtw_level_args &a, unsigned char *bt /* boundary rows (BND_LDS) */) {
+  const long long t_start = a.dbg ? clock64() : 0;
   // (strip << 32) | (last finished column + 1).  Plain LDS words written/read with relaxed
   // workgroup-scope atomics: a volatile (generic) access would be a flat_ instruction with a
   // vmcnt(0) wait behind it, i.e. every progress update would also wait for the distance
@@ -223,68 +327,69 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
 // fence writes the L2 back and costs ~20 us each)
 #define DTW_RELEASE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); } while (0)
 #define DTW_ACQUIRE() do { if (BND_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (*status != 0) {
-    if (threadIdx.x == 0) { *path_len = 0; *out_dist = NAN; }
-    // keep the next level's tables defined (full windows: its distance kernel sees the overflow and leaves the status)
-    if (next_len_x > 0)
-      dtw_window_scan_body<64 * DTW_WAVES>((const int32_t *)nullptr, 0, radius, next_len_x, next_len_y, lo_w, hi_w, off_w,
-                                           (uint64_t *)bt);
-    return;
-  }
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (wave-uniform: a scalar)
+  if (a.status[0] != 0) return;
+  const int len_x = a.len_x, len_y = a.len_y;
+  const int32_t *lo = a.lo, *hi = a.hi;
+  const uint64_t *off = a.off;
+  long long *dbg = a.dbg;
   const double INF = INFINITY;
   const int rowlen = len_y + 2;  // boundary rows are indexed by j + 1 (entry 0 is column -1)
   double *const lds_rows = (double *)bt;
+  double *const bnd_global = a.bnd_global;
 #define BROW(buf, ix) (BND_LDS ? lds_rows[(buf) * rowlen + (ix)] : bnd_global[(size_t)(buf) * rowlen + (ix)])
   if (threadIdx.x < DTW_WAVES) DTW_PROG_STORE(threadIdx.x, -1);
+  if (dbg && lane == 0) dbg[16 + wv] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_ID: where the wave runs
   __syncthreads();
   const int nstrips = (len_x + 63) / 64;
   for (int k = wv; k < nstrips; k += DTW_WAVES) {
     const int i0 = k * 64;
     const int i = i0 + lane;
     const bool valid = i < len_x;
-    const int rl = valid ? lo[i] : 0, rh = valid ? hi[i] : -1 - DTW_ROWPAD;
-    const int rw = rh - rl;  // last valid index of the row (no row: every fetch lands in the left pad)
+    const int rl = valid ? lo[i] : 0, rh = valid ? hi[i] : -1;
+    const int rw = rh - rl;  // last valid index of the row
     const int ilast = min(i0 + 63, len_x - 1);
     const int L = ilast - i0;  // lane of the strip's last row
-    const int jmin = lo[i0], jmax = hi[ilast];
+    // (wave-uniform values through readfirstlane: the tables are not restrict-qualified -- the trace's tail rewrites
+    // them -- and a uniform value left in a vector register turns every test on it into vector compares)
+    const int jmin = __builtin_amdgcn_readfirstlane(lo[i0]), jmax = __builtin_amdgcn_readfirstlane(hi[ilast]);
     // the previous strip's last row: where its boundary values are valid
-    const int plo = k > 0 ? lo[i0 - 1] : 0, phi = k > 0 ? hi[i0 - 1] : -1;
+    const int plo = k > 0 ? __builtin_amdgcn_readfirstlane(lo[i0 - 1]) : 0;
+    const int phi = k > 0 ? __builtin_amdgcn_readfirstlane(hi[i0 - 1]) : -1;
     const int pbuf = (k + DTW_WAVES - 1) % DTW_WAVES, nbuf = k % DTW_WAVES;
-    // distances: a scalar base per strip (the first row's left pad) plus a 32-bit per-lane byte offset
-    char *dbase = (char *)(dist + dtw_row_base(off, i0) - DTW_ROWPAD);
-    const uint32_t boff = (uint32_t)((dtw_row_base(off, valid ? i : i0) - dtw_row_base(off, i0)) * 8ull);
-    uint32_t *pwrow = predw + (valid ? dtw_word_base(off, i) : 0);
+    // both bands: the strip's base plus the lane; two steps per 16-byte element, 64 elements per pair of steps
+    const uint64_t sbv = a.soff[k];
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sbv >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sbv);
+    const dtw_d2 *dbase = (const dtw_d2 *)(a.dist + sb) + lane;
+    dtw_d2 *vbase = (dtw_d2 *)(a.dval + sb) + lane;
     double v1 = INF;      // this lane's value at the previous step
     double up_prev = INF; // the `up` input of the previous step = this step's diagonal input
-    // entry column of the best path into this strip, per cell (same selection as the value): lane 0's
-    // `up` / diagonal cells are boundary cells, which are their own entry columns
-    int o1 = 0, oup_prev = jmin - 1;
-    const int nsteps = (jmax - jmin + 1) + 63;
+    const int nsteps = (jmax - jmin + 1) + 63, nsteps16 = (nsteps + 15) & ~15;
     if (dbg && lane == 0 && k < 48) { dbg[64 + 4 * k] = clock64() - t_start; dbg[64 + 4 * k + 2] = nsteps; dbg[64 + 4 * k + 3] = jmin; }
     const int shift = lane + rl - jmin;  // this lane's row index at step s is s - shift
     // the last row's range of steps and last column, as scalars: its boundary writes are guarded on the scalar unit
     const int shL = __builtin_amdgcn_readlane(shift, L), rwL = __builtin_amdgcn_readlane(rw, L);
     const int rhL = __builtin_amdgcn_readlane(rh, L);
-    uint32_t pw = 0u;                    // predecessor codes of the current 16-cell word
+    // blocks of DTW_BLK steps (s0 a multiple of it) that lie wholly inside the last row: s0 in [sIn0, sIn0 + inSpan]
+    int sIn0 = (shL + DTW_BLK - 1) & ~(DTW_BLK - 1);
+    const int sIn1 = (shL + rwL - (DTW_BLK - 1)) & ~(DTW_BLK - 1);
+    if (sIn1 < sIn0) sIn0 = 0x40000000;
+    const unsigned inSpan = sIn1 >= sIn0 ? (unsigned)(sIn1 - sIn0) : 0u;
     // lane 0's diagonal input at the first step: D[i0-1][jmin-1]
     if (k == 0 && lane == 0 && jmin == 0) up_prev = 0.0;  // D[-1][-1] = 0: the origin of the recurrence
     // Distances of this lane's row: a ring of DTW_RING chunks of 16 steps in registers, each fetched
-    // DTW_RING - 1 chunks (48 steps) before it is used -- the band was written by another kernel on
+    // DTW_RING - 1 chunks before it is used -- the band was written by another kernel on
     // other XCDs and comes from memory (about 3500 cycles on an otherwise idle chip), and a step is
-    // only ~100 cycles.  Two 8-cell fetches per chunk, each from a clamped start (see DTW_ROWPAD).
+    // only ~50 cycles.  (A fetch beyond the strip's last chunk repeats that chunk: nobody uses it.)
     double ring[DTW_RING][DTW_CHUNK];
     auto fetch = [&](double (&b)[DTW_CHUNK], int cstart) {
+      const dtw_d2 *p = dbase + (size_t)(min(cstart, nsteps16 - DTW_CHUNK) >> 1) * 64;
 #pragma unroll
-      for (int half = 0; half < DTW_CHUNK / 8; ++half) {
-        const int start = min(max(cstart + 8 * half - shift, -DTW_ROWPAD), rw + 1);
-        const dtw_d2 *p = (const dtw_d2 *)(dbase + (boff + 8u * (uint32_t)(start + DTW_ROWPAD)));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const dtw_d2 v = p[q];
-          b[8 * half + 2 * q] = v.x;
-          b[8 * half + 2 * q + 1] = v.y;
-        }
+      for (int q = 0; q < DTW_CHUNK / 2; ++q) {
+        const dtw_d2 v = p[q * 64];
+        b[2 * q] = v.x;
+        b[2 * q + 1] = v.y;
       }
     };
 #pragma unroll
@@ -296,17 +401,15 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
       // wait until the previous strip's last row has produced the columns this chunk reads
       if (k > 0) {
         const int need = min(jmin + c0 + DTW_CHUNK - 1, phi);  // last column we may read (valid ones only)
-        const long long tw0 = dbg ? clock64() : 0;
         while (true) {
-          const long long pv = DTW_PROG_LOAD(pbuf);
-          const int ps = (int)(pv >> 32), pc = (int)(pv & 0xffffffffll) - 1;
+          const long long pv = DTW_PROG_LOAD(pbuf);          // (every lane reads the same word: tests on the scalar unit)
+          const int ps = __builtin_amdgcn_readfirstlane((int)(pv >> 32));
+          const int pc = __builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffll)) - 1;
           if (ps > k - 1 || (ps == k - 1 && pc >= need)) break;
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
         }
         DTW_ACQUIRE();
-        if (dbg && lane == 0) { atomicAdd((unsigned long long *)&dbg[8 + wv], (unsigned long long)(clock64() - tw0)); }
       }
-      if (dbg && lane == 0) atomicAdd((unsigned long long *)&dbg[12 + wv], 1ull);
       // the boundary values lane 0 needs in the next DTW_CHUNK steps: lane t holds the one of step c0 + t;
       // the vector is rotated by one lane per step, so that lane 0 always holds the current one
       const int jb = jmin + c0 + lane;
@@ -319,12 +422,11 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
         first_chunk = false;
       }
 #pragma unroll
-      for (int half = 0; half < DTW_CHUNK / 8; ++half) {
-        const int s0 = c0 + 8 * half;
-        double hist[8];
-        int ohist[8];
+      for (int blk = 0; blk < DTW_CHUNK / DTW_BLK; ++blk) {
+        const int s0 = c0 + DTW_BLK * blk;
+        double hist[DTW_BLK];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < DTW_BLK; ++u) {
           // up = D[i-1][j]: the neighbouring lane's value of the previous step (lane 0: the boundary row).
           // The diagonal D[i-1][j-1] is what `up` was one step ago -- no second shift.
           const double nbrot = dtw_wave_rol1(brot);
@@ -332,103 +434,272 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
           brot = nbrot;
           const double dg = up_prev;
           up_prev = up;
-          // a lane outside its row adds +inf: every candidate is +inf, the code stays 0
-          const double dt = cur[8 * half + u];
-          // fastdtw's min() keeps the first of equal candidates in the order (i-1,j), (i,j-1), (i-1,j-1):
-          // the value is the plain minimum (two v_min_f64 on the loop-carried chain instead of two
-          // compare-and-select pairs), the code is the first candidate equal to it (off the chain)
-          const double c0v = up + dt, c1v = v1 + dt, c2v = dg + dt;
-          const double best = fmin(c0v, fmin(c1v, c2v));
-          const bool e0 = best == c0v, e1 = best == c1v;
-          const uint32_t pb = e0 ? 0u : (e1 ? 1u : 2u);
-          pw |= pb << (2 * (8 * half + u));   // c0 is a multiple of 16: the step's place in its word
-          const int oup = dtw_wave_shr1_i32(o1, jmin + s0 + u);
-          const int odg = oup_prev;
-          oup_prev = oup;
-          o1 = e0 ? oup : (e1 ? o1 : odg);
-          ohist[u] = o1;
+          // D = min(up + d, left + d, diagonal + d) = min(up, left, diagonal) + d, bit for bit: rounding is monotone
+          // (x <= y => fl(x + d) <= fl(y + d)), so the smallest sum is the sum of the smallest.  One addition instead
+          // of three; which candidate attains the minimum, in fastdtw's order and on the three sums, is k_dtw_codes'
+          // business.  A lane outside its row adds +inf.
+          const double best = dtw_min_raw(up, dtw_min_raw(v1, dg)) + cur[DTW_BLK * blk + u];
           hist[u] = best;
           v1 = best;
-          // keep the compare masks of at most four steps alive (left alone, the scheduler collects the
-          // masks of all 16 steps in SGPRs and spills them)
-          if (u == 3 || u == 7) __builtin_amdgcn_sched_barrier(0);
         }
-        // the strip's last row goes to the boundary buffer (its lane only, the steps inside its row only)
-        if (s0 >= shL && s0 + 7 <= shL + rwL) {          // wave-uniform: the whole block lies inside the row
+        // the values go to the band of D values, same places as the distances (a lane outside its row: +inf)
+        {
+          dtw_d2 *p = vbase + (size_t)(s0 >> 1) * 64;
+#pragma unroll
+          for (int q = 0; q < DTW_BLK / 2; ++q) p[q * 64] = dtw_d2{hist[2 * q], hist[2 * q + 1]};
+        }
+        // The strip's last row goes to the boundary buffer (its lane only, the steps inside its row only), and how
+        // far it has got is published after the writes.  A lone wavefront on its SIMD issues one instruction of ANY
+        // kind per ~5 cycles: the scalar bookkeeping here counts like the arithmetic, so the common case (the whole
+        // block inside the row) is one wave-uniform test and one masked region.
+        if ((unsigned)(s0 - sIn0) <= inSpan) {            // wave-uniform: all steps inside the last row
+          DTW_RELEASE();
           if (lane == L) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) BROW(nbuf, jmin + s0 - L + 1 + u) = hist[u];
-            // the entry columns, as an int array laid over the start of the row's own distances (entry p
-            // sits inside cell p/2, which this lane fetched long ago)
-            dtw_i4 *op = (dtw_i4 *)(dbase + (boff + 8u * DTW_ROWPAD + 4u * (uint32_t)(s0 - shift)));
-            op[0] = dtw_i4{ohist[0], ohist[1], ohist[2], ohist[3]};
-            op[1] = dtw_i4{ohist[4], ohist[5], ohist[6], ohist[7]};
+            for (int u = 0; u < DTW_BLK; ++u) BROW(nbuf, jmin + s0 - L + 1 + u) = hist[u];
+            DTW_PROG_STORE(nbuf, ((long long)k << 32) | (long long)(unsigned int)(jmin + s0 + DTW_BLK - L));
           }
-        } else if (s0 + 7 >= shL && s0 <= shL + rwL) {   // the block straddles one of the row's ends
+        } else if ((unsigned)(s0 - (shL - (DTW_BLK - 1))) <= (unsigned)(rwL + (DTW_BLK - 1))) {   // straddles an end
+          DTW_RELEASE();
           if (lane == L) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < DTW_BLK; ++u) {
               const int s = s0 + u;
-              if (s >= shL && s <= shL + rwL) {
-                BROW(nbuf, jmin + s - L + 1) = hist[u];
-                *(int32_t *)(dbase + (boff + 8u * DTW_ROWPAD + 4u * (uint32_t)(s - shift))) = ohist[u];
-              }
+              if (s >= shL && s <= shL + rwL) BROW(nbuf, jmin + s - L + 1) = hist[u];
             }
+            const int jdone = min(jmin + (s0 + DTW_BLK - 1) - L, rhL);
+            DTW_PROG_STORE(nbuf, ((long long)k << 32) | (long long)(unsigned int)(jdone + 1 > 0 ? jdone + 1 : 0));
           }
-        }
-        // publish how far this strip's last row has got (after its boundary writes)
-        DTW_RELEASE();
-        if (lane == L) {
-          const int jdone = min(jmin + (s0 + 7) - L, rhL);
-          DTW_PROG_STORE(nbuf, ((long long)k << 32) | (long long)(unsigned int)(jdone + 1 > 0 ? jdone + 1 : 0));
         }
       }
-      // one predecessor word per lane and chunk, if the lane's row has cells in it
-      if (valid && shift <= c0 + DTW_CHUNK - 1 && shift + rw >= c0) pwrow[(c0 >> 4) - (shift >> 4)] = pw;
-      pw = 0u;
     };
     // whole chunks (the steps behind nsteps see +inf only), the ring's phases unrolled
     for (int c0 = 0; c0 < nsteps; c0 += DTW_RING * DTW_CHUNK) {
-      chunk(c0, ring[0], ring[3]);
-      if (c0 + DTW_CHUNK >= nsteps) break;
-      chunk(c0 + DTW_CHUNK, ring[1], ring[0]);
-      if (c0 + 2 * DTW_CHUNK >= nsteps) break;
-      chunk(c0 + 2 * DTW_CHUNK, ring[2], ring[1]);
-      if (c0 + 3 * DTW_CHUNK >= nsteps) break;
-      chunk(c0 + 3 * DTW_CHUNK, ring[3], ring[2]);
+#pragma unroll
+      for (int ph = 0; ph < DTW_RING; ++ph) {
+        if (ph > 0 && c0 + ph * DTW_CHUNK >= nsteps) break;
+        chunk(c0 + ph * DTW_CHUNK, ring[ph], ring[(ph + DTW_RING - 1) % DTW_RING]);
+      }
     }
     DTW_RELEASE();
     if (lane == L) DTW_PROG_STORE(nbuf, ((long long)k << 32) | 0x7fffffffll);
     if (dbg && lane == 0 && k < 48) dbg[64 + 4 * k + 1] = clock64() - t_start;
   }
-  __syncthreads();
-  // D[len_x-1][len_y-1]: the last strip's last row is in its boundary buffer
-  const double last_val = BROW((nstrips - 1) % DTW_WAVES, len_y);
 #undef BROW
-  __syncthreads();   // every thread holds last_val: the back-trace staging may overwrite the boundary rows
-  const long long t_dp = dbg ? clock64() : 0;
-  if (threadIdx.x == 0) *out_dist = last_val;
-  __syncthreads();   // predecessor codes and entry columns written above are read back below through global memory
-                     // (by this workgroup only: the barrier's workgroup-scope fence is enough)
-
-  // ---- back-trace.  (1) one thread hops from strip to strip: the path leaves strip k through
-  //      (last row, exitc[k]) and the entry column stored there is where it leaves strip k-1.
-  //      (2) every strip is walked by its own lane, all at once, over the predecessor codes.
-  //      (3) the strips' cell counts are summed, (4) the segments are copied to their places.
-  // A walk is a chain of dependent loads (row window -> word address -> predecessor word), ~1500 cycles per cell
-  // from global memory: the per-row table {lo, hi, first word} and, when they fit, the predecessor words are
-  // staged in LDS first (the boundary rows are dead by now).
-  int32_t *exitc = sinfo, *sbase = sinfo + nstrips, *cnt = sinfo + 2 * nstrips;
-  const bool tbl_ok = (size_t)lds_bytes >= 12ull * (size_t)len_x;
-  int32_t *t_lo = (int32_t *)bt, *t_hi = t_lo + len_x;
-  uint32_t *t_wb = (uint32_t *)(t_hi + len_x), *t_pw = t_wb + len_x;
-  const uint64_t nwords = dtw_row_words_end(off, lo, hi, len_x - 1);
-  const bool pw_ok = tbl_ok && nwords <= (uint64_t)(((size_t)lds_bytes - 12ull * (size_t)len_x) / 4);
-  if (tbl_ok) {
-    for (int i = threadIdx.x; i < len_x; i += 64 * DTW_WAVES) {
-      t_lo[i] = lo[i]; t_hi[i] = hi[i]; t_wb[i] = (uint32_t)dtw_word_base(off, i);
+  if (dbg) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const long long t = clock64() - t_start;
+      atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)t);
+      dbg[2] = t;
     }
-    if (pw_ok) for (uint32_t w = threadIdx.x; w < (uint32_t)nwords; w += 64 * DTW_WAVES) t_pw[w] = predw[w];
+  }
+}
+template <bool BND_LDS>
+__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_values(dtw_level_args a) {
+  extern __shared__ unsigned char bt[];
+  dtw_values_body<BND_LDS>(a, bt);
+}
+
+// Codes and entry columns of one strip.
+// Phase 1 works in the recurrence's own coordinates (lane = row, step by step: every load is coalesced): the
+// predecessor of a cell is the first of (i-1, j), (i, j-1), (i-1, j-1) whose value plus the cell's distance equals
+// D[i][j] (fastdtw's min() keeps the first of equal candidates; the sums are the ones the recurrence formed).  A lane
+// collects the bits of its row over 64 steps -- 64 consecutive columns -- and ORs them into the row's planes.
+// Phase 2, a wavefront per row: for every cell the place in the row above where the best path into the cell comes
+// from (the nearest cell at or left of it whose predecessor is not (i, j-1), and that cell's own predecessor).
+// Phase 3, a thread per cell of the strip's last row: follow those places up through the strip's rows, all of them in
+// LDS.  A strip whose planes and places do not fit there builds the planes in memory and flags the level: the trace
+// then walks the path in one piece.
+template <int DTW_CODES_NT>
+__device__ __forceinline__ void dtw_codes_body(const dtw_level_args &a, int k, unsigned char *bt) {
+  __shared__ int s_lo[64], s_w[64], s_po[65], s_gb[65];
+  if (a.status[0] != 0) return;
+  const int len_x = a.len_x;
+  const int32_t *lo = a.lo, *hi = a.hi;
+  const uint64_t *off = a.off;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i0 = 64 * k, ilast = min(i0 + 63, len_x - 1), nrows = ilast - i0 + 1;
+  const double INF = INFINITY;
+  const uint64_t gb0 = dtw_group_base(off, i0);
+  __syncthreads();          // (the tables below may still be in use by the previous strip of a fused launch)
+  if (tid < 64) {
+    const int r = min(i0 + tid, ilast);
+    s_lo[tid] = lo[r];
+    s_w[tid] = tid < nrows ? hi[r] - lo[r] + 1 : 0;
+    s_gb[tid] = (int)(dtw_group_base(off, r) - gb0);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int r = 0; r < 64; ++r) { s_po[r] = acc; acc += s_w[r]; }
+    s_po[64] = acc;
+    s_gb[64] = s_gb[nrows - 1] + ((s_w[nrows - 1] - 1) >> 6) + 1;     // groups of the strip
+  }
+  __syncthreads();
+  const int gtot = s_gb[64];
+  const size_t m_bytes = (size_t)gtot * 16;
+  const bool fits = m_bytes + (size_t)s_po[64] * sizeof(int32_t) <= (size_t)a.lds_bytes;
+  uint64_t *M = (uint64_t *)bt;                    // planes of the strip: 2 words per group
+  int32_t *P = (int32_t *)(bt + m_bytes);
+  uint64_t *Mg = a.predm + 2 * gb0;
+  if (fits) { for (int w = tid; w < 2 * gtot; w += DTW_CODES_NT) M[w] = 0ull; }
+  else      { for (int w = tid; w < 2 * gtot; w += DTW_CODES_NT) Mg[w] = 0ull; }
+  __syncthreads();
+  // ---- phase 1
+  const int jmin = s_lo[0];
+  const int nsteps16 = dtw_strip_steps16(lo, hi, len_x, k);
+  const uint64_t sb = a.soff[k];
+  const bool valid = lane < nrows;
+  const int l = s_lo[lane], wdt = s_w[lane];       // this lane's row
+  const int groups = valid ? ((wdt - 1) >> 6) + 1 : 0;
+  // lane 0's (i-1, j): the previous strip's last row, lane 63 of that strip's band
+  const int plo = k > 0 ? lo[i0 - 1] : 0, phi = k > 0 ? hi[i0 - 1] : -1;
+  const int pjmin = k > 0 ? lo[i0 - 64] : 0;
+  const uint64_t psb = k > 0 ? a.soff[k - 1] : 0;
+  auto phase1 = [&](uint64_t *planes) {
+    for (int b = wv; 64 * b < nsteps16; b += DTW_CODES_NT / 64) {
+      const int sb0 = 64 * b, cnt = min(64, nsteps16 - sb0);
+      // the boundary values of the block's steps: lane t holds D[i0-1][jmin + sb0 + t]
+      double bvec = INF;
+      {
+        const int jb = jmin + sb0 + lane;
+        if (jb >= plo && jb <= phi) bvec = a.dval[dtw_skew_index(psb, jb - pjmin + 63, 63)];
+      }
+      double prevD = sb0 > 0 ? a.dval[dtw_skew_index(sb, sb0 - 1, lane)] : INF;
+      uint64_t w0 = 0, w1 = 0;
+      for (int t0 = 0; t0 < cnt; t0 += 16) {       // cnt is a multiple of 16
+        double Dc[16], dt[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          Dc[u] = a.dval[dtw_skew_index(sb, sb0 + t0 + u, lane)];
+          dt[u] = a.dist[dtw_skew_index(sb, sb0 + t0 + u, lane)];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int t = t0 + u;
+          const double bfirst = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bvec), t),
+                                                 __builtin_amdgcn_readlane(__double2loint(bvec), t));
+          const double up = dtw_wave_shr1(prevD, bfirst);
+          const double left = prevD;
+          const int c = (jmin + sb0 + t - lane) - l;     // the cell's place in its row's window
+          const bool in = valid && c >= 0 && c < wdt;
+          const bool e0 = in && (up + dt[u] == Dc[u]), e1 = in && (left + dt[u] == Dc[u]);
+          w0 |= (uint64_t)e0 << t;
+          w1 |= (uint64_t)e1 << t;
+          prevD = Dc[u];
+        }
+      }
+      // bit t of the words = column c0 + t of the row's window
+      const int c0 = (jmin + sb0 - lane) - l;
+      const int g = c0 >> 6, sh = c0 & 63;
+      const uint64_t lo0 = w0 << sh, lo1 = w1 << sh;
+      const uint64_t hi0 = sh ? w0 >> (64 - sh) : 0ull, hi1 = sh ? w1 >> (64 - sh) : 0ull;
+      uint64_t *row = planes + 2 * (size_t)s_gb[lane];
+      if (g >= 0 && g < groups) {
+        if (lo0) atomicOr((unsigned long long *)&row[2 * g], (unsigned long long)lo0);
+        if (lo1) atomicOr((unsigned long long *)&row[2 * g + 1], (unsigned long long)lo1);
+      }
+      if (g + 1 >= 0 && g + 1 < groups) {
+        if (hi0) atomicOr((unsigned long long *)&row[2 * (g + 1)], (unsigned long long)hi0);
+        if (hi1) atomicOr((unsigned long long *)&row[2 * (g + 1) + 1], (unsigned long long)hi1);
+      }
+    }
+  };
+  if (!fits) {
+    phase1(Mg);
+    if (tid == 0) atomicExch(&a.status[1], 1);
+    return;
+  }
+  phase1(M);
+  __syncthreads();
+  // ---- phase 2: the planes go to memory, the places to LDS
+  for (int w = tid; w < 2 * gtot; w += DTW_CODES_NT) Mg[w] = M[w];
+  for (int rr = wv; rr < nrows; rr += DTW_CODES_NT / 64) {
+    const int rl = s_lo[rr], w = s_w[rr];
+    const uint64_t *row = M + 2 * (size_t)s_gb[rr];
+    int32_t *Pr = P + s_po[rr];
+    int carry = rl - 1;                      // the place of the last cell seen whose predecessor is not (i, j-1)
+    for (int c0 = 0, g = 0; c0 < w; c0 += 64, ++g) {
+      const uint64_t m0 = row[2 * g], m1 = row[2 * g + 1];
+      const uint64_t mi = w - c0 >= 64 ? ~0ull : (~0ull >> (64 - (w - c0)));
+      const uint64_t vm = (m0 | ~m1) & mi;              // cells that do not copy their left neighbour
+      const uint64_t below = vm & (~0ull >> (63 - lane));
+      int place;                                        // a column of the row above (or of the boundary row)
+      if (below) {
+        const int pos = 63 - __clzll((long long)below);
+        place = (rl + c0 + pos) - (int)(((m0 >> pos) & 1ull) ? 0 : 1);
+      } else {
+        place = carry;
+      }
+      if (c0 + lane < w) Pr[c0 + lane] = place;
+      if (vm) {
+        const int pos = 63 - __clzll((long long)vm);
+        carry = (rl + c0 + pos) - (int)(((m0 >> pos) & 1ull) ? 0 : 1);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: the last row's cells, up through the rows; a place outside a row's window belongs to an
+  //      unreachable cell.  The entry column of cell (last row, j) is kept in the cell's own (dead) distance.
+  const int wl = s_w[nrows - 1], ll = s_lo[nrows - 1], L = nrows - 1;
+  for (int c = tid; c < wl; c += DTW_CODES_NT) {
+    int col = P[s_po[L] + c];
+    for (int rr = L - 1; rr >= 0; --rr) {
+      const int cc = min(max(col - s_lo[rr], 0), s_w[rr] - 1);
+      col = P[s_po[rr] + cc];
+    }
+    *(int32_t *)&a.dist[dtw_skew_index(sb, (ll + c) - jmin + L, L)] = col;
+  }
+}
+#define DTW_CODES_THREADS 1024
+__global__ __launch_bounds__(DTW_CODES_THREADS) void k_dtw_codes(dtw_level_args a) {
+  extern __shared__ unsigned char bt[];
+  dtw_codes_body<DTW_CODES_THREADS>(a, blockIdx.x, bt);
+}
+
+// The back-trace of one level and the next level's windows: ONE workgroup.
+#define DTW_TRACE_NT 256
+__device__ __forceinline__ void dtw_trace_body(const dtw_level_args &a, unsigned char *bt) {
+  __shared__ int s_n;
+  const int len_x = a.len_x, len_y = a.len_y;
+  const int32_t *lo = a.lo, *hi = a.hi;
+  const uint64_t *off = a.off;
+  long long *dbg = a.dbg;
+  if (a.status[0] != 0) {
+    if (threadIdx.x == 0) { *a.path_len = 0; *a.out_dist = NAN; }
+    // keep the next level's tables defined (full windows: its distance kernel sees the overflow and leaves the status)
+    if (a.next_len_x > 0)
+      dtw_window_scan_body<DTW_TRACE_NT>((const int32_t *)nullptr, 0, a.radius, a.next_len_x, a.next_len_y, a.lo_w,
+                                         a.hi_w, a.off_w, a.soff_w, a.cap_rows, a.cap_skew, a.status, bt,
+                                         (size_t)a.lds_bytes);
+    return;
+  }
+  const long long t_dp = dbg ? clock64() : 0;
+  const bool serial = a.status[1] != 0;       // no entry columns: the whole path is one segment
+  const int nstrips = serial ? 1 : (len_x + 63) / 64;
+  if (threadIdx.x == 0) {
+    const int ks = (len_x - 1) / 64, Ls = (len_x - 1) - 64 * ks;
+    *a.out_dist = a.dval[dtw_skew_index(a.soff[ks], (len_y - 1) - lo[64 * ks] + Ls, Ls)];
+  }
+  // ---- (1) one thread hops from strip to strip: the path leaves strip k through
+  //      (last row, exitc[k]) and the entry column stored there is where it leaves strip k-1.
+  //      (2) every strip is walked by its own lane, all at once, over the predecessor planes.
+  //      (3) the strips' cell counts are summed, (4) the segments are copied to their places.
+  // A walk is a chain of dependent loads (row window -> group address -> planes), ~1300 cycles per cell
+  // from global memory: the rows' windows are staged in LDS first, and after the hop -- which says between which
+  // columns each strip's segment runs -- the groups of the planes that cover those columns (two or three per row
+  // instead of the whole window), when they fit.
+  int32_t *exitc = a.sinfo, *sbase = a.sinfo + nstrips, *cnt = a.sinfo + 2 * nstrips;
+  const size_t lds_bytes = (size_t)a.lds_bytes;
+  const size_t tbl_bytes = ((8ull * (size_t)len_x + 15) & ~15ull) + 8ull * DTW_TRACE_NT + 8ull * ((size_t)len_x + 2);
+  const bool tbl_ok = lds_bytes >= tbl_bytes + 64;
+  int32_t *t_lo = (int32_t *)bt, *t_hi = t_lo + len_x;
+  uint64_t *t_tot = (uint64_t *)(bt + ((8ull * (size_t)len_x + 15) & ~15ull));
+  uint64_t *t_so = t_tot + DTW_TRACE_NT;              // first staged group of every row
+  uint64_t *t_pm = (uint64_t *)(bt + ((tbl_bytes + 15) & ~15ull));
+  if (tbl_ok) {
+    for (int i = threadIdx.x; i < len_x; i += DTW_TRACE_NT) { t_lo[i] = lo[i]; t_hi[i] = hi[i]; }
   }
   __syncthreads();
   if (dbg && threadIdx.x == 0) dbg[20] = clock64() - t_dp;
@@ -444,7 +715,7 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
       if (k > 0) {
         const int l = LO[il];
         const int c = min(max(cj, l), HI[il]);
-        e = ((const int32_t *)(dist + dtw_row_base(off, il)))[c - l];
+        e = *(const int32_t *)&a.dist[dtw_skew_index(a.soff[k], c - LO[i0] + (il - i0), il - i0)];
         e = min(max(e, 0), cj);
       }
       sbase[k] = base;
@@ -453,41 +724,89 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     }
   };
   if (threadIdx.x == 0) {
-    if (tbl_ok) hop(t_lo, t_hi); else hop(lo, hi);
+    if (serial) { exitc[0] = len_y - 1; sbase[0] = 0; }
+    else if (tbl_ok) hop(t_lo, t_hi);
+    else hop(lo, hi);
   }
   __syncthreads();
   if (dbg && threadIdx.x == 0) dbg[21] = clock64() - t_dp;
-  auto walk = [&](int k, const int32_t *LO, const int32_t *HI, const uint32_t *WB, const uint32_t *PW) {
-    const int i0 = 64 * k, lo0 = LO[i0];
-    int i = min(i0 + 63, len_x - 1), j = exitc[k], m = 0;
-    int32_t *out = rev + 2 * (int64_t)sbase[k];
-    int crow = -1, l = 0, h = -1, sh = 0;
-    uint64_t wb = 0, cw = ~0ull;
-    uint32_t word = 0u;
-    while (i >= i0) {
+  // the groups row i's part of the segment can touch: columns [entry of its strip, exit of its strip] of its window
+  auto first_group = [&](int i, int l) { const int k = serial ? 0 : i >> 6; const int e = k > 0 ? exitc[k - 1] : 0; return (max(l, e) - l) >> 6; };
+  auto last_group = [&](int i, int l, int h) { const int k = serial ? 0 : i >> 6; return (max(min(h, exitc[k]), l) - l) >> 6; };
+  bool pm_ok = false;
+  if (tbl_ok) {
+    kwy_block_count_scan<DTW_TRACE_NT>([&](int64_t i) -> uint64_t {
+      const int l = t_lo[i], h = t_hi[i];
+      return (uint64_t)(max(last_group((int)i, l, h) - first_group((int)i, l), 0) + 1);
+    }, len_x, t_so, t_tot);
+    __syncthreads();
+    pm_ok = t_so[len_x] * 16 + ((tbl_bytes + 15) & ~15ull) <= lds_bytes;
+    if (pm_ok) {
+      for (int i = threadIdx.x; i < len_x; i += DTW_TRACE_NT) {
+        const int l = t_lo[i], h = t_hi[i];
+        const int g0 = first_group(i, l), g1 = max(last_group(i, l, h), g0);
+        const uint64_t *src = a.predm + 2 * (dtw_group_base(off, i) + (uint64_t)g0);
+        uint64_t *dst = t_pm + 2 * t_so[i];
+        for (int g = 0; g <= g1 - g0; ++g) { dst[2 * g] = src[2 * g]; dst[2 * g + 1] = src[2 * g + 1]; }
+      }
+    }
+    __syncthreads();
+  }
+  if (dbg && threadIdx.x == 0) { dbg[24] = clock64() - t_dp; dbg[25] = (pm_ok ? 1 : 0) + (tbl_ok ? 2 : 0); dbg[26] = 0; dbg[27] = tbl_ok ? (long long)t_so[len_x] : -1; }
+  auto walk = [&](int k, int i_stop, int i_from, const int32_t *LO, const int32_t *HI) {
+    int i = i_from, j = exitc[k], m = 0;
+    int32_t *out = a.rev + 2 * (int64_t)sbase[k];
+    int crow = -1, l = 0, h = -1, cg = -1;
+    uint64_t gb = 0, m0 = 0, m1 = 0;
+    while (i >= i_stop) {
       out[2 * m] = i; out[2 * m + 1] = j; ++m;
       if (i == 0 && j == 0) break;
-      if (i != crow) {
-        crow = i; l = LO[i]; h = HI[i]; sh = (i - i0) + l - lo0;
-        wb = WB ? (uint64_t)WB[i] : dtw_word_base(off, i);
-        cw = ~0ull;
-      }
+      if (i != crow) { crow = i; l = LO[i]; h = HI[i]; gb = dtw_group_base(off, i); cg = -1; }
       unsigned int pb = 0;
       if (j >= l && j <= h) {
-        const int st = sh + (j - l);  // the step at which this cell was computed
-        const uint64_t w = wb + (uint64_t)((st >> 4) - (sh >> 4));
-        if (w != cw) { cw = w; word = PW[w]; }
-        pb = (word >> (2 * (st & 15))) & 3u;
+        const int c = j - l, g = c >> 6;
+        if (g != cg) { cg = g; m0 = a.predm[2 * (gb + g)]; m1 = a.predm[2 * (gb + g) + 1]; }
+        pb = ((m0 >> (c & 63)) & 1ull) ? 0u : (((m1 >> (c & 63)) & 1ull) ? 1u : 2u);
       }
       if (pb == 0) --i; else if (pb == 1) --j; else { --i; --j; }
       if (j < 0) break;
     }
     cnt[k] = m;
   };
-  for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
-    if (pw_ok) walk(k, t_lo, t_hi, t_wb, t_pw);
-    else if (tbl_ok) walk(k, t_lo, t_hi, t_wb, predw);
-    else walk(k, lo, hi, (const uint32_t *)nullptr, predw);
+  // The same walk on the staged planes, without branches (35 lanes of one wavefront each walk ~130 cells: what
+  // costs is the number of instructions per cell and the two dependent LDS reads, row table -> planes).
+  auto walk_staged = [&](int k, int i_stop, int i_from) -> bool {
+    int i = i_from, j = exitc[k], m = 0;
+    const int ek = k > 0 ? exitc[k - 1] : 0;
+    int2 *out = (int2 *)a.rev + (int64_t)sbase[k];
+    bool ok = true;
+    while (true) {
+      out[m] = make_int2(i, j); ++m;
+      const int l = t_lo[i], h = t_hi[i];
+      const int so = (int)t_so[i], ng = (int)t_so[i + 1] - so;
+      const int c = j - l, g = (c >> 6) - ((max(l, ek) - l) >> 6);
+      const bool inwin = (unsigned)c <= (unsigned)(h - l);
+      ok = ok && (!inwin || (unsigned)g < (unsigned)ng);
+      const uint64_t *pm = t_pm + 2 * (so + min(max(g, 0), ng - 1));
+      const uint64_t m0 = pm[0], m1 = pm[1];
+      const unsigned pb = !inwin || ((m0 >> (c & 63)) & 1ull) ? 0u : (((m1 >> (c & 63)) & 1ull) ? 1u : 2u);
+      const bool origin = i == 0 && j == 0;
+      i -= pb != 1u;
+      j -= pb != 0u;
+      if (origin || i < i_stop || j < 0) break;
+    }
+    cnt[k] = m;
+    return ok;
+  };
+  for (int k = threadIdx.x; k < nstrips; k += DTW_TRACE_NT) {
+    const int i_stop = serial ? 0 : 64 * k, i_from = serial ? len_x - 1 : min(64 * k + 63, len_x - 1);
+    bool done = false;
+    if (pm_ok) done = walk_staged(k, i_stop, i_from);
+    if (!done) {          // the planes in memory (not staged, or -- not expected -- a segment left its columns)
+      if (dbg) atomicAdd((unsigned long long *)&dbg[26], 1ull);
+      if (tbl_ok) walk(k, i_stop, i_from, t_lo, t_hi);
+      else walk(k, i_stop, i_from, lo, hi);
+    }
   }
   __syncthreads();
   if (dbg && threadIdx.x == 0) dbg[22] = clock64() - t_dp;
@@ -495,7 +814,8 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     int n = 0;
     for (int k = 0; k < nstrips; ++k) { const int c = cnt[k]; exitc[k] = n; n += c; }   // exitc: now the output offset
     s_n = n;
-    *path_len = n;
+    *a.path_len = n;
+    a.status[1] = 0;                            // the flag belongs to the level
   }
   __syncthreads();
   if (dbg && threadIdx.x == 0) dbg[23] = clock64() - t_dp;
@@ -506,46 +826,75 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_dp(int len_x, int len_y,
     constexpr int MAXS = 256;
     __shared__ int s_meta[3][MAXS];
     if (nstrips <= MAXS) {
-      for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
+      for (int k = threadIdx.x; k < nstrips; k += DTW_TRACE_NT) {
         s_meta[0][k] = cnt[k]; s_meta[1][k] = sbase[k]; s_meta[2][k] = exitc[k];
       }
       __syncthreads();
       const int n = s_n;
-      for (int pos = threadIdx.x; pos < n; pos += 64 * DTW_WAVES) {
-        int a = 0, b = nstrips - 1;                  // last strip whose offset is <= pos
-        while (a < b) { const int mid = (a + b + 1) >> 1; if (s_meta[2][mid] <= pos) a = mid; else b = mid - 1; }
-        const int c = s_meta[0][a], q = pos - s_meta[2][a];
-        ((int2 *)path)[pos] = ((const int2 *)rev)[(int64_t)s_meta[1][a] + (c - 1 - q)];
+      for (int pos = threadIdx.x; pos < n; pos += DTW_TRACE_NT) {
+        int lo_s = 0, hi_s = nstrips - 1;            // last strip whose offset is <= pos
+        while (lo_s < hi_s) { const int mid = (lo_s + hi_s + 1) >> 1; if (s_meta[2][mid] <= pos) lo_s = mid; else hi_s = mid - 1; }
+        const int c = s_meta[0][lo_s], q = pos - s_meta[2][lo_s];
+        ((int2 *)a.path)[pos] = ((const int2 *)a.rev)[(int64_t)s_meta[1][lo_s] + (c - 1 - q)];
       }
     } else {
-      for (int k = threadIdx.x; k < nstrips; k += 64 * DTW_WAVES) {
+      for (int k = threadIdx.x; k < nstrips; k += DTW_TRACE_NT) {
         const int c = cnt[k];
-        const int2 *in = (const int2 *)rev + (int64_t)sbase[k];
-        int2 *out = (int2 *)path + (int64_t)exitc[k];
+        const int2 *in = (const int2 *)a.rev + (int64_t)sbase[k];
+        int2 *out = (int2 *)a.path + (int64_t)exitc[k];
         for (int m = 0; m < c; ++m) out[c - 1 - m] = in[m];
       }
     }
   }
   if (dbg && threadIdx.x == 0) {
     const long long t_end = clock64();
-    atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t_dp - t_start));
     atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(t_end - t_dp));
-    dbg[2] = t_dp - t_start; dbg[3] = t_end - t_dp; dbg[4] = s_n;
+    dbg[3] = t_end - t_dp; dbg[4] = s_n;
   }
   // ---- the next (finer) level's windows from this path: lo / hi / off of this level are dead now
-  if (next_len_x > 0) {
+  if (a.next_len_x > 0) {
     __syncthreads();    // the path is complete (workgroup scope), the LDS tables are free
-    dtw_window_scan_body<64 * DTW_WAVES>(path, s_n, radius, next_len_x, next_len_y, lo_w, hi_w, off_w, (uint64_t *)bt);
+    dtw_window_scan_body<DTW_TRACE_NT>(a.path, s_n, a.radius, a.next_len_x, a.next_len_y, a.lo_w, a.hi_w, a.off_w,
+                                       a.soff_w, a.cap_rows, a.cap_skew, a.status, bt, (size_t)a.lds_bytes);
   }
+}
+__global__ __launch_bounds__(DTW_TRACE_NT) void k_dtw_trace(dtw_level_args a) {
+  extern __shared__ unsigned char bt[];
+  dtw_trace_body(a, bt);
+}
+
+// A level of at most DTW_SMALL_STRIPS strips: recurrence, codes and trace in ONE launch of one workgroup, one after
+// the other (the coarse levels: launches of ~12 us each, most of it the first touch of what the launch before wrote
+// on another CU, for a few microseconds of work).  Everything a phase writes is read back by the same CU.  The
+// distances keep their own launch: one workgroup would take the units one after the other.
+#define DTW_SMALL_STRIPS 1
+__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_small(dtw_level_args a) {
+  extern __shared__ unsigned char bt[];
+  dtw_values_body<true>(a, bt);
+  __syncthreads();
+  const int nstrips = (a.len_x + 63) / 64;
+  for (int k = 0; k < nstrips; ++k) dtw_codes_body<64 * DTW_WAVES>(a, k, bt);
+  __syncthreads();
+  dtw_trace_body(a, bt);
 }
 
 // ---- host side -----------------------------------------------------------------------------
 struct dtw_level { int len_x, len_y; };
 
+// cells of the rows' windows (the predecessor planes' capacity): an estimate, or the full matrix
 static uint64_t dtw_cap(int len_x, int len_y, int radius, bool full) {
   uint64_t worst = (uint64_t)len_x * (uint64_t)len_y;
   if (full) return worst;
   uint64_t est = (uint64_t)len_x * (uint64_t)(8 * radius + 64) * 2;
+  return est < worst ? est : worst;
+}
+// cells of the strips' rectangles in the skewed bands: 64 lanes x (columns the strip spans + the skew, rounded up to
+// whole chunks).  The strips' spans add up to at most len_y + strips x (one window width): same estimate of the width.
+static uint64_t dtw_cap_skew(int len_x, int len_y, int radius, bool full) {
+  const uint64_t strips = ((uint64_t)len_x + 63) / 64;
+  const uint64_t worst = 64 * strips * ((uint64_t)len_y + 80);
+  if (full) return worst;
+  const uint64_t est = 64 * ((uint64_t)len_y + strips * ((uint64_t)(8 * radius + 64) * 2 + 80));
   return est < worst ? est : worst;
 }
 
@@ -557,9 +906,9 @@ static size_t dtw_scratch_bytes(int64_t Tx, int64_t Ty, int dim, int radius, boo
     lx /= 2; ly /= 2;
     tot += kwy_pad(sizeof(double) * (size_t)lx * dim) + kwy_pad(sizeof(double) * (size_t)ly * dim);
   }
-  uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
-  tot += kwy_pad(sizeof(double) * (cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD)) + kwy_pad(4 * (cap / 16 + 2 * Tx + 64));
-  tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1));
+  uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full), cap_skew = dtw_cap_skew((int)Tx, (int)Ty, radius, full);
+  tot += 2 * kwy_pad(sizeof(double) * cap_skew) + kwy_pad(16 * (cap / 64 + Tx + 8));
+  tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1)) + kwy_pad(sizeof(uint64_t) * (Tx / 64 + 2));
   tot += kwy_pad(sizeof(double) * 4 * (Ty + 2));
   tot += 2 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + Tx / 64 + 8)) +
          kwy_pad(sizeof(int32_t) * 3 * (Tx / 64 + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
@@ -603,8 +952,11 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     }
   }
   const uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
-  double *dist = kwy_arena<double>(ctx, cap + 2 * DTW_ROWPAD * Tx + 2 * DTW_PAD);   // + the +inf cells of every row
-  uint32_t *pred = kwy_arena<uint32_t>(ctx, cap / 16 + 2 * Tx + 64);
+  const uint64_t cap_skew = dtw_cap_skew((int)Tx, (int)Ty, radius, full);
+  double *dist = kwy_arena<double>(ctx, cap_skew);
+  double *dval = kwy_arena<double>(ctx, cap_skew);
+  uint64_t *soff = kwy_arena<uint64_t>(ctx, Tx / 64 + 2);
+  uint64_t *predm = kwy_arena<uint64_t>(ctx, 2 * (cap / 64 + Tx + 8));
   int32_t *lo = kwy_arena<int32_t>(ctx, Tx), *hi = kwy_arena<int32_t>(ctx, Tx);
   uint64_t *off = kwy_arena<uint64_t>(ctx, Tx + 1);
   double *bnd = kwy_arena<double>(ctx, DTW_WAVES * (Ty + 2));
@@ -614,46 +966,70 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   int32_t *sinfo = kwy_arena<int32_t>(ctx, 3 * (Tx / 64 + 2));
   int64_t *lenA = kwy_arena<int64_t>(ctx, 8), *lenB = kwy_arena<int64_t>(ctx, 8);
   int *status = kwy_arena<int>(ctx, 16);
-  if (!dist || !pred || !lo || !hi || !off || !bnd || !pathA || !pathB || !rev || !sinfo || !lenA || !lenB || !status) {
+  if (!dist || !dval || !soff || !predm || !lo || !hi || !off || !bnd || !pathA || !pathB || !rev || !sinfo || !lenA || !lenB ||
+      !status) {
     ctx->err = "fastdtw: scratch arena too small";
     return KWY_ENOMEM;
   }
   *status_out = status;
+  // the boundary rows of the strips live in LDS when they fit (the other instantiation keeps them in memory)
   const size_t bnd_bytes = sizeof(double) * DTW_WAVES * (Ty + 2);
-  // the boundary rows of the strips live in LDS when they fit
   const bool bnd_lds = bnd_bytes <= 150 * 1024;
-  // ... and the back-trace stages its row table and predecessor words in the same LDS: ask for all a workgroup may
-  // have beside the static variables (the kernel takes what fits)
-  const size_t dp_lds = 150 * 1024;
-  (void)bnd_bytes;
-  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
-  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds));
+  // the codes' places and the back-trace's tables: all a workgroup may have beside the static variables (the kernels
+  // take what fits and have a slower way for the rest)
+  const size_t big_lds = 150 * 1024;
+  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_values<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_codes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+  KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
 
-  const int32_t *cpath = nullptr;
-  const int64_t *clen = nullptr;
   for (int l = (int)lv.size() - 1; l >= 0; --l) {
     const int len_x = lv[l].len_x, len_y = lv[l].len_y;
     const bool top = (l == 0);
-    int32_t *opath = top ? d_path : ((l & 1) ? pathA : pathB);
-    int64_t *olen = top ? d_path_len : ((l & 1) ? lenA : lenB);
     if (l == (int)lv.size() - 1)
-      hipLaunchKernelGGL(k_dtw_window_scan, dim3(1), dim3(DTW_WS_NT), 0, ctx->stream, (const int32_t *)nullptr,
-                         (const int64_t *)nullptr, radius, len_x, len_y, lo, hi, off, status);
-    const int nlx = top ? 0 : lv[l - 1].len_x, nly = top ? 0 : lv[l - 1].len_y;
-    KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3(len_x), dim3(KWY_THREADS), sizeof(double) * dim, ctx->stream, xs[l],
-                       ys[l], dim, lo, hi, off, cap, dist, status));
+      hipLaunchKernelGGL(k_dtw_window_scan, dim3(1), dim3(DTW_WS_NT), 0, ctx->stream, radius, len_x, len_y, lo, hi, off,
+                         soff, cap, cap_skew, status);
+    dtw_level_args a;
+    a.len_x = len_x; a.len_y = len_y;
+    a.lo = lo; a.hi = hi; a.off = off; a.soff = soff;
+    a.cap_rows = cap; a.cap_skew = cap_skew;
+    a.dist = dist; a.dval = dval; a.predm = predm;
+    a.bnd_global = bnd_lds ? nullptr : bnd;
+    a.path = top ? d_path : ((l & 1) ? pathA : pathB);
+    a.rev = rev; a.sinfo = sinfo;
+    a.path_len = top ? d_path_len : ((l & 1) ? lenA : lenB);
+    a.out_dist = d_dist;
+    a.status = status;
+    a.dbg = (long long *)ctx->dbg;
+    a.next_len_x = top ? 0 : lv[l - 1].len_x;
+    a.next_len_y = top ? 0 : lv[l - 1].len_y;
+    a.radius = radius;
+    a.lo_w = lo; a.hi_w = hi; a.off_w = off; a.soff_w = soff;
+    const int nstrips = (len_x + 63) / 64;
+    // a workgroup per 16 steps of a strip; how many there are is known on the device only: as many workgroups as
+    // this level's rectangles are estimated to have (the others return at once; more units: the workgroups loop)
+    const uint64_t lv_units = std::min(cap_skew, dtw_cap_skew(len_x, len_y, radius, full)) / 1024 + 1;
+    KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3((unsigned)lv_units), dim3(KWY_THREADS), 0, ctx->stream, xs[l],
+                       ys[l], dim, len_x, len_y, lo, hi, soff, dist, status));
+
+    if (nstrips <= DTW_SMALL_STRIPS && bnd_lds) {
+      a.lds_bytes = (int)big_lds;
+      KWY_PROF(ctx, "k_dtw_small", hipLaunchKernelGGL(k_dtw_small, dim3(1), dim3(64 * DTW_WAVES), big_lds, ctx->stream, a));
+      continue;
+    }
+    // the codes kernel asks for the LDS its strips are likely to need (rows x a generous window), not for all of it:
+    // several strips then share a CU
+    const size_t want = (size_t)64 * 4 * (size_t)std::min<int64_t>(len_y, 8 * (int64_t)radius + 128);
+    const size_t codes_lds = std::min(big_lds, std::max<size_t>(want, 16 * 1024));
+    a.lds_bytes = 0;
     if (bnd_lds)
-      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<true>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
-                                                     lo, hi, off, cap, dist, pred, (double *)nullptr, opath, rev, sinfo, olen,
-                                                     d_dist, status, (long long *)ctx->dbg, (int)dp_lds, nlx, nly, radius,
-                                                     lo, hi, off));
+      KWY_PROF(ctx, "k_dtw_values", hipLaunchKernelGGL(k_dtw_values<true>, dim3(1), dim3(64 * DTW_WAVES), bnd_bytes, ctx->stream, a));
     else
-      KWY_PROF(ctx, "k_dtw_dp", hipLaunchKernelGGL(k_dtw_dp<false>, dim3(1), dim3(64 * DTW_WAVES), dp_lds, ctx->stream, len_x, len_y,
-                                                     lo, hi, off, cap, dist, pred, bnd, opath, rev, sinfo, olen, d_dist,
-                                                     status, (long long *)ctx->dbg, (int)dp_lds, nlx, nly, radius, lo, hi,
-                                                     off));
-    cpath = opath;
-    clen = olen;
+      KWY_PROF(ctx, "k_dtw_values", hipLaunchKernelGGL(k_dtw_values<false>, dim3(1), dim3(64 * DTW_WAVES), 0, ctx->stream, a));
+    a.lds_bytes = (int)codes_lds;
+    KWY_PROF(ctx, "k_dtw_codes", hipLaunchKernelGGL(k_dtw_codes, dim3(nstrips), dim3(DTW_CODES_THREADS), codes_lds, ctx->stream, a));
+    a.lds_bytes = (int)big_lds;
+    KWY_PROF(ctx, "k_dtw_trace", hipLaunchKernelGGL(k_dtw_trace, dim3(1), dim3(DTW_TRACE_NT), big_lds, ctx->stream, a));
   }
   KWY_HIP(hipGetLastError());
   return KWY_OK;

@@ -93,7 +93,9 @@ def _series(rng, T, dim, warp):
 @pytest.mark.parametrize('Tx,Ty,dim,radius', [
     (1, 1, 2, 1), (2, 5, 3, 1), (20, 17, 3, 32), (33, 34, 4, 32), (35, 70, 4, 32), (70, 90, 5, 1),
     (300, 350, 26, 32), (737, 801, 25, 1), (2201, 2401, 26, 32), (2401, 2201, 26, 32),
-    (4700, 5300, 3, 8)])    # the last one: boundary rows too long for LDS (the global-memory variant of the DP)
+    (4700, 5300, 3, 8),     # boundary rows too long for LDS (the global-memory variant of the recurrence)
+    (40, 9000, 2, 32), (9000, 40, 2, 32),   # windows wider than a strip's LDS (the back-trace in one piece) / 141 strips
+    (1500, 1400, 2, 300), (900, 1000, 3, 100)])   # wide bands: some strips keep their entry columns, some do not
 def test_fastdtw_bit_exact(ko, Tx, Ty, dim, radius):
     from kwiiyatta_amd.backend import dtw
     rng = np.random.default_rng(Tx * 7919 + Ty)

@@ -17,7 +17,9 @@ lib.kwy_ctx_debug_buffer(ctx.handle, c_vp(dbg.data_ptr()))
 dtw.fastdtw(x,y,radius=32)
 d=dbg.cpu().numpy()
 print('total dp cycles', d[0], 'total bt cycles', d[1], 'finest level dp', d[2], 'bt', d[3], 'path', d[4])
-print('spin cycles per wave', d[8:12], 'chunks per wave', d[12:16])
+print('finest level trace: staged', d[20], 'hopped', d[21], 'planes staged', d[24], 'walked', d[22], 'counted', d[23], 'end', d[3])
+print('trace flags (1 planes staged, 2 tables staged)', d[25], 'walks from memory', d[26], 'groups staged', d[27])
+print('simd of the four wavefronts', [(int(v) >> 4) & 3 for v in d[16:20]], 'cu', [(int(v) >> 8) & 15 for v in d[16:20]])
 print('finest level strips: k, start, end, steps, jmin')
 for k in range(48):
     if d[64+4*k+1]: print(k, d[64+4*k], d[64+4*k+1], d[64+4*k+2], d[64+4*k+3])
