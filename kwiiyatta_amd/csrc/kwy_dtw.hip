@@ -395,31 +395,45 @@ __device__ __forceinline__ void dtw_values_body(const dtw_level_args &a, unsigne
 #pragma unroll
     for (int r = 0; r < DTW_RING - 1; ++r) fetch(ring[r], DTW_CHUNK * r);
     bool first_chunk = true;
+    // the boundary values lane 0 needs in the DTW_CHUNK steps from c0 on: lane t holds the one of step c0 + t (the
+    // vector is rotated by one lane per step, so that lane 0 always holds the current one)
+    auto load_brot = [&](int c0) {
+      const int jb = jmin + c0 + lane;
+      double b = INF;
+      if (jb >= plo && jb <= phi) b = BROW(pbuf, jb + 1);
+      return b;
+    };
+    auto covered = [&](long long pv, int need) {     // (every lane holds the same word: tests on the scalar unit)
+      const int ps = __builtin_amdgcn_readfirstlane((int)(pv >> 32));
+      const int pc = __builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffll)) - 1;
+      return ps > k - 1 || (ps == k - 1 && pc >= need);
+    };
+    // The progress word and the boundary values of the NEXT chunk are read before the steps of the current one
+    // (an LDS round trip is ~130 cycles, two of them one after the other a fifth of a chunk): if the word read
+    // then already covered the columns, the values read behind it are the final ones.
+    long long pv_ahead = k > 0 ? DTW_PROG_LOAD(pbuf) : 0;
+    double brot_ahead = k > 0 ? load_brot(0) : INF;
     // one chunk of DTW_CHUNK steps on `cur`; `fill` (the buffer used one chunk ago) is refilled meanwhile
     auto chunk = [&](int c0, const double (&cur)[DTW_CHUNK], double (&fill)[DTW_CHUNK]) {
       fetch(fill, c0 + DTW_CHUNK * (DTW_RING - 1));
-      // wait until the previous strip's last row has produced the columns this chunk reads
+      double brot = brot_ahead;
       if (k > 0) {
+        // wait until the previous strip's last row has produced the columns this chunk reads
         const int need = min(jmin + c0 + DTW_CHUNK - 1, phi);  // last column we may read (valid ones only)
-        while (true) {
-          const long long pv = DTW_PROG_LOAD(pbuf);          // (every lane reads the same word: tests on the scalar unit)
-          const int ps = __builtin_amdgcn_readfirstlane((int)(pv >> 32));
-          const int pc = __builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffll)) - 1;
-          if (ps > k - 1 || (ps == k - 1 && pc >= need)) break;
-          __builtin_amdgcn_s_sleep(1);
+        if (!covered(pv_ahead, need)) {
+          while (!covered(DTW_PROG_LOAD(pbuf), need)) __builtin_amdgcn_s_sleep(1);
+          DTW_ACQUIRE();
+          brot = load_brot(c0);
         }
+        if (first_chunk) {
+          const int jd = jmin - 1;
+          const double dv = (jd >= plo && jd <= phi) ? BROW(pbuf, jd + 1) : INF;
+          if (lane == 0) up_prev = dv;
+          first_chunk = false;
+        }
+        pv_ahead = DTW_PROG_LOAD(pbuf);
         DTW_ACQUIRE();
-      }
-      // the boundary values lane 0 needs in the next DTW_CHUNK steps: lane t holds the one of step c0 + t;
-      // the vector is rotated by one lane per step, so that lane 0 always holds the current one
-      const int jb = jmin + c0 + lane;
-      double brot = INF;
-      if (k > 0 && jb >= plo && jb <= phi) brot = BROW(pbuf, jb + 1);
-      if (first_chunk && k > 0) {
-        const int jd = jmin - 1;
-        const double dv = (jd >= plo && jd <= phi) ? BROW(pbuf, jd + 1) : INF;
-        if (lane == 0) up_prev = dv;
-        first_chunk = false;
+        brot_ahead = load_brot(c0 + DTW_CHUNK);
       }
 #pragma unroll
       for (int blk = 0; blk < DTW_CHUNK / DTW_BLK; ++blk) {
@@ -558,43 +572,41 @@ __device__ __forceinline__ void dtw_codes_body(const dtw_level_args &a, int k, u
   const int pjmin = k > 0 ? lo[i0 - 64] : 0;
   const uint64_t psb = k > 0 ? a.soff[k - 1] : 0;
   auto phase1 = [&](uint64_t *planes) {
-    for (int b = wv; 64 * b < nsteps16; b += DTW_CODES_NT / 64) {
-      const int sb0 = 64 * b, cnt = min(64, nsteps16 - sb0);
-      // the boundary values of the block's steps: lane t holds D[i0-1][jmin + sb0 + t]
+    // blocks of 16 steps: enough of them for all the wavefronts, one batch of loads each
+    for (int b = wv; 16 * b < nsteps16; b += DTW_CODES_NT / 64) {
+      const int sb0 = 16 * b;
+      // the boundary values of the block's steps: lane t < 16 holds D[i0-1][jmin + sb0 + t]
       double bvec = INF;
       {
         const int jb = jmin + sb0 + lane;
-        if (jb >= plo && jb <= phi) bvec = a.dval[dtw_skew_index(psb, jb - pjmin + 63, 63)];
+        if (lane < 16 && jb >= plo && jb <= phi) bvec = a.dval[dtw_skew_index(psb, jb - pjmin + 63, 63)];
       }
       double prevD = sb0 > 0 ? a.dval[dtw_skew_index(sb, sb0 - 1, lane)] : INF;
-      uint64_t w0 = 0, w1 = 0;
-      for (int t0 = 0; t0 < cnt; t0 += 16) {       // cnt is a multiple of 16
-        double Dc[16], dt[16];
+      double Dc[16], dt[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          Dc[u] = a.dval[dtw_skew_index(sb, sb0 + t0 + u, lane)];
-          dt[u] = a.dist[dtw_skew_index(sb, sb0 + t0 + u, lane)];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int t = t0 + u;
-          const double bfirst = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bvec), t),
-                                                 __builtin_amdgcn_readlane(__double2loint(bvec), t));
-          const double up = dtw_wave_shr1(prevD, bfirst);
-          const double left = prevD;
-          const int c = (jmin + sb0 + t - lane) - l;     // the cell's place in its row's window
-          const bool in = valid && c >= 0 && c < wdt;
-          const bool e0 = in && (up + dt[u] == Dc[u]), e1 = in && (left + dt[u] == Dc[u]);
-          w0 |= (uint64_t)e0 << t;
-          w1 |= (uint64_t)e1 << t;
-          prevD = Dc[u];
-        }
+      for (int u = 0; u < 16; ++u) {
+        Dc[u] = a.dval[dtw_skew_index(sb, sb0 + u, lane)];
+        dt[u] = a.dist[dtw_skew_index(sb, sb0 + u, lane)];
       }
-      // bit t of the words = column c0 + t of the row's window
+      uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const double bfirst = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(bvec), u),
+                                               __builtin_amdgcn_readlane(__double2loint(bvec), u));
+        const double up = dtw_wave_shr1(prevD, bfirst);
+        const double left = prevD;
+        const int c = (jmin + sb0 + u - lane) - l;     // the cell's place in its row's window
+        const bool in = valid && c >= 0 && c < wdt;
+        const bool e0 = in && (up + dt[u] == Dc[u]), e1 = in && (left + dt[u] == Dc[u]);
+        w0 |= (uint32_t)e0 << u;
+        w1 |= (uint32_t)e1 << u;
+        prevD = Dc[u];
+      }
+      // bit u of the words = column c0 + u of the row's window
       const int c0 = (jmin + sb0 - lane) - l;
       const int g = c0 >> 6, sh = c0 & 63;
-      const uint64_t lo0 = w0 << sh, lo1 = w1 << sh;
-      const uint64_t hi0 = sh ? w0 >> (64 - sh) : 0ull, hi1 = sh ? w1 >> (64 - sh) : 0ull;
+      const uint64_t lo0 = (uint64_t)w0 << sh, lo1 = (uint64_t)w1 << sh;
+      const uint64_t hi0 = sh > 48 ? (uint64_t)w0 >> (64 - sh) : 0ull, hi1 = sh > 48 ? (uint64_t)w1 >> (64 - sh) : 0ull;
       uint64_t *row = planes + 2 * (size_t)s_gb[lane];
       if (g >= 0 && g < groups) {
         if (lo0) atomicOr((unsigned long long *)&row[2 * g], (unsigned long long)lo0);
@@ -742,12 +754,37 @@ __device__ __forceinline__ void dtw_trace_body(const dtw_level_args &a, unsigned
     __syncthreads();
     pm_ok = t_so[len_x] * 16 + ((tbl_bytes + 15) & ~15ull) <= lds_bytes;
     if (pm_ok) {
-      for (int i = threadIdx.x; i < len_x; i += DTW_TRACE_NT) {
-        const int l = t_lo[i], h = t_hi[i];
-        const int g0 = first_group(i, l), g1 = max(last_group(i, l, h), g0);
-        const uint64_t *src = a.predm + 2 * (dtw_group_base(off, i) + (uint64_t)g0);
-        uint64_t *dst = t_pm + 2 * t_so[i];
-        for (int g = 0; g <= g1 - g0; ++g) { dst[2 * g] = src[2 * g]; dst[2 * g + 1] = src[2 * g + 1]; }
+      // four rows per thread at a time, all their loads in flight together (two round trips to memory per batch:
+      // the row's offset, then its groups; a row has rarely more than three)
+      for (int ib = threadIdx.x; ib < len_x; ib += 4 * DTW_TRACE_NT) {
+        const uint64_t *src[4];
+        uint64_t *dst[4];
+        int n[4];
+        uint64_t v[4][3][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ib + r * DTW_TRACE_NT;
+          n[r] = 0;
+          if (i < len_x) {
+            const int l = t_lo[i], h = t_hi[i];
+            const int g0 = first_group(i, l), g1 = max(last_group(i, l, h), g0);
+            n[r] = g1 - g0 + 1;
+            src[r] = a.predm + 2 * (dtw_group_base(off, i) + (uint64_t)g0);
+            dst[r] = t_pm + 2 * t_so[i];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            if (g < n[r]) { v[r][g][0] = src[r][2 * g]; v[r][g][1] = src[r][2 * g + 1]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            if (g < n[r]) { dst[r][2 * g] = v[r][g][0]; dst[r][2 * g + 1] = v[r][g][1]; }
+          for (int g = 3; g < n[r]; ++g) { dst[r][2 * g] = src[r][2 * g]; dst[r][2 * g + 1] = src[r][2 * g + 1]; }
+        }
       }
     }
     __syncthreads();
@@ -780,19 +817,24 @@ __device__ __forceinline__ void dtw_trace_body(const dtw_level_args &a, unsigned
     const int ek = k > 0 ? exitc[k - 1] : 0;
     int2 *out = (int2 *)a.rev + (int64_t)sbase[k];
     bool ok = true;
+    // the row's table entry {lo, hi, first staged group, staged groups}; the row above is fetched one cell ahead
+    struct row_t { int l, h, so, ng; };
+    auto load_row = [&](int r) { r = max(r, 0); row_t x; x.l = t_lo[r]; x.h = t_hi[r]; x.so = (int)t_so[r]; x.ng = (int)t_so[r + 1] - x.so; return x; };
+    row_t cur = load_row(i), nxt = load_row(i - 1);
     while (true) {
       out[m] = make_int2(i, j); ++m;
-      const int l = t_lo[i], h = t_hi[i];
-      const int so = (int)t_so[i], ng = (int)t_so[i + 1] - so;
-      const int c = j - l, g = (c >> 6) - ((max(l, ek) - l) >> 6);
-      const bool inwin = (unsigned)c <= (unsigned)(h - l);
-      ok = ok && (!inwin || (unsigned)g < (unsigned)ng);
-      const uint64_t *pm = t_pm + 2 * (so + min(max(g, 0), ng - 1));
+      const int c = j - cur.l, g = (c >> 6) - ((max(cur.l, ek) - cur.l) >> 6);
+      const bool inwin = (unsigned)c <= (unsigned)(cur.h - cur.l);
+      ok = ok && (!inwin || (unsigned)g < (unsigned)cur.ng);
+      const uint64_t *pm = t_pm + 2 * (cur.so + min(max(g, 0), cur.ng - 1));
       const uint64_t m0 = pm[0], m1 = pm[1];
       const unsigned pb = !inwin || ((m0 >> (c & 63)) & 1ull) ? 0u : (((m1 >> (c & 63)) & 1ull) ? 1u : 2u);
       const bool origin = i == 0 && j == 0;
-      i -= pb != 1u;
+      const bool up = pb != 1u;
+      i -= up;
       j -= pb != 0u;
+      cur.l = up ? nxt.l : cur.l; cur.h = up ? nxt.h : cur.h; cur.so = up ? nxt.so : cur.so; cur.ng = up ? nxt.ng : cur.ng;
+      nxt = load_row(i - 1);
       if (origin || i < i_stop || j < 0) break;
     }
     cnt[k] = m;

@@ -185,6 +185,7 @@ __device__ __forceinline__ syn_ff syn_ff_make(double c, int k) {
 
 // ordered exclusive scan of one map per thread over the workgroup (NW waves);
 // returns the composition of all earlier threads' maps, *total = the whole block's.
+// wtot: 2 NW + 1 maps of LDS.  (The waves' totals are scanned once, by the first wave, not by every thread.)
 template <int NW>
 __device__ __forceinline__ syn_ff syn_ff_block_exscan(syn_ff mine, syn_ff *wtot, syn_ff *total) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -199,17 +200,29 @@ __device__ __forceinline__ syn_ff syn_ff_block_exscan(syn_ff mine, syn_ff *wtot,
   __syncthreads();
   if (lane == 63) wtot[wv] = incl;
   __syncthreads();
-  syn_ff pre = {0, 0}, all = {0, 0};
+  if (wv == 0) {
+    syn_ff w = lane < NW ? wtot[lane] : syn_ff{0, 0};
 #pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    if (w < wv) pre = syn_ff_compose(pre, wtot[w]);
-    all = syn_ff_compose(all, wtot[w]);
+    for (int o = 1; o < NW; o <<= 1) {
+      syn_ff u;
+      u.d0 = __shfl_up(w.d0, o);
+      u.d1 = __shfl_up(w.d1, o);
+      if (lane >= o) w = syn_ff_compose(u, w);
+    }
+    syn_ff ex;
+    ex.d0 = __shfl_up(w.d0, 1);
+    ex.d1 = __shfl_up(w.d1, 1);
+    if (lane == 0) ex = syn_ff{0, 0};
+    if (lane < NW) wtot[NW + lane] = ex;
+    if (lane == NW - 1) wtot[2 * NW] = w;
   }
+  __syncthreads();
+  const syn_ff pre = wtot[NW + wv];
   syn_ff prev;
   prev.d0 = __shfl_up(incl.d0, 1);
   prev.d1 = __shfl_up(incl.d1, 1);
   if (lane == 0) prev = syn_ff{0, 0};
-  *total = all;
+  *total = wtot[2 * NW];
   return syn_ff_compose(pre, prev);
 }
 
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_summary(const double *
                                                                  int64_t y_length,
                                                                  const double *__restrict__ tsum, int ntiles,
                                                                  long long *__restrict__ summ /* 3 per tile */) {
-  __shared__ syn_ff wtot[KWY_WAVES];
+  __shared__ syn_ff wtot[2 * KWY_WAVES + 1];
   __shared__ double s_lo;
   const int t = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
@@ -271,37 +284,67 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_summary(const double *
 }
 
 // phase B3: the serial chain over tiles.  Fast tiles cost a few scalar operations (apply the
-// summary to the exact running phase); slow tiles (binade changes, the very beginning) are
-// produced here, sample by sample exactly, with workgroup-wide scans.
+// summary to the exact running phase).  Slow tiles (binade changes, the very beginning) are cut
+// here, with workgroup-wide scans, into segments that stay inside one binade: where each starts,
+// where it ends and the exact phase it starts from; their samples' phases (an fmod each: most of
+// what a round of this one workgroup used to cost) are left to the parallel pass like the fast
+// tiles'.  Only the samples that carry the phase into the next binade are produced here.
+#define SYN_MAXSEG 30
+#define SYN_WARM 512              // additions made one by one when the phase leaves zero
+struct syn_segs {                 // of one slow tile
+  int n;
+  int start[SYN_MAXSEG], end[SYN_MAXSEG];
+  double tp[SYN_MAXSEG];
+};
 __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__restrict__ inc,
                                                              int64_t y_length,
                                                              const long long *__restrict__ summ,
                                                              double *__restrict__ tin,
-                                                             double *__restrict__ wrap) {
-  __shared__ syn_ff wtot[SYN_PH_THREADS / 64];
-  __shared__ int s_cross;
+                                                             syn_segs *__restrict__ segs,
+                                                             double *__restrict__ wrap, long long *__restrict__ dbg) {
+  __shared__ syn_ff wtot[2 * (SYN_PH_THREADS / 64) + 1];
+  __shared__ int s_cross, s_tix;
   __shared__ double s_tp;
+  __shared__ double s_c[SYN_WARM + 1], s_tps[SYN_WARM];
   const int tid = threadIdx.x;
+  const int ntiles = (int)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE);
   double tp = 0.0;  // running phase (uniform across the block)
   int tix = 0;
-  for (int64_t tile0 = 0; tile0 < y_length; tile0 += SYN_PH_TILE, ++tix) {
-    const int tile_n = (int)min((int64_t)SYN_PH_TILE, y_length - tile0);
-    // ---- fast tile?  (the summaries come through the scalar cache: staging them in LDS was measured slower)
-    {
-      const long long d0 = summ[3 * tix], d1 = summ[3 * tix + 1];
-      const int k = (int)summ[3 * tix + 2];
-      if (k != SYN_SLOW && tp > 0.0 && syn_exponent(tp) == k) {
+  // in-kernel stamps (diagnostic: tools/syn_phase_stamps.py): [40] clock64 of the launch, [41] the same on the 100 MHz
+  // wall clock, [42] spent on fast tiles, [43] on slow tiles, [44] fast tiles, [45] slow tiles, [46] rounds
+  long long t_fast = 0, t_slow = 0, t_mark = dbg ? clock64() : 0;
+  const long long t_begin = t_mark, w_begin = dbg ? wall_clock64() : 0;
+  int n_fast = 0, n_slow = 0, n_rounds = 0;
+#define SYN_DBG_FAST() do { if (dbg) { const long long t_ = clock64(); t_fast += t_ - t_mark; t_mark = t_; ++n_fast; } } while (0)
+#define SYN_DBG_SLOW() do { if (dbg) { const long long t_ = clock64(); t_slow += t_ - t_mark; t_mark = t_; ++n_slow; } } while (0)
+  while (true) {
+    // ---- fast tiles: the first wavefront alone takes them one after the other (sixteen wavefronts stepping through
+    //      the same scalar chain took sixteen times the issue slots), until a tile needs the whole workgroup
+    if (tid < 64) {
+      while (tix < ntiles) {
+        const long long d0 = summ[3 * tix], d1 = summ[3 * tix + 1];
+        const int k = (int)summ[3 * tix + 2];
+        if (!(k != SYN_SLOW && tp > 0.0 && syn_exponent(tp) == k)) break;
         const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
         const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
         const long long m_out = m_in + ((m_in & 1) ? d1 : d0);
-        if ((m_out >> 53) == 0) {
-          if (tid == 0) tin[tix] = tp;
-          tp = ldexp((double)m_out, k - 52);
-          continue;
-        }
+        if ((m_out >> 53) != 0) break;
+        if (tid == 0) tin[tix] = tp;
+        tp = ldexp((double)m_out, k - 52);
+        ++tix;
+        SYN_DBG_FAST();
       }
-      if (tid == 0) tin[tix] = -1.0;  // produced here
+      if (tid == 0) { s_tix = tix; s_tp = tp; }
     }
+    __syncthreads();
+    tix = s_tix;
+    tp = s_tp;
+    __syncthreads();
+    if (tix >= ntiles) break;
+    const int64_t tile0 = (int64_t)tix * SYN_PH_TILE;
+    const int tile_n = (int)min((int64_t)SYN_PH_TILE, y_length - tile0);
+    if (tid == 0) tin[tix] = -1.0;  // cut into segments here
+    int nseg = 0;
     double c[SYN_PH_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
@@ -312,6 +355,7 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
     while (pos < tile_n) {
       if (tid == 0) s_cross = tile_n;
       __syncthreads();
+
       int cross;
       if (tp == 0.0) {
         // 0 + c is a plain addition, and while the increments are zero (an unvoiced beginning: leading silence
@@ -323,7 +367,12 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
           const int i = tid * SYN_PH_PER_THREAD + j;
           if (i >= pos && i < tile_n && c[j] != 0.0) my_first = i;
         }
-        if (my_first < tile_n) atomicMin(&s_cross, my_first);
+        {
+          int wmin = my_first;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) wmin = min(wmin, __shfl_xor(wmin, o));
+          if ((tid & 63) == 0 && wmin < tile_n) atomicMin(&s_cross, wmin);
+        }
         __syncthreads();
         cross = s_cross;
 #pragma unroll
@@ -338,43 +387,72 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
         syn_ff f[SYN_PH_PER_THREAD];
         syn_ff mine = {0, 0};
 #pragma unroll
-        for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
-          int i = tid * SYN_PH_PER_THREAD + j;
-          f[j] = (i >= pos && i < tile_n) ? syn_ff_make(c[j], k) : syn_ff{0, 0};
-          mine = syn_ff_compose(mine, f[j]);
+        for (int j = 0; j < SYN_PH_PER_THREAD; ++j) f[j] = syn_ff{0, 0};
+        if (((tid | 63) + 1) * SYN_PH_PER_THREAD > pos) {     // (a wavefront whose samples are all done has no maps to make)
+#pragma unroll
+          for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
+            int i = tid * SYN_PH_PER_THREAD + j;
+            if (i >= pos && i < tile_n) f[j] = syn_ff_make(c[j], k);
+            mine = syn_ff_compose(mine, f[j]);
+          }
         }
         syn_ff all;
         const syn_ff excl = syn_ff_block_exscan<SYN_PH_THREADS / 64>(mine, wtot, &all);
         long long m = m_in + ((m_in & 1) ? excl.d1 : excl.d0);
         int my_cross = tile_n;
-        double tpv[SYN_PH_PER_THREAD];
+        long long mv[SYN_PH_PER_THREAD];
 #pragma unroll
         for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
           int i = tid * SYN_PH_PER_THREAD + j;
           if (i >= pos && i < tile_n) {
             m += (m & 1) ? f[j].d1 : f[j].d0;
             if ((m >> 53) != 0 && my_cross == tile_n) my_cross = i;
-            tpv[j] = ldexp((double)m, k - 52);
-          } else {
-            tpv[j] = 0.0;
           }
+          mv[j] = m;
         }
-        if (my_cross < tile_n) atomicMin(&s_cross, my_cross);
+        // (behind a crossing every mantissa is out of range: one atomic per wavefront, not one per thread)
+        {
+          int wmin = my_cross;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) wmin = min(wmin, __shfl_xor(wmin, o));
+          if ((tid & 63) == 0 && wmin < tile_n) atomicMin(&s_cross, wmin);
+        }
         __syncthreads();
         cross = s_cross;
+        const bool direct = nseg >= SYN_MAXSEG;      // (no room for another segment: its samples are produced here)
 #pragma unroll
         for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
           int i = tid * SYN_PH_PER_THREAD + j;
           if (i >= pos && i < cross) {
-            wrap[tile0 + i] = fmod(tpv[j], SYN_TWO_PI);
-            if (i == cross - 1) s_tp = tpv[j];
+            if (direct) wrap[tile0 + i] = fmod(ldexp((double)mv[j], k - 52), SYN_TWO_PI);
+            if (i == cross - 1) s_tp = ldexp((double)mv[j], k - 52);
           }
+        }
+        if (cross > pos && !direct) {
+          if (tid == 0) { segs[tix].start[nseg] = pos; segs[tix].end[nseg] = cross; segs[tix].tp[nseg] = tp; }
+          ++nseg;
         }
         __syncthreads();
         if (cross > pos) tp = s_tp;
       }
-      if (cross < tile_n) {
-        // this addition leaves the binade (or starts from 0): do it for real
+      if (cross < tile_n && tp == 0.0) {
+        // The phase leaves zero: the next few hundred additions cross a binade every few samples (each crossing a
+        // round of the whole workgroup).  One thread makes them for real, one after the other; their fmods are
+        // taken by as many threads.
+        const int nw = min(SYN_WARM, tile_n - cross);
+        if (tid < nw) s_c[tid] = inc[tile0 + cross + tid];
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+          for (int q = 0; q < nw; ++q) { t = t + s_c[q]; s_tps[q] = t; }
+          s_tp = t;
+        }
+        __syncthreads();
+        if (tid < nw) wrap[tile0 + cross + tid] = fmod(s_tps[tid], SYN_TWO_PI);
+        tp = s_tp;
+        pos = cross + nw;
+      } else if (cross < tile_n) {
+        // this addition leaves the binade: do it for real
         tp = tp + inc[tile0 + cross];
         if (tid == 0) wrap[tile0 + cross] = fmod(tp, SYN_TWO_PI);
         pos = cross + 1;
@@ -382,39 +460,73 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
         pos = tile_n;
       }
       __syncthreads();
+      ++n_rounds;
     }
+    if (tid == 0) segs[tix].n = nseg;
+    ++tix;
+    SYN_DBG_SLOW();
+  }
+  if (dbg && tid == 0) {
+    dbg[40] = clock64() - t_begin; dbg[41] = wall_clock64() - w_begin; dbg[42] = t_fast; dbg[43] = t_slow;
+    dbg[44] = n_fast; dbg[45] = n_slow; dbg[46] = n_rounds;
   }
 }
 
-// phase B4: fast tiles, in parallel: every sample's exact phase from the tile's exact start
+// phase B4, in parallel: every sample's exact phase from the exact phase its tile (or its segment of a slow tile)
+// starts from
 __global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_apply(const double *__restrict__ inc, int64_t y_length,
                                                                const double *__restrict__ tin,
+                                                               const syn_segs *__restrict__ segs,
                                                                double *__restrict__ wrap) {
-  __shared__ syn_ff wtot[KWY_WAVES];
+  __shared__ syn_ff wtot[2 * KWY_WAVES + 1];
   const int t = blockIdx.x, tid = threadIdx.x;
-  const double tp = tin[t];
-  if (!(tp > 0.0)) return;  // produced by the chain kernel
-  const int k = syn_exponent(tp);
-  const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
-  const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
+  const double tp_tile = tin[t];
+  const bool fast = tp_tile > 0.0;
+  const int ns = fast ? 1 : segs[t].n;
   const int64_t base = (int64_t)t * SYN_PH_TILE + (int64_t)tid * SYN_TL_PER_THREAD;
-  syn_ff f[SYN_TL_PER_THREAD];
-  syn_ff mine = {0, 0};
+  double c[SYN_TL_PER_THREAD];
 #pragma unroll
-  for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
-    f[j] = (base + j < y_length) ? syn_ff_make(inc[base + j], k) : syn_ff{0, 0};
-    mine = syn_ff_compose(mine, f[j]);
-  }
-  syn_ff all;
-  const syn_ff excl = syn_ff_block_exscan<KWY_WAVES>(mine, wtot, &all);
-  long long m = m_in + ((m_in & 1) ? excl.d1 : excl.d0);
+  for (int j = 0; j < SYN_TL_PER_THREAD; ++j) c[j] = (base + j < y_length) ? inc[base + j] : 0.0;
+  // a sample's exact phase, from the segment it lies in; its fmod is taken once, behind the segments' scans
+  double tpv[SYN_TL_PER_THREAD];
 #pragma unroll
-  for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
-    if (base + j < y_length) {
-      m += (m & 1) ? f[j].d1 : f[j].d0;
-      wrap[base + j] = fmod(ldexp((double)m, k - 52), SYN_TWO_PI);
+  for (int j = 0; j < SYN_TL_PER_THREAD; ++j) tpv[j] = -1.0;
+  for (int q = 0; q < ns; ++q) {
+    const double tp = fast ? tp_tile : segs[t].tp[q];
+    const int s0 = fast ? 0 : segs[t].start[q], s1 = fast ? SYN_PH_TILE : segs[t].end[q];   // samples of the tile
+    const int k = syn_exponent(tp);
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
+    const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
+    // (a wavefront none of whose samples lies in the segment only takes part in the scan)
+    const bool active = ((tid | 63) + 1) * SYN_TL_PER_THREAD > s0 && (tid & ~63) * SYN_TL_PER_THREAD < s1;
+    syn_ff f[SYN_TL_PER_THREAD];
+    syn_ff mine = {0, 0};
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
+        const int li = tid * SYN_TL_PER_THREAD + j;
+        f[j] = (li >= s0 && li < s1 && base + j < y_length) ? syn_ff_make(c[j], k) : syn_ff{0, 0};
+        mine = syn_ff_compose(mine, f[j]);
+      }
     }
+    syn_ff all;
+    const syn_ff excl = syn_ff_block_exscan<KWY_WAVES>(mine, wtot, &all);
+    if (active) {
+      long long m = m_in + ((m_in & 1) ? excl.d1 : excl.d0);
+#pragma unroll
+      for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
+        const int li = tid * SYN_TL_PER_THREAD + j;
+        if (li >= s0 && li < s1 && base + j < y_length) {
+          m += (m & 1) ? f[j].d1 : f[j].d0;
+          tpv[j] = ldexp((double)m, k - 52);
+        }
+      }
+    }
+    __syncthreads();      // (wtot is reused by the next segment)
   }
+#pragma unroll
+  for (int j = 0; j < SYN_TL_PER_THREAD; ++j)
+    if (tpv[j] >= 0.0) wrap[base + j] = fmod(tpv[j], SYN_TWO_PI);
 }
 
 __device__ __forceinline__ bool syn_is_pulse(const double *__restrict__ wrap, int64_t n, int64_t y_length) {
@@ -867,7 +979,8 @@ static int syn_make_params(kwy_ctx *ctx, int64_t T, int fft_size, double frame_p
 
 // scratch of the placement alone (phase scan): from the context's arena
 static size_t syn_plan_scratch_bytes(int64_t y_length) {
-  return 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) + kwy_pad(64);
+  return 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) + kwy_pad(64) +
+         kwy_pad(sizeof(syn_segs) * (y_length / 4096 + 2));
 }
 
 static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const syn_plan &pl) {
@@ -878,8 +991,9 @@ static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const
   const size_t npt_alloc = (size_t)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE) + 1;
   double *ph_tsum = kwy_arena<double>(ctx, npt_alloc), *ph_tin = kwy_arena<double>(ctx, npt_alloc);
   long long *ph_summ = kwy_arena<long long>(ctx, 3 * npt_alloc);
+  syn_segs *ph_segs = kwy_arena<syn_segs>(ctx, npt_alloc);
   double *wrap = kwy_arena<double>(ctx, y_length);
-  if (!incr || !ph_tsum || !ph_tin || !ph_summ || !wrap) {
+  if (!incr || !ph_tsum || !ph_tin || !ph_summ || !ph_segs || !wrap) {
     ctx->err = "synthesize: scratch arena too small";
     return KWY_ENOMEM;
   }
@@ -891,9 +1005,9 @@ static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const
     hipLaunchKernelGGL(k_syn_tile_summary, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum,
                        npt, ph_summ);
     KWY_PROF(ctx, "k_syn_phase", hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream,
-                                                      incr, y_length, ph_summ, ph_tin, wrap));
+                                                      incr, y_length, ph_summ, ph_tin, ph_segs, wrap, (long long *)ctx->dbg));
     hipLaunchKernelGGL(k_syn_tile_apply, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tin,
-                       wrap);
+                       ph_segs, wrap);
   }
   hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, pl.tile_cnt);
   hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, pl.tile_cnt, nt, pl.npulse);
