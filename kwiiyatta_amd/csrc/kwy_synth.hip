@@ -321,9 +321,13 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
     // ---- fast tiles: the first wavefront alone takes them one after the other (sixteen wavefronts stepping through
     //      the same scalar chain took sixteen times the issue slots), until a tile needs the whole workgroup
     if (tid < 64) {
+      // (the next tile's summary is fetched while this one is applied: the chain waits for the phase, not for memory)
+      long long d0n = 0, d1n = 0, kn = SYN_SLOW;
+      if (tix < ntiles) { d0n = summ[3 * tix]; d1n = summ[3 * tix + 1]; kn = summ[3 * tix + 2]; }
       while (tix < ntiles) {
-        const long long d0 = summ[3 * tix], d1 = summ[3 * tix + 1];
-        const int k = (int)summ[3 * tix + 2];
+        const long long d0 = d0n, d1 = d1n;
+        const int k = (int)kn;
+        if (tix + 1 < ntiles) { d0n = summ[3 * (tix + 1)]; d1n = summ[3 * (tix + 1) + 1]; kn = summ[3 * (tix + 1) + 2]; }
         if (!(k != SYN_SLOW && tp > 0.0 && syn_exponent(tp) == k)) break;
         const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
         const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
@@ -444,7 +448,17 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
         __syncthreads();
         if (tid == 0) {
           double t = 0.0;
-          for (int q = 0; q < nw; ++q) { t = t + s_c[q]; s_tps[q] = t; }
+          int q = 0;
+          for (; q + 8 <= nw; q += 8) {          // eight at a time: one LDS round trip per eight dependent additions
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = s_c[q + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t = t + v[u]; v[u] = t; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s_tps[q + u] = v[u];
+          }
+          for (; q < nw; ++q) { t = t + s_c[q]; s_tps[q] = t; }
           s_tp = t;
         }
         __syncthreads();
