@@ -253,9 +253,10 @@ __device__ __forceinline__ double dtw_wave_rol1(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// v_min_f64 as is: fmin() puts a canonicalising v_max_f64 x, x in front of every operand that comes out of a load or
-// a lane shift (its contract for signalling NaNs), on the recurrence's dependence chain.  No NaN arises from finite
-// distances and +inf.
+// The recurrence's minimum.  fmin() puts a canonicalising v_max_f64 x, x in front of an operand that comes out of a
+// lane shift (its contract for signalling NaNs): one per step, on the dependence chain.  Measured and left alone: a
+// v_min_f64 in inline asm made the compiler pad every chunk with 17 s_nop; compiling the file without NaN
+// semantics removes the v_max (517 -> 501 us over the levels of 2201 x 2401) but covers every kernel of the file.
 __device__ __forceinline__ double dtw_min_raw(double a, double b) {
   return fmin(a, b);
 }

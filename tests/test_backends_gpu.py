@@ -114,8 +114,9 @@ def test_fastdtw_bit_exact(ko, Tx, Ty, dim, radius):
 def test_fastdtw_fuzz(ko):
     """Random shapes, radii and kinds of series (smooth, quantised with many exact ties, piecewise constant with long
     plateaux, steep local slopes): path and distance bit-exact.  The kernels take different routes with the size
-    (number of levels, strips per level, windows computed by the previous level's DP kernel, back-trace tables and
-    predecessor words staged in LDS or read from memory)."""
+    (number of levels, strips per level, single-strip levels in one fused launch, windows computed by the previous
+    level's trace from a table or by binary searches, entry columns per strip or the path walked in one piece,
+    predecessor planes staged in LDS or read from memory)."""
     from kwiiyatta_amd.backend import dtw
     rng = np.random.default_rng(20261004)
     kinds = ('smooth', 'ties', 'plateaux', 'steep')
