@@ -299,6 +299,8 @@ struct dtw_level_args {
   int next_len_x, next_len_y, radius;
   int32_t *lo_w, *hi_w;
   uint64_t *off_w, *soff_w;
+  const double *x, *y;          // this level's series, or null (k_dtw_small: distances computed by the kernel itself)
+  int dim;
 };
 
 #define DTW_WAVES 4
@@ -911,8 +913,35 @@ __global__ __launch_bounds__(DTW_TRACE_NT) void k_dtw_trace(dtw_level_args a) {
 // on another CU, for a few microseconds of work).  Everything a phase writes is read back by the same CU.  The
 // distances keep their own launch: one workgroup would take the units one after the other.
 #define DTW_SMALL_STRIPS 1
+// The distances of a single-strip level from series that fit the LDS whole (a few dozen frames each): one batch of
+// loads, then every cell from LDS -- no launch of its own (~10 us plus the gap) for a microsecond of work.
+__device__ __forceinline__ void dtw_dist_small(const dtw_level_args &a, unsigned char *lds) {
+  if (a.status[0] != 0) return;
+  const int len_x = a.len_x, len_y = a.len_y, dim = a.dim, dp = a.dim | 1;     // odd row stride: no bank conflicts
+  double *xs = (double *)lds, *ys = xs + (size_t)len_x * dp;
+  for (int e = threadIdx.x; e < len_x * dim; e += 64 * DTW_WAVES) { const int r = e / dim, c = e - r * dim; xs[r * dp + c] = a.x[e]; }
+  for (int e = threadIdx.x; e < len_y * dim; e += 64 * DTW_WAVES) { const int r = e / dim, c = e - r * dim; ys[r * dp + c] = a.y[e]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const bool valid = lane < len_x;
+  const int jmin = a.lo[0], l = valid ? a.lo[lane] : 0, h = valid ? a.hi[lane] : -1;
+  const int steps = (int)(a.soff[1] >> 6);            // one strip: its rectangle starts at 0
+  const double *xr = xs + (valid ? lane : 0) * dp;
+  for (int s = sub; s < steps; s += DTW_WAVES) {
+    const int j = jmin + s - lane;
+    double d = INFINITY;
+    if (j >= l && j <= h) {
+      const double *yr = ys + j * dp;
+      double acc = 0.0;
+      for (int c = 0; c < dim; ++c) { const double df = xr[c] - yr[c]; acc += df * df; }
+      d = sqrt(acc);
+    }
+    a.dist[dtw_skew_index(0, s, lane)] = d;
+  }
+}
 __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_small(dtw_level_args a) {
   extern __shared__ unsigned char bt[];
+  if (a.x) { dtw_dist_small(a, bt); __syncthreads(); }
   dtw_values_body<true>(a, bt);
   __syncthreads();
   const int nstrips = (a.len_x + 63) / 64;
@@ -1049,13 +1078,18 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
     a.radius = radius;
     a.lo_w = lo; a.hi_w = hi; a.off_w = off; a.soff_w = soff;
     const int nstrips = (len_x + 63) / 64;
+    const bool small = nstrips <= DTW_SMALL_STRIPS && bnd_lds;
+    // (the small kernel takes the distances along when both series fit its LDS)
+    const bool small_dist = small && sizeof(double) * (size_t)(len_x + len_y) * (size_t)(dim | 1) <= 96 * 1024;
+    a.x = small_dist ? xs[l] : nullptr; a.y = small_dist ? ys[l] : nullptr; a.dim = dim;
     // a workgroup per 16 steps of a strip; how many there are is known on the device only: as many workgroups as
     // this level's rectangles are estimated to have (the others return at once; more units: the workgroups loop)
     const uint64_t lv_units = std::min(cap_skew, dtw_cap_skew(len_x, len_y, radius, full)) / 1024 + 1;
-    KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3((unsigned)lv_units), dim3(KWY_THREADS), 0, ctx->stream, xs[l],
-                       ys[l], dim, len_x, len_y, lo, hi, soff, dist, status));
+    if (!small_dist)
+      KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3((unsigned)lv_units), dim3(KWY_THREADS), 0, ctx->stream, xs[l],
+                         ys[l], dim, len_x, len_y, lo, hi, soff, dist, status));
 
-    if (nstrips <= DTW_SMALL_STRIPS && bnd_lds) {
+    if (small) {
       a.lds_bytes = (int)big_lds;
       KWY_PROF(ctx, "k_dtw_small", hipLaunchKernelGGL(k_dtw_small, dim3(1), dim3(64 * DTW_WAVES), big_lds, ctx->stream, a));
       continue;
