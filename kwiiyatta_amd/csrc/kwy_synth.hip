@@ -246,11 +246,17 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_sums(const double *__r
 }
 
 // phase B2: per tile, guess the binade from the estimated start/end phase; if the tile safely stays
-// inside one binade, reduce its samples to ONE parity map (summary); otherwise mark it slow.
+// inside one binade, reduce its samples to ONE parity map (summary); otherwise mark it slow.  A slow tile whose
+// start is estimated in binade ka gets the maps of its 16 chunks of 256 samples for BOTH ka and ka + 1: the chain
+// then steps over the chunks and looks at single samples only inside the chunk where the phase changes binade.
+#define SYN_CHUNK 256
+#define SYN_NCHUNK (SYN_PH_TILE / SYN_CHUNK)
+struct syn_chunks { int ka; int pad; syn_ff m[SYN_NCHUNK][2]; };      // ka == SYN_SLOW: no chunk maps
 __global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_summary(const double *__restrict__ inc,
                                                                  int64_t y_length,
                                                                  const double *__restrict__ tsum, int ntiles,
-                                                                 long long *__restrict__ summ /* 3 per tile */) {
+                                                                 long long *__restrict__ summ /* 3 per tile */,
+                                                                 syn_chunks *__restrict__ chunks) {
   __shared__ syn_ff wtot[2 * KWY_WAVES + 1];
   __shared__ double s_lo;
   const int t = blockIdx.x, tid = threadIdx.x;
@@ -267,11 +273,34 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_summary(const double *
     if (ka == kb) k = ka;
   }
   long long *o = summ + 3 * (int64_t)t;
+  const int64_t tile0 = (int64_t)t * SYN_PH_TILE;
   if (k == SYN_SLOW) {
     if (tid == 0) { o[0] = 0; o[1] = 0; o[2] = SYN_SLOW; }
+    const int ka = lo > 0.0 ? syn_exponent(lo * (1.0 - 1e-9)) : SYN_SLOW;
+    if (tid == 0) chunks[t].ka = ka;
+    if (ka == SYN_SLOW) return;
+    // 16 threads x 16 samples = one chunk: the maps of a row of 16 lanes composed in order
+    syn_ff m0 = {0, 0}, m1 = {0, 0};
+#pragma unroll
+    for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
+      const int64_t n = tile0 + tid * SYN_TL_PER_THREAD + j;
+      if (n < y_length) {
+        const double cj = inc[n];
+        m0 = syn_ff_compose(m0, syn_ff_make(cj, ka));
+        m1 = syn_ff_compose(m1, syn_ff_make(cj, ka + 1));
+      }
+    }
+#pragma unroll
+    for (int ofs = 1; ofs < 16; ofs <<= 1) {
+      syn_ff u0, u1;
+      u0.d0 = __shfl_up(m0.d0, ofs, 16); u0.d1 = __shfl_up(m0.d1, ofs, 16);
+      u1.d0 = __shfl_up(m1.d0, ofs, 16); u1.d1 = __shfl_up(m1.d1, ofs, 16);
+      if ((tid & 15) >= ofs) { m0 = syn_ff_compose(u0, m0); m1 = syn_ff_compose(u1, m1); }
+    }
+    if ((tid & 15) == 15) { chunks[t].m[tid >> 4][0] = m0; chunks[t].m[tid >> 4][1] = m1; }
     return;
   }
-  const int64_t tile0 = (int64_t)t * SYN_PH_TILE;
+  if (tid == 0) chunks[t].ka = SYN_SLOW;
   syn_ff mine = {0, 0};
 #pragma unroll
   for (int j = 0; j < SYN_TL_PER_THREAD; ++j) {
@@ -301,9 +330,10 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
                                                              const long long *__restrict__ summ,
                                                              double *__restrict__ tin,
                                                              syn_segs *__restrict__ segs,
+                                                             const syn_chunks *__restrict__ chunks,
                                                              double *__restrict__ wrap, long long *__restrict__ dbg) {
   __shared__ syn_ff wtot[2 * (SYN_PH_THREADS / 64) + 1];
-  __shared__ int s_cross, s_tix;
+  __shared__ int s_cross, s_tix, s_pos, s_nseg;
   __shared__ double s_tp;
   __shared__ double s_c[SYN_WARM + 1], s_tps[SYN_WARM];
   const int tid = threadIdx.x;
@@ -349,13 +379,132 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
     const int tile_n = (int)min((int64_t)SYN_PH_TILE, y_length - tile0);
     if (tid == 0) tin[tix] = -1.0;  // cut into segments here
     int nseg = 0;
+    int pos = 0;  // first element of the tile not yet produced
+    // ---- a tile with chunk maps: the first wavefront steps over the chunks with the map of the current binade and
+    //      goes down to single samples (four per lane, wave-level scans, no barrier) only in a chunk where the
+    //      phase leaves the binade.  What it cannot finish (no maps for the binade reached) is left to the rounds.
+    if (tid < 64 && tp > 0.0 && chunks[tix].ka != SYN_SLOW) {
+      const int lane = tid;
+      const int ka = chunks[tix].ka;
+      // (the 32 maps of the tile in one load, handed out by lane: a load per chunk would be a round trip per chunk)
+      const syn_ff mymap = lane < 2 * SYN_NCHUNK ? chunks[tix].m[lane >> 1][lane & 1] : syn_ff{0, 0};
+      int seg_start = 0;
+      double seg_tp = tp;
+      bool give_up = false;
+      for (int ch = 0; ch < SYN_NCHUNK && pos < tile_n && !give_up; ++ch) {
+        int k = syn_exponent(tp);
+        if (k < ka || k > ka + 1) break;
+        {
+          syn_ff cm;
+          cm.d0 = __shfl(mymap.d0, 2 * ch + (k - ka));
+          cm.d1 = __shfl(mymap.d1, 2 * ch + (k - ka));
+          const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
+          const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
+          const long long m_out = m_in + ((m_in & 1) ? cm.d1 : cm.d0);
+          if ((m_out >> 53) == 0) {                    // the whole chunk stays in the binade
+            tp = ldexp((double)m_out, k - 52);
+            pos = min(tile_n, (ch + 1) * SYN_CHUNK);
+            continue;
+          }
+        }
+        // the chunk's samples one by one: lane l has samples 4 l .. 4 l + 3 of the chunk
+        double cc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = ch * SYN_CHUNK + 4 * lane + j;
+          cc[j] = i < tile_n ? inc[tile0 + i] : 0.0;
+        }
+        int p0 = ch * SYN_CHUNK;                       // first sample of the chunk not yet passed
+        const int pend = min(tile_n, (ch + 1) * SYN_CHUNK);
+        while (p0 < pend) {
+          k = syn_exponent(tp);
+          if (k < ka || k > ka + 1) { give_up = true; break; }
+          const unsigned long long tb = (unsigned long long)__double_as_longlong(tp);
+          const long long m_in = (long long)((tb & 0xfffffffffffffULL) | 0x10000000000000ULL);
+          syn_ff f[4], mine = {0, 0};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = ch * SYN_CHUNK + 4 * lane + j;
+            f[j] = (i >= p0 && i < pend) ? syn_ff_make(cc[j], k) : syn_ff{0, 0};
+            mine = syn_ff_compose(mine, f[j]);
+          }
+          syn_ff incl = mine;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            syn_ff u;
+            u.d0 = __shfl_up(incl.d0, o);
+            u.d1 = __shfl_up(incl.d1, o);
+            if (lane >= o) incl = syn_ff_compose(u, incl);
+          }
+          syn_ff ex;
+          ex.d0 = __shfl_up(incl.d0, 1);
+          ex.d1 = __shfl_up(incl.d1, 1);
+          if (lane == 0) ex = syn_ff{0, 0};
+          long long m = m_in + ((m_in & 1) ? ex.d1 : ex.d0);
+          long long mv[4];
+          int my_cross = pend;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = ch * SYN_CHUNK + 4 * lane + j;
+            if (i >= p0 && i < pend) {
+              m += (m & 1) ? f[j].d1 : f[j].d0;
+              if ((m >> 53) != 0 && my_cross == pend) my_cross = i;
+            }
+            mv[j] = m;
+          }
+          int cross = my_cross;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) cross = min(cross, __shfl_xor(cross, o));
+          // the phase in front of `cross` (or at the chunk's end): the mantissa of sample cross - 1
+          if (cross > p0) {
+            const int q = cross - 1 - ch * SYN_CHUNK;                 // its place in the chunk
+            const long long cand = (q & 3) == 0 ? mv[0] : (q & 3) == 1 ? mv[1] : (q & 3) == 2 ? mv[2] : mv[3];
+            const long long mq = __shfl(cand, q >> 2);
+            tp = ldexp((double)mq, k - 52);
+          }
+          if (cross >= pend) { p0 = pend; break; }
+          // sample `cross` carries the phase into the next binade: close the segment in front of it, add for real
+          if (cross > seg_start) {
+            if (nseg < SYN_MAXSEG) {
+              if (lane == 0) { segs[tix].start[nseg] = seg_start; segs[tix].end[nseg] = cross; segs[tix].tp[nseg] = seg_tp; }
+              ++nseg;
+            } else { give_up = true; break; }          // (the rounds below produce the rest themselves)
+          }
+          {
+            const int q = cross - ch * SYN_CHUNK;
+            const double cand = (q & 3) == 0 ? cc[0] : (q & 3) == 1 ? cc[1] : (q & 3) == 2 ? cc[2] : cc[3];
+            tp = tp + __shfl(cand, q >> 2);
+          }
+          if (lane == 0) wrap[tile0 + cross] = fmod(tp, SYN_TWO_PI);
+          p0 = cross + 1;
+          seg_start = p0;
+          seg_tp = tp;
+        }
+        if (give_up) { pos = seg_start; tp = seg_tp; break; }
+        pos = pend;
+      }
+      // the segment that is still open
+      if (!give_up && pos > seg_start) {
+        if (nseg < SYN_MAXSEG) {
+          if (lane == 0) { segs[tix].start[nseg] = seg_start; segs[tix].end[nseg] = pos; segs[tix].tp[nseg] = seg_tp; }
+          ++nseg;
+        } else { pos = seg_start; tp = seg_tp; }
+      }
+      if (lane == 0) { s_pos = pos; s_nseg = nseg; s_tp = tp; }
+    } else if (tid == 0) {
+      s_pos = 0; s_nseg = 0; s_tp = tp;
+    }
+    __syncthreads();
+    pos = s_pos;
+    nseg = s_nseg;
+    tp = s_tp;
+    __syncthreads();
     double c[SYN_PH_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < SYN_PH_PER_THREAD; ++j) {
       int i = tid * SYN_PH_PER_THREAD + j;
-      c[j] = i < tile_n ? inc[tile0 + i] : 0.0;
+      c[j] = (i < tile_n && pos < tile_n) ? inc[tile0 + i] : 0.0;
     }
-    int pos = 0;  // first element of the tile not yet produced
     while (pos < tile_n) {
       if (tid == 0) s_cross = tile_n;
       __syncthreads();
@@ -994,7 +1143,7 @@ static int syn_make_params(kwy_ctx *ctx, int64_t T, int fft_size, double frame_p
 // scratch of the placement alone (phase scan): from the context's arena
 static size_t syn_plan_scratch_bytes(int64_t y_length) {
   return 2 * kwy_pad(sizeof(double) * y_length) + 5 * kwy_pad(8 * (y_length / 4096 + 2)) + kwy_pad(64) +
-         kwy_pad(sizeof(syn_segs) * (y_length / 4096 + 2));
+         kwy_pad(sizeof(syn_segs) * (y_length / 4096 + 2)) + kwy_pad(sizeof(syn_chunks) * (y_length / 4096 + 2));
 }
 
 static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const syn_plan &pl) {
@@ -1006,8 +1155,9 @@ static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const
   double *ph_tsum = kwy_arena<double>(ctx, npt_alloc), *ph_tin = kwy_arena<double>(ctx, npt_alloc);
   long long *ph_summ = kwy_arena<long long>(ctx, 3 * npt_alloc);
   syn_segs *ph_segs = kwy_arena<syn_segs>(ctx, npt_alloc);
+  syn_chunks *ph_chunks = kwy_arena<syn_chunks>(ctx, npt_alloc);
   double *wrap = kwy_arena<double>(ctx, y_length);
-  if (!incr || !ph_tsum || !ph_tin || !ph_summ || !ph_segs || !wrap) {
+  if (!incr || !ph_tsum || !ph_tin || !ph_summ || !ph_segs || !ph_chunks || !wrap) {
     ctx->err = "synthesize: scratch arena too small";
     return KWY_ENOMEM;
   }
@@ -1017,9 +1167,9 @@ static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const
     const int npt = (int)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE);
     hipLaunchKernelGGL(k_syn_tile_sums, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum);
     hipLaunchKernelGGL(k_syn_tile_summary, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum,
-                       npt, ph_summ);
+                       npt, ph_summ, ph_chunks);
     KWY_PROF(ctx, "k_syn_phase", hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream,
-                                                      incr, y_length, ph_summ, ph_tin, ph_segs, wrap, (long long *)ctx->dbg));
+                                                      incr, y_length, ph_summ, ph_tin, ph_segs, ph_chunks, wrap, (long long *)ctx->dbg));
     hipLaunchKernelGGL(k_syn_tile_apply, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tin,
                        ph_segs, wrap);
   }
