@@ -17,6 +17,7 @@ for f in config4 corpus_ref_em corpus_hostpads fit_2rank_gloo corpus_2rank_gloo 
 done
 cp "$(newest "$S/stats_pair_b32/*/*kernel_stats.csv")" $P/${RND}_pair_b32_kernel_stats.csv
 cp "$(newest "$S/stats_pair_b1/*/*kernel_stats.csv")" $P/${RND}_pair_b1_kernel_stats.csv
+[ -d $S/stats_pair_b1_single ] && cp "$(newest "$S/stats_pair_b1_single/*/*kernel_stats.csv")" $P/${RND}_pair_b1_single_stream_kernel_stats.csv
 F=$(newest "$S/pmc_fetch/*/*counter_collection.csv"); W=$(newest "$S/pmc_write/*/*counter_collection.csv")
 cp "$F" $P/${RND}_pmc_fetch_counter_collection.csv
 cp "$W" $P/${RND}_pmc_write_counter_collection.csv

@@ -33,6 +33,9 @@ if [ "$PART" = a ]; then
 else
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b32 -- python $R/bench.py --no-cpu-baseline --no-pcie-variant > $O/stats_pair_b32.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b1 -- python $R/bench.py --batch 1 --steps 5 --no-cpu-baseline --no-pcie-variant > $O/stats_pair_b1.log 2>&1
+  # one pair on ONE stream: the analysis kernels take both utterances per launch (4 202 frames), alone on the chip --
+  # the launch `roofline.avg_launch_ms` of the bench line is about
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b1_single -- python $R/bench.py --batch 1 --side-stream off --steps 5 --no-cpu-baseline --no-pcie-variant > $O/stats_pair_b1_single.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
   KWY_MEASURE_OUT=$O/pmc_sq bash $R/tools/pmc_sq.sh
