@@ -170,6 +170,34 @@ def test_synthesis_voicing_patterns(ko, kw):
         assert np.array_equal(got, kw.synthesize(f0, sp, ap, fs, 5.0))
 
 
+@pytest.mark.parametrize('fs,seconds,f0_hz,lead', [
+    (16000, 30.0, 1250.0, 0),      # large increments (f0 < fs / 12): the first tiles cross several binades each, 18 binades in all
+    (48000, 20.0, 55.0, 0),        # small increments: long runs of fast tiles between the crossings
+    (16000, 12.0, 1200.0, 700),    # 3.5 s of silence in front, then a steep start in the middle of a tile
+    (48000, 6.0, 0.0, 0),          # nothing voiced: the 500 Hz default throughout
+])
+def test_synthesis_phase_chain_extremes(ko, kw, fs, seconds, f0_hz, lead):
+    """The exact-rounding phase chain on inputs that push it through its rarer routes: tiles with more than one
+    binade change (the chunk walk gives up and the workgroup rounds take over), many slow tiles, a warm-up that
+    starts inside a tile, segments handed to the parallel pass.  Pulse placement decides the waveform: it must equal
+    the oracle's."""
+    rng = np.random.default_rng(int(fs + f0_hz))
+    T = int(seconds * 200)
+    K = kw.get_cheaptrick_fft_size(fs) // 2 + 1
+    f0 = np.full(T, f0_hz) * np.exp(0.05 * np.sin(np.arange(T) / 23.0)) if f0_hz > 0 else np.zeros(T)
+    f0[:lead] = 0.0
+    if f0_hz > 0:
+        f0[T // 2:T // 2 + 40] = 0.0                      # an unvoiced stretch in the middle
+    k = np.arange(K)
+    sp = np.ascontiguousarray(np.exp(-k[None, :] / (K / 6.0)) * (1.0 + 0.3 * rng.random((T, 1))) * 1e-3 + 1e-9)
+    ap = np.ascontiguousarray(np.clip(0.1 + 0.8 * k[None, :] / K + np.zeros((T, 1)), 0.001, 0.999))
+    got, ref = kw.synthesize(f0, sp, ap, fs, 5.0), ko.synthesize(f0, sp, ap, fs, 5.0)
+    assert got.shape == ref.shape
+    scale = max(np.sqrt(np.mean(ref ** 2)), 1e-12)
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-9 * max(scale, 1.0) + 1e-12 * scale
+    assert np.array_equal(got, kw.synthesize(f0, sp, ap, fs, 5.0))
+
+
 def test_synthesis_is_deterministic(ko, kw):
     """Two runs give the same bits (ordered overlap-add, no floating-point atomics): what the reference asserts
     with `(analyzer_wav.data == feature_wav.data).all()`, tests/kwiiyatta/test_vocoder.py:171."""
