@@ -150,6 +150,20 @@ int kwy_synth_plan_dev(kwy_ctx *ctx, const double *f0, int64_t f0_length, int ff
                        int fs, int64_t y_length, void *plan);
 int kwy_synth_render_dev(kwy_ctx *ctx, const void *plan, int64_t f0_length, const double *sp, const double *ap,
                          int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length, double *y);
+/* ... for a batch of utterances: one pass of launches renders the pulses of all of them (every utterance a slice of
+ * the grids), as kwy_cheaptrick_batch_dev / kwy_d4c_batch_dev analyse them.  What Synthesizer.synthesize does file
+ * after file (kwiiyatta/vocoder/world.py:63-80, resynthesize_voice.py:46-79).  Every job's waveform equals
+ * kwy_synth_render_dev's bit for bit. */
+typedef struct kwy_synth_job {
+  const void *plan;             /* kwy_synth_plan_dev's output for this utterance */
+  const double *spectrogram;    /* f0_length x (fft_size/2+1) */
+  const double *aperiodicity;   /* f0_length x (fft_size/2+1) */
+  int64_t f0_length;
+  int64_t y_length;
+  double *y;                    /* y_length samples */
+} kwy_synth_job;
+int kwy_synth_render_batch_dev(kwy_ctx *ctx, const kwy_synth_job *jobs, int count, int fft_size,
+                               double frame_period_ms, int fs, double sp_mul);
 
 /* ---- mel-cepstrum ---------------------------------------------------------------- */
 /* pysptk.sp2mc(spec, order, alpha) row-wise          kwiiyatta/vocoder/mcep.py:71

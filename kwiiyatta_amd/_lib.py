@@ -90,6 +90,7 @@ SIGNATURES = {
     'kwy_synth_plan_bytes': (c_i64, [c_i64]),
     'kwy_synth_plan_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_i64, c_vp]),
     'kwy_synth_render_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_i64, c_vp]),
+    'kwy_synth_render_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_int, c_dbl]),
     'kwy_sp2mc': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_dbl, c_vp]),
     'kwy_sp2mc_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_dbl, c_vp]),
     'kwy_mc2sp': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_vp]),
@@ -170,6 +171,22 @@ def utterance_array(items):
         q.x, q.x_length = x.data_ptr(), x.numel()
         q.temporal_positions, q.f0, q.f0_length = t.data_ptr(), f0.data_ptr(), f0.numel()
         q.out = out.data_ptr()
+    return arr
+
+
+class SynthJob(ctypes.Structure):
+    """kwy_synth_job (include/kwy.h): one utterance of a batched rendering call"""
+    _fields_ = [('plan', c_vp), ('spectrogram', c_vp), ('aperiodicity', c_vp), ('f0_length', c_i64),
+                ('y_length', c_i64), ('y', c_vp)]
+
+
+def synth_job_array(items):
+    """items: (plan, sp, ap, y) device tensors per utterance (sp, ap: T x K; y: the waveform) -> a ctypes array of
+    kwy_synth_job"""
+    arr = (SynthJob * len(items))()
+    for q, (plan, sp, ap, y) in zip(arr, items):
+        q.plan, q.spectrogram, q.aperiodicity = plan.data_ptr(), sp.data_ptr(), ap.data_ptr()
+        q.f0_length, q.y_length, q.y = sp.shape[0], y.numel(), y.data_ptr()
     return arr
 
 

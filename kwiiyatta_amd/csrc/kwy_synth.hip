@@ -793,15 +793,38 @@ __device__ __forceinline__ double syn_safe_ap(double x) {
 // workgroups per CU.  The noise spectrum waits in registers (bins tid + 256 r) while the
 // buffer computes the aperiodic minimum-phase response.
 // (workgroups per CU by LDS: three up to 2048 points, two at 4096, one at 8192 -- the register budget follows)
+// One utterance of a rendering launch (descriptors by value in the kernel arguments, as for the analysis kernels):
+// a launch renders the pulses of up to KWY_BATCH_MAX utterances, each with its own slice of the grid.
+struct syn_view {
+  const double *sp, *ap;
+  syn_params p;
+  const int32_t *pidx;
+  const double *pshift;
+  const unsigned char *vuv8;
+  const int *npulse, *tile_off;
+  int cap, slots, nt;
+  double *resp, *y;
+};
+typedef kwy_batch<syn_view> syn_batch;
+
 template <int LOG2N, bool DIRECT>
 __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1)) void k_syn_pulse(
-    const double *__restrict__ sp, const double *__restrict__ ap, syn_params p,
-    const int32_t *__restrict__ pidx, const double *__restrict__ pshift,
-    const unsigned char *__restrict__ vuv8, const int *__restrict__ npulse, int cap,
-    kwy_randn_src rs, const uint4 *__restrict__ poly,
+    syn_batch batch, kwy_randn_src rs, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    const double *__restrict__ dc_remover, int first_pulse, int slots, double *__restrict__ resp,
-    double *__restrict__ y) {
+    const double *__restrict__ dc_remover) {
+  const int utt = batch.find(blockIdx.x);
+  const int lblock = (int)blockIdx.x - batch.start[utt], lgrid = batch.start[utt + 1] - batch.start[utt];
+  const double *__restrict__ sp = batch.u[utt].sp, *__restrict__ ap = batch.u[utt].ap;
+  const syn_params p = batch.u[utt].p;
+  const int32_t *__restrict__ pidx = batch.u[utt].pidx;
+  const double *__restrict__ pshift = batch.u[utt].pshift;
+  const unsigned char *__restrict__ vuv8 = batch.u[utt].vuv8;
+  const int *__restrict__ npulse = batch.u[utt].npulse;
+  const int cap = batch.u[utt].cap;
+  // the slots' round (every pulse its own slot), or the pulses beyond them (DIRECT: one workgroup, in order, onto y)
+  const int first_pulse = DIRECT ? batch.u[utt].slots : 0, slots = DIRECT ? cap : batch.u[utt].slots;
+  double *__restrict__ resp = batch.u[utt].resp;
+  double *__restrict__ y = batch.u[utt].y;
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   constexpr int C = N / KWY_THREADS;  // draws / output samples per thread
   constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
@@ -824,7 +847,7 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
   const kwy_c twb = twN[tid];
   const int P = min(npulse[0], cap);
   const int pend = min(P, first_pulse + slots);    // this round's pulses
-  for (int pp = first_pulse + blockIdx.x; pp < pend; pp += gridDim.x) {
+  for (int pp = first_pulse + lblock; pp < pend; pp += lgrid) {
     const int tid = kwy_tid_opaque();  // keeps address arithmetic local to the pulse (no spills across the FFTs)
     const int idx = pidx[pp];
     const int nxt = pidx[min(P - 1, pp + 1)];
@@ -989,14 +1012,17 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
 
 // y[n] (+)= the responses of this round's pulses that reach sample n, in pulse order.  The pulses of the
 // SYN_TILE-sample tiles within `reach` tiles of the output tile are candidates (tile_off: first pulse of a tile).
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_ola(const double *__restrict__ resp,
-                                                        const int32_t *__restrict__ pidx,
-                                                        const int *__restrict__ tile_off,
-                                                        const int *__restrict__ npulse, int cap, int nt, int N,
-                                                        int first_pulse, int slots, int64_t y_length,
-                                                        double *__restrict__ y) {
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_ola(syn_batch batch, int N) {
+  const int utt = batch.find(blockIdx.x);
+  const double *__restrict__ resp = batch.u[utt].resp;
+  const int32_t *__restrict__ pidx = batch.u[utt].pidx;
+  const int *__restrict__ tile_off = batch.u[utt].tile_off;
+  const int *__restrict__ npulse = batch.u[utt].npulse;
+  const int cap = batch.u[utt].cap, nt = batch.u[utt].nt, first_pulse = 0, slots = batch.u[utt].slots;
+  const int64_t y_length = batch.u[utt].p.y_length;
+  double *__restrict__ y = batch.u[utt].y;
   const int H = N / 2;
-  const int tile = blockIdx.x;
+  const int tile = (int)blockIdx.x - batch.start[utt];
   const int P = min(npulse[0], cap);
   if (first_pulse >= P && first_pulse > 0) return;     // a round without pulses leaves y alone
   const int reach = (H + SYN_TILE - 1) / SYN_TILE;
@@ -1055,31 +1081,37 @@ static int get_dc_remover(kwy_ctx *ctx, int fft_size, const double **out) {
 }
 
 template <int LOG2N>
-static int launch_pulse(kwy_ctx *ctx, const double *sp, const double *ap, const syn_params &p,
-                        const int32_t *pidx, const double *pshift, const unsigned char *vuv8,
-                        const int *npulse, int cap, const double *dcrem,
-                        const int *tile_off, int nt, int slots, double *resp, double *y) {
+static int launch_pulse(kwy_ctx *ctx, syn_batch &batch) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   const kwy_c *twH, *twN;
   const uint4 *poly;
+  const double *dcrem;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
   KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
+  KWY_TRY(get_dc_remover(ctx, N, &dcrem));
   size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) +
                sizeof(double) * (2 * (K + 1) + (LOG2N <= 11 ? N : 0) + 8) + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int grid = slots < 2048 ? slots : 2048;
-  if (grid < 1) grid = 1;
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL((k_syn_pulse<LOG2N, false>), dim3(grid), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
-                     pidx, pshift, vuv8, npulse, cap, kwy_randn(ctx), poly, twH, twN, dcrem, 0, slots, resp, y));
-  KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, resp, pidx, tile_off,
-                     npulse, cap, nt, N, 0, slots, p.y_length, y));
-  // pulses beyond the slots (none for speech): one workgroup, serial, same order
-  KWY_PROF(ctx, "k_syn_pulse_more", hipLaunchKernelGGL((k_syn_pulse<LOG2N, true>), dim3(1), dim3(KWY_THREADS), lds, ctx->stream, sp, ap, p,
-                     pidx, pshift, vuv8, npulse, cap, kwy_randn(ctx), poly, twH, twN, dcrem, slots, cap, resp, y));
+  // every utterance its slice of a persistent grid (a pulse's slot does not depend on the slice: the waveform
+  // is the same whatever the batch)
+  const int share = batch.n > 1 ? std::max(64, 4096 / batch.n) : 2048;
+  int g = 0;
+  for (int u = 0; u < batch.n; ++u) { batch.start[u] = g; g += std::max(1, std::min(batch.u[u].slots, share)); }
+  batch.start[batch.n] = g;
+  KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL((k_syn_pulse<LOG2N, false>), dim3(g), dim3(KWY_THREADS), lds, ctx->stream, batch,
+                     kwy_randn(ctx), poly, twH, twN, dcrem));
+  g = 0;
+  for (int u = 0; u < batch.n; ++u) { batch.start[u] = g; g += batch.u[u].nt; }
+  batch.start[batch.n] = g;
+  KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(g), dim3(KWY_THREADS), 0, ctx->stream, batch, N));
+  // pulses beyond the slots (none for speech): one workgroup per utterance, serial, same order
+  for (int u = 0; u <= batch.n; ++u) batch.start[u] = u;
+  KWY_PROF(ctx, "k_syn_pulse_more", hipLaunchKernelGGL((k_syn_pulse<LOG2N, true>), dim3(batch.n), dim3(KWY_THREADS), lds, ctx->stream,
+                     batch, kwy_randn(ctx), poly, twH, twN, dcrem));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -1181,25 +1213,38 @@ static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const
   return KWY_OK;
 }
 
-static int synth_render(kwy_ctx *ctx, const syn_plan &pl, const double *sp, const double *ap, const syn_params &p,
-                        int log2n, double *y) {
+static int syn_fill_view(kwy_ctx *ctx, const syn_plan &pl, const double *sp, const double *ap, const syn_params &p,
+                         double *y, syn_view *v) {
   const int64_t y_length = p.y_length;
-  const int nt = (int)((y_length + SYN_TILE - 1) / SYN_TILE);
-  const int cap = syn_pulse_cap(y_length);
-  const int slots = SYN_SLOTS(y_length, p.fs);
-  double *resp = kwy_arena<double>(ctx, (size_t)slots * p.fft_size);
-  if (!resp) { ctx->err = "synthesize: scratch arena too small"; return KWY_ENOMEM; }
-  const double *dcrem;
-  KWY_TRY(get_dc_remover(ctx, p.fft_size, &dcrem));
+  v->sp = sp; v->ap = ap; v->p = p;
+  v->pidx = pl.pidx; v->pshift = pl.pshift; v->vuv8 = pl.vuv8; v->npulse = pl.npulse; v->tile_off = pl.tile_cnt;
+  v->cap = syn_pulse_cap(y_length);
+  v->slots = SYN_SLOTS(y_length, p.fs);
+  v->nt = (int)((y_length + SYN_TILE - 1) / SYN_TILE);
+  v->resp = kwy_arena<double>(ctx, (size_t)v->slots * p.fft_size);
+  v->y = y;
+  if (!v->resp) { ctx->err = "synthesize: scratch arena too small"; return KWY_ENOMEM; }
+  return KWY_OK;
+}
+
+static int syn_launch(kwy_ctx *ctx, syn_batch &batch, int log2n) {
   switch (log2n) {
-    case 9: return launch_pulse<9>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
-    case 10: return launch_pulse<10>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
-    case 11: return launch_pulse<11>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
-    case 12: return launch_pulse<12>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    case 9: return launch_pulse<9>(ctx, batch);
+    case 10: return launch_pulse<10>(ctx, batch);
+    case 11: return launch_pulse<11>(ctx, batch);
+    case 12: return launch_pulse<12>(ctx, batch);
     // 8192: features resampled up to 96 kHz (3078 bins -> 4097, kwiiyatta/vocoder/world.py:71-78); rare, runs
     // with the 256-thread layout of the shorter transforms (register spills accepted)
-    default: return launch_pulse<13>(ctx, sp, ap, p, pl.pidx, pl.pshift, pl.vuv8, pl.npulse, cap, dcrem, pl.tile_cnt, nt, slots, resp, y);
+    default: return launch_pulse<13>(ctx, batch);
   }
+}
+
+static int synth_render(kwy_ctx *ctx, const syn_plan &pl, const double *sp, const double *ap, const syn_params &p,
+                        int log2n, double *y) {
+  syn_batch batch;
+  batch.n = 1;
+  KWY_TRY(syn_fill_view(ctx, pl, sp, ap, p, y, &batch.u[0]));
+  return syn_launch(ctx, batch, log2n);
 }
 
 static int synth_core(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp, const double *ap,
@@ -1273,6 +1318,41 @@ extern "C" int kwy_synth_render_dev(kwy_ctx *ctx, const void *plan, int64_t T, c
   }
   KWY_TRY(kwy_arena_begin(ctx, syn_render_scratch_bytes(y_length, fft_size, fs)));
   return synth_render(ctx, syn_plan_carve(const_cast<void *>(plan), y_length), sp, ap, p, log2n, y);
+}
+
+// The rendering of several utterances in one pass of launches (include/kwy.h).
+extern "C" int kwy_synth_render_batch_dev(kwy_ctx *ctx, const kwy_synth_job *jobs, int count, int fft_size,
+                                          double frame_period_ms, int fs, double sp_mul) {
+  if (!ctx) return KWY_EINVAL;
+  if (!jobs || count < 0) { ctx->err = "synth_render_batch: bad argument"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  size_t bytes = 0;
+  for (int j = 0; j < count; ++j) {
+    const kwy_synth_job &q = jobs[j];
+    KWY_TRY(syn_check(ctx, q.spectrogram, q.f0_length, q.spectrogram, q.aperiodicity, fft_size, frame_period_ms, fs,
+                      q.y_length, q.y));
+    if (!q.plan) { ctx->err = "synth_render_batch: bad argument"; return KWY_EINVAL; }
+    bytes += syn_render_scratch_bytes(q.y_length, fft_size, fs);
+  }
+  KWY_TRY(kwy_arena_begin(ctx, bytes));
+  syn_batch batch;
+  batch.n = 0;
+  int log2n = 0;
+  for (int j = 0; j < count; ++j) {
+    const kwy_synth_job &q = jobs[j];
+    if (q.y_length == 0) continue;
+    syn_params p;
+    KWY_TRY(syn_make_params(ctx, q.f0_length, fft_size, frame_period_ms, fs, sp_mul, q.y_length, &p, &log2n));
+    if (q.y_length < 2 || q.f0_length < 2) {
+      KWY_HIP(hipMemsetAsync(q.y, 0, sizeof(double) * q.y_length, ctx->stream));
+      continue;
+    }
+    KWY_TRY(syn_fill_view(ctx, syn_plan_carve(const_cast<void *>(q.plan), q.y_length), q.spectrogram, q.aperiodicity, p,
+                          q.y, &batch.u[batch.n]));
+    if (++batch.n == KWY_BATCH_MAX) { KWY_TRY(syn_launch(ctx, batch, log2n)); batch.n = 0; }
+  }
+  if (batch.n > 0) KWY_TRY(syn_launch(ctx, batch, log2n));
+  return KWY_OK;
 }
 
 extern "C" int kwy_synthesize(kwy_ctx *ctx, const double *f0, int64_t T, const double *sp,

@@ -140,6 +140,46 @@ def test_synthesis_plan_render_split(ko, kw):
     assert np.array_equal(whole.cpu().numpy(), kw.synthesize(f0, sp, ap, fs, 5.0))
 
 
+def test_synthesis_render_batch(ko, kw):
+    """kwy_synth_render_batch_dev: the pulses of several utterances (different lengths, one of them unvoiced
+    throughout) rendered by one pass of launches -- every waveform equals the single-utterance call's bit for bit."""
+    import torch
+    from kwiiyatta_amd import _lib
+    lib = _lib.lib
+    fs, x = load(clb_variant('48'))
+    f0, t = f0_track(ko, x, fs)
+    sp, ap = kw.cheaptrick(x, f0, t, fs), kw.d4c(x, f0, t, fs)
+    dev = torch.device('cuda', 0)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)    # noqa: E731
+    p = lambda a: _lib.c_vp(a.data_ptr())                              # noqa: E731
+    ctx = _lib.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    fft = (sp.shape[1] - 1) * 2
+    cuts = [(0, len(f0)), (40, 300), (100, 101 + 2), (0, 150)]
+    jobs, want = [], []
+    for n, (a, b) in enumerate(cuts):
+        f = f0[a:b].copy()
+        if n == 3:
+            f[:] = 0.0
+        T = len(f)
+        ylen = lib.kwy_synth_length(T, 5.0, fs)
+        df0, dsp, dap = d(f), d(sp[a:b]), d(ap[a:b])
+        plan = torch.empty(lib.kwy_synth_plan_bytes(ylen), dtype=torch.uint8, device=dev)
+        _lib.check(ctx, lib.kwy_synth_plan_dev(ctx.handle, p(df0), T, fft, 5.0, fs, ylen, p(plan)))
+        single = torch.empty(ylen, dtype=torch.float64, device=dev)
+        _lib.check(ctx, lib.kwy_synth_render_dev(ctx.handle, p(plan), T, p(dsp), p(dap), fft, 5.0, fs, 1.0, ylen,
+                                                 p(single)))
+        torch.cuda.synchronize()        # (the context has its own stream: torch's copies do not wait for it)
+        want.append(single.cpu().numpy())
+        jobs.append((plan, dsp, dap, torch.full((ylen,), np.nan, dtype=torch.float64, device=dev)))
+    torch.cuda.synchronize()
+    arr = _lib.synth_job_array(jobs)
+    _lib.check(ctx, lib.kwy_synth_render_batch_dev(ctx.handle, arr, len(jobs), fft, 5.0, fs, 1.0))
+    torch.cuda.synchronize()
+    for (plan, dsp, dap, y), w in zip(jobs, want):
+        assert np.array_equal(y.cpu().numpy(), w)
+    assert np.array_equal(want[0], kw.synthesize(f0, sp, ap, fs, 5.0))
+
+
 def test_synthesis_voicing_patterns(ko, kw):
     """Random voiced / unvoiced schedules -- silence at the start, in the middle, at the end, single voiced frames,
     f0 jumps -- at two rates: the exact-rounding phase scan takes different routes through its tiles (fast tiles,
