@@ -181,7 +181,8 @@ int kwy_mc2sp_dev(kwy_ctx *ctx, const double *mc, int64_t T, int order, double a
 /* ---- alignment -------------------------------------------------------------------- */
 /* fastdtw.fastdtw(x, y, radius, dist=2) -> (dist, path)
  *                                                    kwiiyatta/vocoder/align.py:71
- * x: Tx x dim, y: Ty x dim; path: capacity (Tx+Ty) x 2 int32, *path_len pairs written. */
+ * x: Tx x dim, y: Ty x dim; path: capacity (Tx+Ty) x 2 int32, *path_len pairs written.
+ * radius >= 1 (KWY_EINVAL otherwise: fastdtw 0.3.2 raises a KeyError for radius 0). */
 int kwy_fastdtw(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty,
                 int dim, int radius, double *dist, int32_t *path, int64_t *path_len);
 int kwy_fastdtw_dev(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty,

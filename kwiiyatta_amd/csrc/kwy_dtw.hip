@@ -1120,6 +1120,8 @@ static int dtw_check(kwy_ctx *ctx, const void *x, int64_t Tx, const void *y, int
     ctx->err = "fastdtw: bad argument";
     return KWY_EINVAL;
   }
+  // radius 0: fastdtw 0.3.2 itself fails there (a KeyError: with an odd length the last row gets no window cells)
+  if (radius < 1) { ctx->err = "fastdtw: radius must be >= 1"; return KWY_EINVAL; }
   return KWY_OK;
 }
 

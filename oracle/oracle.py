@@ -317,6 +317,8 @@ def mcepalpha(fs, start=0.0, stop=1.0, step=0.001, num_points=1000):
 
 def fastdtw(x, y, radius=1, dist=2):
     assert dist == 2, 'oracle restates the dist=2 (Euclidean) call only'
+    if int(radius) < 1:        # fastdtw 0.3.2 itself fails there (a KeyError: the last odd row gets no window)
+        raise ValueError('fastdtw: radius must be >= 1')
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     if x.ndim == 1:

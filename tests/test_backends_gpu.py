@@ -95,7 +95,8 @@ def _series(rng, T, dim, warp):
     (300, 350, 26, 32), (737, 801, 25, 1), (2201, 2401, 26, 32), (2401, 2201, 26, 32),
     (4700, 5300, 3, 8),     # boundary rows too long for LDS (the global-memory variant of the recurrence)
     (40, 9000, 2, 32), (9000, 40, 2, 32),   # windows wider than a strip's LDS (the back-trace in one piece) / 141 strips
-    (1500, 1400, 2, 300), (900, 1000, 3, 100)])   # wide bands: some strips keep their entry columns, some do not
+    (1500, 1400, 2, 300), (900, 1000, 3, 100),    # wide bands: some strips keep their entry columns, some do not
+    (130, 150, 70, 32)])   # more dimensions than one LDS tile of the distances
 def test_fastdtw_bit_exact(ko, Tx, Ty, dim, radius):
     from kwiiyatta_amd.backend import dtw
     rng = np.random.default_rng(Tx * 7919 + Ty)
@@ -109,6 +110,17 @@ def test_fastdtw_bit_exact(ko, Tx, Ty, dim, radius):
     assert tuple(p[0]) == (0, 0) and tuple(p[-1]) == (Tx - 1, Ty - 1)
     dp = np.diff(p, axis=0)
     assert ((dp >= 0) & (dp <= 1)).all() and (dp.sum(axis=1) >= 1).all()
+
+
+def test_fastdtw_rejects_radius_zero(ko):
+    """radius 0 leaves the last row of an odd-length series without window cells: fastdtw 0.3.2 raises a KeyError
+    there; the library and the oracle refuse the call."""
+    from kwiiyatta_amd.backend import dtw
+    x, y = np.zeros((5, 2)), np.ones((7, 2))
+    with pytest.raises(ValueError):
+        dtw.fastdtw(x, y, radius=0, dist=2)
+    with pytest.raises(ValueError):
+        ko.fastdtw(x, y, radius=0, dist=2)
 
 
 def test_fastdtw_fuzz(ko):
