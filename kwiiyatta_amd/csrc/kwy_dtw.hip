@@ -5,17 +5,18 @@
 // on the host (sizes depend only on Tx, Ty, radius); everything else stays on
 // the device with no host synchronisation:
 //
-//   k_dtw_halve    coarsen a series: (x[2i] + x[2i+1]) / 2
-//   k_dtw_window   per-row column window from the coarser level's path
-//                  (monotone path => two binary searches per row, no atomics)
-//   k_dtw_dist     Euclidean frame distances for every cell of the band (parallel)
-//   k_dtw_dp       one workgroup: rows are processed in strips of 64, lane = row,
-//                  skewed so that lane l works on column j - l; the three
-//                  predecessors arrive by wave shuffles (DPP), the strip boundary
-//                  row goes through LDS, four wavefronts pipeline the strips.  Every
-//                  cell also carries the column at which its best path entered the
-//                  strip, so that the back-trace first hops from strip to strip and
-//                  then walks all strips at once, one lane per strip.
+//   k_dtw_halve_all    all coarsening levels of both series: (x[2i] + x[2i+1]) / 2, level after level in LDS
+//   k_dtw_window_scan  the coarsest level's (full) windows; every other level's windows come out of the tail of the
+//                      level before (k_dtw_trace): a table {first column, last column} per coarse row, two look-ups
+//   k_dtw_dist         Euclidean frame distances for every cell of the strips' rectangles (skewed band: see below)
+//   k_dtw_values       ONE workgroup, the recurrence and nothing else: rows in strips of 64, lane = row, lane l works
+//                      on column j - l; the neighbours' values arrive by DPP shifts, the strip boundary row goes
+//                      through LDS, four wavefronts pipeline the strips; D is written to a second skewed band
+//   k_dtw_codes        one workgroup per strip: predecessor of every cell (two bit planes) and, for the cells of the
+//                      strip's last row, the column at which the best path entered the strip
+//   k_dtw_trace        ONE workgroup: hops from strip to strip over the entry columns, walks all strips at once (one
+//                      lane each), copies the segments, computes the next level's windows
+//   k_dtw_small        a level of a single strip: distances, recurrence, codes and trace in one launch
 //
 // Tie-breaking follows fastdtw's pure-Python min(): (i-1,j), (i,j-1), (i-1,j-1).
 #include <math.h>
