@@ -244,7 +244,9 @@ def main():
     ap_ = argparse.ArgumentParser()
     ap_.add_argument('--gpus', type=int, default=1)
     ap_.add_argument('--steps', type=int, default=20)
-    ap_.add_argument('--warmup', type=int, default=5)
+    ap_.add_argument('--warmup', type=int, default=25,
+                     help='untimed steps first (a box that has just started needs more than a few: its first ~0.3 s of '
+                          'work run 5 %% slower -- clocks, first touches -- whatever the code does)')
     ap_.add_argument('--batch', type=int, default=32, help='utterance pairs per GPU per step (one stream each)')
     ap_.add_argument('--seconds', type=float, default=10.0, help='source utterance length')
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
