@@ -40,9 +40,8 @@ class _TrainSide:
     def __init__(self, x, f0, t, fs, K, order, dev):
         f64 = dict(dtype=torch.float64, device=dev)
         self.N, self.T = len(x), len(f0)
-        self.x = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-        self.f0 = torch.from_numpy(np.ascontiguousarray(f0)).to(dev)
-        self.t = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+        up = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+        self.x, self.f0, self.t = up(x), up(f0), up(t)
         Tp = self.T + 2 * PAD_LEN
         self.sp_pad = torch.empty((Tp, K), **f64)
         self.ap_pad = torch.full((Tp, K), 1 - SAFE_GUARD_MINIMUM, **f64)
@@ -193,7 +192,11 @@ class ConvertPipeline(_Graphed):
         self.mcep_fs = int(mcep_fs) if mcep_fs is not None and int(mcep_fs) != self.fs else None
         self.rng = rng
         with torch.cuda.stream(self.stream):
-            self.x, self.f0, self.t = (torch.from_numpy(np.ascontiguousarray(a)).to(self.dev) for a in (x, f0, t))
+            for a in (x, f0, t):
+                if torch.is_tensor(a):
+                    a.record_stream(self.stream)        # (cloned below on this stream; the caller may drop it)
+            self.x, self.f0, self.t = (a.clone() if torch.is_tensor(a) else
+                                       torch.from_numpy(np.ascontiguousarray(a)).to(self.dev) for a in (x, f0, t))
             self.sp = torch.empty((self.T, self.K), **f64)
             self.ap = torch.empty((self.T, self.K), **f64)
             self.mc = torch.empty((self.T, order + 1), **f64)
@@ -232,6 +235,8 @@ class ConvertPipeline(_Graphed):
             raise ValueError('ConvertPipeline.load: shape differs from the pipeline\'s')
         with torch.cuda.stream(self.stream):
             for dst, src in ((self.x, x), (self.f0, f0), (self.t, t)):
+                if torch.is_tensor(src):
+                    src.record_stream(self.stream)      # (the caller may drop it while the copy is still queued)
                 dst.copy_(src if torch.is_tensor(src) else torch.from_numpy(np.ascontiguousarray(src)),
                           non_blocking=True)
 
@@ -357,6 +362,51 @@ class _silence_ahead:
         self.thread.join(timeout=5.0)
 
 
+class _upload_ahead:
+    """The waveforms, f0 tracks and frame times of the pairs as device tensors, uploaded by a helper thread in pair
+    order while the caller enqueues GPU work: a copy from pageable host memory blocks its caller (0.2 ms per 5 s
+    waveform at 48 kHz, six copies per pair: 0.5 ms of the ~1.3 ms of host time a pair costs) and releases the
+    interpreter lock meanwhile.  A copy is complete when the helper hands the tensors over.  `stop()` ends the thread."""
+
+    def __init__(self, pairs, dev, depth):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.halt = threading.Event()
+
+        def side_up(side):
+            return tuple(a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in side)
+
+        def hand(item):
+            while not self.halt.is_set():
+                try:
+                    self.q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                for it in pairs:
+                    if not hand(tuple(side_up(side) for side in it)):
+                        return
+            except Exception as exc:        # handed to the consumer: it raises where the pair would have been built
+                hand(exc)
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+
+    def get(self):
+        item = self.q.get()
+        if isinstance(item, Exception):
+            raise item
+        return item
+
+    def stop(self):
+        self.halt.set()
+        self.thread.join(timeout=5.0)
+
+
 def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_period=5.0, streams=16,
                           silence_for=None, pool=None, rng=None, pairs_before=0):
     """pairs: list of ((x, f0, t), (x, f0, t)) numpy triples of THIS rank, in corpus order.  Returns the
@@ -380,6 +430,7 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
             for _ in range(pairs_before):
                 rng.abs_normal_blocks(scale, sink)
     ahead = _silence_ahead(len(pairs), fs, 2 * len(pool)) if silence_for is None and rng is None and pairs else None
+    uploads = _upload_ahead(pairs, dev, 2 * len(pool)) if pairs else None
     blocks, frames = [], 0
 
     def finish(wave):
@@ -399,7 +450,8 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
         prev = None
         for w0 in range(0, len(pairs), len(pool)):
             wave = []
-            for k, (src, tgt) in enumerate(pairs[w0:w0 + len(pool)]):
+            for k in range(len(pairs[w0:w0 + len(pool)])):
+                src, tgt = uploads.get()        # (the pair's arrays, on the device already)
                 ready = None
                 if silence_for is not None:
                     sil = silence_for(w0 + k)
@@ -424,6 +476,8 @@ def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_
     finally:
         if ahead is not None:
             ahead.stop()
+        if uploads is not None:
+            uploads.stop()
     if not blocks:
         return torch.empty((0, 6 * order), dtype=torch.float64, device=dev), 0
     X = torch.cat(blocks).contiguous()

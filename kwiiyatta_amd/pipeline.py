@@ -332,6 +332,8 @@ class UtterancePipeline(_Graphed):
             raise ValueError('UtterancePipeline.load: shape differs from the pipeline\'s')
         with torch.cuda.stream(self.stream):
             for dst, src in ((self.x, x), (self.f0, f0), (self.t, t)):
+                if torch.is_tensor(src):
+                    src.record_stream(self.stream)      # (the caller may drop it while the copy is still queued)
                 dst.copy_(src if torch.is_tensor(src) else torch.from_numpy(np.ascontiguousarray(src)),
                           non_blocking=True)
 
