@@ -150,6 +150,17 @@ int kwy_synth_plan_dev(kwy_ctx *ctx, const double *f0, int64_t f0_length, int ff
                        int fs, int64_t y_length, void *plan);
 int kwy_synth_render_dev(kwy_ctx *ctx, const void *plan, int64_t f0_length, const double *sp, const double *ap,
                          int fft_size, double frame_period_ms, int fs, double sp_mul, int64_t y_length, double *y);
+/* The pulse placement of several utterances in one pass of launches: the serial phase chain of an utterance is one
+ * workgroup, so N utterances occupy N compute units side by side (Synthesizer.synthesize runs file after file,
+ * kwiiyatta/vocoder/world.py:80-92).  Every plan equals kwy_synth_plan_dev's bit for bit. */
+typedef struct kwy_synth_plan_job {
+  const double *f0;      /* f0_length */
+  int64_t f0_length;
+  int64_t y_length;
+  void *plan;            /* kwy_synth_plan_bytes(y_length) bytes */
+} kwy_synth_plan_job;
+int kwy_synth_plan_batch_dev(kwy_ctx *ctx, const kwy_synth_plan_job *jobs, int count, int fft_size,
+                             double frame_period_ms, int fs);
 /* ... for a batch of utterances: one pass of launches renders the pulses of all of them (every utterance a slice of
  * the grids), as kwy_cheaptrick_batch_dev / kwy_d4c_batch_dev analyse them.  What Synthesizer.synthesize does file
  * after file (kwiiyatta/vocoder/world.py:63-80, resynthesize_voice.py:46-79).  Every job's waveform equals
@@ -187,6 +198,21 @@ int kwy_fastdtw(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int6
                 int dim, int radius, double *dist, int32_t *path, int64_t *path_len);
 int kwy_fastdtw_dev(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty,
                     int dim, int radius, double *dist, int32_t *path, int64_t *path_len);
+/* ... for a batch of pairs (device pointers): every kernel of the level recursion runs all pairs in one grid -- the
+ * serial recurrence of a pair is one workgroup, so N pairs occupy N compute units instead of one after the other --
+ * what align does pair after pair over a corpus (kwiiyatta/vocoder/align.py:61-96,123-131, convert_voice.py:35-46).
+ * Every job's distance and path equal kwy_fastdtw_dev's bit for bit.  The scratch capacities are bounds for any
+ * pair of lengths (no overflow, whatever the length ratio). */
+typedef struct kwy_dtw_job {
+  const double *x;       /* x_length x dim */
+  int64_t x_length;
+  const double *y;       /* y_length x dim */
+  int64_t y_length;
+  double *dist;          /* 1 */
+  int32_t *path;         /* capacity (x_length + y_length) x 2 */
+  int64_t *path_len;     /* 1 */
+} kwy_dtw_job;
+int kwy_fastdtw_batch_dev(kwy_ctx *ctx, const kwy_dtw_job *jobs, int count, int dim, int radius);
 
 /* Device-side glue that keeps a source/target pair resident in HBM between the
  * stages (used by the batched pipeline; the host API does these in numpy):
@@ -196,14 +222,38 @@ int kwy_fastdtw_dev(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, 
 int kwy_align_features_dev(kwy_ctx *ctx, const double *mc, int64_t T, int ncoef, const double *f0,
                            double power_weight, double power_threshold, double vuv_weight,
                            double *out);
+typedef struct kwy_align_job {
+  const double *mc;      /* T x ncoef */
+  const double *f0;      /* T (or any per-frame voicing value: > 0 = voiced) */
+  int64_t T;
+  double *out;           /* T x (ncoef + 1) */
+} kwy_align_job;
+int kwy_align_features_batch_dev(kwy_ctx *ctx, const kwy_align_job *jobs, int count, int ncoef, double power_weight,
+                                 double power_threshold, double vuv_weight);
 /* project_path_iter(path, trim, trim_len): one x index per y frame
  *                                                    kwiiyatta/vocoder/align.py:99-120
  * path / path_len as produced by kwy_fastdtw_dev (device); trim_len = 0: no trimming. */
 int kwy_align_project_dev(kwy_ctx *ctx, const int32_t *path, const int64_t *path_len, int trim_len,
                           int32_t *idx, int64_t idx_capacity, int64_t *n_out);
+typedef struct kwy_project_job {
+  const int32_t *path;
+  const int64_t *path_len;
+  int32_t *idx;
+  int64_t idx_capacity;
+  int64_t *n_out;
+} kwy_project_job;
+int kwy_align_project_batch_dev(kwy_ctx *ctx, const kwy_project_job *jobs, int count, int trim_len);
 /* Feature.__getitem__(list): dst[i] = src[idx[i]]    kwiiyatta/vocoder/abc/feature.py:170-194 */
 int kwy_gather_rows_dev(kwy_ctx *ctx, const double *src, int64_t src_rows, int width,
                         const int32_t *idx, int64_t n, double *dst);
+typedef struct kwy_gather_job {
+  const double *src;     /* src_rows x width */
+  int64_t src_rows;
+  const int32_t *idx;    /* n */
+  int64_t n;
+  double *dst;           /* n x width */
+} kwy_gather_job;
+int kwy_gather_rows_batch_dev(kwy_ctx *ctx, const kwy_gather_job *jobs, int count, int width);
 
 /* ---- converter apply ---------------------------------------------------------------- */
 /* delta_features(X, DELTA_WINDOWS) + MLPG(gmm, windows, diff).transform(X)[:, :d]
@@ -242,6 +292,16 @@ int kwy_gmm_mlpg_model_dev(kwy_ctx *ctx, const double *x, int64_t T, int d, int 
  * GMM, MLPG) with a prepared model (diff = 0 or 1 as given to kwy_gmm_prepare_dev). */
 int kwy_convert_mcep_dev(kwy_ctx *ctx, const double *mc, int64_t T, int d, int M, const double *model,
                          double *mc_out);
+/* ... for a batch of utterances: the frame-parallel kernels (deltas, mixture log-densities on the matrix cores,
+ * conditional means) run over the frames of all of them, the trajectory solves of all of them share two launches
+ * (convert_voice.py:35-46 converts file after file).  Every job's result equals kwy_convert_mcep_dev's bit for bit. */
+typedef struct kwy_convert_job {
+  const double *mc;      /* T x (d + 1) */
+  int64_t T;
+  double *mc_out;        /* T x (d + 1) */
+} kwy_convert_job;
+int kwy_convert_mcep_batch_dev(kwy_ctx *ctx, const kwy_convert_job *jobs, int count, int d, int M,
+                               const double *model);
 
 /* ---- cross-rate aperiodicity codec ------------------------------------------------------
  * pyworld.code_aperiodicity(ap, fs) / pyworld.decode_aperiodicity(coded, fs, fft_size)

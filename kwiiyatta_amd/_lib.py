@@ -89,6 +89,7 @@ SIGNATURES = {
                                    c_i64, c_vp]),
     'kwy_synth_plan_bytes': (c_i64, [c_i64]),
     'kwy_synth_plan_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_i64, c_vp]),
+    'kwy_synth_plan_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_int]),
     'kwy_synth_render_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_i64, c_vp]),
     'kwy_synth_render_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_int, c_dbl]),
     'kwy_sp2mc': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_dbl, c_vp]),
@@ -97,9 +98,13 @@ SIGNATURES = {
     'kwy_mc2sp_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_int, c_vp]),
     'kwy_fastdtw': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'kwy_fastdtw_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'kwy_fastdtw_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int]),
     'kwy_align_features_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_dbl, c_dbl, c_dbl, c_vp]),
+    'kwy_align_features_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_dbl]),
     'kwy_align_project_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp]),
+    'kwy_align_project_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int]),
     'kwy_gather_rows_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_vp]),
+    'kwy_gather_rows_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int]),
     'kwy_gmm_em_estep_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'kwy_gmm_em_sums_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     'kwy_gmm_em_means_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
@@ -145,6 +150,7 @@ SIGNATURES = {
     'kwy_gmm_prepare_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_gmm_mlpg_model_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     'kwy_convert_mcep_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
+    'kwy_convert_mcep_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp]),
 }
 
 MISSING = []
@@ -187,6 +193,34 @@ def synth_job_array(items):
     for q, (plan, sp, ap, y) in zip(arr, items):
         q.plan, q.spectrogram, q.aperiodicity = plan.data_ptr(), sp.data_ptr(), ap.data_ptr()
         q.f0_length, q.y_length, q.y = sp.shape[0], y.numel(), y.data_ptr()
+    return arr
+
+
+def _job_struct(name, doc, fields):
+    return type(name, (ctypes.Structure,), {'__doc__': doc, '_fields_': fields})
+
+
+DtwJob = _job_struct('DtwJob', 'kwy_dtw_job (include/kwy.h): one pair of a batched FastDTW call',
+                     [('x', c_vp), ('x_length', c_i64), ('y', c_vp), ('y_length', c_i64), ('dist', c_vp), ('path', c_vp),
+                      ('path_len', c_vp)])
+AlignJob = _job_struct('AlignJob', 'kwy_align_job: DTW feature rows of one utterance',
+                       [('mc', c_vp), ('f0', c_vp), ('T', c_i64), ('out', c_vp)])
+ProjectJob = _job_struct('ProjectJob', 'kwy_project_job: one path projected onto its target axis',
+                         [('path', c_vp), ('path_len', c_vp), ('idx', c_vp), ('idx_capacity', c_i64), ('n_out', c_vp)])
+GatherJob = _job_struct('GatherJob', 'kwy_gather_job: one row gather',
+                        [('src', c_vp), ('src_rows', c_i64), ('idx', c_vp), ('n', c_i64), ('dst', c_vp)])
+ConvertJob = _job_struct('ConvertJob', 'kwy_convert_job: one utterance of a batched conversion',
+                         [('mc', c_vp), ('T', c_i64), ('mc_out', c_vp)])
+SynthPlanJob = _job_struct('SynthPlanJob', 'kwy_synth_plan_job: the pulse placement of one utterance',
+                           [('f0', c_vp), ('f0_length', c_i64), ('y_length', c_i64), ('plan', c_vp)])
+
+
+def job_array(struct, rows):
+    """rows: tuples in the struct's field order; device tensors become their data pointers"""
+    arr = (struct * len(rows))()
+    for q, row in zip(arr, rows):
+        for (name, _), v in zip(struct._fields_, row):
+            setattr(q, name, v.data_ptr() if hasattr(v, 'data_ptr') else v)
     return arr
 
 

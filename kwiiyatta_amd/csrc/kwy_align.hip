@@ -15,10 +15,10 @@
 // Every workgroup finds the power threshold (max over all frames of c0, minus the offset) for itself -- T loads of
 // an L2-resident column -- and then writes the feature rows of its 8 frames: one launch instead of a reduction
 // kernel followed by a row kernel.
-__global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__restrict__ mc, int64_t T,
-                                                               int ncoef, const double *__restrict__ f0,
-                                                               double power_threshold, double power_weight,
-                                                               double vuv_weight, double *__restrict__ out) {
+__device__ __forceinline__ void align_features_body(const double *__restrict__ mc, int64_t T,
+                                                    int ncoef, const double *__restrict__ f0,
+                                                    double power_threshold, double power_weight,
+                                                    double vuv_weight, double *__restrict__ out) {
   __shared__ double red[KWY_WAVES];
   const int tid = threadIdx.x;
   double mx = -INFINITY;
@@ -49,10 +49,10 @@ __global__ __launch_bounds__(KWY_THREADS) void k_align_features(const double *__
 // the produced indices leave through LDS as well.
 #define AL_TILE 1024
 #define AL_NT 256
-__global__ __launch_bounds__(AL_NT) void k_align_project(const int32_t *__restrict__ path,
-                                                        const int64_t *__restrict__ path_len, int trim_len,
-                                                        int32_t *__restrict__ idx, int64_t cap,
-                                                        int64_t *__restrict__ n_out) {
+__device__ __forceinline__ void align_project_body(const int32_t *__restrict__ path,
+                                                   const int64_t *__restrict__ path_len, int trim_len,
+                                                   int32_t *__restrict__ idx, int64_t cap,
+                                                   int64_t *__restrict__ n_out) {
   __shared__ int32_t sp[2 * AL_TILE];
   __shared__ int32_t so[AL_TILE];
   __shared__ long long st[4];  // prev_x, prev_y, n, stop
@@ -144,8 +144,31 @@ __global__ __launch_bounds__(AL_NT) void k_align_project(const int32_t *__restri
   if (lane == 0) *n_out = st[2];
 }
 
-__global__ void k_gather_rows(const double *__restrict__ src, int64_t src_rows, int width,
-                              const int32_t *__restrict__ idx, int64_t n, double *__restrict__ dst) {
+// The three kernels take their jobs by value (up to AL_BATCH per launch, blockIdx.y = job): the pairs of a batch
+// driver share one launch, a single call is a batch of one.
+#define AL_BATCH 64
+template <class JOB>
+struct al_jobs { int n; JOB j[AL_BATCH]; };
+
+__global__ __launch_bounds__(KWY_THREADS) void k_align_features(al_jobs<kwy_align_job> b, int ncoef,
+                                                               double power_threshold, double power_weight,
+                                                               double vuv_weight) {
+  const kwy_align_job &q = b.j[blockIdx.y];
+  if ((int64_t)blockIdx.x * 8 >= q.T) return;
+  align_features_body(q.mc, q.T, ncoef, q.f0, power_threshold, power_weight, vuv_weight, q.out);
+}
+
+__global__ __launch_bounds__(AL_NT) void k_align_project(al_jobs<kwy_project_job> b, int trim_len) {
+  const kwy_project_job &q = b.j[blockIdx.x];
+  align_project_body(q.path, q.path_len, trim_len, q.idx, q.idx_capacity, q.n_out);
+}
+
+__global__ void k_gather_rows(al_jobs<kwy_gather_job> b, int width) {
+  const kwy_gather_job &q = b.j[blockIdx.y];
+  const double *__restrict__ src = q.src;
+  const int32_t *__restrict__ idx = q.idx;
+  double *__restrict__ dst = q.dst;
+  const int64_t src_rows = q.src_rows, n = q.n;
   const int64_t row = blockIdx.x;
   if (row >= n) return;
   int64_t r = idx[row];
@@ -156,40 +179,84 @@ __global__ void k_gather_rows(const double *__restrict__ src, int64_t src_rows, 
   for (int c = threadIdx.x; c < width; c += blockDim.x) d[c] = s[c];
 }
 
+template <class JOB, class LAUNCH>
+static int al_for_batches(const JOB *jobs, int count, LAUNCH launch) {
+  for (int j0 = 0; j0 < count; j0 += AL_BATCH) {
+    al_jobs<JOB> b;
+    b.n = count - j0 < AL_BATCH ? count - j0 : AL_BATCH;
+    for (int k = 0; k < AL_BATCH; ++k) b.j[k] = jobs[j0 + (k < b.n ? k : 0)];
+    launch(b);
+  }
+  return KWY_OK;
+}
+
+extern "C" int kwy_align_features_batch_dev(kwy_ctx *ctx, const kwy_align_job *jobs, int count, int ncoef,
+                                            double power_weight, double power_threshold, double vuv_weight) {
+  if (!ctx) return KWY_EINVAL;
+  if (!jobs || count < 0 || ncoef < 1) { ctx->err = "align_features: bad argument"; return KWY_EINVAL; }
+  for (int j = 0; j < count; ++j)
+    if (!jobs[j].mc || !jobs[j].f0 || !jobs[j].out || jobs[j].T <= 0) { ctx->err = "align_features: bad argument"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  al_for_batches(jobs, count, [&](const al_jobs<kwy_align_job> &b) {
+    int64_t T = 0;
+    for (int k = 0; k < b.n; ++k) T = b.j[k].T > T ? b.j[k].T : T;
+    hipLaunchKernelGGL(k_align_features, dim3((unsigned)((T + 7) / 8), b.n), dim3(KWY_THREADS), 0, ctx->stream, b, ncoef,
+                       power_threshold, power_weight, vuv_weight);
+  });
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
 extern "C" int kwy_align_features_dev(kwy_ctx *ctx, const double *mc, int64_t T, int ncoef, const double *f0,
                                       double power_weight, double power_threshold, double vuv_weight,
                                       double *out) {
+  const kwy_align_job job = {mc, f0, T, out};
+  return kwy_align_features_batch_dev(ctx, &job, 1, ncoef, power_weight, power_threshold, vuv_weight);
+}
+
+extern "C" int kwy_align_project_batch_dev(kwy_ctx *ctx, const kwy_project_job *jobs, int count, int trim_len) {
   if (!ctx) return KWY_EINVAL;
-  if (!mc || !f0 || !out || T <= 0 || ncoef < 1) { ctx->err = "align_features: bad argument"; return KWY_EINVAL; }
+  if (!jobs || count < 0 || trim_len < 0) { ctx->err = "align_project: bad argument"; return KWY_EINVAL; }
+  for (int j = 0; j < count; ++j)
+    if (!jobs[j].path || !jobs[j].path_len || !jobs[j].idx || !jobs[j].n_out || jobs[j].idx_capacity <= 0) {
+      ctx->err = "align_project: bad argument";
+      return KWY_EINVAL;
+    }
   KWY_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_align_features, dim3((unsigned)((T + 7) / 8)), dim3(KWY_THREADS), 0, ctx->stream, mc, T,
-                     ncoef, f0, power_threshold, power_weight, vuv_weight, out);
+  al_for_batches(jobs, count, [&](const al_jobs<kwy_project_job> &b) {
+    hipLaunchKernelGGL(k_align_project, dim3(b.n), dim3(AL_NT), 0, ctx->stream, b, trim_len);
+  });
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
 
 extern "C" int kwy_align_project_dev(kwy_ctx *ctx, const int32_t *path, const int64_t *path_len, int trim_len,
                                      int32_t *idx, int64_t idx_capacity, int64_t *n_out) {
+  const kwy_project_job job = {path, path_len, idx, idx_capacity, n_out};
+  return kwy_align_project_batch_dev(ctx, &job, 1, trim_len);
+}
+
+extern "C" int kwy_gather_rows_batch_dev(kwy_ctx *ctx, const kwy_gather_job *jobs, int count, int width) {
   if (!ctx) return KWY_EINVAL;
-  if (!path || !path_len || !idx || !n_out || trim_len < 0 || idx_capacity <= 0) {
-    ctx->err = "align_project: bad argument";
-    return KWY_EINVAL;
-  }
+  if (!jobs || count < 0 || width <= 0) { ctx->err = "gather_rows: bad argument"; return KWY_EINVAL; }
+  for (int j = 0; j < count; ++j)
+    if (!jobs[j].src || !jobs[j].idx || !jobs[j].dst || jobs[j].src_rows <= 0 || jobs[j].n < 0) {
+      ctx->err = "gather_rows: bad argument";
+      return KWY_EINVAL;
+    }
   KWY_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_align_project, dim3(1), dim3(AL_NT), 0, ctx->stream, path, path_len, trim_len, idx,
-                     idx_capacity, n_out);
+  al_for_batches(jobs, count, [&](const al_jobs<kwy_gather_job> &b) {
+    int64_t n = 0;
+    for (int k = 0; k < b.n; ++k) n = b.j[k].n > n ? b.j[k].n : n;
+    if (n > 0)
+      hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n, b.n), dim3(width >= 256 ? 256 : 64), 0, ctx->stream, b, width);
+  });
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
 
 extern "C" int kwy_gather_rows_dev(kwy_ctx *ctx, const double *src, int64_t src_rows, int width,
                                    const int32_t *idx, int64_t n, double *dst) {
-  if (!ctx) return KWY_EINVAL;
-  if (!src || !idx || !dst || src_rows <= 0 || width <= 0 || n < 0) { ctx->err = "gather_rows: bad argument"; return KWY_EINVAL; }
-  if (n == 0) return KWY_OK;
-  KWY_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n), dim3(width >= 256 ? 256 : 64), 0, ctx->stream, src,
-                     src_rows, width, idx, n, dst);
-  KWY_HIP(hipGetLastError());
-  return KWY_OK;
+  const kwy_gather_job job = {src, src_rows, idx, n, dst};
+  return kwy_gather_rows_batch_dev(ctx, &job, 1, width);
 }

@@ -40,38 +40,6 @@ __global__ void k_dtw_halve(const double *__restrict__ in, int n_out, int dim, d
 // level after level, so the values are bit-identical to k_dtw_halve's.  (n_l = n >> l: the odd frame left over at
 // a level is dropped there, as fastdtw's x[:len(x) // 2 * 2] does.)
 #define DTW_MAXLV 12
-struct dtw_halve_desc {
-  const double *src[2];
-  double *lv[2][DTW_MAXLV];     // lv[s][l - 1]: level l of series s
-  int n[2];
-  int chunks0;                  // workgroups of series 0
-  int levels, dim;
-};
-__global__ __launch_bounds__(KWY_THREADS) void k_dtw_halve_all(dtw_halve_desc d) {
-  extern __shared__ double hb[];
-  const int s = blockIdx.x < d.chunks0 ? 0 : 1;
-  const int c = s == 0 ? blockIdx.x : blockIdx.x - d.chunks0;
-  const int C = 1 << d.levels, dim = d.dim, n = d.n[s];
-  double *A = hb, *B = hb + (size_t)C * dim;
-  const int64_t f0 = (int64_t)c * C;
-  const int have = (int)min((int64_t)C, (int64_t)n - f0);
-  for (int e = threadIdx.x; e < have * dim; e += KWY_THREADS) A[e] = d.src[s][f0 * dim + e];
-  __syncthreads();
-  for (int l = 1; l <= d.levels; ++l) {
-    const int nl = n >> l, per = C >> l;
-    const int i0 = c * per;
-    const int cnt = min(per, nl - i0);           // level-l elements of this workgroup (may be <= 0)
-    double *out = d.lv[s][l - 1];
-    for (int e = threadIdx.x; e < cnt * dim; e += KWY_THREADS) {
-      const int i = e / dim, k = e - i * dim;
-      const double v = (A[(2 * i) * dim + k] + A[(2 * i + 1) * dim + k]) / 2;
-      B[e] = v;
-      out[(int64_t)(i0 + i) * dim + k] = v;
-    }
-    __syncthreads();
-    double *t = A; A = B; B = t;
-  }
-}
 
 // Window rows.  cpath == nullptr: full window (the coarsest level).  Otherwise cpath is the coarser level's path (cn
 // cells, both coordinates non-decreasing): row i takes the columns of the path cells within +-radius rows of i / 2,
@@ -151,14 +119,13 @@ __device__ __forceinline__ void dtw_window_scan_body(const int32_t *__restrict__
 // The coarsest level (full window) has its own launch, which also clears the status words of the call; every other
 // level's windows are computed by the tail of the previous level's k_dtw_trace (same workgroup, path still hot).
 #define DTW_WS_NT 1024
-__global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(int radius, int len_x, int len_y, int32_t *lo, int32_t *hi,
-                                                              uint64_t *off, uint64_t *soff, uint64_t cap_rows,
-                                                              uint64_t cap_skew, int *status) {
-  __shared__ uint64_t tot[DTW_WS_NT];
+__device__ __forceinline__ void dtw_window_scan_first(int radius, int len_x, int len_y, int32_t *lo, int32_t *hi,
+                                                      uint64_t *off, uint64_t *soff, uint64_t cap_rows,
+                                                      uint64_t cap_skew, int *status, uint64_t *tot, size_t tot_bytes) {
   if (threadIdx.x < 16) status[threadIdx.x] = 0;
   __syncthreads();
   dtw_window_scan_body<DTW_WS_NT>((const int32_t *)nullptr, 0, radius, len_x, len_y, lo, hi, off, soff, cap_rows,
-                                  cap_skew, status, (unsigned char *)tot, sizeof(tot));
+                                  cap_skew, status, (unsigned char *)tot, tot_bytes);
 }
 
 // dist(i, j) = || x_i - y_j ||_2 (sequential sum over the dimensions) for every cell of the strips' rectangles that
@@ -228,14 +195,7 @@ __device__ __forceinline__ void dtw_dist_body(const double *x, const double *y, 
     __syncthreads();        // (the tiles are rewritten by the next unit)
   }
 }
-__global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(const double *__restrict__ x, const double *__restrict__ y,
-                                                         int dim, int len_x, int len_y, const int32_t *__restrict__ lo,
-                                                         const int32_t *__restrict__ hi,
-                                                         const uint64_t *__restrict__ soff,
-                                                         double *__restrict__ dist, const int *__restrict__ status) {
-  __shared__ double tiles[(64 + 80) * DTW_DTP];
-  dtw_dist_body(x, y, dim, len_x, len_y, lo, hi, soff, dist, status, blockIdx.x, gridDim.x, (unsigned char *)tiles);
-}
+// (the kernels themselves follow the batch descriptor's helpers: see k_dtw_* below)
 
 // lane l <- lane l-1 across the whole wavefront (DPP wave_shr:1, no LDS round trip);
 // lane 0, which has no source, gets its own lane of `first`.
@@ -303,6 +263,71 @@ struct dtw_level_args {
   const double *x, *y;          // this level's series, or null (k_dtw_small: distances computed by the kernel itself)
   int dim;
 };
+
+// ---- batches of pairs ------------------------------------------------------------------------------------
+// Every kernel of the level recursion takes a batch of up to KWY_BATCH_MAX pairs (descriptors by value in the kernel
+// arguments, as for the analysis kernels) and the level to work on; workgroup (.., pair) builds the pair's
+// dtw_level_args itself.  All pairs share one scratch layout, sized by the longest series of the batch: the pieces of
+// pair p live at scratch + p * stride + off_*.  A pair has its own number of levels (lengths halve until one is
+// shorter than radius + 2); the launches go from the batch's coarsest level down to 0 and a pair that has no such
+// level yet sits the launch out.  A single call is a batch of one: the same kernels everywhere.
+#define DTW_OFFLV 32      // (lengths below 2^30: fewer levels than this)
+struct dtw_pair {
+  const double *x, *y;
+  int Tx, Ty;
+  double *dist;
+  int32_t *path;
+  int64_t *path_len;
+};
+struct dtw_batch {
+  int n, dim, radius;
+  int lds_bytes;
+  char *scratch;
+  uint64_t stride;
+  uint64_t cap_rows, cap_skew;
+  uint64_t off_x[DTW_OFFLV], off_y[DTW_OFFLV];                // coarsened series of level l >= 1
+  uint64_t off_dist, off_dval, off_soff, off_predm, off_lo, off_hi, off_off, off_bnd, off_pathA, off_pathB, off_rev,
+      off_sinfo, off_lenA, off_lenB, off_status;
+  int bnd_lds;                  // boundary rows of the strips in LDS (else off_bnd)
+  long long *dbg;
+  dtw_pair p[KWY_BATCH_MAX];
+};
+__host__ __device__ static inline int dtw_num_levels(int Tx, int Ty, int radius) {
+  int n = 1;
+  while (!(Tx < radius + 2 || Ty < radius + 2)) { Tx /= 2; Ty /= 2; ++n; }
+  return n;
+}
+// the arguments of pair `pi` at level `lev` (0 = the finest); false: the pair has no such level
+__device__ __forceinline__ bool dtw_make_args(const dtw_batch &b, int pi, int lev, bool with_series, dtw_level_args &a) {
+  const dtw_pair &q = b.p[pi];
+  const int nlev = dtw_num_levels(q.Tx, q.Ty, b.radius);
+  if (lev >= nlev) return false;
+  char *base = b.scratch + (uint64_t)pi * b.stride;
+  a.len_x = q.Tx >> lev; a.len_y = q.Ty >> lev;
+  a.lo = (int32_t *)(base + b.off_lo); a.hi = (int32_t *)(base + b.off_hi);
+  a.off = (uint64_t *)(base + b.off_off); a.soff = (uint64_t *)(base + b.off_soff);
+  a.cap_rows = b.cap_rows; a.cap_skew = b.cap_skew;
+  a.dist = (double *)(base + b.off_dist); a.dval = (double *)(base + b.off_dval);
+  a.predm = (uint64_t *)(base + b.off_predm);
+  a.bnd_global = b.bnd_lds ? nullptr : (double *)(base + b.off_bnd);
+  const bool top = lev == 0;
+  a.path = top ? q.path : (int32_t *)(base + ((lev & 1) ? b.off_pathA : b.off_pathB));
+  a.path_len = top ? q.path_len : (int64_t *)(base + ((lev & 1) ? b.off_lenA : b.off_lenB));
+  a.rev = (int32_t *)(base + b.off_rev); a.sinfo = (int32_t *)(base + b.off_sinfo);
+  a.out_dist = q.dist;
+  a.status = (int *)(base + b.off_status);
+  a.dbg = b.dbg;
+  a.lds_bytes = b.lds_bytes;
+  a.next_len_x = top ? 0 : q.Tx >> (lev - 1);
+  a.next_len_y = top ? 0 : q.Ty >> (lev - 1);
+  a.radius = b.radius;
+  a.lo_w = (int32_t *)(base + b.off_lo); a.hi_w = (int32_t *)(base + b.off_hi);
+  a.off_w = (uint64_t *)(base + b.off_off); a.soff_w = (uint64_t *)(base + b.off_soff);
+  a.x = with_series ? (lev == 0 ? q.x : (const double *)(base + b.off_x[lev])) : nullptr;
+  a.y = with_series ? (lev == 0 ? q.y : (const double *)(base + b.off_y[lev])) : nullptr;
+  a.dim = b.dim;
+  return true;
+}
 
 #define DTW_WAVES 4
 // Steps between two looks at the previous strip's progress.  Strip k+1 trails strip k by the 63
@@ -513,11 +538,6 @@ __device__ __forceinline__ void dtw_values_body(const dtw_level_args &a, unsigne
     }
   }
 }
-template <bool BND_LDS>
-__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_values(dtw_level_args a) {
-  extern __shared__ unsigned char bt[];
-  dtw_values_body<BND_LDS>(a, bt);
-}
 
 // Codes and entry columns of one strip.
 // Phase 1 works in the recurrence's own coordinates (lane = row, step by step: every load is coalesced): the
@@ -669,10 +689,6 @@ __device__ __forceinline__ void dtw_codes_body(const dtw_level_args &a, int k, u
   }
 }
 #define DTW_CODES_THREADS 1024
-__global__ __launch_bounds__(DTW_CODES_THREADS) void k_dtw_codes(dtw_level_args a) {
-  extern __shared__ unsigned char bt[];
-  dtw_codes_body<DTW_CODES_THREADS>(a, blockIdx.x, bt);
-}
 
 // The back-trace of one level and the next level's windows: ONE workgroup.
 #define DTW_TRACE_NT 256
@@ -904,10 +920,6 @@ __device__ __forceinline__ void dtw_trace_body(const dtw_level_args &a, unsigned
                                        a.soff_w, a.cap_rows, a.cap_skew, a.status, bt, (size_t)a.lds_bytes);
   }
 }
-__global__ __launch_bounds__(DTW_TRACE_NT) void k_dtw_trace(dtw_level_args a) {
-  extern __shared__ unsigned char bt[];
-  dtw_trace_body(a, bt);
-}
 
 // A level of at most DTW_SMALL_STRIPS strips: recurrence, codes and trace in ONE launch of one workgroup, one after
 // the other (the coarse levels: launches of ~12 us each, most of it the first touch of what the launch before wrote
@@ -940,8 +952,81 @@ __device__ __forceinline__ void dtw_dist_small(const dtw_level_args &a, unsigned
     a.dist[dtw_skew_index(0, s, lane)] = d;
   }
 }
-__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_small(dtw_level_args a) {
+// ---- the kernels: (batch, level); the pair is the last grid dimension in use -------------------------------------
+__global__ __launch_bounds__(KWY_THREADS) void k_dtw_halve_all(dtw_batch b) {
+  extern __shared__ double hb[];
+  const dtw_pair &q = b.p[blockIdx.y];
+  const int levels = dtw_num_levels(q.Tx, q.Ty, b.radius) - 1;
+  if (levels < 1) return;
+  const int C = 1 << levels, dim = b.dim;
+  const int chunks0 = (q.Tx + C - 1) / C;
+  if ((int)blockIdx.x >= chunks0 + (q.Ty + C - 1) / C) return;
+  char *base = b.scratch + (uint64_t)blockIdx.y * b.stride;
+  const int s = (int)blockIdx.x < chunks0 ? 0 : 1;
+  const int c = s == 0 ? blockIdx.x : blockIdx.x - chunks0;
+  const int n = s == 0 ? q.Tx : q.Ty;
+  const double *src = s == 0 ? q.x : q.y;
+  double *A = hb, *B = hb + (size_t)C * dim;
+  const int64_t f0 = (int64_t)c * C;
+  const int have = (int)min((int64_t)C, (int64_t)n - f0);
+  for (int e = threadIdx.x; e < have * dim; e += KWY_THREADS) A[e] = src[f0 * dim + e];
+  __syncthreads();
+  for (int l = 1; l <= levels; ++l) {
+    const int nl = n >> l, per = C >> l;
+    const int i0 = c * per;
+    const int cnt = min(per, nl - i0);           // level-l elements of this workgroup (may be <= 0)
+    double *out = (double *)(base + (s == 0 ? b.off_x[l] : b.off_y[l]));
+    for (int e = threadIdx.x; e < cnt * dim; e += KWY_THREADS) {
+      const int i = e / dim, k = e - i * dim;
+      const double v = (A[(2 * i) * dim + k] + A[(2 * i + 1) * dim + k]) / 2;
+      B[e] = v;
+      out[(int64_t)(i0 + i) * dim + k] = v;
+    }
+    __syncthreads();
+    double *t = A; A = B; B = t;
+  }
+}
+// the coarsest level of every pair that has `lev` levels below it
+__global__ __launch_bounds__(DTW_WS_NT) void k_dtw_window_scan(dtw_batch b, int lev) {
+  __shared__ uint64_t tot[DTW_WS_NT];
+  dtw_level_args a;
+  const dtw_pair &q = b.p[blockIdx.x];
+  if (lev != dtw_num_levels(q.Tx, q.Ty, b.radius) - 1 || !dtw_make_args(b, blockIdx.x, lev, false, a)) return;
+  dtw_window_scan_first(b.radius, a.len_x, a.len_y, a.lo_w, a.hi_w, a.off_w, a.soff_w, a.cap_rows, a.cap_skew, a.status,
+                        tot, sizeof(tot));
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_dtw_dist(dtw_batch b, int lev) {
+  __shared__ double tiles[(64 + 80) * DTW_DTP];
+  dtw_level_args a;
+  if (!dtw_make_args(b, blockIdx.y, lev, true, a)) return;
+  dtw_dist_body(a.x, a.y, a.dim, a.len_x, a.len_y, a.lo, a.hi, a.soff, a.dist, a.status, blockIdx.x, gridDim.x,
+                (unsigned char *)tiles);
+}
+template <bool BND_LDS>
+__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_values(dtw_batch b, int lev) {
   extern __shared__ unsigned char bt[];
+  dtw_level_args a;
+  if (!dtw_make_args(b, blockIdx.x, lev, false, a)) return;
+  dtw_values_body<BND_LDS>(a, bt);
+}
+__global__ __launch_bounds__(DTW_CODES_THREADS) void k_dtw_codes(dtw_batch b, int lev) {
+  extern __shared__ unsigned char bt[];
+  dtw_level_args a;
+  if (!dtw_make_args(b, blockIdx.y, lev, false, a)) return;
+  if ((int)blockIdx.x >= (a.len_x + 63) / 64) return;
+  dtw_codes_body<DTW_CODES_THREADS>(a, blockIdx.x, bt);
+}
+__global__ __launch_bounds__(DTW_TRACE_NT) void k_dtw_trace(dtw_batch b, int lev) {
+  extern __shared__ unsigned char bt[];
+  dtw_level_args a;
+  if (!dtw_make_args(b, blockIdx.x, lev, false, a)) return;
+  dtw_trace_body(a, bt);
+}
+// (with_dist: the distances from series staged in LDS -- the host has checked that every pair's fit)
+__global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_small(dtw_batch b, int lev, int with_dist) {
+  extern __shared__ unsigned char bt[];
+  dtw_level_args a;
+  if (!dtw_make_args(b, blockIdx.x, lev, with_dist != 0, a)) return;
   if (a.x) { dtw_dist_small(a, bt); __syncthreads(); }
   dtw_values_body<true>(a, bt);
   __syncthreads();
@@ -952,102 +1037,114 @@ __global__ __launch_bounds__(64 * DTW_WAVES) void k_dtw_small(dtw_level_args a) 
 }
 
 // ---- host side -----------------------------------------------------------------------------
-struct dtw_level { int len_x, len_y; };
-
-// cells of the rows' windows (the predecessor planes' capacity): an estimate, or the full matrix
+// Capacities.  Both are BOUNDS, not estimates (until round 4 they were estimates that a pair with a length ratio
+// beyond ~4 overflowed: the device entry then returned an empty path).  With (lx, ly) the lengths of a level, r the
+// radius and the coarser level's path (monotone, at most one step in either direction per cell):
+//   rows' windows   row i takes the columns [2 (jf - r), 2 (jl + r) + 1], jf / jl the path's first / last column in
+//                   the coarse rows i/2 - r / i/2 + r: width 2 ext(i/2 - r, i/2 + r) + 4 r + 2, ext = the path's
+//                   column extent over those rows.  A coarse row's (or row step's) part of the extent is counted by
+//                   at most 2 r + 1 windows, twice each (two fine rows per coarse row):
+//                       sum of widths <= 2 (2 r + 1) ly + (lx + 1) (4 r + 2)
+//   skewed bands    strip k spans the columns from lo[64 k] to hi[64 k + 63]: 2 ext(32 k - r, 32 k + 31 + r) + 4 r + 2;
+//                   a coarse row lies in at most m = (31 + 2 r) / 32 + 1 such ranges:
+//                       sum of spans <= m ly + strips (4 r + 2),  plus 63 (skew) + 15 (rounding) steps per strip
+// and neither exceeds the full matrix.  (The coarsest level has the full window: lx ly cells with one side shorter
+// than r + 2 and the other at most half the finest level's -- below both bounds.)
 static uint64_t dtw_cap(int len_x, int len_y, int radius, bool full) {
-  uint64_t worst = (uint64_t)len_x * (uint64_t)len_y;
+  const uint64_t worst = (uint64_t)len_x * (uint64_t)len_y;
   if (full) return worst;
-  uint64_t est = (uint64_t)len_x * (uint64_t)(8 * radius + 64) * 2;
-  return est < worst ? est : worst;
+  const uint64_t r = (uint64_t)radius;
+  const uint64_t bound = 2 * (2 * r + 1) * ((uint64_t)len_y + 2) + ((uint64_t)len_x + 2) * (4 * r + 2);
+  return bound < worst ? bound : worst;
 }
-// cells of the strips' rectangles in the skewed bands: 64 lanes x (columns the strip spans + the skew, rounded up to
-// whole chunks).  The strips' spans add up to at most len_y + strips x (one window width): same estimate of the width.
 static uint64_t dtw_cap_skew(int len_x, int len_y, int radius, bool full) {
   const uint64_t strips = ((uint64_t)len_x + 63) / 64;
   const uint64_t worst = 64 * strips * ((uint64_t)len_y + 80);
   if (full) return worst;
-  const uint64_t est = 64 * ((uint64_t)len_y + strips * ((uint64_t)(8 * radius + 64) * 2 + 80));
-  return est < worst ? est : worst;
+  const uint64_t r = (uint64_t)radius, m = (31 + 2 * r) / 32 + 1;
+  const uint64_t bound = 64 * (m * ((uint64_t)len_y + 2) + strips * (4 * r + 2 + 63 + 15 + 16));
+  return bound < worst ? bound : worst;
 }
 
-static size_t dtw_scratch_bytes(int64_t Tx, int64_t Ty, int dim, int radius, bool full) {
+// the scratch of ONE pair with series of at most (Tx, Ty) frames: the offsets go into `b`, the size is returned
+static size_t dtw_layout(int64_t Tx, int64_t Ty, int dim, int radius, bool full, dtw_batch *b) {
   size_t tot = 0;
+  auto take = [&](size_t bytes) { const size_t at = tot; tot += kwy_pad(bytes); return (uint64_t)at; };
+  dtw_batch tmp;
+  if (!b) b = &tmp;
   int lx = (int)Tx, ly = (int)Ty;
-  // coarsened series
-  while (!(lx < radius + 2 || ly < radius + 2)) {
+  for (int l = 1; l < DTW_OFFLV; ++l) {
+    b->off_x[l] = b->off_y[l] = 0;
+    if (lx < radius + 2 || ly < radius + 2) continue;
     lx /= 2; ly /= 2;
-    tot += kwy_pad(sizeof(double) * (size_t)lx * dim) + kwy_pad(sizeof(double) * (size_t)ly * dim);
+    b->off_x[l] = take(sizeof(double) * (size_t)lx * dim);
+    b->off_y[l] = take(sizeof(double) * (size_t)ly * dim);
   }
-  uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full), cap_skew = dtw_cap_skew((int)Tx, (int)Ty, radius, full);
-  tot += 2 * kwy_pad(sizeof(double) * cap_skew) + kwy_pad(16 * (cap / 64 + Tx + 8));
-  tot += 2 * kwy_pad(sizeof(int32_t) * Tx) + kwy_pad(sizeof(uint64_t) * (Tx + 1)) + kwy_pad(sizeof(uint64_t) * (Tx / 64 + 2));
-  tot += kwy_pad(sizeof(double) * 4 * (Ty + 2));
-  tot += 2 * kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2)) + kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + Tx / 64 + 8)) +
-         kwy_pad(sizeof(int32_t) * 3 * (Tx / 64 + 2)) + 2 * kwy_pad(64) + kwy_pad(64);
-  return tot + 16 * 256;
+  b->off_x[0] = b->off_y[0] = 0;
+  b->cap_rows = dtw_cap((int)Tx, (int)Ty, radius, full);
+  b->cap_skew = dtw_cap_skew((int)Tx, (int)Ty, radius, full);
+  b->off_dist = take(sizeof(double) * b->cap_skew);
+  b->off_dval = take(sizeof(double) * b->cap_skew);
+  b->off_soff = take(sizeof(uint64_t) * (Tx / 64 + 2));
+  b->off_predm = take(16 * (b->cap_rows / 64 + Tx + 8));
+  b->off_lo = take(sizeof(int32_t) * Tx);
+  b->off_hi = take(sizeof(int32_t) * Tx);
+  b->off_off = take(sizeof(uint64_t) * (Tx + 1));
+  b->off_bnd = take(sizeof(double) * DTW_WAVES * (Ty + 2));
+  b->off_pathA = take(sizeof(int32_t) * 2 * (Tx + Ty + 2));
+  b->off_pathB = take(sizeof(int32_t) * 2 * (Tx + Ty + 2));
+  b->off_rev = take(sizeof(int32_t) * 2 * (Tx + Ty + Tx / 64 + 8));   // the strips' segments, with slack per strip
+  b->off_sinfo = take(sizeof(int32_t) * 3 * (Tx / 64 + 2));
+  b->off_lenA = take(64);
+  b->off_lenB = take(64);
+  b->off_status = take(64);
+  return tot;
 }
 
-static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty, int dim,
-                        int radius, bool full, double *d_dist, int32_t *d_path, int64_t *d_path_len,
-                        int **status_out) {
-  std::vector<dtw_level> lv;
-  std::vector<const double *> xs, ys;
-  lv.push_back({(int)Tx, (int)Ty});
-  xs.push_back(x); ys.push_back(y);
-  while (!(lv.back().len_x < radius + 2 || lv.back().len_y < radius + 2)) {
-    dtw_level c = {lv.back().len_x / 2, lv.back().len_y / 2};
-    double *cx = kwy_arena<double>(ctx, (size_t)c.len_x * dim);
-    double *cy = kwy_arena<double>(ctx, (size_t)c.len_y * dim);
-    if (!cx || !cy) { ctx->err = "fastdtw: scratch arena too small"; return KWY_ENOMEM; }
-    lv.push_back(c); xs.push_back(cx); ys.push_back(cy);
-  }
+// `pairs`: n <= KWY_BATCH_MAX descriptors with device pointers.  status_out[p]: the pair's status words (device).
+static int fastdtw_core(kwy_ctx *ctx, const dtw_pair *pairs, int n, int dim, int radius, bool full, int **status_out) {
+  dtw_batch b;
+  b.n = n; b.dim = dim; b.radius = radius;
+  int64_t Tx = 0, Ty = 0;
+  for (int p = 0; p < n; ++p) { b.p[p] = pairs[p]; Tx = std::max<int64_t>(Tx, pairs[p].Tx); Ty = std::max<int64_t>(Ty, pairs[p].Ty); }
+  for (int p = n; p < KWY_BATCH_MAX; ++p) b.p[p] = pairs[0];
+  b.stride = dtw_layout(Tx, Ty, dim, radius, full, &b);
+  b.scratch = (char *)kwy_arena_alloc(ctx, b.stride * (size_t)n);
+  if (!b.scratch) { ctx->err = "fastdtw: scratch arena too small"; return KWY_ENOMEM; }
+  b.dbg = (long long *)ctx->dbg;
+  for (int p = 0; p < n; ++p) status_out[p] = (int *)(b.scratch + (size_t)p * b.stride + b.off_status);
+  // levels of the pairs; level l of the batch = level l of every pair that has one
+  int nlev[KWY_BATCH_MAX], top = 0;
+  for (int p = 0; p < n; ++p) { nlev[p] = dtw_num_levels(pairs[p].Tx, pairs[p].Ty, radius); top = std::max(top, nlev[p]); }
   {
-    const int levels = (int)lv.size() - 1;
+    const int levels = top - 1;
     const size_t halve_lds = levels > 0 ? sizeof(double) * (((size_t)3 << levels) / 2) * dim : 0;
     if (levels > 0 && levels <= DTW_MAXLV && halve_lds <= 64 * 1024) {
-      dtw_halve_desc d;
-      d.src[0] = x; d.src[1] = y;
-      d.n[0] = (int)Tx; d.n[1] = (int)Ty;
-      d.levels = levels; d.dim = dim;
-      for (int l = 1; l <= levels; ++l) { d.lv[0][l - 1] = (double *)xs[l]; d.lv[1][l - 1] = (double *)ys[l]; }
-      const int C = 1 << levels;
-      d.chunks0 = (int)((Tx + C - 1) / C);
-      const int chunks1 = (int)((Ty + C - 1) / C);
-      hipLaunchKernelGGL(k_dtw_halve_all, dim3(d.chunks0 + chunks1), dim3(KWY_THREADS), halve_lds, ctx->stream, d);
+      unsigned chunks = 1;
+      for (int p = 0; p < n; ++p) {
+        const int C = 1 << (nlev[p] - 1);
+        chunks = std::max(chunks, (unsigned)((pairs[p].Tx + C - 1) / C + (pairs[p].Ty + C - 1) / C));
+      }
+      hipLaunchKernelGGL(k_dtw_halve_all, dim3(chunks, n), dim3(KWY_THREADS), halve_lds, ctx->stream, b);
     } else {
-      for (int l = 1; l <= levels; ++l) {      // long series / wide features: level by level
-        hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)lv[l].len_x * dim + 255) / 256)), dim3(256), 0,
-                           ctx->stream, xs[l - 1], lv[l].len_x, dim, (double *)xs[l]);
-        hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)lv[l].len_y * dim + 255) / 256)), dim3(256), 0,
-                           ctx->stream, ys[l - 1], lv[l].len_y, dim, (double *)ys[l]);
+      for (int p = 0; p < n; ++p) {              // long series / wide features: level by level
+        const double *px = pairs[p].x, *py = pairs[p].y;
+        char *base = b.scratch + (size_t)p * b.stride;
+        for (int l = 1; l < nlev[p]; ++l) {
+          const int lx = pairs[p].Tx >> l, ly = pairs[p].Ty >> l;
+          double *cx = (double *)(base + b.off_x[l]), *cy = (double *)(base + b.off_y[l]);
+          hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)lx * dim + 255) / 256)), dim3(256), 0, ctx->stream, px,
+                             lx, dim, cx);
+          hipLaunchKernelGGL(k_dtw_halve, dim3((unsigned)(((size_t)ly * dim + 255) / 256)), dim3(256), 0, ctx->stream, py,
+                             ly, dim, cy);
+          px = cx; py = cy;
+        }
       }
     }
   }
-  const uint64_t cap = dtw_cap((int)Tx, (int)Ty, radius, full);
-  const uint64_t cap_skew = dtw_cap_skew((int)Tx, (int)Ty, radius, full);
-  double *dist = kwy_arena<double>(ctx, cap_skew);
-  double *dval = kwy_arena<double>(ctx, cap_skew);
-  uint64_t *soff = kwy_arena<uint64_t>(ctx, Tx / 64 + 2);
-  uint64_t *predm = kwy_arena<uint64_t>(ctx, 2 * (cap / 64 + Tx + 8));
-  int32_t *lo = kwy_arena<int32_t>(ctx, Tx), *hi = kwy_arena<int32_t>(ctx, Tx);
-  uint64_t *off = kwy_arena<uint64_t>(ctx, Tx + 1);
-  double *bnd = kwy_arena<double>(ctx, DTW_WAVES * (Ty + 2));
-  int32_t *pathA = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
-  int32_t *pathB = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
-  int32_t *rev = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + Tx / 64 + 8));   // the strips' segments, with slack per strip
-  int32_t *sinfo = kwy_arena<int32_t>(ctx, 3 * (Tx / 64 + 2));
-  int64_t *lenA = kwy_arena<int64_t>(ctx, 8), *lenB = kwy_arena<int64_t>(ctx, 8);
-  int *status = kwy_arena<int>(ctx, 16);
-  if (!dist || !dval || !soff || !predm || !lo || !hi || !off || !bnd || !pathA || !pathB || !rev || !sinfo || !lenA || !lenB ||
-      !status) {
-    ctx->err = "fastdtw: scratch arena too small";
-    return KWY_ENOMEM;
-  }
-  *status_out = status;
   // the boundary rows of the strips live in LDS when they fit (the other instantiation keeps them in memory)
   const size_t bnd_bytes = sizeof(double) * DTW_WAVES * (Ty + 2);
-  const bool bnd_lds = bnd_bytes <= 150 * 1024;
+  b.bnd_lds = bnd_bytes <= 150 * 1024 ? 1 : 0;
   // the codes' places and the back-trace's tables: all a workgroup may have beside the static variables (the kernels
   // take what fits and have a slower way for the rest)
   const size_t big_lds = 150 * 1024;
@@ -1056,58 +1153,47 @@ static int fastdtw_core(kwy_ctx *ctx, const double *x, int64_t Tx, const double 
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
   KWY_HIP(hipFuncSetAttribute((const void *)k_dtw_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
 
-  for (int l = (int)lv.size() - 1; l >= 0; --l) {
-    const int len_x = lv[l].len_x, len_y = lv[l].len_y;
-    const bool top = (l == 0);
-    if (l == (int)lv.size() - 1)
-      hipLaunchKernelGGL(k_dtw_window_scan, dim3(1), dim3(DTW_WS_NT), 0, ctx->stream, radius, len_x, len_y, lo, hi, off,
-                         soff, cap, cap_skew, status);
-    dtw_level_args a;
-    a.len_x = len_x; a.len_y = len_y;
-    a.lo = lo; a.hi = hi; a.off = off; a.soff = soff;
-    a.cap_rows = cap; a.cap_skew = cap_skew;
-    a.dist = dist; a.dval = dval; a.predm = predm;
-    a.bnd_global = bnd_lds ? nullptr : bnd;
-    a.path = top ? d_path : ((l & 1) ? pathA : pathB);
-    a.rev = rev; a.sinfo = sinfo;
-    a.path_len = top ? d_path_len : ((l & 1) ? lenA : lenB);
-    a.out_dist = d_dist;
-    a.status = status;
-    a.dbg = (long long *)ctx->dbg;
-    a.next_len_x = top ? 0 : lv[l - 1].len_x;
-    a.next_len_y = top ? 0 : lv[l - 1].len_y;
-    a.radius = radius;
-    a.lo_w = lo; a.hi_w = hi; a.off_w = off; a.soff_w = soff;
+  for (int l = top - 1; l >= 0; --l) {
+    // what the pairs that take part in this level need, at most
+    int len_x = 0, len_y = 0;
+    bool first = false, small = b.bnd_lds != 0, small_dist = true;
+    for (int p = 0; p < n; ++p) {
+      if (l >= nlev[p]) continue;
+      const int lx = pairs[p].Tx >> l, ly = pairs[p].Ty >> l;
+      len_x = std::max(len_x, lx); len_y = std::max(len_y, ly);
+      first = first || l == nlev[p] - 1;
+      small = small && (lx + 63) / 64 <= DTW_SMALL_STRIPS;
+      // (the small kernel takes the distances along when both series fit its LDS)
+      small_dist = small_dist && sizeof(double) * (size_t)(lx + ly) * (size_t)(dim | 1) <= 96 * 1024;
+    }
+    small_dist = small_dist && small;
+    if (first)
+      hipLaunchKernelGGL(k_dtw_window_scan, dim3(n), dim3(DTW_WS_NT), 0, ctx->stream, b, l);
     const int nstrips = (len_x + 63) / 64;
-    const bool small = nstrips <= DTW_SMALL_STRIPS && bnd_lds;
-    // (the small kernel takes the distances along when both series fit its LDS)
-    const bool small_dist = small && sizeof(double) * (size_t)(len_x + len_y) * (size_t)(dim | 1) <= 96 * 1024;
-    a.x = small_dist ? xs[l] : nullptr; a.y = small_dist ? ys[l] : nullptr; a.dim = dim;
     // a workgroup per 16 steps of a strip; how many there are is known on the device only: as many workgroups as
-    // this level's rectangles are estimated to have (the others return at once; more units: the workgroups loop)
-    const uint64_t lv_units = std::min(cap_skew, dtw_cap_skew(len_x, len_y, radius, full)) / 1024 + 1;
+    // this level's rectangles can have (the others return at once; more units: the workgroups loop)
+    const uint64_t lv_units = std::min(b.cap_skew, dtw_cap_skew(len_x, len_y, radius, full)) / 1024 + 1;
+    b.lds_bytes = 0;
     if (!small_dist)
-      KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3((unsigned)lv_units), dim3(KWY_THREADS), 0, ctx->stream, xs[l],
-                         ys[l], dim, len_x, len_y, lo, hi, soff, dist, status));
-
+      KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3((unsigned)lv_units, n), dim3(KWY_THREADS), 0, ctx->stream, b, l));
     if (small) {
-      a.lds_bytes = (int)big_lds;
-      KWY_PROF(ctx, "k_dtw_small", hipLaunchKernelGGL(k_dtw_small, dim3(1), dim3(64 * DTW_WAVES), big_lds, ctx->stream, a));
+      b.lds_bytes = (int)big_lds;
+      KWY_PROF(ctx, "k_dtw_small", hipLaunchKernelGGL(k_dtw_small, dim3(n), dim3(64 * DTW_WAVES), big_lds, ctx->stream, b, l,
+                                                       small_dist ? 1 : 0));
       continue;
     }
     // the codes kernel asks for the LDS its strips are likely to need (rows x a generous window), not for all of it:
     // several strips then share a CU
     const size_t want = (size_t)64 * 4 * (size_t)std::min<int64_t>(len_y, 8 * (int64_t)radius + 128);
     const size_t codes_lds = std::min(big_lds, std::max<size_t>(want, 16 * 1024));
-    a.lds_bytes = 0;
-    if (bnd_lds)
-      KWY_PROF(ctx, "k_dtw_values", hipLaunchKernelGGL(k_dtw_values<true>, dim3(1), dim3(64 * DTW_WAVES), bnd_bytes, ctx->stream, a));
+    if (b.bnd_lds)
+      KWY_PROF(ctx, "k_dtw_values", hipLaunchKernelGGL(k_dtw_values<true>, dim3(n), dim3(64 * DTW_WAVES), bnd_bytes, ctx->stream, b, l));
     else
-      KWY_PROF(ctx, "k_dtw_values", hipLaunchKernelGGL(k_dtw_values<false>, dim3(1), dim3(64 * DTW_WAVES), 0, ctx->stream, a));
-    a.lds_bytes = (int)codes_lds;
-    KWY_PROF(ctx, "k_dtw_codes", hipLaunchKernelGGL(k_dtw_codes, dim3(nstrips), dim3(DTW_CODES_THREADS), codes_lds, ctx->stream, a));
-    a.lds_bytes = (int)big_lds;
-    KWY_PROF(ctx, "k_dtw_trace", hipLaunchKernelGGL(k_dtw_trace, dim3(1), dim3(DTW_TRACE_NT), big_lds, ctx->stream, a));
+      KWY_PROF(ctx, "k_dtw_values", hipLaunchKernelGGL(k_dtw_values<false>, dim3(n), dim3(64 * DTW_WAVES), 0, ctx->stream, b, l));
+    b.lds_bytes = (int)codes_lds;
+    KWY_PROF(ctx, "k_dtw_codes", hipLaunchKernelGGL(k_dtw_codes, dim3(nstrips, n), dim3(DTW_CODES_THREADS), codes_lds, ctx->stream, b, l));
+    b.lds_bytes = (int)big_lds;
+    KWY_PROF(ctx, "k_dtw_trace", hipLaunchKernelGGL(k_dtw_trace, dim3(n), dim3(DTW_TRACE_NT), big_lds, ctx->stream, b, l));
   }
   KWY_HIP(hipGetLastError());
   return KWY_OK;
@@ -1126,13 +1212,46 @@ static int dtw_check(kwy_ctx *ctx, const void *x, int64_t Tx, const void *y, int
   return KWY_OK;
 }
 
+extern "C" int kwy_fastdtw_batch_dev(kwy_ctx *ctx, const kwy_dtw_job *jobs, int count, int dim, int radius) {
+  if (!ctx) return KWY_EINVAL;
+  if (!jobs || count < 0) { ctx->err = "fastdtw_batch: bad argument"; return KWY_EINVAL; }
+  if (count == 0) return KWY_OK;
+  int64_t Tx = 0, Ty = 0;
+  for (int j = 0; j < count; ++j) {
+    KWY_TRY(dtw_check(ctx, jobs[j].x, jobs[j].x_length, jobs[j].y, jobs[j].y_length, dim, radius, jobs[j].dist,
+                      jobs[j].path, jobs[j].path_len));
+    Tx = std::max(Tx, jobs[j].x_length); Ty = std::max(Ty, jobs[j].y_length);
+  }
+  KWY_HIP(hipSetDevice(ctx->device));
+  // launches of up to KWY_BATCH_MAX pairs, each with its own slice of the arena
+  size_t bytes = 0;
+  for (int j0 = 0; j0 < count; j0 += KWY_BATCH_MAX) {
+    int64_t tx = 0, ty = 0;
+    for (int j = j0; j < std::min(count, j0 + KWY_BATCH_MAX); ++j) { tx = std::max(tx, jobs[j].x_length); ty = std::max(ty, jobs[j].y_length); }
+    bytes += kwy_pad(dtw_layout(tx, ty, dim, radius, false, nullptr) * (size_t)std::min(KWY_BATCH_MAX, count - j0));
+  }
+  KWY_TRY(kwy_arena_begin(ctx, bytes));
+  for (int j0 = 0; j0 < count; j0 += KWY_BATCH_MAX) {
+    const int n = std::min(KWY_BATCH_MAX, count - j0);
+    dtw_pair pr[KWY_BATCH_MAX];
+    int *status[KWY_BATCH_MAX];
+    for (int j = 0; j < n; ++j) {
+      const kwy_dtw_job &q = jobs[j0 + j];
+      pr[j] = dtw_pair{q.x, q.y, (int)q.x_length, (int)q.y_length, q.dist, q.path, q.path_len};
+    }
+    KWY_TRY(fastdtw_core(ctx, pr, n, dim, radius, false, status));
+  }
+  return KWY_OK;
+}
+
 extern "C" int kwy_fastdtw_dev(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty, int dim,
                                int radius, double *dist, int32_t *path, int64_t *path_len) {
   KWY_TRY(dtw_check(ctx, x, Tx, y, Ty, dim, radius, dist, path, path_len));
   KWY_HIP(hipSetDevice(ctx->device));
-  KWY_TRY(kwy_arena_begin(ctx, dtw_scratch_bytes(Tx, Ty, dim, radius, false)));
+  KWY_TRY(kwy_arena_begin(ctx, dtw_layout(Tx, Ty, dim, radius, false, nullptr)));
   int *status;
-  return fastdtw_core(ctx, x, Tx, y, Ty, dim, radius, false, dist, path, path_len, &status);
+  const dtw_pair pr = {x, y, (int)Tx, (int)Ty, dist, path, path_len};
+  return fastdtw_core(ctx, &pr, 1, dim, radius, false, &status);
 }
 
 extern "C" int kwy_fastdtw(kwy_ctx *ctx, const double *x, int64_t Tx, const double *y, int64_t Ty, int dim,
@@ -1140,10 +1259,10 @@ extern "C" int kwy_fastdtw(kwy_ctx *ctx, const double *x, int64_t Tx, const doub
   KWY_TRY(dtw_check(ctx, x, Tx, y, Ty, dim, radius, dist, path, path_len));
   KWY_HIP(hipSetDevice(ctx->device));
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const bool full = attempt == 1;
+    const bool full = attempt == 1;     // (the capacities are bounds: the second attempt is a safeguard only)
     size_t bx = kwy_pad(sizeof(double) * Tx * dim), by = kwy_pad(sizeof(double) * Ty * dim);
     size_t bp = kwy_pad(sizeof(int32_t) * 2 * (Tx + Ty + 2));
-    KWY_TRY(kwy_arena_begin(ctx, dtw_scratch_bytes(Tx, Ty, dim, radius, full) + bx + by + bp + 2 * kwy_pad(64)));
+    KWY_TRY(kwy_arena_begin(ctx, dtw_layout(Tx, Ty, dim, radius, full, nullptr) + bx + by + bp + 2 * kwy_pad(64)));
     double *dx = kwy_arena<double>(ctx, (size_t)Tx * dim), *dy = kwy_arena<double>(ctx, (size_t)Ty * dim);
     int32_t *dpath = kwy_arena<int32_t>(ctx, 2 * (Tx + Ty + 2));
     double *ddist = kwy_arena<double>(ctx, 8);
@@ -1151,14 +1270,15 @@ extern "C" int kwy_fastdtw(kwy_ctx *ctx, const double *x, int64_t Tx, const doub
     KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * Tx * dim, hipMemcpyHostToDevice, ctx->stream));
     KWY_HIP(hipMemcpyAsync(dy, y, sizeof(double) * Ty * dim, hipMemcpyHostToDevice, ctx->stream));
     int *status;
-    KWY_TRY(fastdtw_core(ctx, dx, Tx, dy, Ty, dim, radius, full, ddist, dpath, dlen, &status));
+    const dtw_pair pr = {dx, dy, (int)Tx, (int)Ty, ddist, dpath, dlen};
+    KWY_TRY(fastdtw_core(ctx, &pr, 1, dim, radius, full, &status));
     int hstatus = 0;
     int64_t hlen = 0;
     KWY_HIP(hipMemcpyAsync(&hstatus, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     KWY_HIP(hipMemcpyAsync(&hlen, dlen, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     KWY_HIP(hipMemcpyAsync(dist, ddist, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     KWY_HIP(hipStreamSynchronize(ctx->stream));
-    if (hstatus != 0) continue;  // band storage estimate exceeded: retry with the full matrix
+    if (hstatus != 0) continue;  // band storage exceeded
     if (hlen > Tx + Ty) { ctx->err = "fastdtw: path overflow"; return KWY_EHIP; }
     KWY_HIP(hipMemcpy(path, dpath, sizeof(int32_t) * 2 * hlen, hipMemcpyDeviceToHost));
     *path_len = hlen;

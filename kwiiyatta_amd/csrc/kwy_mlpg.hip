@@ -17,11 +17,36 @@
 // Algorithmic HBM bytes per frame: d*8 in, d*8 out (+ the GMM once per call).
 #include <math.h>
 
+#include <algorithm>
+
 #include "kwy_internal.hpp"
 
 #define ML_TILE 64  // frames per k_gmm_logp workgroup
 
 struct ml_dims { int d, D, M; int64_t T; };
+
+// A conversion call handles a batch of up to KWY_BATCH_MAX utterances (a single call is a batch of one).  The frames of
+// all of them form ONE matrix for the frame-parallel kernels (log-densities, conditional means: dm.T = all frames);
+// the kernels that look at neighbouring frames (deltas, normal equations) and the trajectory solves find their
+// utterance u by start[u] <= frame < start[u + 1].  Descriptors travel by value in the kernel arguments.
+struct ml_part { int P, base, extra; };
+struct ml_seg {
+  const double *x;          // T x d static features, rows ldx doubles apart
+  double *y;                // T x d converted, rows ldy apart
+  const double *keep_in;    // (may be null) one more column copied through, ldx / ldy apart
+  double *keep_out;
+  ml_part pt;               // chunks of the partitioned trajectory solve
+};
+struct ml_batch {
+  int n, ldx, ldy;
+  int64_t start[KWY_BATCH_MAX + 1];
+  ml_seg u[KWY_BATCH_MAX];
+  __device__ __forceinline__ int find(int64_t t) const {
+    int k = 0;
+    while (k + 1 < n && t >= start[k + 1]) ++k;
+    return k;
+  }
+};
 
 // ---- per-mixture preparation -----------------------------------------------------
 // layout of the prepared model (doubles), per mixture m:
@@ -112,27 +137,30 @@ __global__ __launch_bounds__(KWY_THREADS) void k_gmm_prep(const double *__restri
 // DELTA_WINDOWS (kwiiyatta/converter/delta.py:8-12): [1], [-0.5, 0, 0.5], [1, -2, 1]
 // x rows are ldx doubles apart.  keep_in / keep_out (may be null): one more column that is copied through
 // unchanged (the power coefficient c0 of a mel-cepstrum, kwiiyatta/converter/mcep.py:57-59), ldx / ldy apart.
-__global__ void k_delta(const double *__restrict__ x, int ldx, ml_dims dm, double *__restrict__ X,
-                        const double *__restrict__ keep_in, double *__restrict__ keep_out, int ldy) {
+__global__ void k_delta(ml_batch b, ml_dims dm, double *__restrict__ X) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= dm.T * dm.d) return;
-  const int64_t t = e / dm.d;
+  const int64_t tg = e / dm.d;              // frame of the batch
   const int c = (int)(e % dm.d);
-  if (keep_out && c == 0) keep_out[t * ldy] = keep_in[t * ldx];
+  const int u = b.find(tg);
+  const int64_t t = tg - b.start[u], T = b.start[u + 1] - b.start[u];
+  const double *__restrict__ x = b.u[u].x;
+  const int ldx = b.ldx, ldy = b.ldy;
+  if (b.u[u].keep_out && c == 0) b.u[u].keep_out[t * ldy] = b.u[u].keep_in[t * ldx];
   const double xm = t > 0 ? x[(t - 1) * ldx + c] : 0.0;
   const double x0 = x[t * ldx + c];
-  const double xp = t + 1 < dm.T ? x[(t + 1) * ldx + c] : 0.0;
-  double *o = X + t * dm.D;
+  const double xp = t + 1 < T ? x[(t + 1) * ldx + c] : 0.0;
+  double *o = X + tg * dm.D;
   o[c] = 0.0 + x0 * 1.0;
   double s = 0.0;
   if (t > 0) s += xm * -0.5;
   s += x0 * 0.0;
-  if (t + 1 < dm.T) s += xp * 0.5;
+  if (t + 1 < T) s += xp * 0.5;
   o[dm.d + c] = s;
   s = 0.0;
   if (t > 0) s += xm * 1.0;
   s += x0 * -2.0;
-  if (t + 1 < dm.T) s += xp * 1.0;
+  if (t + 1 < T) s += xp * 1.0;
   o[2 * dm.d + c] = s;
 }
 
@@ -327,17 +355,21 @@ __device__ __forceinline__ double ml_wcoef(int w, int k) {  // window w at offse
   return k == 0 ? -2.0 : 1.0;
 }
 
-__global__ void k_mlpg_build(const double *__restrict__ E, const double *__restrict__ Dv, ml_dims dm,
+__global__ void k_mlpg_build(const double *__restrict__ E, const double *__restrict__ Dv, ml_batch bt, ml_dims dm,
                              double *__restrict__ rec) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= dm.T * dm.d) return;
-  const int64_t a = e / dm.d;
+  const int64_t ag = e / dm.d;
   const int c = (int)(e % dm.d);
+  const int u = bt.find(ag);
+  const int64_t t0 = bt.start[u], a = ag - t0, T = bt.start[u + 1] - t0;    // row a of utterance u's system
+  E += t0 * dm.D;
+  Dv += t0 * dm.D;
   double p0 = 0.0, p1 = 0.0, p2 = 0.0, b = 0.0;
   for (int w = 0; w < 3; ++w) {
     const int l = w == 0 ? 0 : 1;
     for (int64_t t = a - l; t <= a + l; ++t) {  // frames whose window touches row a (ascending t)
-      if (t < 0 || t >= dm.T) continue;
+      if (t < 0 || t >= T) continue;
       const int k1 = (int)(a - t);
       const double prec = 1 / Dv[t * dm.D + w * dm.d + c];
       const double bm = prec * E[t * dm.D + w * dm.d + c];
@@ -345,7 +377,7 @@ __global__ void k_mlpg_build(const double *__restrict__ E, const double *__restr
       b += ca * bm;
       for (int k2 = -l; k2 <= k1; ++k2) {
         const int64_t cc = t + k2;
-        if (cc < 0 || cc >= dm.T) continue;
+        if (cc < 0 || cc >= T) continue;
         const double v = ca * prec * ml_wcoef(w, k2);
         const int off = (int)(a - cc);
         if (off == 0) p0 += v; else if (off == 1) p1 += v; else p2 += v;
@@ -395,7 +427,6 @@ __device__ __forceinline__ double ml_rsqrt(double v) {
   return r;
 }
 
-struct ml_part { int P, base, extra; };
 __device__ __forceinline__ int ml_chunk_rows(const ml_part &q, int j) { return q.base + (j < q.extra ? 1 : 0); }
 __device__ __forceinline__ int64_t ml_chunk_start(const ml_part &q, int j) {
   return (int64_t)j * q.base + (j < q.extra ? j : q.extra) + 2 * j;
@@ -403,7 +434,14 @@ __device__ __forceinline__ int64_t ml_chunk_start(const ml_part &q, int j) {
 
 __global__ __launch_bounds__(64) void k_mlpg_chunks(double *__restrict__ rec, double *__restrict__ zz,
                                                     double *__restrict__ Y, double *__restrict__ bnd, ml_dims dm,
-                                                    ml_part pt, int *__restrict__ status, long long *__restrict__ dbg) {
+                                                    ml_batch bt, int *__restrict__ status, long long *__restrict__ dbg) {
+  // utterance blockIdx.y: its rows start at start[u] in the batch's arrays; its boundary records have their own block
+  const ml_part pt = bt.u[blockIdx.y].pt;
+  {
+    const int64_t r0 = bt.start[blockIdx.y] * dm.d;
+    rec += r0 * 4; zz += r0 * 2; Y += r0 * 4;
+    bnd += (size_t)blockIdx.y * ML_CHUNK_WGS * 64 * ML_BD;
+  }
   const int lane = threadIdx.x, d = dm.d, P = pt.P;
 #define ML_STAMP(n) do { if (dbg && lane == 0 && blockIdx.x == 0) dbg[n] = clock64(); } while (0)
   ML_STAMP(0);
@@ -568,14 +606,21 @@ __global__ __launch_bounds__(64) void k_mlpg_chunks(double *__restrict__ rec, do
 }
 
 __global__ __launch_bounds__(ML_FIN_NT) void k_mlpg_finish(const double *__restrict__ rec, const double *__restrict__ Y,
-                                                          const double *__restrict__ bnd, ml_dims dm, ml_part pt,
-                                                          double *__restrict__ y, int ldy, int *__restrict__ status,
-                                                          long long *__restrict__ dbg) {
+                                                          const double *__restrict__ bnd, ml_dims dm, ml_batch bt,
+                                                          int *__restrict__ status, long long *__restrict__ dbg) {
   extern __shared__ double sm[];
+  const ml_part pt = bt.u[blockIdx.y].pt;
+  double *__restrict__ y = bt.u[blockIdx.y].y;
+  const int ldy = bt.ldy;
+  {
+    const int64_t r0 = bt.start[blockIdx.y] * dm.d;
+    rec += r0 * 4; Y += r0 * 4;
+    bnd += (size_t)blockIdx.y * ML_CHUNK_WGS * 64 * ML_BD;
+  }
   const int tid = threadIdx.x, d = dm.d, P = pt.P;
 #define ML_STAMP(n) do { if (dbg && tid == 0 && blockIdx.x == 0) dbg[n] = clock64(); } while (0)
   ML_STAMP(3);
-  const int64_t T = dm.T;
+  const int64_t T = bt.start[blockIdx.y + 1] - bt.start[blockIdx.y];
   const int m = 2 * (P - 1);
   double *red = sm;                    // [d][m][5]: lower band (diag, 3 sub-diagonals) and right-hand side
 
@@ -694,11 +739,13 @@ __global__ __launch_bounds__(ML_FIN_NT) void k_mlpg_finish(const double *__restr
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-static size_t ml_scratch_bytes(int64_t T, int d, int M) {
+// T: the frames of all utterances of the call, n: their number
+static size_t ml_scratch_bytes(int64_t T, int d, int M, int n = 1) {
   const int D = 3 * d;
   return kwy_pad(sizeof(double) * ml_model_stride(D) * M) + 3 * kwy_pad(sizeof(double) * T * D) +
          kwy_pad(sizeof(double) * T * M) + kwy_pad(sizeof(int) * T) + kwy_pad(sizeof(double) * T * d * 4) +
-         kwy_pad(sizeof(double) * T * d * 2) + kwy_pad(sizeof(double) * T * d * 4) + kwy_pad(sizeof(double) * ML_CHUNK_WGS * 64 * ML_BD) + kwy_pad(64);
+         kwy_pad(sizeof(double) * T * d * 2) + kwy_pad(sizeof(double) * T * d * 4) +
+         kwy_pad(sizeof(double) * (size_t)n * ML_CHUNK_WGS * 64 * ML_BD) + kwy_pad(64);
 }
 
 // frame-tile walkers per mixture: enough workgroups for every CU (one fits per CU), not more than tiles
@@ -709,15 +756,36 @@ static int ml_logp_splits(int64_t T, int M) {
   return (int)(s < 1 ? 1 : s);
 }
 
-// `prepared`: a model made by kwy_gmm_prepare_dev (then weights/means/covs are unused), or null
-// x / y: T x d with rows ldx / ldy doubles apart (0: packed); keep_in / keep_out: see k_delta
-static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,
-                     const double *means, const double *covs, int diff, double *y, int **status_out,
-                     const double *prepared = nullptr, int ldx = 0, int ldy = 0, const double *keep_in = nullptr,
-                     double *keep_out = nullptr) {
-  if (ldx <= 0) ldx = d;
-  if (ldy <= 0) ldy = d;
-  const int D = 3 * d;
+// chunks of the partitioned solve of a T-row system: 64/d per wavefront, at least 16 rows each
+static ml_part ml_partition(int64_t T, int d) {
+  ml_part pt;
+  const int cpw = 64 / d;
+  pt.P = ML_CHUNK_WGS * cpw;
+  if (pt.P > ML_MAX_CHUNKS) pt.P = ML_MAX_CHUNKS;
+  if ((int64_t)pt.P > T / 16) pt.P = (int)(T / 16);
+  if (pt.P < 1) pt.P = 1;
+  pt.base = (int)((T - 2 * (pt.P - 1)) / pt.P);
+  pt.extra = (int)((T - 2 * (pt.P - 1)) % pt.P);
+  return pt;
+}
+
+// One conversion call over a batch of utterances: bt.n, bt.ldx / ldy and every u[k].x / y / keep_* filled in by the
+// caller, Ts[k] the utterances' frames.  `prepared`: a model made by kwy_gmm_prepare_dev (then weights / means / covs
+// are unused), or null.
+static int mlpg_batch_core(kwy_ctx *ctx, ml_batch &bt, const int64_t *Ts, int d, int M, const double *weights,
+                           const double *means, const double *covs, int diff, int **status_out,
+                           const double *prepared) {
+  const int D = 3 * d, n = bt.n;
+  int64_t T = 0;
+  int Pmax = 1;
+  for (int k = 0; k < n; ++k) {
+    bt.start[k] = T;
+    T += Ts[k];
+    bt.u[k].pt = ml_partition(Ts[k], d);
+    Pmax = std::max(Pmax, bt.u[k].pt.P);
+  }
+  for (int k = n; k <= KWY_BATCH_MAX; ++k) bt.start[k] = T;
+  for (int k = n; k < KWY_BATCH_MAX; ++k) bt.u[k] = bt.u[0];
   ml_dims dm = {d, D, M, T};
   double *model = prepared ? const_cast<double *>(prepared) : kwy_arena<double>(ctx, ml_model_stride(D) * M);
   double *X = kwy_arena<double>(ctx, (size_t)T * D);
@@ -728,7 +796,7 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   double *band = kwy_arena<double>(ctx, (size_t)T * d * 4);   // records {P0, P1, P2, rhs}
   double *rhs = kwy_arena<double>(ctx, (size_t)T * d * 2);    // forward solutions of the two top columns
   double *Ysp = kwy_arena<double>(ctx, (size_t)T * d * 4);
-  double *bnd = kwy_arena<double>(ctx, (size_t)ML_CHUNK_WGS * 64 * ML_BD);
+  double *bnd = kwy_arena<double>(ctx, (size_t)n * ML_CHUNK_WGS * 64 * ML_BD);
   int *status = kwy_arena<int>(ctx, 16);
   if (!model || !X || !E || !Dv || !logp || !mix || !band || !rhs || !Ysp || !bnd || !status) {
     ctx->err = "gmm_mlpg: scratch arena too small";
@@ -741,16 +809,8 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024) { ctx->err = "gmm_mlpg: feature dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
-  // chunks of the partitioned solve: 64/d per wavefront, at least 16 rows each
-  ml_part pt;
   const int cpw = 64 / d;
-  pt.P = ML_CHUNK_WGS * cpw;
-  if (pt.P > ML_MAX_CHUNKS) pt.P = ML_MAX_CHUNKS;
-  if ((int64_t)pt.P > T / 16) pt.P = (int)(T / 16);
-  if (pt.P < 1) pt.P = 1;
-  pt.base = (int)((T - 2 * (pt.P - 1)) / pt.P);
-  pt.extra = (int)((T - 2 * (pt.P - 1)) % pt.P);
-  const size_t lds_solve = sizeof(double) * ((size_t)d * 2 * (pt.P - 1) * 5 + 8);
+  const size_t lds_solve = sizeof(double) * ((size_t)d * 2 * (Pmax - 1) * 5 + 8);
   if (lds_solve > 160 * 1024) { ctx->err = "gmm_mlpg: static dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_mlpg_finish, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_solve));
@@ -758,21 +818,36 @@ static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, con
     hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D,
                        diff, model, status);
   const unsigned ge = (unsigned)((T * d + 255) / 256);
-  hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, x, ldx, dm, X, keep_in, keep_out, ldy);
+  hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, bt, dm, X);
   KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)ml_logp_splits(T, M), M), dim3(KWY_THREADS), lds_logp,
                      ctx->stream, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
-  hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, dm, band);
-  KWY_PROF(ctx, "k_mlpg_chunks", hipLaunchKernelGGL(k_mlpg_chunks, dim3((unsigned)((pt.P + cpw - 1) / cpw)), dim3(64), 0, ctx->stream,
-                                                     band, rhs, Ysp, bnd, dm, pt, status, (long long *)ctx->dbg));
+  hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, bt, dm, band);
+  KWY_PROF(ctx, "k_mlpg_chunks", hipLaunchKernelGGL(k_mlpg_chunks, dim3((unsigned)((Pmax + cpw - 1) / cpw), n), dim3(64), 0, ctx->stream,
+                                                     band, rhs, Ysp, bnd, dm, bt, status, (long long *)ctx->dbg));
   {
-    int fin = (int)((T * d + 4 * ML_FIN_NT - 1) / (4 * ML_FIN_NT));
+    int64_t Tmax = 0;
+    for (int k = 0; k < n; ++k) Tmax = std::max(Tmax, Ts[k]);
+    int fin = (int)((Tmax * d + 4 * ML_FIN_NT - 1) / (4 * ML_FIN_NT));
     if (fin > ML_FIN_WGS) fin = ML_FIN_WGS;
-    KWY_PROF(ctx, "k_mlpg_finish", hipLaunchKernelGGL(k_mlpg_finish, dim3((unsigned)fin), dim3(ML_FIN_NT), lds_solve, ctx->stream,
-                                                       band, Ysp, bnd, dm, pt, y, ldy, status, (long long *)ctx->dbg));
+    KWY_PROF(ctx, "k_mlpg_finish", hipLaunchKernelGGL(k_mlpg_finish, dim3((unsigned)fin, n), dim3(ML_FIN_NT), lds_solve, ctx->stream,
+                                                       band, Ysp, bnd, dm, bt, status, (long long *)ctx->dbg));
   }
   KWY_HIP(hipGetLastError());
   return KWY_OK;
+}
+
+// one utterance.  x / y: T x d with rows ldx / ldy doubles apart (0: packed); keep_in / keep_out: see k_delta
+static int mlpg_core(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,
+                     const double *means, const double *covs, int diff, double *y, int **status_out,
+                     const double *prepared = nullptr, int ldx = 0, int ldy = 0, const double *keep_in = nullptr,
+                     double *keep_out = nullptr) {
+  ml_batch bt;
+  bt.n = 1;
+  bt.ldx = ldx > 0 ? ldx : d;
+  bt.ldy = ldy > 0 ? ldy : d;
+  bt.u[0].x = x; bt.u[0].y = y; bt.u[0].keep_in = keep_in; bt.u[0].keep_out = keep_out;
+  return mlpg_batch_core(ctx, bt, &T, d, M, weights, means, covs, diff, status_out, prepared);
 }
 
 // x, y: T x D device rows; weights / means / covs: the joint mixture over 2 D dimensions, on the device
@@ -921,6 +996,39 @@ extern "C" int kwy_convert_mcep_dev(kwy_ctx *ctx, const double *mc, int64_t T, i
   int *status;
   return mlpg_core(ctx, mc + 1, T, d, M, nullptr, nullptr, nullptr, 0, mc_out + 1, &status, model, d + 1, d + 1, mc,
                    mc_out);
+}
+
+extern "C" int kwy_convert_mcep_batch_dev(kwy_ctx *ctx, const kwy_convert_job *jobs, int count, int d, int M,
+                                          const double *model) {
+  if (!ctx) return KWY_EINVAL;
+  if (!jobs || count < 0) { ctx->err = "convert_mcep_batch: bad argument"; return KWY_EINVAL; }
+  if (count == 0) return KWY_OK;
+  size_t bytes = 0;
+  for (int j0 = 0; j0 < count; j0 += KWY_BATCH_MAX) {
+    int64_t T = 0;
+    const int n = std::min(KWY_BATCH_MAX, count - j0);
+    for (int j = j0; j < j0 + n; ++j) {
+      KWY_TRY(ml_check(ctx, jobs[j].mc, jobs[j].T, d, M, model, model, model, jobs[j].mc_out));
+      T += jobs[j].T;
+    }
+    bytes += ml_scratch_bytes(T, d, M, n);
+  }
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, bytes));
+  for (int j0 = 0; j0 < count; j0 += KWY_BATCH_MAX) {
+    ml_batch bt;
+    int64_t Ts[KWY_BATCH_MAX];
+    bt.n = std::min(KWY_BATCH_MAX, count - j0);
+    bt.ldx = bt.ldy = d + 1;
+    for (int k = 0; k < bt.n; ++k) {
+      const kwy_convert_job &q = jobs[j0 + k];
+      bt.u[k].x = q.mc + 1; bt.u[k].y = q.mc_out + 1; bt.u[k].keep_in = q.mc; bt.u[k].keep_out = q.mc_out;
+      Ts[k] = q.T;
+    }
+    int *status;
+    KWY_TRY(mlpg_batch_core(ctx, bt, Ts, d, M, nullptr, nullptr, nullptr, 0, &status, model));
+  }
+  return KWY_OK;
 }
 
 extern "C" int kwy_gmm_mlpg(kwy_ctx *ctx, const double *x, int64_t T, int d, int M, const double *weights,

@@ -23,6 +23,11 @@
 // (<= 1 ulp).  The generator state (key[624], pos, has_gauss, gauss: numpy's get_state() tuple) lives in device
 // memory between calls and can be copied from / to numpy.
 #include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "kwy_internal.hpp"
 
@@ -158,14 +163,29 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_normal(np_state *__restrict_
   }
 }
 
-// ------------------------------------------------------------------ large requests: five launches
+// ------------------------------------------------------------------ large requests
 // The single-workgroup kernel above spends most of its time on the Box-Muller arithmetic of 156 attempts per round with
-// one wavefront per SIMD.  For large requests only the MT19937 recurrence stays serial (one workgroup writes the raw
-// state words of as many 624-word blocks as the request can possibly consume); the attempts are then judged by the
-// whole chip: count the accepted ones per tile, scan the tile counts, write the outputs of the first `need` accepted
-// attempts in order, and move the generator state to the word after the last one used.
+// one wavefront per SIMD.  For large requests the raw state words of as many 624-word blocks as the request can
+// possibly consume are laid out first; the attempts are then judged by the whole chip: count the accepted ones per
+// tile, scan the tile counts, write the outputs of the first `need` accepted attempts in order, and move the generator
+// state to the word after the last one used.
 //   kbuf[b][624]  block 0 = the state's current key, block b its b-th successor; attempt a takes the words
 //                 pos + 4a .. pos + 4a + 3 of that stream (tempered on the fly)
+//
+// Laying out the words was ONE workgroup until round 4 (the recurrence z[t] = z[t - 227] ^ f(z[t - 624], z[t - 623])
+// reaches back only 227 words: 0.62 ms per aligned pair, the one serial kernel of the pad spectra).  The stream is a
+// linear recurrence over GF(2) with the primitive characteristic polynomial phi of degree 19937, so the window
+// z[N .. N + 623] at any distance N is a fixed linear combination of the first 19937 windows:
+//     z[N + k] = XOR over the set coefficients i of (x^(N-1) mod phi) of z[k + 1 + i]          (k = 0 .. 623)
+// (the identity holds for every bit of every word from index 1 on; word 0 of a freshly seeded key has 31 bits that
+// belong to no state).  The blocks are cut into segments of NP_SEG blocks: segment 0 runs from the state's key, the
+// start key of segment s is the combination above with N = 624 NP_SEG s, read off the first 33 blocks -- one workgroup
+// per segment, ~10 000 XORs per word --, and all segments then generate side by side, a workgroup each.
+//   host, once per process   phi by Berlekamp-Massey on one output bit (2 x 19937 terms), h = x^(624 NP_SEG) mod phi,
+//                            coefficient words of x^(624 NP_SEG s - 1) = h^s / x for the segments in use
+//   k_np_words               1 workgroup: the first 33 blocks (all of them when the request is short)
+//   k_np_jump                1 workgroup per segment >= 1: its start key
+//   k_np_words_seg           1 workgroup per segment: its blocks
 struct np_job {
   int64_t n;            // outputs wanted
   int64_t attempts;     // attempts laid out (an upper bound of those needed)
@@ -176,16 +196,70 @@ struct np_job {
 };
 #define NP_TILE (KWY_THREADS * 4)     // attempts per workgroup of the counting / writing kernels
 
+__device__ __forceinline__ void np_words_run(uint32_t *__restrict__ kbuf, int first, int last);
+// the first `nblocks` blocks, one workgroup
+// (A serial workgroup shares its CU with workgroups of whatever else the chip is running and runs ~2.7x
+// slower beside a full load than alone; raising its wave priority with s_setprio was measured: no effect.)
 __global__ __launch_bounds__(KWY_THREADS) void k_np_words(const np_state *__restrict__ st, int nblocks,
                                                          uint32_t *__restrict__ kbuf) {
+  for (int i = threadIdx.x; i < MT_N; i += KWY_THREADS) kbuf[i] = st->key[i];
+  __syncthreads();         // (workgroup-scope fence: the key is read back from kbuf below)
+  np_words_run(kbuf, 0, nblocks);
+}
+
+#define NP_SEG 512                 // blocks per segment
+#define NP_HEAD 33                 // blocks the jumps read: 33 x 624 >= 624 + 19937 words
+#define NP_MAXSEG 1024             // segments a request may have (beyond: the one-workgroup layout)
+#define NP_POLY_WORDS 624          // 19968 coefficient bits per jump polynomial
+#define NP_JUMP_NT 1024
+
+// kbuf block NP_SEG s <- the key of segment s = blockIdx.x + 1 (see above).  z = the first NP_HEAD blocks, staged in
+// LDS; thread t of tap group q accumulates words t, t + 256, t + 512 over the q-th quarter of the polynomial's words.
+__global__ __launch_bounds__(NP_JUMP_NT) void k_np_jump(uint32_t *__restrict__ kbuf, const uint32_t *__restrict__ polys) {
+  extern __shared__ uint32_t zs[];                 // NP_HEAD * 624 words, the polynomial, 3 x 3 x 256 partial sums
+  const int tid = threadIdx.x, t = tid & 255, q = tid >> 8;
+  const int seg = blockIdx.x + 1;
+  uint32_t *gs = zs + NP_HEAD * MT_N, *part = gs + NP_POLY_WORDS;
+  for (int i = tid; i < NP_HEAD * MT_N; i += NP_JUMP_NT) zs[i] = kbuf[i];
+  if (tid < NP_POLY_WORDS) gs[tid] = polys[(size_t)(seg - 1) * NP_POLY_WORDS + tid];
+  __syncthreads();
+  uint32_t a0 = 0, a1 = 0, a2 = 0;
+  const uint32_t *z0 = zs + t + 1;
+  const int w0 = q * (NP_POLY_WORDS / 4), w1 = w0 + NP_POLY_WORDS / 4;
+  uint32_t next = gs[w0];
+  for (int w = w0; w < w1; ++w) {
+    uint32_t bits = __builtin_amdgcn_readfirstlane(next);
+    next = gs[min(w + 1, w1 - 1)];                 // (the next word is on its way while this one's taps are applied)
+    const uint32_t *zw = z0 + 32 * w;
+    while (bits) {
+      const int i = __builtin_ctz(bits);
+      bits &= bits - 1;
+      a0 ^= zw[i];
+      a1 ^= zw[i + 256];
+      if (t < MT_N - 512) a2 ^= zw[i + 512];
+    }
+  }
+  if (q > 0) { part[((q - 1) * 3 + 0) * 256 + t] = a0; part[((q - 1) * 3 + 1) * 256 + t] = a1; part[((q - 1) * 3 + 2) * 256 + t] = a2; }
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { a0 ^= part[(r * 3 + 0) * 256 + t]; a1 ^= part[(r * 3 + 1) * 256 + t]; a2 ^= part[(r * 3 + 2) * 256 + t]; }
+    uint32_t *dst = kbuf + (size_t)seg * NP_SEG * MT_N;
+    dst[t] = a0;
+    dst[t + 256] = a1;
+    if (t < MT_N - 512) dst[t + 512] = a2;
+  }
+}
+#define NP_JUMP_LDS (sizeof(uint32_t) * (NP_HEAD * MT_N + NP_POLY_WORDS + 9 * 256))
+
+// the blocks behind kbuf block `first` up to (not including) block `last`, from the key stored at `first`
+__device__ __forceinline__ void np_words_run(uint32_t *__restrict__ kbuf, int first, int last) {
   __shared__ uint32_t mt[2][MT_N];
   const int tid = threadIdx.x;
-  // (This one serial workgroup shares its CU with workgroups of whatever else the chip is running and runs ~2.7x
-  // slower beside a full load than alone; raising its wave priority with s_setprio was measured: no effect.)
-  for (int i = tid; i < MT_N; i += KWY_THREADS) { const uint32_t v = st->key[i]; mt[0][i] = v; kbuf[i] = v; }
+  for (int i = tid; i < MT_N; i += KWY_THREADS) mt[0][i] = kbuf[(size_t)first * MT_N + i];
   __syncthreads();
   int cur = 0;
-  for (int b = 1; b < nblocks; ++b) {
+  for (int b = first + 1; b < last; ++b) {
     const uint32_t *o = mt[cur];
     uint32_t *w = mt[cur ^ 1];
     uint32_t *dst = kbuf + (size_t)b * MT_N;
@@ -207,6 +281,13 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_words(const np_state *__rest
     kwy_lds_barrier();
     cur ^= 1;
   }
+}
+// segment s = blockIdx.x: blocks NP_SEG s .. NP_SEG (s + 1) - 1 (segment 0 continues behind the head)
+__global__ __launch_bounds__(KWY_THREADS) void k_np_words_seg(uint32_t *__restrict__ kbuf, int nblocks) {
+  const int s = blockIdx.x;
+  const int first = s == 0 ? NP_HEAD - 1 : s * NP_SEG;
+  const int last = min(nblocks, (s + 1) * NP_SEG);
+  if (first + 1 < last) np_words_run(kbuf, first, last);
 }
 
 __device__ __forceinline__ bool np_attempt(const uint32_t *__restrict__ kbuf, int pos, int64_t a, double *x1, double *x2,
@@ -304,7 +385,10 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_emit(np_state *__restrict__ 
 // the state moves to the word after the last attempt used
 __global__ __launch_bounds__(KWY_THREADS) void k_np_advance(np_state *__restrict__ st, const uint32_t *__restrict__ kbuf,
                                                            const int64_t *__restrict__ info, int *__restrict__ status) {
-  if (info[3] != 0) { if (threadIdx.x == 0) atomicExch(status, 1); return; }
+  // a shortage of attempts (the layout's margin is ~14 standard deviations): outputs are missing.  The state is
+  // poisoned (pos = -1: no numpy state has it) so that whoever reads it back learns of it instead of a silent
+  // divergence from numpy's stream.
+  if (info[3] != 0) { if (threadIdx.x == 0) { atomicExch(status, 1); st->pos = -1; } return; }
   const int64_t last = info[2];
   if (last < 0) return;                                  // nothing but the cached value was needed
   const int64_t g_last = (int64_t)st->pos + 4 * last + 3;    // stream index of the last word consumed
@@ -312,6 +396,173 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_advance(np_state *__restrict
   __syncthreads();
   for (int i = threadIdx.x; i < MT_N; i += KWY_THREADS) st->key[i] = kbuf[(size_t)b * MT_N + i];
   if (threadIdx.x == 0) st->pos = (int)(g_last - b * MT_N) + 1;
+}
+
+// ------------------------------------------------------------------ host: MT19937's jump polynomials
+namespace {
+constexpr int MTD = 19937;                 // degree of the characteristic polynomial
+constexpr int PW = 313;                    // 64-bit words of a polynomial of degree <= 19937 (and some)
+typedef std::vector<uint64_t> poly;        // coefficient i = bit i
+
+inline int pbit(const poly &p, int i) { return (int)((p[i >> 6] >> (i & 63)) & 1u); }
+// r ^= a << sh  (r long enough)
+inline void pxor_shift(poly &r, const poly &a, int na, int sh) {
+  const int ws = sh >> 6, bs = sh & 63;
+  if (bs == 0) { for (int q = 0; q < na; ++q) r[q + ws] ^= a[q]; return; }
+  for (int q = 0; q < na; ++q) {
+    const uint64_t v = a[q];
+    if (!v) continue;
+    r[q + ws] ^= v << bs;
+    r[q + ws + 1] ^= v >> (64 - bs);
+  }
+}
+struct MtJump {
+  std::mutex mu;
+  bool ready = false, failed = false;
+  poly phi;                         // characteristic polynomial, PW words
+  poly h;                           // x^(624 NP_SEG) mod phi
+  std::vector<poly> g;              // g[s - 1] = x^(624 NP_SEG s - 1) mod phi
+  poly hs;                          // h^(number of polynomials made)
+  void reduce(poly &r) const {      // r: 2 PW + 1 words -> degree < MTD
+    for (int i = 2 * 64 * PW - 1; i >= MTD; --i)
+      if (pbit(r, i)) pxor_shift(r, phi, PW, i - MTD);
+  }
+  poly mulmod(const poly &a, const poly &b) const {
+    poly r(2 * PW + 2, 0);
+    for (int q = 0; q < PW; ++q) {
+      uint64_t bits = a[q];
+      while (bits) {
+        const int i = __builtin_ctzll(bits) + 64 * q;
+        bits &= bits - 1;
+        pxor_shift(r, b, PW, i);
+      }
+    }
+    reduce(r);
+    r.resize(PW);
+    return r;
+  }
+  // a / x mod phi (phi's constant term is 1: it is irreducible)
+  poly divx(const poly &a) const {
+    poly r = a;
+    if (r[0] & 1u) for (int q = 0; q < PW; ++q) r[q] ^= phi[q];
+    for (int q = 0; q < PW; ++q) r[q] = (r[q] >> 1) | (q + 1 < PW ? r[q + 1] << 63 : 0);
+    return r;
+  }
+  static void host_words(std::vector<uint32_t> &z, size_t n) {      // z: 624 words in, n words out
+    z.resize(n);
+    for (size_t t = MT_N; t < n; ++t) {
+      const uint32_t y = (z[t - MT_N] & 0x80000000u) | (z[t - MT_N + 1] & 0x7fffffffu);
+      z[t] = z[t - MT_N + MT_M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+  }
+  bool init(std::string &err) {
+    if (ready) return true;
+    if (failed) { err = "np_normal: MT19937 jump tables failed their self-check"; return false; }
+    // any stream will do: init_genrand(5489)
+    std::vector<uint32_t> z(MT_N);
+    z[0] = 5489u;
+    for (int i = 1; i < MT_N; ++i) z[i] = 1812433253u * (z[i - 1] ^ (z[i - 1] >> 30)) + (uint32_t)i;
+    const int nseq = 2 * MTD + 64;
+    host_words(z, (size_t)nseq + MT_N + 64 * MT_N);
+    // Berlekamp-Massey on a_t = bit 0 of z[t + 1].  C, B: connection polynomials; R: the sequence seen so far,
+    // newest term in bit 0 (the discrepancy is the parity of C & R).
+    poly C(PW + 1, 0), B(PW + 1, 0), R(PW + 1, 0), T;
+    C[0] = B[0] = 1;
+    int L = 0, m = 1;
+    for (int i = 0; i < nseq; ++i) {
+      for (int q = PW; q > 0; --q) R[q] = (R[q] << 1) | (R[q - 1] >> 63);
+      R[0] = (R[0] << 1) | (uint64_t)(z[i + 1] & 1u);
+      uint64_t acc = 0;
+      for (int q = 0; q <= PW; ++q) acc ^= C[q] & R[q];
+      if ((__builtin_popcountll(acc) & 1) == 0) { ++m; continue; }
+      if (2 * L <= i) {
+        T = C;
+        if (m <= 64 * PW) pxor_shift(C, B, PW - (m >> 6), m);
+        L = i + 1 - L; B = T; m = 1;
+      } else {
+        if (m <= 64 * PW) pxor_shift(C, B, PW - (m >> 6), m);
+        ++m;
+      }
+    }
+    if (L != MTD) { failed = true; err = "np_normal: MT19937: unexpected linear complexity"; return false; }
+    phi.assign(PW, 0);
+    for (int j = 0; j <= MTD; ++j)
+      if (pbit(C, j)) phi[(MTD - j) >> 6] ^= (uint64_t)1 << ((MTD - j) & 63);    // phi(x) = x^L C(1/x)
+    // h = x^(624 NP_SEG) mod phi
+    {
+      poly result(PW, 0), base(PW, 0);
+      result[0] = 1; base[0] = 2;
+      for (uint64_t n = (uint64_t)MT_N * NP_SEG; n; n >>= 1) {
+        if (n & 1) result = mulmod(result, base);
+        if (n > 1) base = mulmod(base, base);
+      }
+      h = result;
+    }
+    hs.assign(PW, 0);
+    hs[0] = 1;
+    // self-check on the host stream: the key of segment 1 from the first NP_HEAD blocks
+    {
+      extend(1);
+      std::vector<uint32_t> w(MT_N);
+      w[0] = 19650218u;
+      for (int i = 1; i < MT_N; ++i) w[i] = 1812433253u * (w[i - 1] ^ (w[i - 1] >> 30)) + (uint32_t)i;
+      host_words(w, (size_t)MT_N * NP_SEG + MT_N);
+      const poly &g1 = g[0];
+      for (int k : {0, 1, 227, 623}) {
+        uint32_t acc = 0;
+        for (int i = 0; i < MTD; ++i) if (pbit(g1, i)) acc ^= w[(size_t)k + 1 + i];
+        if (acc != w[(size_t)MT_N * NP_SEG + k]) { failed = true; err = "np_normal: MT19937 jump tables failed their self-check"; return false; }
+      }
+    }
+    ready = true;
+    return true;
+  }
+  void extend(int nseg) {           // polynomials of segments 1 .. nseg
+    while ((int)g.size() < nseg) {
+      hs = mulmod(hs, h);
+      g.push_back(divx(hs));
+    }
+  }
+} g_mt;
+}  // namespace
+
+// the device table of the jump polynomials of segments 1 .. nseg (NP_MAXSEG rows allocated once per context: the
+// pointer stays valid for captured graphs; rows are filled as requests need them)
+static int np_get_polys(kwy_ctx *ctx, int nseg, const uint32_t **out) {
+  std::lock_guard<std::mutex> lock(g_mt.mu);
+  if (!g_mt.init(ctx->err)) return KWY_EHIP;
+  g_mt.extend(nseg);
+  auto it = ctx->d_mats.find("mtjump");
+  if (it == ctx->d_mats.end()) {
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(uint32_t) * (size_t)NP_MAXSEG * NP_POLY_WORDS));
+    it = ctx->d_mats.emplace("mtjump", d).first;
+    ctx->i_vals["mtjump"] = 0;
+  }
+  uint32_t *d = (uint32_t *)it->second;
+  int64_t &have = ctx->i_vals["mtjump"];
+  if (have < nseg) {
+    std::vector<uint32_t> hbuf((size_t)(nseg - have) * NP_POLY_WORDS, 0u);
+    for (int64_t sgi = have; sgi < nseg; ++sgi)
+      memcpy(hbuf.data() + (size_t)(sgi - have) * NP_POLY_WORDS, g_mt.g[(size_t)sgi].data(), sizeof(uint32_t) * NP_POLY_WORDS);
+    KWY_HIP(hipMemcpy(d + (size_t)have * NP_POLY_WORDS, hbuf.data(), sizeof(uint32_t) * hbuf.size(), hipMemcpyHostToDevice));
+    have = nseg;
+  }
+  *out = d;
+  return KWY_OK;
+}
+
+// Not part of the ABI (include/kwy.h): the host half of the jump tables alone -- characteristic polynomial, the
+// polynomials of `nseg` segments and the self-check against a directly generated stream -- for the CPU test suite.
+// words: optional nseg x 624 uint32 output.  Returns 0 when the tables passed.
+extern "C" int kwy_np_jump_tables_host(int nseg, uint32_t *words) {
+  std::lock_guard<std::mutex> lock(g_mt.mu);
+  std::string err;
+  if (nseg < 1 || nseg > NP_MAXSEG || !g_mt.init(err)) return -1;
+  g_mt.extend(nseg);
+  if (words)
+    for (int sgi = 0; sgi < nseg; ++sgi) memcpy(words + (size_t)sgi * NP_POLY_WORDS, g_mt.g[(size_t)sgi].data(), sizeof(uint32_t) * NP_POLY_WORDS);
+  return 0;
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -334,6 +585,14 @@ static size_t np_scratch_bytes(int64_t n, int count = 1) {
   const int64_t ntiles = (attempts + NP_TILE - 1) / NP_TILE;
   return kwy_pad(sizeof(uint32_t) * (size_t)nblocks * MT_N) + kwy_pad(sizeof(int) * ntiles) +
          kwy_pad(sizeof(int64_t) * (size_t)(ntiles + 16)) + kwy_pad(64) + kwy_pad(sizeof(double *) * (size_t)count);
+}
+
+// the destination list travels in kernel arguments (a copy node from a caller's host array would not survive in a
+// captured graph): NP_PTRS pointers per launch
+#define NP_PTRS 128
+struct np_ptrs { int n, first; double *p[NP_PTRS]; };
+__global__ void k_np_set_outs(np_ptrs a, double **__restrict__ douts) {
+  if ((int)threadIdx.x < a.n) douts[a.first + threadIdx.x] = a.p[threadIdx.x];
 }
 
 // outs: HOST array of `count` device pointers to blocks of n_each doubles each, filled in order from one continuous
@@ -360,11 +619,25 @@ static int np_core(kwy_ctx *ctx, np_state *state, double loc, double scale, int 
   int *status = kwy_arena<int>(ctx, 16);
   double **douts = kwy_arena<double *>(ctx, (size_t)count);
   if (!kbuf || !counts || !info || !status || !douts) { ctx->err = "np_normal: scratch arena too small"; return KWY_ENOMEM; }
-  // (the pointer list is small and comes from pageable host memory: the copy is done when the call returns)
-  KWY_HIP(hipMemcpyAsync(douts, outs, sizeof(double *) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  for (int c0 = 0; c0 < count; c0 += NP_PTRS) {
+    np_ptrs a;
+    a.n = std::min(NP_PTRS, count - c0); a.first = c0;
+    for (int c = 0; c < NP_PTRS; ++c) a.p[c] = outs[c0 + (c < a.n ? c : 0)];
+    hipLaunchKernelGGL(k_np_set_outs, dim3(1), dim3(NP_PTRS), 0, ctx->stream, a, douts);
+  }
   job.outs = douts;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
-  KWY_PROF(ctx, "k_np_words", hipLaunchKernelGGL(k_np_words, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, nblocks, kbuf));
+  const int nseg = (nblocks + NP_SEG - 1) / NP_SEG;
+  if (nseg < 2 || nseg > NP_MAXSEG) {
+    KWY_PROF(ctx, "k_np_words", hipLaunchKernelGGL(k_np_words, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, nblocks, kbuf));
+  } else {
+    const uint32_t *polys;
+    KWY_TRY(np_get_polys(ctx, nseg - 1, &polys));
+    KWY_HIP(hipFuncSetAttribute((const void *)k_np_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)NP_JUMP_LDS));
+    KWY_PROF(ctx, "k_np_words", hipLaunchKernelGGL(k_np_words, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, NP_HEAD, kbuf));
+    KWY_PROF(ctx, "k_np_jump", hipLaunchKernelGGL(k_np_jump, dim3(nseg - 1), dim3(NP_JUMP_NT), NP_JUMP_LDS, ctx->stream, kbuf, polys));
+    KWY_PROF(ctx, "k_np_words_seg", hipLaunchKernelGGL(k_np_words_seg, dim3(nseg), dim3(KWY_THREADS), 0, ctx->stream, kbuf, nblocks));
+  }
   hipLaunchKernelGGL(k_np_count, dim3(ntiles), dim3(KWY_THREADS), 0, ctx->stream, state, kbuf, job, counts);
   hipLaunchKernelGGL(k_np_scan, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, state, job, ntiles, counts, info);
   KWY_PROF(ctx, "k_np_emit", hipLaunchKernelGGL(k_np_emit, dim3(ntiles), dim3(KWY_THREADS), 0, ctx->stream, state, kbuf, job, info));

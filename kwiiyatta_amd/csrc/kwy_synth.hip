@@ -102,7 +102,7 @@ __device__ __forceinline__ int syn_block_exscan_int(int v, int *sh, int *total) 
   return woff + (inc - v);
 }
 
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_scan_counts(int *__restrict__ cnt, int nt,
+__device__ __forceinline__ void syn_scan_counts_body(int *__restrict__ cnt, int nt,
                                                                 int *__restrict__ npulse) {
   __shared__ int tot[KWY_THREADS];
   const int t = threadIdx.x;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_scan_counts(int *__restrict
 }
 
 // phase A: per-sample phase increment 2*pi*f0/fs and vuv flag
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_inc(const double *__restrict__ f0, syn_params p,
+__device__ __forceinline__ void syn_inc_body(const double *__restrict__ f0, syn_params p,
                                                         double *__restrict__ inc,
                                                         unsigned char *__restrict__ vuv8) {
   const int64_t n = (int64_t)blockIdx.x * KWY_THREADS + threadIdx.x;
@@ -234,7 +234,7 @@ __device__ __forceinline__ int syn_exponent(double v) {
 #define SYN_SLOW (-100000)
 
 // phase B1: plain f64 sum of every tile's increments (an estimate of where each tile starts)
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_sums(const double *__restrict__ inc, int64_t y_length,
+__device__ __forceinline__ void syn_tile_sums_body(const double *__restrict__ inc, int64_t y_length,
                                                               double *__restrict__ tsum) {
   __shared__ double red[8];
   const int64_t tile0 = (int64_t)blockIdx.x * SYN_PH_TILE;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_sums(const double *__r
 #define SYN_CHUNK 256
 #define SYN_NCHUNK (SYN_PH_TILE / SYN_CHUNK)
 struct syn_chunks { int ka; int pad; syn_ff m[SYN_NCHUNK][2]; };      // ka == SYN_SLOW: no chunk maps
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_summary(const double *__restrict__ inc,
+__device__ __forceinline__ void syn_tile_summary_body(const double *__restrict__ inc,
                                                                  int64_t y_length,
                                                                  const double *__restrict__ tsum, int ntiles,
                                                                  long long *__restrict__ summ /* 3 per tile */,
@@ -325,7 +325,7 @@ struct syn_segs {                 // of one slow tile
   int start[SYN_MAXSEG], end[SYN_MAXSEG];
   double tp[SYN_MAXSEG];
 };
-__global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__restrict__ inc,
+__device__ __forceinline__ void syn_phase_body(const double *__restrict__ inc,
                                                              int64_t y_length,
                                                              const long long *__restrict__ summ,
                                                              double *__restrict__ tin,
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(const double *__re
 
 // phase B4, in parallel: every sample's exact phase from the exact phase its tile (or its segment of a slow tile)
 // starts from
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_apply(const double *__restrict__ inc, int64_t y_length,
+__device__ __forceinline__ void syn_tile_apply_body(const double *__restrict__ inc, int64_t y_length,
                                                                const double *__restrict__ tin,
                                                                const syn_segs *__restrict__ segs,
                                                                double *__restrict__ wrap) {
@@ -697,7 +697,7 @@ __device__ __forceinline__ bool syn_is_pulse(const double *__restrict__ wrap, in
 }
 
 // phase D: pulses per tile
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_count(const double *__restrict__ wrap,
+__device__ __forceinline__ void syn_pulse_count_body(const double *__restrict__ wrap,
                                                                 int64_t y_length, int *__restrict__ cnt) {
   __shared__ int sh[KWY_WAVES];
   const int64_t base = (int64_t)blockIdx.x * SYN_TILE + (int64_t)threadIdx.x * SYN_TILE_PER_THREAD;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_count(const double *_
 }
 
 // phase E: ordered pulse list
-__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_emit(const double *__restrict__ wrap,
+__device__ __forceinline__ void syn_pulse_emit_body(const double *__restrict__ wrap,
                                                                int64_t y_length, int fs,
                                                                const int *__restrict__ tile_off,
                                                                int cap, int32_t *__restrict__ pidx,
@@ -736,6 +736,74 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_emit(const double *__
       ++pos;
     }
   }
+}
+
+// ---- the placement kernels: one launch per step for a batch of utterances (blockIdx.y = utterance) ----------------
+// The pulse placement -- everything that depends on f0 only -- and the rendering of the pulses are separate steps, so
+// that a pipeline can place the pulses on another stream while the spectral features are still being computed
+// (kwy_synth_plan_dev / kwy_synth_render_dev); kwy_synthesize_dev runs both.
+struct syn_plan {
+  int *npulse;             // 16 ints
+  int *tile_cnt;           // nt + 1: pulses per output tile, then their offsets
+  unsigned char *vuv8;     // y_length
+  int32_t *pidx;           // cap
+  double *pshift;          // cap
+};
+struct syn_plan_view {
+  const double *f0;
+  syn_params p;
+  syn_plan pl;
+  double *incr, *wrap, *tsum, *tin;    // scratch: increments, wrapped phase, tile sums, tile start phases
+  long long *summ;
+  syn_segs *segs;
+  syn_chunks *chunks;
+  int cap;
+};
+struct syn_plan_batch {
+  int n;
+  long long *dbg;
+  syn_plan_view u[KWY_BATCH_MAX];
+};
+__device__ __forceinline__ int syn_npt(int64_t y_length) { return (int)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE); }
+__device__ __forceinline__ int syn_nt(int64_t y_length) { return (int)((y_length + SYN_TILE - 1) / SYN_TILE); }
+
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_inc(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.y];
+  syn_inc_body(v.f0, v.p, v.incr, v.pl.vuv8);
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_sums(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.y];
+  if ((int)blockIdx.x >= syn_npt(v.p.y_length)) return;
+  syn_tile_sums_body(v.incr, v.p.y_length, v.tsum);
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_summary(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.y];
+  const int npt = syn_npt(v.p.y_length);
+  if ((int)blockIdx.x >= npt) return;
+  syn_tile_summary_body(v.incr, v.p.y_length, v.tsum, npt, v.summ, v.chunks);
+}
+__global__ __launch_bounds__(SYN_PH_THREADS) void k_syn_phase(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.x];
+  syn_phase_body(v.incr, v.p.y_length, v.summ, v.tin, v.segs, v.chunks, v.wrap, b.dbg);
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_tile_apply(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.y];
+  if ((int)blockIdx.x >= syn_npt(v.p.y_length)) return;
+  syn_tile_apply_body(v.incr, v.p.y_length, v.tin, v.segs, v.wrap);
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_count(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.y];
+  if ((int)blockIdx.x >= syn_nt(v.p.y_length)) return;
+  syn_pulse_count_body(v.wrap, v.p.y_length, v.pl.tile_cnt);
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_scan_counts(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.x];
+  syn_scan_counts_body(v.pl.tile_cnt, syn_nt(v.p.y_length), v.pl.npulse);
+}
+__global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_emit(syn_plan_batch b) {
+  const syn_plan_view &v = b.u[blockIdx.y];
+  if ((int)blockIdx.x >= syn_nt(v.p.y_length)) return;
+  syn_pulse_emit_body(v.wrap, v.p.y_length, v.p.fs, v.pl.tile_cnt, v.cap, v.pl.pidx, v.pl.pshift);
 }
 
 // Minimum-phase spectrum (common.cpp GetMinimumPhaseSpectrum), in place: buf holds the half
@@ -1127,17 +1195,6 @@ static size_t syn_scratch_bytes(int64_t y_length, int fft_size, int fs) {
   return syn_plan_bytes(y_length) + syn_plan_scratch_bytes(y_length) + syn_render_scratch_bytes(y_length, fft_size, fs);
 }
 
-// The pulse placement -- everything that depends on f0 only -- and the rendering of the pulses are separate steps, so
-// that a pipeline can place the pulses on another stream while the spectral features are still being computed
-// (kwy_synth_plan_dev / kwy_synth_render_dev); kwy_synthesize_dev runs both.
-struct syn_plan {
-  int *npulse;             // 16 ints
-  int *tile_cnt;           // nt + 1: pulses per output tile, then their offsets
-  unsigned char *vuv8;     // y_length
-  int32_t *pidx;           // cap
-  double *pshift;          // cap
-};
-
 static size_t syn_plan_bytes(int64_t y_length) {
   const int64_t nt = (y_length + SYN_TILE - 1) / SYN_TILE;
   const int cap = syn_pulse_cap(y_length);
@@ -1178,39 +1235,52 @@ static size_t syn_plan_scratch_bytes(int64_t y_length) {
          kwy_pad(sizeof(syn_segs) * (y_length / 4096 + 2)) + kwy_pad(sizeof(syn_chunks) * (y_length / 4096 + 2));
 }
 
-static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const syn_plan &pl) {
+// the scratch of one utterance's placement from the context's arena into `v`
+static int syn_plan_fill(kwy_ctx *ctx, const double *f0, const syn_params &p, const syn_plan &pl, syn_plan_view *v) {
   const int64_t y_length = p.y_length;
-  const int nt = (int)((y_length + SYN_TILE - 1) / SYN_TILE);
-  const int cap = syn_pulse_cap(y_length);
-  double *incr = kwy_arena<double>(ctx, y_length);
   const size_t npt_alloc = (size_t)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE) + 1;
-  double *ph_tsum = kwy_arena<double>(ctx, npt_alloc), *ph_tin = kwy_arena<double>(ctx, npt_alloc);
-  long long *ph_summ = kwy_arena<long long>(ctx, 3 * npt_alloc);
-  syn_segs *ph_segs = kwy_arena<syn_segs>(ctx, npt_alloc);
-  syn_chunks *ph_chunks = kwy_arena<syn_chunks>(ctx, npt_alloc);
-  double *wrap = kwy_arena<double>(ctx, y_length);
-  if (!incr || !ph_tsum || !ph_tin || !ph_summ || !ph_segs || !ph_chunks || !wrap) {
+  v->f0 = f0; v->p = p; v->pl = pl;
+  v->cap = syn_pulse_cap(y_length);
+  v->incr = kwy_arena<double>(ctx, y_length);
+  v->tsum = kwy_arena<double>(ctx, npt_alloc);
+  v->tin = kwy_arena<double>(ctx, npt_alloc);
+  v->summ = kwy_arena<long long>(ctx, 3 * npt_alloc);
+  v->segs = kwy_arena<syn_segs>(ctx, npt_alloc);
+  v->chunks = kwy_arena<syn_chunks>(ctx, npt_alloc);
+  v->wrap = kwy_arena<double>(ctx, y_length);
+  if (!v->incr || !v->tsum || !v->tin || !v->summ || !v->segs || !v->chunks || !v->wrap) {
     ctx->err = "synthesize: scratch arena too small";
     return KWY_ENOMEM;
   }
-  hipLaunchKernelGGL(k_syn_inc, dim3((unsigned)((y_length + KWY_THREADS - 1) / KWY_THREADS)),
-                     dim3(KWY_THREADS), 0, ctx->stream, f0, p, incr, pl.vuv8);
-  {
-    const int npt = (int)((y_length + SYN_PH_TILE - 1) / SYN_PH_TILE);
-    hipLaunchKernelGGL(k_syn_tile_sums, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum);
-    hipLaunchKernelGGL(k_syn_tile_summary, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tsum,
-                       npt, ph_summ, ph_chunks);
-    KWY_PROF(ctx, "k_syn_phase", hipLaunchKernelGGL(k_syn_phase, dim3(1), dim3(SYN_PH_THREADS), 0, ctx->stream,
-                                                      incr, y_length, ph_summ, ph_tin, ph_segs, ph_chunks, wrap, (long long *)ctx->dbg));
-    hipLaunchKernelGGL(k_syn_tile_apply, dim3(npt), dim3(KWY_THREADS), 0, ctx->stream, incr, y_length, ph_tin,
-                       ph_segs, wrap);
-  }
-  hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, pl.tile_cnt);
-  hipLaunchKernelGGL(k_syn_scan_counts, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, pl.tile_cnt, nt, pl.npulse);
-  hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt), dim3(KWY_THREADS), 0, ctx->stream, wrap, y_length, p.fs,
-                     pl.tile_cnt, cap, pl.pidx, pl.pshift);
+  return KWY_OK;
+}
+
+// the placement of the batch's utterances: eight launches whatever their number
+static int synth_plan_launch(kwy_ctx *ctx, syn_plan_batch &b) {
+  int64_t ymax = 0;
+  for (int u = 0; u < b.n; ++u) ymax = std::max(ymax, b.u[u].p.y_length);
+  for (int u = b.n; u < KWY_BATCH_MAX; ++u) b.u[u] = b.u[0];
+  b.dbg = (long long *)ctx->dbg;
+  const unsigned n = (unsigned)b.n;
+  const unsigned npt = (unsigned)((ymax + SYN_PH_TILE - 1) / SYN_PH_TILE), nt = (unsigned)((ymax + SYN_TILE - 1) / SYN_TILE);
+  hipLaunchKernelGGL(k_syn_inc, dim3((unsigned)((ymax + KWY_THREADS - 1) / KWY_THREADS), n), dim3(KWY_THREADS), 0,
+                     ctx->stream, b);
+  hipLaunchKernelGGL(k_syn_tile_sums, dim3(npt, n), dim3(KWY_THREADS), 0, ctx->stream, b);
+  hipLaunchKernelGGL(k_syn_tile_summary, dim3(npt, n), dim3(KWY_THREADS), 0, ctx->stream, b);
+  KWY_PROF(ctx, "k_syn_phase", hipLaunchKernelGGL(k_syn_phase, dim3(n), dim3(SYN_PH_THREADS), 0, ctx->stream, b));
+  hipLaunchKernelGGL(k_syn_tile_apply, dim3(npt, n), dim3(KWY_THREADS), 0, ctx->stream, b);
+  hipLaunchKernelGGL(k_syn_pulse_count, dim3(nt, n), dim3(KWY_THREADS), 0, ctx->stream, b);
+  hipLaunchKernelGGL(k_syn_scan_counts, dim3(n), dim3(KWY_THREADS), 0, ctx->stream, b);
+  hipLaunchKernelGGL(k_syn_pulse_emit, dim3(nt, n), dim3(KWY_THREADS), 0, ctx->stream, b);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
+}
+
+static int synth_plan(kwy_ctx *ctx, const double *f0, const syn_params &p, const syn_plan &pl) {
+  syn_plan_batch b;
+  b.n = 1;
+  KWY_TRY(syn_plan_fill(ctx, f0, p, pl, &b.u[0]));
+  return synth_plan_launch(ctx, b);
 }
 
 static int syn_fill_view(kwy_ctx *ctx, const syn_plan &pl, const double *sp, const double *ap, const syn_params &p,
@@ -1300,6 +1370,34 @@ extern "C" int kwy_synth_plan_dev(kwy_ctx *ctx, const double *f0, int64_t T, int
   if (y_length < 2 || T < 2) return KWY_OK;
   KWY_TRY(kwy_arena_begin(ctx, syn_plan_scratch_bytes(y_length)));
   return synth_plan(ctx, f0, p, syn_plan_carve(plan, y_length));
+}
+
+extern "C" int kwy_synth_plan_batch_dev(kwy_ctx *ctx, const kwy_synth_plan_job *jobs, int count, int fft_size,
+                                        double frame_period_ms, int fs) {
+  if (!ctx) return KWY_EINVAL;
+  if (!jobs || count < 0) { ctx->err = "synth_plan_batch: bad argument"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  size_t bytes = 0;
+  for (int j = 0; j < count; ++j) {
+    const kwy_synth_plan_job &q = jobs[j];
+    KWY_TRY(syn_check(ctx, q.f0, q.f0_length, q.f0, q.f0, fft_size, frame_period_ms, fs, q.y_length, q.f0));
+    if (!q.plan) { ctx->err = "synth_plan_batch: bad argument"; return KWY_EINVAL; }
+    bytes += syn_plan_scratch_bytes(q.y_length);
+  }
+  KWY_TRY(kwy_arena_begin(ctx, bytes));
+  syn_plan_batch b;
+  b.n = 0;
+  for (int j = 0; j < count; ++j) {
+    const kwy_synth_plan_job &q = jobs[j];
+    syn_params p;
+    int log2n;
+    KWY_TRY(syn_make_params(ctx, q.f0_length, fft_size, frame_period_ms, fs, 1.0, q.y_length, &p, &log2n));
+    if (q.y_length < 2 || q.f0_length < 2) continue;
+    KWY_TRY(syn_plan_fill(ctx, q.f0, p, syn_plan_carve(q.plan, q.y_length), &b.u[b.n]));
+    if (++b.n == KWY_BATCH_MAX) { KWY_TRY(synth_plan_launch(ctx, b)); b.n = 0; }
+  }
+  if (b.n > 0) KWY_TRY(synth_plan_launch(ctx, b));
+  return KWY_OK;
 }
 
 extern "C" int kwy_synth_render_dev(kwy_ctx *ctx, const void *plan, int64_t T, const double *sp, const double *ap,

@@ -300,6 +300,220 @@ class PairPipeline(_Graphed):
         self.ctx.sync()
 
 
+class _Wave:
+    """The pairs of one wave of a PairBatchPipeline: two streams with a library context each, and the wave's buffers
+    as CONTIGUOUS blocks -- the padded features of all its utterances form one (rows, K) matrix, so the row-wise
+    stages (sp2mc, mc2sp) are one launch over the wave, and the ragged stages take per-utterance views of it."""
+
+    def __init__(self, owner, pairs, main_stream=None):
+        dev, K, order, fs = owner.dev, owner.K, owner.order, owner.fs
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.n = len(pairs)
+        self.stream = main_stream if main_stream is not None else torch.cuda.Stream(device=dev)
+        self.side = torch.cuda.Stream(device=dev)
+        self.ctx = _lib.Context(dev.index, stream=self.stream.cuda_stream)
+        self.side_ctx = _lib.Context(dev.index, stream=self.side.cuda_stream)
+        sides = [s for pair in pairs for s in pair]               # source 0, target 0, source 1, ...
+        self.N = [len(s[0]) for s in sides]
+        self.T = [len(s[1]) for s in sides]
+        self.Tp = [t + 2 * PAD_LEN for t in self.T]
+        cat = lambda k: torch.from_numpy(np.concatenate([np.ascontiguousarray(s[k], dtype=np.float64)  # noqa: E731
+                                                         for s in sides])).to(dev)
+        with torch.cuda.stream(self.stream):
+            self.x_all, self.f0_all, self.t_all = cat(0), cat(1), cat(2)
+            rows = int(sum(self.Tp))
+            self.sp_pad = torch.zeros((rows, K), **f64)
+            self.ap_pad = torch.full((rows, K), 1 - SAFE_GUARD_MINIMUM, **f64)
+            self.f0_pad = torch.zeros(rows, **f64)
+            self.mc_pad = torch.empty((rows, order + 1), **f64)
+            self.feat = torch.empty((rows, order + 2), **f64)
+            xo = np.concatenate(([0], np.cumsum(self.N)))
+            to = np.concatenate(([0], np.cumsum(self.T)))
+            po = np.concatenate(([0], np.cumsum(self.Tp)))
+            cut = lambda a, o, i, lo=0, hi=0: a[int(o[i]) + lo:int(o[i + 1]) - hi]  # noqa: E731
+            ns = len(sides)
+            self.x = [cut(self.x_all, xo, i) for i in range(ns)]
+            self.f0 = [cut(self.f0_all, to, i) for i in range(ns)]
+            self.t = [cut(self.t_all, to, i) for i in range(ns)]
+            self.sp = [cut(self.sp_pad, po, i, PAD_LEN, PAD_LEN) for i in range(ns)]      # the un-padded middle parts
+            self.ap = [cut(self.ap_pad, po, i, PAD_LEN, PAD_LEN) for i in range(ns)]
+            self.sp_p = [cut(self.sp_pad, po, i) for i in range(ns)]
+            self.ap_p = [cut(self.ap_pad, po, i) for i in range(ns)]
+            self.mc_p = [cut(self.mc_pad, po, i) for i in range(ns)]
+            self.f0_p = [cut(self.f0_pad, po, i) for i in range(ns)]
+            self.feat_p = [cut(self.feat, po, i) for i in range(ns)]
+            for i in range(ns):
+                self.f0_p[i][PAD_LEN:PAD_LEN + self.T[i]] = self.f0[i]
+            # pad rows in the reference's order of draws: source head, source tail, target head, target tail
+            self.pad_rows = [blk for i in range(ns) for blk in (self.sp_p[i][:PAD_LEN], self.sp_p[i][PAD_LEN + self.T[i]:])]
+            # per pair, on the target's time axis
+            Tt = [self.T[2 * k + 1] for k in range(self.n)]
+            self.Tt = Tt
+            ao = np.concatenate(([0], np.cumsum(Tt)))
+            arows = int(ao[-1])
+            self.ap_al = torch.empty((arows, K), **f64)
+            self.mc_al = torch.empty((arows, order + 1), **f64)
+            self.mc_conv = torch.empty((arows, order + 1), **f64)
+            self.sp_conv = torch.empty((arows, K), **f64)
+            self.ylen = [lib.kwy_synth_length(t, owner.frame_period, fs) for t in Tt]
+            yo = np.concatenate(([0], np.cumsum(self.ylen)))
+            self.wave_all = torch.empty(int(yo[-1]), **f64)
+            self.wave = [cut(self.wave_all, yo, k) for k in range(self.n)]
+            cap = [self.Tp[2 * k] + self.Tp[2 * k + 1] + 2 for k in range(self.n)]
+            self.path = [torch.zeros((c, 2), dtype=torch.int32, device=dev) for c in cap]
+            self.path_len = torch.zeros(self.n, dtype=torch.int64, device=dev)
+            self.dist = torch.zeros(self.n, **f64)
+            self.idx = [torch.zeros(self.Tp[2 * k + 1], dtype=torch.int32, device=dev) for k in range(self.n)]
+            self.n_idx = torch.zeros(self.n, dtype=torch.int64, device=dev)
+            self.plan = [torch.empty(lib.kwy_synth_plan_bytes(y), dtype=torch.uint8, device=dev) for y in self.ylen]
+            one = lambda a, k: a[k:k + 1]  # noqa: E731
+            J = _lib.job_array
+            both = range(ns)
+            self.j_env = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], self.sp[i]) for i in both])
+            self.j_ap = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], self.ap[i]) for i in both])
+            self.j_feat = J(_lib.AlignJob, [(self.mc_p[i], self.f0_p[i], self.Tp[i], self.feat_p[i]) for i in both])
+            self.j_dtw = J(_lib.DtwJob, [(self.feat_p[2 * k], self.Tp[2 * k], self.feat_p[2 * k + 1], self.Tp[2 * k + 1],
+                                          one(self.dist, k), self.path[k], one(self.path_len, k)) for k in range(self.n)])
+            self.j_proj = J(_lib.ProjectJob, [(self.path[k], one(self.path_len, k), self.idx[k], self.Tp[2 * k + 1],
+                                               one(self.n_idx, k)) for k in range(self.n)])
+            self.j_gap = J(_lib.GatherJob, [(self.ap_p[2 * k], self.Tp[2 * k], self.idx[k], Tt[k], cut(self.ap_al, ao, k))
+                                            for k in range(self.n)])
+            self.j_gmc = J(_lib.GatherJob, [(self.mc_p[2 * k], self.Tp[2 * k], self.idx[k], Tt[k], cut(self.mc_al, ao, k))
+                                            for k in range(self.n)])
+            self.j_conv = J(_lib.ConvertJob, [(cut(self.mc_al, ao, k), Tt[k], cut(self.mc_conv, ao, k)) for k in range(self.n)])
+            self.j_plan = J(_lib.SynthPlanJob, [(self.f0[2 * k + 1], Tt[k], self.ylen[k], self.plan[k]) for k in range(self.n)])
+            self.j_render = _lib.synth_job_array([(self.plan[k], cut(self.sp_conv, ao, k), cut(self.ap_al, ao, k), self.wave[k])
+                                                  for k in range(self.n)])
+        self.rows, self.arows = rows, arows
+        self.frames = sum(self.T[0::2])
+
+
+class PairBatchPipeline(_Graphed):
+    """The hot path of a BATCH of pairs in lockstep: every stage is one launch (or one pass of launches) over all pairs
+    of a wave -- the batched entries of include/kwy.h -- instead of one stream per pair.
+
+    The serial stages of a pair (FastDTW's recurrence, the synthesis' phase chain, the trajectory solve) are one
+    workgroup each; with N pairs in one grid they occupy N compute units side by side, and the chip-wide stages run over
+    N times the frames.  A wave (<= 16 pairs: the batch limit of one launch) uses two streams:
+
+        main   CheapTrick of both sides -> [pads] -> sp2mc -> DTW features -> FastDTW -> projection
+               -> [aperiodicity] -> gathers -> conversion -> mc2sp -> [plan] -> rendering
+        side   D4C of both sides (waveform, f0 and frame times only) -> pulse placement (target f0 only)
+
+    and `waves` waves run side by side (default 2: four streams, the number of hardware queues the HIP runtime creates
+    by default -- no GPU_MAX_HW_QUEUES needed).  One wave's serial kernels overlap with the other waves' chip-wide
+    ones.  The whole step is one HIP graph (`capture()` / `replay()`).
+
+    rng: a backend.nprandom.DeviceRandomState.  Every run then draws FRESH pad spectra for all pairs from numpy's
+    legacy stream -- source head, source tail, target head, target tail, pair after pair: the draws `align` makes
+    (kwiiyatta/vocoder/feature.py:19-41, world.py:158-161) -- in one call at the head of the step.  Without it the
+    pads are `silence` (4 blocks per pair) or drawn here once from numpy's global generator, as PairPipeline does.
+
+    Outputs per pair k: `wave(k)`; equal to PairPipeline's bit for bit given the same pads."""
+
+    def __init__(self, device_index, fs, pairs, gmm, order=24, radius=32, frame_period=5.0, waves=2, rng=None,
+                 silence=None):
+        self.dev = torch.device('cuda', device_index)
+        self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
+        self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
+        self.K = self.fft // 2 + 1
+        from .backend import sptk
+        self.alpha = sptk.mcepalpha(self.fs)
+        self.gmm = gmm
+        assert gmm.D2 == 6 * order
+        self.gmm_model = gmm.model(diff=False)
+        self.rng = rng
+        pairs = list(pairs)
+        nw = max(1, min(int(waves), len(pairs)))
+        while (len(pairs) + nw - 1) // nw > 16:        # a wave is one launch of the batched entries
+            nw += 1
+        per = (len(pairs) + nw - 1) // nw
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.waves = []
+        for w in range(nw):
+            chunk = pairs[w * per:(w + 1) * per]
+            if chunk:
+                self.waves.append(_Wave(self, chunk, main_stream=self.stream if w == 0 else None))
+        self.ctx = self.waves[0].ctx
+        self.where = [(w, k) for w, wv in enumerate(self.waves) for k in range(wv.n)]
+        self.pad_rows = [blk for wv in self.waves for blk in wv.pad_rows]
+        if rng is None:
+            if silence is None:
+                silence = [draw_silence(self.fs, self.K) for _ in range(4 * len(pairs))]
+            with torch.cuda.stream(self.stream):
+                for dst, sil in zip(self.pad_rows, silence):
+                    dst.copy_(torch.from_numpy(np.ascontiguousarray(sil)))
+        for wv in self.waves:
+            wv.stream.synchronize()
+        self.frames = sum(wv.frames for wv in self.waves)
+        self.n_pairs = len(pairs)
+
+    def wave(self, k):
+        w, i = self.where[k]
+        return self.waves[w].wave[i]
+
+    def path(self, k):
+        """(path, path_len, dist) device tensors of pair k"""
+        w, i = self.where[k]
+        wv = self.waves[w]
+        return wv.path[i], wv.path_len[i:i + 1], wv.dist[i:i + 1]
+
+    def contexts(self):
+        cs = [c for wv in self.waves for c in (wv.ctx, wv.side_ctx)]
+        return cs + ([self.rng.ctx] if self.rng is not None else [])
+
+    def run(self):
+        fs, fft, K, order = self.fs, self.fft, self.K, self.order
+        origin = self.stream
+        pads = None
+        with torch.cuda.stream(origin):
+            if self.rng is not None:
+                # ONE draw for the step, on the generator's own stream: the pads are needed first by sp2mc, behind
+                # CheapTrick, which the draw overlaps with
+                self.rng.stream.wait_stream(origin)
+                self.rng.abs_normal_blocks(EPS / fs, self.pad_rows)
+                pads = self.rng.record_event()
+            for wv in self.waves:
+                if wv.stream is not origin:
+                    wv.stream.wait_stream(origin)
+                wv.side.wait_stream(origin)
+        for wv in self.waves:
+            h, hs, n = wv.ctx.handle, wv.side_ctx.handle, wv.n
+            with torch.cuda.stream(wv.side):
+                _lib.check(wv.side_ctx, lib.kwy_d4c_batch_dev(hs, wv.j_ap, 2 * n, fs, 0.85, fft))
+                ap_done = torch.cuda.Event()
+                ap_done.record(wv.side)
+                _lib.check(wv.side_ctx, lib.kwy_synth_plan_batch_dev(hs, wv.j_plan, n, fft, self.frame_period, fs))
+            with torch.cuda.stream(wv.stream):
+                chk = lambda rc, c=wv.ctx: _lib.check(c, rc)  # noqa: E731
+                chk(lib.kwy_cheaptrick_batch_dev(h, wv.j_env, 2 * n, fs, -0.15, 71.0, fft, float(fs)))
+                if pads is not None:
+                    wv.stream.wait_event(pads)
+                chk(lib.kwy_sp2mc_dev(h, _p(wv.sp_pad), wv.rows, K, order, self.alpha, _p(wv.mc_pad)))
+                chk(lib.kwy_align_features_batch_dev(h, wv.j_feat, 2 * n, order + 1, POWER_WEIGHT, POWER_THRESHOLD,
+                                                     VUV_WEIGHT))
+                chk(lib.kwy_fastdtw_batch_dev(h, wv.j_dtw, n, order + 2, self.radius))
+                chk(lib.kwy_align_project_batch_dev(h, wv.j_proj, n, PAD_LEN))
+                wv.stream.wait_event(ap_done)
+                chk(lib.kwy_gather_rows_batch_dev(h, wv.j_gap, n, K))
+                chk(lib.kwy_gather_rows_batch_dev(h, wv.j_gmc, n, order + 1))
+                chk(lib.kwy_convert_mcep_batch_dev(h, wv.j_conv, n, order, self.gmm.M, _p(self.gmm_model)))
+                chk(lib.kwy_mc2sp_dev(h, _p(wv.mc_conv), wv.arows, order, self.alpha, fft, _p(wv.sp_conv)))
+                wv.stream.wait_stream(wv.side)                      # join: the plans are there
+                chk(lib.kwy_synth_render_batch_dev(h, wv.j_render, n, fft, self.frame_period, fs, float(fs)))
+        with torch.cuda.stream(origin):
+            for wv in self.waves:
+                if wv.stream is not origin:
+                    origin.wait_stream(wv.stream)
+            if self.rng is not None:
+                origin.wait_stream(self.rng.stream)
+
+    def sync(self):
+        for wv in self.waves:
+            wv.ctx.sync()
+            wv.side_ctx.sync()
+
+
 class UtterancePipeline(_Graphed):
     """analyse -> resynthesise of one utterance (BASELINE config 2; resynthesize_voice.py without a carrier,
     /root/reference/kwiiyatta/resynthesize_voice.py:46-79), HBM-resident."""
