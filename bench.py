@@ -6,12 +6,20 @@
 
 A step = one pass of the hot path over one batch of synthetic 48 kHz utterance
 pairs that are already resident in HBM.  Default workload = BASELINE config 3:
-analyse source and target (CheapTrick + D4C over given f0 tracks), pad, sp2mc,
-DTW-align source onto target (FastDTW, radius 32), convert with a 64-component
-GMM (delta + MLPG), mc2sp, WORLD synthesis.  Pairs are independent: each pair
-runs on its own HIP stream, ranks shard pairs with NO collective on the data
-path (weak scaling: pairs per GPU fixed); only the timing is reduced (MAX).
-One frame = 5 ms of SOURCE audio (240 samples).  Rank 0 prints one JSON line.
+analyse source and target (CheapTrick + D4C over given f0 tracks), pad with
+freshly drawn silent spectra (numpy's legacy generator continued on the GPU),
+sp2mc, DTW-align source onto target (FastDTW, radius 32), convert with a
+64-component GMM (delta + MLPG), mc2sp, WORLD synthesis.  Pairs are independent:
+the default driver runs a rank's pairs in LOCKSTEP through the batched entries
+of include/kwy.h (kwiiyatta_amd.pipeline.PairBatchPipeline: two waves of 16
+pairs on four streams, the whole step one HIP graph); ranks shard pairs with NO
+collective on the data path (weak scaling: pairs per GPU fixed); only the
+timing is reduced (MAX).  One frame = 5 ms of SOURCE audio (240 samples).
+Rank 0 prints one JSON line.
+
+--driver streams is round 3's driver (one stream and one graph per pair; it
+needs GPU_MAX_HW_QUEUES, see below), --driver serial runs one wave of the
+lockstep driver on ONE stream (per-kernel durations as rocprofv3 sees them).
 """
 import argparse
 import json
@@ -23,17 +31,23 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# One HIP stream per pair only overlaps with the others if the streams land on different hardware queues; the runtime's
-# default of 4 serialises the rest.  Measured at 32 pairs per step (frames/s, three runs each, round 2): 8 queues
-# 1.34 M, 16: 1.48 M, 24: 1.60 M, 28: 1.49 M, 32: 1.51 M, 36 and more: 1.60-1.63 M -- as many queues as streams still
-# leaves some of them sharing with the process's other streams, so ask for more than that.
-# Must be in the environment before the HIP runtime starts; the package itself leaves the environment alone.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '64')
+
+
+def _argv_value(flag, default):
+    return sys.argv[sys.argv.index(flag) + 1] if flag in sys.argv[:-1] else default
+
+
+# The stream-per-pair drivers (--driver streams, the utterance workloads) only overlap their streams if these land on
+# different hardware queues; the runtime's default of 4 serialises the rest (round 3: 4 queues 1.43 M frames/s, 64:
+# 1.91 M).  The variable must be in the environment before the HIP runtime starts.  The default lockstep driver uses
+# four streams and leaves the environment alone.
+if _argv_value('--driver', 'batch') == 'streams' or _argv_value('--workload', 'pair') == 'utterance':
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '64')
 
 FS = 48000
 FRAME_PERIOD = 5.0
 # counter summaries of the current kernels (tools/final_measure.sh + tools/collect_profiles.sh)
-PMC_TRAFFIC, PMC_SQ = 'r3_pmc_traffic.json', 'r3_pmc_sq_summary.json'
+PMC_TRAFFIC, PMC_SQ = 'r4_pmc_traffic.json', 'r4_pmc_sq_summary.json'
 METRIC = 'frames/sec end-to-end analyse->align->convert->synth, 48 kHz 5 ms hop'
 
 
@@ -238,6 +252,280 @@ def main_batch(args):
         dist.destroy_process_group()
 
 
+def main_lockstep(args):
+    """BASELINE config 3 on the lockstep driver (kwiiyatta_amd.pipeline.PairBatchPipeline): a rank's pairs as waves of
+    <= 16 through the batched entries of include/kwy.h, the step one HIP graph on four streams; the pad spectra of
+    every pair are drawn INSIDE the step from numpy's legacy generator continued on the device (what `align` does per
+    call: /root/reference/kwiiyatta/vocoder/feature.py:19-41, world.py:158-161)."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    rdev = dev if args.backend == 'nccl' else torch.device('cpu')   # where the timing reductions live
+
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    from kwiiyatta_amd.parallel import shard_indices
+
+    serial = args.driver == 'serial'
+    mine = shard_indices(world * args.batch, rank, world)
+    nbase = min(len(mine), args.distinct)      # distinct host-generated signal pairs, reused round-robin
+    base = [make_pair(mine[i], args.seconds) for i in range(nbase)]
+    gmm = pl.synthetic_gmm(order=24, components=args.components, seed=0)
+    dgmm = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
+    pairs = [base[i % nbase] for i in range(len(mine))]
+    seed = 1000 + rank
+    rng = DeviceRandomState.from_seed(seed, device_index=local_rank)
+    pipe = pl.PairBatchPipeline(local_rank, FS, pairs, dgmm, waves=1 if serial else args.waves, rng=rng, serial=serial)
+    torch.cuda.synchronize()
+
+    def sync_all():
+        pipe.sync()
+        torch.cuda.synchronize()
+
+    def reduce_max(seconds):
+        if world > 1:
+            tt = torch.tensor([seconds], dtype=torch.float64, device=rdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            seconds = float(tt.item())
+        return seconds
+
+    def timed(step_fn, steps, finish=None):
+        """barrier + synchronize, `steps` steps, synchronize + barrier; MAX over ranks"""
+        sync_all()
+        if finish:
+            finish()
+        if world > 1:
+            dist.barrier()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync_all()
+        if finish:
+            finish()
+        if world > 1:
+            dist.barrier()
+        return reduce_max(time.perf_counter() - t0)
+
+    if args.graph:
+        pipe.capture()
+        step = pipe.replay
+    else:
+        step = pipe.run
+    for _ in range(args.warmup):
+        step()
+    el = timed(step, args.steps)
+    frames_rank = pipe.frames * args.steps
+    if world > 1:
+        ft = torch.tensor([float(frames_rank)], dtype=torch.float64, device=rdev)
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        frames_total = float(ft.item())
+    else:
+        frames_total = float(frames_rank)
+    value = frames_total / el
+
+    # One more (untimed) pass with the generator's state read before it: numpy, set to that state, must draw the same
+    # pads for all pairs and end in the same state.  Pair 0's pads, DTW path and waveform of that pass feed the parity
+    # check against the CPU chain below.
+    state_before = rng.get_state()
+    step()
+    sync_all()
+    draws_equal = None
+    if rank == 0:
+        ref = np.random.RandomState()
+        ref.set_state(state_before)
+        worst = 0.0
+        for blk in pipe.pad_rows:
+            exp = np.abs(ref.normal(0, pl.EPS / FS, (pl.PAD_LEN, pipe.K)))
+            worst = max(worst, float(np.abs(blk.cpu().numpy() - exp).max() / exp.max()))
+        st_d, st_n = rng.get_state(), ref.get_state()
+        draws_equal = {'state_equals_numpy': bool(np.array_equal(st_d[1], st_n[1]) and st_d[2:] == tuple(st_n[2:])),
+                       'pads_max_rel_diff_vs_numpy': worst, 'blocks': len(pipe.pad_rows),
+                       'note': 'one extra pass after the timed region: np.random.RandomState set to the device '
+                               'generator\'s state before the pass draws the same ' + str(len(pipe.pad_rows)) +
+                               ' blocks (values to the rounding of log) and ends in the same state'}
+    pads0 = [blk.cpu().numpy() for blk in pipe.pad_rows[:4]]
+    path_t, plen_t, _ = pipe.path(0)
+    path0 = [tuple(r) for r in path_t.cpu().numpy()[:int(plen_t.item())].tolist()]
+    wave0 = pipe.wave(0).cpu().numpy()
+
+    # ---- per-kernel durations: the same step enqueued kernel by kernel right after the timed region (HIP events
+    #      cannot be recorded inside a captured graph here), the library's events around its tracked kernels
+    names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_d4c_bands', 'k_syn_phase', 'k_syn_pulse', 'k_syn_ola', 'k_sp2mc',
+             'k_mc2sp', 'k_dtw_dist', 'k_dtw_values', 'k_dtw_codes', 'k_dtw_trace', 'k_dtw_small', 'k_gmm_logp', 'k_mlpg_chunks',
+             'k_mlpg_finish', 'k_np_words', 'k_np_jump', 'k_np_words_seg', 'k_np_emit']
+    pipe.profile(True)
+    for _ in range(min(args.steps, 3)):
+        pipe.run()
+    sync_all()
+    pipe.profile(False)
+    kernel_ms = {}
+    for nme in names:
+        ms, n = pipe.profile_read(nme)
+        if n:
+            kernel_ms[nme] = [ms, n]
+
+    # ---- variants (every rank takes part): pads replayed instead of drawn; transfers inside the step
+    variants = {}
+    if not args.no_variants and not serial:
+        pipe.rng = None                       # the pads of the last pass stay in place
+        if args.graph:
+            pipe.capture()
+        elp = timed(pipe.replay if args.graph else pipe.run, args.steps)
+        variants['pads_replayed'] = {'ms_per_step': 1000.0 * elp / args.steps, 'frames_per_s_rank': pipe.frames * args.steps / elp,
+                                     'note': 'the same step WITHOUT the draw (the pad rows keep the last draw): what the '
+                                             'fresh pads cost is the difference to `value`'}
+        pipe.rng = rng
+        if args.graph:
+            pipe.capture()
+        feeder = pl.BatchHostFeeder(pipe)
+        launch = (lambda p: p.replay()) if args.graph else (lambda p: p.run())
+        feeder.step(launch)
+        elp = timed(lambda: feeder.step(launch), args.steps, feeder.sync)
+        variants['with_pcie'] = {'ms_per_step': 1000.0 * elp / args.steps, 'frames_per_s_rank': pipe.frames * args.steps / elp,
+                                 'bytes_per_pair': int((feeder.host_in.numel() + feeder.host_out[0].numel()) * 8 // len(pairs)),
+                                 'note': 'same steps with all waveforms uploaded from pinned host memory and the synthesised '
+                                         'waveforms downloaded inside the timed region: one upload and one download per step on '
+                                         'two service streams, two staging slots each way '
+                                         '(kwiiyatta_amd.pipeline.BatchHostFeeder); never `value`'}
+        del feeder
+
+    if rank == 0:
+        K = pipe.K
+        hop = FS * FRAME_PERIOD / 1000.0
+        # the kernels with the GPU to themselves: ONE wave (<= 16 pairs) on ONE stream, kernel after kernel
+        lone_pairs = pairs[:min(16, len(pairs))]
+        lone = pipe if serial else pl.PairBatchPipeline(local_rank, FS, lone_pairs, dgmm, waves=1, serial=True,
+                                                        rng=DeviceRandomState.from_seed(7, device_index=local_rank))
+        lone.run(); lone.sync()
+        lone.profile(True)
+        per_pass, alone_n = {}, {}
+        for _ in range(7):
+            lone.run(); lone.sync()
+            for nme in names:
+                ms, n = lone.profile_read(nme)
+                if n:
+                    per_pass.setdefault(nme, []).append(ms / n)
+                    alone_n[nme] = n
+        lone.profile(False)
+        alone_ms = {k: sorted(v)[len(v) // 2] for k, v in per_pass.items()}       # medians over the passes
+        D4C = 'k_d4c_body+k_d4c_bands'
+        if 'k_d4c_body' in alone_ms and 'k_d4c_bands' in alone_ms:
+            alone_ms[D4C] = alone_ms['k_d4c_body'] + alone_ms['k_d4c_bands']
+            alone_n[D4C] = alone_n['k_d4c_body']
+        if 'k_d4c_body' in kernel_ms and 'k_d4c_bands' in kernel_ms:
+            a, b = kernel_ms['k_d4c_body'], kernel_ms['k_d4c_bands']
+            kernel_ms[D4C] = [a[0] + b[0], min(a[1], b[1])]
+        lw = lone.waves[0]
+        frames_both = float(sum(lw.T))                   # analysis: source + target frames of the lone wave
+        frames_tgt = float(sum(lw.Tt))
+        launches = {k: alone_n.get(k, 1) for k in (D4C, 'k_cheaptrick', 'k_d4c_lovetrain', 'k_syn_pulse')}
+        fpl = {k: (frames_tgt if k == 'k_syn_pulse' else frames_both) / max(1, launches[k]) for k in launches}
+        # ALGORITHMIC HBM bytes per launch of the whole-chip kernels (DESIGN.md section 5): hop new samples + (f0, t) in,
+        # one K-bin f64 row out per frame; the synthesis reads sp + ap rows and writes hop samples
+        algo = {D4C: fpl[D4C] * (hop * 8 + 16 + K * 8), 'k_cheaptrick': fpl['k_cheaptrick'] * (hop * 8 + 16 + K * 8),
+                'k_d4c_lovetrain': fpl['k_d4c_lovetrain'] * (hop * 8 + 16 + 8),
+                'k_syn_pulse': fpl['k_syn_pulse'] * (2 * K * 8 + hop * 8)}
+        cand = [k for k in algo if k in kernel_ms]
+        dom = max(cand, key=lambda k: kernel_ms[k][0]) if cand else D4C
+        traffic = None
+        try:        # PMC-measured HBM bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes) per launch
+            with open(os.path.join(ROOT, 'profiles', PMC_TRAFFIC)) as fh:
+                pmc = json.load(fh)
+            traffic = sum(pmc['kernels'][k]['hbm_bytes_per_launch_raw'] for k in dom.split('+')) * fpl[dom] / pmc['frames_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
+        achieved = algo[dom] / (alone_ms[dom] * 1e-3) / 1e9 if dom in alone_ms else None
+        sh = kernel_ms.get(dom)
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': achieved / 8000.0 if achieved else None, 'traffic': traffic,
+                    'avg_launch_ms': alone_ms.get(dom), 'launches': alone_n.get(dom, 0) * 7,
+                    'algorithmic_bytes_per_launch': algo[dom], 'frames_per_launch': fpl[dom],
+                    'shared': {'avg_launch_ms': sh[0] / sh[1] if sh else None, 'launches': sh[1] if sh else 0,
+                               'measured': 'the step enqueued kernel by kernel on its four streams right after the timed '
+                                           'region: the launch shares the chip with the other wave\'s kernels'},
+                    'note': 'the launch analyses 16 utterances (8 pairs\' sources and targets) in one grid; avg_launch_ms: HIP '
+                            'events on the launching stream, one wave of 16 pairs on ONE stream (median of 7 passes), which '
+                            '`bench.py --driver serial` under rocprofv3 reproduces (profiles/); the stage is bound by f64 '
+                            'FFT arithmetic in LDS, not by HBM -- the HBM fraction is reported as asked (DESIGN.md section 5)'}
+        roofline_compute = None
+        if D4C in alone_ms:
+            voiced = float((lw.f0_all > 0).sum().item()) / max(1, alone_n[D4C])
+            flop = voiced * 10 * 5 * 4096 * 12
+            tf = flop / (alone_ms[D4C] * 1e-3) / 1e12
+            roofline_compute = {'bound': 'f64 vector', 'kernel': D4C, 'achieved': tf, 'peak': 78.6, 'unit': 'TFLOP/s',
+                                'frac': tf / 78.6, 'avg_launch_ms': alone_ms[D4C], 'frames_with_work_per_launch': voiced,
+                                'algorithmic_flop_per_frame': 10 * 5 * 4096 * 12,
+                                'note': 'FFT flop only (windows, noise, smoothing, selects not counted); frames with work = '
+                                        'frames with f0 > 0 (upper bound of the frames that pass the gate)'}
+            try:
+                with open(os.path.join(ROOT, 'profiles', PMC_SQ)) as fh:
+                    sq = json.load(fh)
+                roofline_compute['valu_issue'] = {
+                    k: {'busy_share_of_launch_per_simd': sq[k]['VALU_busy_per_SIMD'],
+                        'valu_instructions_per_wavefront': sq[k]['VALU_insts_per_wave']}
+                    for k in ('k_d4c_body', 'k_d4c_bands') if k in sq}
+            except (OSError, KeyError, ValueError):
+                pass
+        out = {
+            'metric': METRIC, 'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1000.0 * el / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': ('config3: 48 kHz source (10 s, T=2001) + target (11 s, T=2201) pairs: CheapTrick+D4C of '
+                             'both, pad with freshly drawn silent spectra, sp2mc, FastDTW(radius 32) align, GMM(%d comp, '
+                             'D=144)+MLPG convert, mc2sp, WORLD synthesis' % args.components),
+                'pairs_per_gpu': args.batch, 'source_frames_per_pair': pipe.waves[0].T[0],
+                'driver': 'one stream, kernel after kernel (--driver serial)' if serial else
+                          'lockstep: %d waves of <= 16 pairs, two streams per wave, batched entries (one grid per stage and '
+                          'wave)' % len(pipe.waves),
+                'streams_per_gpu': 1 if serial else 2 * len(pipe.waves),
+                'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
+                'launch': 'the whole step is one captured HIP graph' if args.graph else 'one host launch per kernel',
+                'pad_spectra': 'drawn INSIDE every step: 4 x 100 x 1025 values per pair from numpy\'s legacy generator '
+                               '(MT19937 + polar Box-Muller) continued on the device, one call per step '
+                               '(kwy_np_normal_blocks_dev); draws_check compares the generator with numpy afterwards',
+                'gmm_model_prepared': 'once per converter (the per-mixture matrices depend on the GMM only)',
+                'parallelism': f'pairs in lockstep x{args.batch} per GPU, pair-per-GPU x{world}, no collective'},
+            'real_time_factor': value / 200.0,
+            'hbm_fraction_whole_path': value / world * 81000 / 8e12,
+            'kernel_ms_per_launch': {k: v[0] / v[1] for k, v in sorted(kernel_ms.items())},
+            'kernel_ms_per_launch_alone': {k: v for k, v in sorted(alone_ms.items())},
+            'roofline': roofline,
+            'roofline_compute': roofline_compute,
+            'draws_check': draws_equal,
+            'pads_replayed': variants.get('pads_replayed'),
+            'with_pcie': variants.get('with_pcie'),
+            'parity': None,
+            'distinct_pairs_per_gpu': nbase,
+            'cpu_baseline': None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            # the CPU chain on the very pads the device drew for pair 0 in the last timed pass
+            out['cpu_baseline'], ref = cpu_baseline_pair(base[0][0], base[0][1], gmm, pads0)
+            out['parity'] = {
+                'wave_rms_vs_cpu_chain': float(np.sqrt(np.mean((wave0 - ref['wave']) ** 2))),
+                'wave_peak': float(np.abs(ref['wave']).max()),
+                'dtw_path_equal': path0 == ref['path'], 'dtw_path_cells': len(ref['path']),
+                'tolerance': 1e-4,
+                'note': 'pair 0 of the pass right after the timed region vs oracle/chain.py on the same waveforms, f0 tracks, GMM and the pad '
+                        'blocks the device drew for that pass, every oracle stage fed by the oracle\'s own previous output'}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == '--cpu-worker':
         return cpu_worker(sys.argv[2])
@@ -247,7 +535,7 @@ def main():
     ap_.add_argument('--warmup', type=int, default=25,
                      help='untimed steps first (a box that has just started needs more than a few: its first ~0.3 s of '
                           'work run 5 %% slower -- clocks, first touches -- whatever the code does)')
-    ap_.add_argument('--batch', type=int, default=32, help='utterance pairs per GPU per step (one stream each)')
+    ap_.add_argument('--batch', type=int, default=32, help='utterance pairs per GPU per step')
     ap_.add_argument('--seconds', type=float, default=10.0, help='source utterance length')
     ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
     ap_.add_argument('--utterances', type=int, default=0,
@@ -256,6 +544,11 @@ def main():
                           'pool of --batch streams (kwiiyatta_amd.corpus.resynthesize_batch); 0 = config 2 (one '
                           'pipeline per stream)')
     ap_.add_argument('--components', type=int, default=64)
+    ap_.add_argument('--driver', choices=['batch', 'streams', 'serial'], default='batch',
+                     help='pair workload: batch = lockstep through the batched entries (default); streams = one stream and '
+                          'one graph per pair (round 3); serial = one wave of the lockstep driver on one stream')
+    ap_.add_argument('--waves', type=int, default=2, help='lockstep driver: waves of <= 16 pairs side by side')
+    ap_.add_argument('--no-variants', action='store_true', help='lockstep driver: skip the pads-replayed and PCIe variants')
     ap_.add_argument('--no-cpu-baseline', action='store_true')
     ap_.add_argument('--distinct', type=int, default=8, help='distinct synthetic signal pairs per rank (cycled over the batch)')
     ap_.add_argument('--no-pcie-variant', action='store_true',
@@ -277,6 +570,10 @@ def main():
     args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.batch == 1)
     if args.workload == 'utterance' and args.utterances > 0:
         return main_batch(args)
+    if args.workload == 'pair' and args.driver != 'streams':
+        if args.driver == 'serial' and args.batch > 16:
+            args.batch = 16
+        return main_lockstep(args)
 
     import torch
     import torch.distributed as dist

@@ -53,6 +53,11 @@ void *kwy_ctx_stream(kwy_ctx *ctx);
  * least `bytes` ahead of time (e.g. for the longest utterance of a batch) so that later calls do not move it. */
 int64_t kwy_ctx_arena_generation(kwy_ctx *ctx);
 int kwy_ctx_reserve(kwy_ctx *ctx, int64_t bytes);
+/* dst[0 .. bytes) <- src[0 .. bytes), device to device, as a KERNEL on the context's stream (bytes a multiple of 8;
+ * the buffers must not overlap).  For drivers that move a step's inputs and results between staging blocks and the
+ * buffers a captured graph reads (Wavdata -> Analyzer's copy, kwiiyatta/vocoder/world.py:14-17): a copy-engine
+ * transfer per stream and direction does not scale over many streams here, a kernel does. */
+int kwy_copy_dev(kwy_ctx *ctx, void *dst, const void *src, int64_t bytes);
 /* WORLD's analysis / synthesis noise is ONE fixed pseudo-random sequence (the generator is reseeded at the entry of
  * every pyworld call); the library keeps its first 2^KWY_RANDN_LOG2 draws (environment, default 25 = 128 MB, 0 = none)
  * in a table per device and computes draws beyond it by jump-ahead -- the same numbers either way.  This call lowers

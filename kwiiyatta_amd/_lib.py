@@ -63,6 +63,7 @@ SIGNATURES = {
     'kwy_ctx_stream': (c_vp, [c_vp]),
     'kwy_ctx_arena_generation': (c_i64, [c_vp]),
     'kwy_ctx_reserve': (c_int, [c_vp, c_i64]),
+    'kwy_copy_dev': (c_int, [c_vp, c_vp, c_vp, c_i64]),
     'kwy_ctx_set_randn_limit': (c_i64, [c_vp, c_i64]),
     'kwy_randn_stream': (c_int, [c_vp, c_i64, c_i64, c_vp]),
     'kwy_ctx_profile': (c_int, [c_vp, c_int]),

@@ -70,7 +70,13 @@ class DeviceRandomState:
         with torch.cuda.stream(self.stream):
             host = self.state.cpu()
         self.stream.synchronize()
-        return _unpack(host.numpy())
+        state = _unpack(host.numpy())
+        if state[2] < 0:
+            # k_np_advance poisons the position when a request ran out of laid-out attempts (a ~14 sigma event of
+            # the acceptance rate): some outputs of that call were never written
+            raise RuntimeError('DeviceRandomState: a draw ran out of attempts; its outputs are incomplete and the '
+                               'stream no longer follows numpy\'s')
+        return state
 
     def to_global(self):
         np.random.set_state(self.get_state())
@@ -89,17 +95,20 @@ class DeviceRandomState:
     def abs_normal(self, scale, size=None, out=None):
         return self.normal(0.0, scale, size=size, out=out, absolute=True)
 
-    def abs_normal_blocks(self, scale, outs):
+    def abs_normal_blocks(self, scale, outs, ctx=None):
         """np.abs(np.random.normal(0, scale, shape)) for equally sized tensors in a row, one library call (the four pad
         blocks of an aligned pair: source head, source tail, target head, target tail -- or those of all pairs of a
-        batch in pair order: the serial part of the generator then runs as ONE kernel)"""
+        batch in pair order: one layout of the generator's words for all of them).
+        ctx: enqueue on this library context's stream instead of the generator's own (a driver that wants the draw in
+        line with its other work; it then also orders the draw against other users of the generator)."""
+        ctx = self.ctx if ctx is None else ctx
         n_each = outs[0].numel()
         for t in outs:
             if t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.dev or t.numel() != n_each:
                 raise ValueError('outs must be equally sized contiguous float64 tensors on the generator\'s device')
         ptrs = (c_vp * len(outs))(*[t.data_ptr() for t in outs])
-        _lib.check(self.ctx, lib.kwy_np_normal_blocks_dev(self.ctx.handle, c_vp(self.state.data_ptr()), 0.0, float(scale),
-                                                          1, len(outs), n_each, ptrs))
+        _lib.check(ctx, lib.kwy_np_normal_blocks_dev(ctx.handle, c_vp(self.state.data_ptr()), 0.0, float(scale),
+                                                     1, len(outs), n_each, ptrs))
         return outs
 
     def sync(self):

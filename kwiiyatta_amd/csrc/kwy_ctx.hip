@@ -316,8 +316,38 @@ int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, int nthreads, const uint4 **out)
   return KWY_OK;
 }
 
+// ================================================================ device-to-device copy kernel
+__global__ __launch_bounds__(KWY_THREADS) void k_copy(double2 *__restrict__ dst, const double2 *__restrict__ src, int64_t n2,
+                                                     double *__restrict__ dst1, const double *__restrict__ src1) {
+  const int64_t stride = (int64_t)gridDim.x * KWY_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * KWY_THREADS + threadIdx.x; i < n2; i += stride) dst[i] = src[i];
+  if (dst1 && blockIdx.x == 0 && threadIdx.x == 0) *dst1 = *src1;        // the odd eighth byte group
+}
+
 // ================================================================ C ABI: context
 extern "C" {
+
+int kwy_copy_dev(kwy_ctx *ctx, void *dst, const void *src, int64_t bytes) {
+  if (!ctx) return KWY_EINVAL;
+  if (!dst || !src || bytes < 0 || (bytes & 7) || ((uintptr_t)dst & 7) || ((uintptr_t)src & 7)) {
+    ctx->err = "copy: bad argument (8-byte granularity)";
+    return KWY_EINVAL;
+  }
+  if (bytes == 0) return KWY_OK;
+  KWY_HIP(hipSetDevice(ctx->device));
+  if (((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) {      // 8-byte aligned only: plain doubles through the same kernel
+    KWY_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return KWY_OK;
+  }
+  const int64_t n2 = bytes / 16;
+  const bool odd = (bytes & 15) != 0;
+  int64_t g = (n2 + KWY_THREADS * 4 - 1) / (KWY_THREADS * 4);
+  g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+  hipLaunchKernelGGL(k_copy, dim3((unsigned)g), dim3(KWY_THREADS), 0, ctx->stream, (double2 *)dst, (const double2 *)src, n2,
+                     odd ? (double *)dst + 2 * n2 : nullptr, odd ? (const double *)src + 2 * n2 : nullptr);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
 
 int kwy_version(void) { return 1; }
 

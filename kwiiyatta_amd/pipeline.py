@@ -305,14 +305,17 @@ class _Wave:
     as CONTIGUOUS blocks -- the padded features of all its utterances form one (rows, K) matrix, so the row-wise
     stages (sp2mc, mc2sp) are one launch over the wave, and the ragged stages take per-utterance views of it."""
 
-    def __init__(self, owner, pairs, main_stream=None):
+    def __init__(self, owner, pairs, main_stream=None, serial=False):
         dev, K, order, fs = owner.dev, owner.K, owner.order, owner.fs
         f64 = dict(dtype=torch.float64, device=dev)
         self.n = len(pairs)
         self.stream = main_stream if main_stream is not None else torch.cuda.Stream(device=dev)
-        self.side = torch.cuda.Stream(device=dev)
         self.ctx = _lib.Context(dev.index, stream=self.stream.cuda_stream)
-        self.side_ctx = _lib.Context(dev.index, stream=self.side.cuda_stream)
+        if serial:          # one stream for everything: kernels one after the other (per-kernel timing, rocprofv3 runs)
+            self.side, self.side_ctx = self.stream, self.ctx
+        else:
+            self.side = torch.cuda.Stream(device=dev)
+            self.side_ctx = _lib.Context(dev.index, stream=self.side.cuda_stream)
         sides = [s for pair in pairs for s in pair]               # source 0, target 0, source 1, ...
         self.N = [len(s[0]) for s in sides]
         self.T = [len(s[1]) for s in sides]
@@ -409,10 +412,15 @@ class PairBatchPipeline(_Graphed):
     (kwiiyatta/vocoder/feature.py:19-41, world.py:158-161) -- in one call at the head of the step.  Without it the
     pads are `silence` (4 blocks per pair) or drawn here once from numpy's global generator, as PairPipeline does.
 
+    rng_place: where the draw runs -- 'side' (default: at the head of the first wave's side stream, in front of its
+    D4C; measured at 32 pairs: 29.7 ms per step against 29.4 without any draw), 'head' (on the main stream before the
+    fork: 30.0), 'own' (the generator's own stream as a fifth branch of the graph: 31.8).
+    serial: everything on ONE stream, kernel after kernel (for per-kernel timing).
+
     Outputs per pair k: `wave(k)`; equal to PairPipeline's bit for bit given the same pads."""
 
     def __init__(self, device_index, fs, pairs, gmm, order=24, radius=32, frame_period=5.0, waves=2, rng=None,
-                 silence=None):
+                 silence=None, rng_place='side', serial=False):
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
@@ -423,6 +431,7 @@ class PairBatchPipeline(_Graphed):
         assert gmm.D2 == 6 * order
         self.gmm_model = gmm.model(diff=False)
         self.rng = rng
+        self.rng_place = rng_place
         pairs = list(pairs)
         nw = max(1, min(int(waves), len(pairs)))
         while (len(pairs) + nw - 1) // nw > 16:        # a wave is one launch of the batched entries
@@ -433,7 +442,7 @@ class PairBatchPipeline(_Graphed):
         for w in range(nw):
             chunk = pairs[w * per:(w + 1) * per]
             if chunk:
-                self.waves.append(_Wave(self, chunk, main_stream=self.stream if w == 0 else None))
+                self.waves.append(_Wave(self, chunk, main_stream=self.stream if (w == 0 or serial) else None, serial=serial))
         self.ctx = self.waves[0].ctx
         self.where = [(w, k) for w, wv in enumerate(self.waves) for k in range(wv.n)]
         self.pad_rows = [blk for wv in self.waves for blk in wv.pad_rows]
@@ -459,20 +468,26 @@ class PairBatchPipeline(_Graphed):
         return wv.path[i], wv.path_len[i:i + 1], wv.dist[i:i + 1]
 
     def contexts(self):
-        cs = [c for wv in self.waves for c in (wv.ctx, wv.side_ctx)]
-        return cs + ([self.rng.ctx] if self.rng is not None else [])
+        cs = []
+        for wv in self.waves:
+            for c in (wv.ctx, wv.side_ctx):
+                if not any(c is o for o in cs):
+                    cs.append(c)
+        return cs + ([self.rng.ctx] if self.rng is not None and self.rng_place == 'own' else [])
 
     def run(self):
         fs, fft, K, order = self.fs, self.fft, self.K, self.order
         origin = self.stream
         pads = None
         with torch.cuda.stream(origin):
-            if self.rng is not None:
+            if self.rng is not None and self.rng_place == 'own':
                 # ONE draw for the step, on the generator's own stream: the pads are needed first by sp2mc, behind
                 # CheapTrick, which the draw overlaps with
                 self.rng.stream.wait_stream(origin)
                 self.rng.abs_normal_blocks(EPS / fs, self.pad_rows)
                 pads = self.rng.record_event()
+            elif self.rng is not None and self.rng_place == 'head':
+                self.rng.abs_normal_blocks(EPS / fs, self.pad_rows, ctx=self.ctx)
             for wv in self.waves:
                 if wv.stream is not origin:
                     wv.stream.wait_stream(origin)
@@ -480,6 +495,10 @@ class PairBatchPipeline(_Graphed):
         for wv in self.waves:
             h, hs, n = wv.ctx.handle, wv.side_ctx.handle, wv.n
             with torch.cuda.stream(wv.side):
+                if self.rng is not None and self.rng_place == 'side' and wv is self.waves[0]:
+                    self.rng.abs_normal_blocks(EPS / fs, self.pad_rows, ctx=wv.side_ctx)
+                    pads = torch.cuda.Event()
+                    pads.record(wv.side)
                 _lib.check(wv.side_ctx, lib.kwy_d4c_batch_dev(hs, wv.j_ap, 2 * n, fs, 0.85, fft))
                 ap_done = torch.cuda.Event()
                 ap_done.record(wv.side)
@@ -505,7 +524,7 @@ class PairBatchPipeline(_Graphed):
             for wv in self.waves:
                 if wv.stream is not origin:
                     origin.wait_stream(wv.stream)
-            if self.rng is not None:
+            if self.rng is not None and self.rng_place == 'own':
                 origin.wait_stream(self.rng.stream)
 
     def sync(self):
@@ -650,6 +669,83 @@ class HostFeeder:
     def sync(self):
         for p in self.pipes:
             p.sync()
+        self.up.synchronize()
+        self.down.synchronize()
+
+
+class BatchHostFeeder:
+    """The waveforms of a PairBatchPipeline's step from pinned host memory and its synthesised waveforms back, inside the
+    step: ONE upload and ONE download per step on two service streams, two staging slots each way, so the transfers of
+    neighbouring steps overlap with the kernels.  The pipeline's buffers keep their addresses (its captured graph stays
+    valid): the step starts with a device-to-device copy kernel of the library out of the staging block
+    (kwy_copy_dev) and ends with one into it.
+
+        feeder = BatchHostFeeder(pipe)
+        feeder.step(lambda p: p.replay())
+        feeder.sync()                          # results of the last step: feeder.result(k)
+    """
+
+    def __init__(self, pipe):
+        self.pipe = pipe
+        dev = pipe.dev
+        self.up, self.down = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        n_in = [wv.x_all.numel() for wv in pipe.waves]
+        n_out = [wv.wave_all.numel() for wv in pipe.waves]
+        self.in_off = np.concatenate(([0], np.cumsum(n_in))).astype(np.int64)
+        self.out_off = np.concatenate(([0], np.cumsum(n_out))).astype(np.int64)
+        f64 = dict(dtype=torch.float64)
+        self.host_in = torch.empty(int(self.in_off[-1]), **f64).pin_memory()
+        self.host_out = [torch.empty(int(self.out_off[-1]), **f64).pin_memory() for _ in range(2)]
+        for w, wv in enumerate(pipe.waves):
+            self.host_in[int(self.in_off[w]):int(self.in_off[w + 1])].copy_(wv.x_all)
+        self.slots = [dict(dev_in=torch.empty(int(self.in_off[-1]), device=dev, **f64),
+                           dev_out=torch.empty(int(self.out_off[-1]), device=dev, **f64),
+                           taken=None, drained=None) for _ in range(2)]
+        self.n = 0
+
+    def step(self, launch):
+        p, k = self.pipe, self.n & 1
+        self.n += 1
+        sl = self.slots[k]
+        if sl['taken'] is not None:              # the step of two steps ago has copied this slot in
+            self.up.wait_event(sl['taken'])
+        with torch.cuda.stream(self.up):
+            sl['dev_in'].copy_(self.host_in, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record(self.up)
+        p.stream.wait_event(arrived)
+        h = p.ctx.handle
+        with torch.cuda.stream(p.stream):
+            for w, wv in enumerate(p.waves):
+                _lib.check(p.ctx, lib.kwy_copy_dev(h, _p(wv.x_all), c_vp(sl['dev_in'].data_ptr() + 8 * int(self.in_off[w])),
+                                                   8 * wv.x_all.numel()))
+            sl['taken'] = torch.cuda.Event()
+            sl['taken'].record(p.stream)
+        launch(p)
+        if sl['drained'] is not None:
+            p.stream.wait_event(sl['drained'])            # the download of two steps ago has left this slot
+        with torch.cuda.stream(p.stream):
+            for w, wv in enumerate(p.waves):
+                _lib.check(p.ctx, lib.kwy_copy_dev(h, c_vp(sl['dev_out'].data_ptr() + 8 * int(self.out_off[w])), _p(wv.wave_all),
+                                                   8 * wv.wave_all.numel()))
+            done = torch.cuda.Event()
+            done.record(p.stream)
+        self.down.wait_event(done)
+        with torch.cuda.stream(self.down):
+            self.host_out[k].copy_(sl['dev_out'], non_blocking=True)
+            sl['drained'] = torch.cuda.Event()
+            sl['drained'].record(self.down)
+
+    def result(self, k):
+        """pair k's waveform of the last step (pinned host memory; call sync() first)"""
+        w, i = self.pipe.where[k]
+        wv = self.pipe.waves[w]
+        off = int(self.out_off[w]) + int(sum(wv.ylen[:i]))
+        return self.host_out[(self.n - 1) & 1][off:off + wv.ylen[i]]
+
+    def sync(self):
+        self.pipe.sync()
+        self.pipe.stream.synchronize()
         self.up.synchronize()
         self.down.synchronize()
 
