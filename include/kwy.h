@@ -439,6 +439,25 @@ int kwy_km_update_dev(kwy_ctx *ctx, const double *stats, const double *centers_o
 /* TrimmedDataset (dataset.py:49-52): n_out[0] = len(trim_zeros_frames(sp)), rows with L1 norm < eps
  * (nnmnkwii: 1e-7) counting as zero; the caller keeps the FIRST n_out frames, as the reference does */
 int kwy_trim_length_dev(kwy_ctx *ctx, const double *sp, int64_t T, int K, double eps, int64_t *n_out);
+typedef struct kwy_trim_job {
+  const double *sp;      /* T x K */
+  int64_t T;
+  int64_t *n_out;        /* 1 */
+} kwy_trim_job;
+int kwy_trim_length_batch_dev(kwy_ctx *ctx, const kwy_trim_job *jobs, int count, int K, double eps);
+/* pad_silence's cheap parts (kwiiyatta/vocoder/feature.py:19-41) on the first n frames of analysed utterances that are
+ * stored with pad_len frames of room on both ends -- f0_pad (n + 2 pad_len): the f0 track between zeros; ap_pad
+ * ((n + 2 pad_len) x K): the rows behind the kept frames = 1 - 1e-12 (the rows in front are the caller's
+ * initialisation) -- and, when `voiced` is not NULL, WorldSynthesizer.extract_is_voiced of the padded feature
+ * (world.py:147-151).  The pad SPECTRA come from kwy_np_normal_blocks_dev. */
+typedef struct kwy_pad_job {
+  const double *f0;      /* >= n */
+  int64_t n;             /* frames kept (kwy_trim_length_dev) */
+  double *f0_pad;        /* n + 2 pad_len */
+  double *ap_pad;        /* (n + 2 pad_len) x K, rows [pad_len, pad_len + n) analysed */
+  double *voiced;        /* n + 2 pad_len, or NULL */
+} kwy_pad_job;
+int kwy_train_pad_batch_dev(kwy_ctx *ctx, const kwy_pad_job *jobs, int count, int K, int fs, int pad_len);
 /* WorldSynthesizer.extract_is_voiced (world.py:147-151): voiced[t] = 1.0 / 0.0 */
 int kwy_is_voiced_dev(kwy_ctx *ctx, const double *f0, const double *ap, int64_t T, int K, int fs,
                       double *voiced);
@@ -457,6 +476,26 @@ int kwy_delta_features_dev(kwy_ctx *ctx, const double *x, const int64_t *n, int6
  * for the rows t < n[0] with L1 norm >= eps, in order; n_out[0] = rows written */
 int kwy_joint_rows_dev(kwy_ctx *ctx, const double *xd, const double *yd, const int64_t *n, int64_t capacity,
                        int width, double eps, double *joint, int64_t *n_out);
+/* Everything between FastDTW and the training matrix for a batch of aligned pairs, counts staying on the device:
+ * dtw_feature's strict filter + align_even's cut (kwy_align_even_dev), the mel-cepstra of the surviving cells without
+ * c0, their delta features, np.hstack + remove_zeros_frames, and the APPEND to the matrix
+ *   (kwiiyatta/vocoder/align.py:73-92,134-146, converter/mcep.py:10-33, delta.py:15-30, dataset.py:61-77)
+ * joint: capacity_rows x (2 * 3 d) doubles; cursor[0]: rows written so far (device; read and advanced in pair order,
+ * so the matrix holds the pairs' rows in job order behind whatever was there).  n_rows[0] <- the pair's rows (a pair
+ * that does not fit the capacity is dropped whole: n_rows = -1 - rows).  No host synchronisation. */
+typedef struct kwy_train_job {
+  const int32_t *path;       /* FastDTW path over the padded DTW features */
+  const int64_t *path_len;
+  const double *feat_x;      /* x_length x (d + 2) DTW features */
+  const double *feat_y;      /* y_length x (d + 2) */
+  const double *mc_x;        /* x_length x (d + 1) padded mel-cepstra */
+  const double *mc_y;        /* y_length x (d + 1) */
+  int64_t x_length, y_length;
+  int64_t *n_rows;           /* 1 */
+} kwy_train_job;
+int kwy_train_rows_batch_dev(kwy_ctx *ctx, const kwy_train_job *jobs, int count, int d, int strict, int use_power,
+                             int use_vuv, int pad_len, double eps, double *joint, int64_t capacity_rows,
+                             int64_t *cursor);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,9 @@ SIGNATURES = {
                                 ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'kwy_gmm_em_scratch_bytes': (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
     'kwy_trim_length_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
+    'kwy_trim_length_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl]),
+    'kwy_train_pad_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int]),
+    'kwy_train_rows_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_vp]),
     'kwy_is_voiced_dev': (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     'kwy_align_even_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int,
                                    c_vp, c_vp, c_i64, c_vp]),
@@ -212,6 +215,11 @@ GatherJob = _job_struct('GatherJob', 'kwy_gather_job: one row gather',
                         [('src', c_vp), ('src_rows', c_i64), ('idx', c_vp), ('n', c_i64), ('dst', c_vp)])
 ConvertJob = _job_struct('ConvertJob', 'kwy_convert_job: one utterance of a batched conversion',
                          [('mc', c_vp), ('T', c_i64), ('mc_out', c_vp)])
+TrimJob = _job_struct('TrimJob', 'kwy_trim_job', [('sp', c_vp), ('T', c_i64), ('n_out', c_vp)])
+PadJob = _job_struct('PadJob', 'kwy_pad_job', [('f0', c_vp), ('n', c_i64), ('f0_pad', c_vp), ('ap_pad', c_vp), ('voiced', c_vp)])
+TrainJob = _job_struct('TrainJob', 'kwy_train_job',
+                       [('path', c_vp), ('path_len', c_vp), ('feat_x', c_vp), ('feat_y', c_vp), ('mc_x', c_vp), ('mc_y', c_vp),
+                        ('x_length', c_i64), ('y_length', c_i64), ('n_rows', c_vp)])
 SynthPlanJob = _job_struct('SynthPlanJob', 'kwy_synth_plan_job: the pulse placement of one utterance',
                            [('f0', c_vp), ('f0_length', c_i64), ('y_length', c_i64), ('plan', c_vp)])
 

@@ -159,6 +159,134 @@ class TrainPair:
             return self.joint[:n]
 
 
+class _Lockstep:
+    """Two streams with a library context each, shared by all waves of a lockstep driver (the default four hardware
+    queues of the HIP runtime are enough: no GPU_MAX_HW_QUEUES)."""
+
+    def __init__(self, device_index):
+        self.dev = torch.device('cuda', device_index)
+        self.main, self.side = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
+        self.ctx = _lib.Context(device_index, stream=self.main.cuda_stream)
+        self.side_ctx = _lib.Context(device_index, stream=self.side.cuda_stream)
+
+    def sync(self):
+        self.main.synchronize()
+        self.side.synchronize()
+
+
+def _resident(side, dev, streams):
+    """(x, f0, t) as device tensors that the given streams may use after the caller has dropped them"""
+    out = []
+    for a in side:
+        t = a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        for s_ in streams:
+            t.record_stream(s_)
+        out.append(t)
+    return out
+
+
+class TrainWave:
+    """<= 16 parallel pairs -> their rows of the training matrix, in lockstep through the batched entries of
+    include/kwy.h (what TrainPair does pair by pair on a stream each):
+
+        w.analyse()   enqueue CheapTrick + D4C of all utterances and their trim lengths; the lengths start their way
+                      to the host (ONE read-back per wave)
+        w.finish(X, cursor, pads)   (waits for the lengths) enqueue padding, voicing, sp2mc, DTW features, FastDTW,
+                      strict filter + cut, deltas and the append of the joint rows behind the device-side cursor
+    """
+
+    def __init__(self, ls, fs, pairs, order=24, radius=32, frame_period=5.0):
+        self.ls, self.fs, self.order, self.radius = ls, int(fs), int(order), int(radius)
+        dev = ls.dev
+        self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
+        self.K = K = self.fft // 2 + 1
+        from .backend import sptk
+        self.alpha = sptk.mcepalpha(self.fs)
+        self.n = len(pairs)
+        f64 = dict(dtype=torch.float64, device=dev)
+        P = PAD_LEN
+        with torch.cuda.stream(ls.main):
+            sides = [_resident(s, dev, (ls.main, ls.side)) for pair in pairs for s in pair]
+            self.x, self.f0, self.t = ([s[k] for s in sides] for k in range(3))
+            self.N = [len(v) for v in self.x]
+            self.T = [len(v) for v in self.f0]
+            off = np.concatenate(([0], np.cumsum([t + 2 * P for t in self.T]))).astype(np.int64)
+            self.off = off
+            rows = int(off[-1])
+            self.rows = rows
+            self.sp_pad = torch.empty((rows, K), **f64)
+            self.ap_pad = torch.full((rows, K), 1 - SAFE_GUARD_MINIMUM, **f64)
+            self.f0_pad = torch.empty(rows, **f64)
+            self.voiced = torch.empty(rows, **f64)
+            self.mc_pad = torch.empty((rows, order + 1), **f64)
+            self.feat = torch.empty((rows, order + 2), **f64)
+            ns = len(sides)
+            self.keep_dev = torch.zeros(ns, dtype=torch.int64, device=dev)
+            self.keep_host = torch.zeros(ns, dtype=torch.int64).pin_memory()
+            reg = lambda a, i: a[int(off[i]):int(off[i + 1])]  # noqa: E731
+            self.sp = [reg(self.sp_pad, i)[P:P + self.T[i]] for i in range(ns)]
+            self.ap = [reg(self.ap_pad, i)[P:P + self.T[i]] for i in range(ns)]
+            self.reg = reg
+            self.j_env = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], self.sp[i]) for i in range(ns)])
+            self.j_ap = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], self.ap[i]) for i in range(ns)])
+            self.j_trim = _lib.job_array(_lib.TrimJob, [(self.sp[i], self.T[i], self.keep_dev[i:i + 1]) for i in range(ns)])
+            cap = [self.T[2 * k] + self.T[2 * k + 1] + 4 * P + 2 for k in range(self.n)]
+            self.path = [torch.zeros((c, 2), dtype=torch.int32, device=dev) for c in cap]
+            self.path_len = torch.zeros(self.n, dtype=torch.int64, device=dev)
+            self.dist = torch.zeros(self.n, **f64)
+            self.n_rows = torch.zeros(self.n, dtype=torch.int64, device=dev)
+        self.frames = sum(self.T[0::2])
+
+    def analyse(self):
+        ls, fs, fft, K, ns = self.ls, self.fs, self.fft, self.K, 2 * self.n
+        ls.side.wait_stream(ls.main)                # (the buffers were made on the main stream)
+        with torch.cuda.stream(ls.side):
+            _lib.check(ls.side_ctx, lib.kwy_d4c_batch_dev(ls.side_ctx.handle, self.j_ap, ns, fs, 0.85, fft))
+            self.ap_done = torch.cuda.Event()
+            self.ap_done.record(ls.side)
+        with torch.cuda.stream(ls.main):
+            h = ls.ctx.handle
+            _lib.check(ls.ctx, lib.kwy_cheaptrick_batch_dev(h, self.j_env, ns, fs, -0.15, 71.0, fft, float(fs)))
+            _lib.check(ls.ctx, lib.kwy_trim_length_batch_dev(h, self.j_trim, ns, K, TRIM_EPS))
+            self.keep_host.copy_(self.keep_dev, non_blocking=True)
+            self.keep_ready = torch.cuda.Event()
+            self.keep_ready.record(ls.main)
+
+    def finish(self, X, cursor, pads):
+        """pads(rows): fills the wave's pad rows -- a list of 4 n device views (source head, source tail, target
+        head, target tail, pair after pair) -- on the main stream"""
+        ls, fs, K, order, P, ns = self.ls, self.fs, self.K, self.order, PAD_LEN, 2 * self.n
+        self.keep_ready.synchronize()
+        keep = [int(v) for v in self.keep_host.tolist()]
+        Tp = [k + 2 * P for k in keep]
+        reg = self.reg
+        with torch.cuda.stream(ls.main):
+            h = ls.ctx.handle
+            chk = lambda rc: _lib.check(ls.ctx, rc)  # noqa: E731
+            sp_r = [reg(self.sp_pad, i) for i in range(ns)]
+            pads([blk for i in range(ns) for blk in (sp_r[i][:P], sp_r[i][P + keep[i]:Tp[i]])])
+            ls.main.wait_event(self.ap_done)
+            J = _lib.job_array
+            chk(lib.kwy_train_pad_batch_dev(h, J(_lib.PadJob, [(self.f0[i], keep[i], reg(self.f0_pad, i), reg(self.ap_pad, i),
+                                                               reg(self.voiced, i)) for i in range(ns)]), ns, K, fs, P))
+            chk(lib.kwy_sp2mc_dev(h, _p(self.sp_pad), self.rows, K, order, self.alpha, _p(self.mc_pad)))
+            # make_feature(vuv='voiced', power='binalize', power_pivot='max')
+            chk(lib.kwy_align_features_batch_dev(h, J(_lib.AlignJob, [(reg(self.mc_pad, i), reg(self.voiced, i), Tp[i],
+                                                                       reg(self.feat, i)) for i in range(ns)]),
+                                                 ns, order + 1, POWER_WEIGHT, POWER_THRESHOLD, VUV_WEIGHT))
+            chk(lib.kwy_fastdtw_batch_dev(h, J(_lib.DtwJob, [(reg(self.feat, 2 * k), Tp[2 * k], reg(self.feat, 2 * k + 1),
+                                                              Tp[2 * k + 1], self.dist[k:k + 1], self.path[k],
+                                                              self.path_len[k:k + 1]) for k in range(self.n)]),
+                                          self.n, order + 2, self.radius))
+            # dtw_feature(strict=True) + align_even's cut, deltas, hstack + remove_zeros_frames, append
+            chk(lib.kwy_train_rows_batch_dev(
+                h, J(_lib.TrainJob, [(self.path[k], self.path_len[k:k + 1], reg(self.feat, 2 * k), reg(self.feat, 2 * k + 1),
+                                      reg(self.mc_pad, 2 * k), reg(self.mc_pad, 2 * k + 1), Tp[2 * k], Tp[2 * k + 1],
+                                      self.n_rows[k:k + 1]) for k in range(self.n)]),
+                self.n, order, 1, 1, 1, P, TRIM_EPS, _p(X), X.shape[0], _p(cursor)))
+        self.keep = keep
+
+
 class ConvertPipeline(_Graphed):
     """convert_voice.convert(diffvc=False) of one utterance, HBM-resident: analyse -> mel-cepstrum -> GMM/MLPG
     conversion (c0 kept) -> spectrum -> synthesis with the utterance's own f0 and aperiodicity.
@@ -291,6 +419,89 @@ class ConvertPipeline(_Graphed):
         self.ctx.sync()
 
 
+class ConvertWave:
+    """<= 16 utterances analysed and rendered in lockstep (the batched entries of include/kwy.h on two streams): with a
+    prepared GMM model the mel-cepstra are converted in between (convert_voice.convert(diffvc=False) of every file,
+    /root/reference/kwiiyatta/convert_voice.py:35-46), without one the features are resynthesised as they are
+    (resynthesize_voice.py:46-79, BASELINE config 4).  Utterances of any lengths; `wave[i]` are views of one block."""
+
+    def __init__(self, ls, fs, utterances, gmm=None, order=24, frame_period=5.0):
+        self.ls, self.fs, self.order, self.frame_period = ls, int(fs), int(order), float(frame_period)
+        dev = ls.dev
+        self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
+        self.K = K = self.fft // 2 + 1
+        from .backend import sptk
+        self.alpha = sptk.mcepalpha(self.fs)
+        self.gmm = gmm
+        self.n = n = len(utterances)
+        f64 = dict(dtype=torch.float64, device=dev)
+        with torch.cuda.stream(ls.main):
+            self.model = gmm.model(diff=False) if gmm is not None else None
+            us = [_resident(u, dev, (ls.main, ls.side)) for u in utterances]
+            self.x, self.f0, self.t = ([u[k] for u in us] for k in range(3))
+            self.T = [len(v) for v in self.f0]
+            off = np.concatenate(([0], np.cumsum(self.T))).astype(np.int64)
+            self.rows = int(off[-1])
+            cut = lambda a, o, i: a[int(o[i]):int(o[i + 1])]  # noqa: E731
+            self.sp_all = torch.empty((self.rows, K), **f64)
+            self.ap_all = torch.empty((self.rows, K), **f64)
+            self.ylen = [int(lib.kwy_synth_length(t, self.frame_period, self.fs)) for t in self.T]
+            yo = np.concatenate(([0], np.cumsum(self.ylen))).astype(np.int64)
+            self.wave_all = torch.empty(int(yo[-1]), **f64)
+            self.wave = [cut(self.wave_all, yo, i) for i in range(n)]
+            self.plan = [torch.empty(int(lib.kwy_synth_plan_bytes(y)), dtype=torch.uint8, device=dev) for y in self.ylen]
+            sp = [cut(self.sp_all, off, i) for i in range(n)]
+            ap = [cut(self.ap_all, off, i) for i in range(n)]
+            self.j_env = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], sp[i]) for i in range(n)])
+            self.j_ap = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], ap[i]) for i in range(n)])
+            self.j_plan = _lib.job_array(_lib.SynthPlanJob, [(self.f0[i], self.T[i], self.ylen[i], self.plan[i]) for i in range(n)])
+            if gmm is not None:
+                assert gmm.D2 == 6 * order
+                self.mc = torch.empty((self.rows, order + 1), **f64)
+                self.mc_conv = torch.empty((self.rows, order + 1), **f64)
+                self.sp_conv = torch.empty((self.rows, K), **f64)
+                self.j_conv = _lib.job_array(_lib.ConvertJob, [(cut(self.mc, off, i), self.T[i], cut(self.mc_conv, off, i))
+                                                               for i in range(n)])
+                sp = [cut(self.sp_conv, off, i) for i in range(n)]
+            self.j_render = _lib.synth_job_array([(self.plan[i], sp[i], ap[i], self.wave[i]) for i in range(n)])
+        self.frames = int(sum(self.T))
+
+    def run(self):
+        ls, fs, fft, K, order, n = self.ls, self.fs, self.fft, self.K, self.order, self.n
+        ls.side.wait_stream(ls.main)
+        with torch.cuda.stream(ls.side):
+            hs = ls.side_ctx.handle
+            _lib.check(ls.side_ctx, lib.kwy_d4c_batch_dev(hs, self.j_ap, n, fs, 0.85, fft))
+            _lib.check(ls.side_ctx, lib.kwy_synth_plan_batch_dev(hs, self.j_plan, n, fft, self.frame_period, fs))
+        with torch.cuda.stream(ls.main):
+            h = ls.ctx.handle
+            chk = lambda rc: _lib.check(ls.ctx, rc)  # noqa: E731
+            chk(lib.kwy_cheaptrick_batch_dev(h, self.j_env, n, fs, -0.15, 71.0, fft, float(fs)))
+            if self.gmm is not None:
+                chk(lib.kwy_sp2mc_dev(h, _p(self.sp_all), self.rows, K, order, self.alpha, _p(self.mc)))
+                chk(lib.kwy_convert_mcep_batch_dev(h, self.j_conv, n, order, self.gmm.M, _p(self.model)))
+                chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), self.rows, order, self.alpha, fft, _p(self.sp_conv)))
+            ls.main.wait_stream(ls.side)
+            chk(lib.kwy_synth_render_batch_dev(h, self.j_render, n, fft, self.frame_period, fs, float(fs)))
+
+
+def _lockstep_batch(utterances, fs, device_index, gmm, order, frame_period, ls, keep, wave_size=16):
+    """utterances in waves of `wave_size` through ConvertWave; keep(i, waveform view) on the main stream"""
+    ls = ls if ls is not None else _Lockstep(device_index)
+    held = []
+    for w0 in range(0, len(utterances), wave_size):
+        wv = ConvertWave(ls, fs, utterances[w0:w0 + wave_size], gmm=gmm, order=order, frame_period=frame_period)
+        wv.run()
+        with torch.cuda.stream(ls.main):
+            for i in range(wv.n):
+                keep(w0 + i, wv.wave[i])
+        held.append(wv)
+        while len(held) > 2:
+            held.pop(0)
+    ls.sync()
+    return ls
+
+
 class StreamPool:
     """`n` HIP streams with one library context each (a context owns constant tables and a scratch arena: built
     once per stream, not once per utterance).
@@ -408,7 +619,84 @@ class _upload_ahead:
 
 
 def build_training_matrix(pairs, fs, device_index=0, order=24, radius=32, frame_period=5.0, streams=16,
-                          silence_for=None, pool=None, rng=None, pairs_before=0):
+                          silence_for=None, pool=None, rng=None, pairs_before=0, driver=None, lockstep=None,
+                          wave_pairs=16):
+    """driver='lockstep' (default): waves of `wave_pairs` pairs through the batched entries on two streams
+    (`TrainWave`; `lockstep`: a _Lockstep to reuse), rows appended behind a device-side cursor, one read-back per wave;
+    driver='streams': round 3's pair-per-stream driver (`TrainPair`, below).  Same matrix either way."""
+    driver = driver or ('streams' if pool is not None else 'lockstep')
+    if driver == 'lockstep':
+        return _build_training_matrix_lockstep(pairs, fs, device_index, order, radius, frame_period, silence_for, rng,
+                                               pairs_before, lockstep, wave_pairs)
+    return _build_training_matrix_streams(pairs, fs, device_index, order, radius, frame_period, streams, silence_for,
+                                          pool, rng, pairs_before)
+
+
+def _build_training_matrix_lockstep(pairs, fs, device_index, order, radius, frame_period, silence_for, rng, pairs_before,
+                                    ls, wave_pairs):
+    dev = torch.device('cuda', device_index)
+    ls = ls if ls is not None else _Lockstep(device_index)
+    K = lib.kwy_cheaptrick_fft_size(int(fs), 71.0) // 2 + 1
+    scale = 2.220446049250313e-16 / fs
+    wave_pairs = max(1, min(16, int(wave_pairs)))
+    if not pairs:
+        return torch.empty((0, 6 * order), dtype=torch.float64, device=dev), 0
+    if rng is not None and pairs_before:
+        with torch.cuda.stream(ls.main):
+            sink = [torch.empty((PAD_LEN, K), dtype=torch.float64, device=dev) for _ in range(4 * 16)]
+            left = pairs_before
+            while left > 0:
+                take = min(16, left)
+                rng.abs_normal_blocks(scale, sink[:4 * take], ctx=ls.ctx)
+                left -= take
+    ahead = _silence_ahead(len(pairs), fs, 2 * wave_pairs) if silence_for is None and rng is None else None
+    uploads = _upload_ahead(pairs, dev, 3 * wave_pairs)
+    # capacity of the matrix: a pair yields at most one row per path cell of its un-padded stretch
+    cap_rows = sum(len(p[0][1]) + len(p[1][1]) for p in pairs)
+    frames = 0
+    done = [0]                # pairs whose pads have been handed out
+
+    def pads(rows):
+        n_pairs = len(rows) // 4
+        if silence_for is not None or ahead is not None:
+            for k in range(n_pairs):
+                sil = silence_for(done[0] + k) if silence_for is not None else ahead.get()
+                for dst, a in zip(rows[4 * k:4 * k + 4], sil):
+                    dst.copy_(a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a)), non_blocking=True)
+        else:
+            rng.abs_normal_blocks(scale, rows, ctx=ls.ctx)
+        done[0] += n_pairs
+
+    try:
+        with torch.cuda.stream(ls.main):
+            X = torch.empty((cap_rows, 6 * order), dtype=torch.float64, device=dev)
+            cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        prev, held = None, []
+        for w0 in range(0, len(pairs), wave_pairs):
+            chunk = [uploads.get() for _ in range(len(pairs[w0:w0 + wave_pairs]))]
+            wave = TrainWave(ls, fs, chunk, order=order, radius=radius, frame_period=frame_period)
+            wave.analyse()                     # enqueued BEFORE the host waits for the previous wave's lengths
+            if prev is not None:
+                prev.finish(X, cursor, pads)
+                held.append(prev)
+            frames += wave.frames
+            prev = wave
+            while len(held) > 2:
+                held.pop(0)                    # (its buffers: all uses are ordered on the main stream before reuse)
+        prev.finish(X, cursor, pads)
+        with torch.cuda.stream(ls.main):
+            n_rows = int(cursor.item())
+        ls.sync()
+    finally:
+        if ahead is not None:
+            ahead.stop()
+        uploads.stop()
+    torch.cuda.current_stream(dev).synchronize()
+    return X[:n_rows], frames
+
+
+def _build_training_matrix_streams(pairs, fs, device_index=0, order=24, radius=32, frame_period=5.0, streams=16,
+                                   silence_for=None, pool=None, rng=None, pairs_before=0):
     """pairs: list of ((x, f0, t), (x, f0, t)) numpy triples of THIS rank, in corpus order.  Returns the
     (n, 2*3*order) float64 device tensor of make_dataset_to_array and the number of source frames analysed.
     Pairs are processed `streams` at a time, each on its own stream (`pool`: a StreamPool to use instead of a new one).
@@ -527,14 +815,21 @@ def _stream_batch(make_pipeline, utterances, pool, shapes_per_stream, keep):
 
 
 def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16, pool=None,
-                  shapes_per_stream=4):
-    """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors);
-    see `_stream_batch` for the scheduling."""
+                  shapes_per_stream=4, driver=None, lockstep=None):
+    """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors).
+    driver='lockstep' (default): waves of 16 utterances through the batched entries on two streams (`ConvertWave`);
+    'streams': round 3's utterance-per-stream driver, see `_stream_batch` for its scheduling."""
     dev = torch.device('cuda', device_index)
     dg = DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
+    out = [None] * len(utterances)
+    driver = driver or ('streams' if pool is not None else 'lockstep')     # (a caller's pool asks for the stream driver)
+    if driver == 'lockstep':
+        def keep_view(i, w):
+            out[i] = w                     # (a view of its wave's block, which lives as long as the views)
+        _lockstep_batch(utterances, fs, device_index, dg, order, frame_period, lockstep, keep_view)
+        return out
     if pool is None:
         pool = StreamPool(device_index, streams)
-    out = [None] * len(utterances)
 
     def keep(i, p):
         out[i] = p.wave.clone()
@@ -544,16 +839,28 @@ def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.
 
 
 def resynthesize_batch(utterances, fs, device_index=0, frame_period=5.0, streams=16, pool=None, shapes_per_stream=4,
-                       out=None):
+                       out=None, driver=None, lockstep=None):
     """BASELINE config 4 on one rank: analyse + resynthesise every utterance ((x, f0, t) triples: numpy arrays or
-    device tensors) through a fixed pool of streams, more utterances than streams.  Returns the list of waveforms
-    (device tensors; written into `out[i]` instead when a list of preallocated tensors is given) and the number of
-    frames analysed."""
+    device tensors), more utterances than the driver has in flight.  Returns the list of waveforms (device tensors;
+    written into `out[i]` instead when a list of preallocated tensors is given) and the number of frames analysed.
+    driver='lockstep' (default): waves of 16 through the batched entries; 'streams': a fixed pool of streams."""
+    res = [None] * len(utterances)
+    frames = 0
+    for u in utterances:
+        frames += len(u[1])
+    driver = driver or ('streams' if pool is not None else 'lockstep')
+    if driver == 'lockstep':
+        def keep_view(i, w):
+            if out is not None:
+                out[i].copy_(w)
+                res[i] = out[i]
+            else:
+                res[i] = w
+        _lockstep_batch(utterances, fs, device_index, None, 24, frame_period, lockstep, keep_view)
+        return res, frames
     from .pipeline import UtterancePipeline
     if pool is None:
         pool = StreamPool(device_index, streams)
-    res = [None] * len(utterances)
-    frames = 0
 
     def keep(i, p):
         if out is not None:
@@ -561,8 +868,6 @@ def resynthesize_batch(utterances, fs, device_index=0, frame_period=5.0, streams
             res[i] = out[i]
         else:
             res[i] = p.wave.clone()
-    for u in utterances:
-        frames += len(u[1])
     _stream_batch(lambda u, st, ctx: UtterancePipeline(device_index, fs, u, frame_period=frame_period, stream=st,
                                                        ctx=ctx), utterances, pool, shapes_per_stream, keep)
     return res, frames

@@ -307,3 +307,37 @@ def test_convert_pipeline_with_converter_at_another_rate(fs_u, fs_c):
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max())
     assert np.abs(p.mc_c2.cpu().numpy() - mcep.data).max() <= 1e-9 * np.abs(mcep.data).max()
+
+
+def test_lockstep_drivers_equal_the_stream_drivers(corpus):
+    """round 4's lockstep drivers (TrainWave / ConvertWave: waves of pairs or utterances through the batched entries on
+    two streams, rows appended behind a device-side cursor) against round 3's stream-per-item drivers: the same
+    training matrix -- several waves, host pads and device pads --, the same converted and resynthesised waveforms,
+    bit for bit"""
+    import torch
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
+    for wave_pairs in (16, 3, 1):
+        np.random.seed(5)
+        a, fa = cp.build_training_matrix(corpus, FS, driver='lockstep', wave_pairs=wave_pairs)
+        np.random.seed(5)
+        b, fb = cp.build_training_matrix(corpus, FS, driver='streams', streams=2)
+        assert fa == fb and torch.equal(a, b), wave_pairs
+    a, _ = cp.build_training_matrix(corpus, FS, driver='lockstep', wave_pairs=2, rng=DeviceRandomState.from_seed(3))
+    b, _ = cp.build_training_matrix(corpus, FS, driver='streams', streams=2, rng=DeviceRandomState.from_seed(3))
+    assert torch.equal(a, b)
+    tail, _ = cp.build_training_matrix(corpus[1:], FS, driver='lockstep', rng=DeviceRandomState.from_seed(3), pairs_before=1)
+    head, _ = cp.build_training_matrix(corpus[:1], FS, driver='lockstep', rng=DeviceRandomState.from_seed(3))
+    assert torch.equal(torch.cat((head, tail)), a)
+    g = GaussianMixtureHIP(n_components=4, max_iter=3, tol=0.0, random_state=0).fit(a)
+    utts = [s for s, _ in corpus] + [t for _, t in corpus] + [corpus[0][0]] * 11      # 19: more than one wave, ragged
+    w1 = cp.convert_batch(utts, FS, g, order=ORDER, driver='lockstep')
+    w2 = cp.convert_batch(utts, FS, g, order=ORDER, driver='streams', streams=2)
+    for u, v in zip(w1, w2):
+        assert torch.equal(u, v)
+    r1, f1 = cp.resynthesize_batch(utts, FS, driver='lockstep')
+    r2, f2 = cp.resynthesize_batch(utts, FS, driver='streams', streams=2)
+    assert f1 == f2
+    for u, v in zip(r1, r2):
+        assert torch.equal(u, v)
