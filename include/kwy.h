@@ -388,11 +388,27 @@ int kwy_gmm_em_scratch_bytes(int64_t n, int D, int M, int64_t *bytes);
  * -- the k-means initialisation below (numpy's RandomState(seed) draws, scikit-learn's seeding and Lloyd loop) and the
  * EM loop above, run by the library.  X: n x D on the device; weights (M), means (M x D), covs (M x D x D): HOST outputs;
  * n_iter / lower_bound / converged / kmeans_iter: scikit-learn's n_iter_, lower_bound_, converged_ and the number of
- * Lloyd iterations (may be NULL).  Synchronous.  The multi-rank fit is driven from kwiiyatta_amd/converter/gmm_fit.py,
- * which owns the communicator. */
+ * Lloyd iterations (may be NULL).  Synchronous. */
 int kwy_gmm_fit_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, int max_iter, double tol, double reg_covar,
                     uint32_t seed, double *weights, double *means, double *covs, int *n_iter, double *lower_bound,
                     int *converged, int *kmeans_iter);
+/* The same fit over the rows of SEVERAL ranks (fit row: "multi-GPU variant takes an RCCL communicator
+ * handle"): every rank calls with its own shard X (global row order: rank 0's rows, then rank 1's, ...) and a
+ * communicator given as an in-place SUM all-reduce of device doubles on a HIP stream --
+ *     int reduce(void *user, double *buf, int64_t count, void *stream) {
+ *       return ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)user, (hipStream_t)stream) != ncclSuccess; }
+ * -- and all ranks return the same model (that of a one-rank fit of the concatenated rows, up to the rounding of the
+ * sums).  What is exchanged: per k-means++ centre the shard totals, <= 8 candidate rows and potentials; per Lloyd
+ * iteration M (D + 1) + 1 doubles; per EM iteration M (D + 1) and M D D doubles and the log-likelihood.  comm == NULL:
+ * kwy_gmm_fit_dev.  The library does not link RCCL: the callback is the caller's. */
+typedef struct kwy_comm {
+  int rank, world;
+  int (*all_reduce_sum)(void *user, double *device_buffer, int64_t count, void *stream);   /* 0 = success */
+  void *user;
+} kwy_comm;
+int kwy_gmm_fit_comm_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, int max_iter, double tol,
+                         double reg_covar, uint32_t seed, const kwy_comm *comm, double *weights, double *means,
+                         double *covs, int *n_iter, double *lower_bound, int *converged, int *kmeans_iter);
 
 /* ---- converter fit: k-means initialisation ------------------------------------------------------
  * The `init_params='kmeans'` step of the same GaussianMixture.fit (kwiiyatta/converter/gmm.py:14-23):

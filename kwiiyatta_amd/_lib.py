@@ -114,6 +114,8 @@ SIGNATURES = {
     'kwy_gmm_fit_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_dbl, c_dbl, ctypes.c_uint32, c_vp, c_vp, c_vp,
                                 ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'kwy_gmm_em_scratch_bytes': (c_int, [c_i64, c_int, c_int, ctypes.POINTER(c_i64)]),
+    'kwy_gmm_fit_comm_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_dbl, c_dbl, ctypes.c_uint32, c_vp, c_vp, c_vp, c_vp,
+                                     ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'kwy_trim_length_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_trim_length_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl]),
     'kwy_train_pad_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int]),

@@ -427,10 +427,51 @@ def _em_fit(stats, n_total, max_iter, tol, reg_covar, verbose):
     return lower_bound, converged, n_iter
 
 
-def fit_one_call(X, n_components, max_iter=100, tol=1e-3, reg_covar=1e-6, random_state=0, device_index=0, ctx=None):
+class _DeviceDoubles:
+    """`count` doubles at a raw device address, as something torch.as_tensor can view without copying"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': '<f8', 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+def library_comm(device_index=0):
+    """torch.distributed's default process group as the library's communicator (`kwy_comm`, include/kwy.h): the
+    all-reduce callback views the library's device buffer as a tensor and reduces it with `Comm` on the stream the
+    library names -- RCCL under 'nccl', a host round trip under 'gloo'.  Returns (struct, keep-alive objects), or
+    (None, ()) without a process group.  (A C or C++ binder hands ncclAllReduce straight to the library instead.)"""
+    import ctypes
+    import torch
+    comm = Comm()
+    if comm.dist is None:
+        return None, ()
+    dev = torch.device('cuda', device_index)
+    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+    class KwyComm(ctypes.Structure):
+        _fields_ = [('rank', ctypes.c_int), ('world', ctypes.c_int), ('all_reduce_sum', CB), ('user', ctypes.c_void_p)]
+
+    def reduce(user, buf, count, stream):
+        try:
+            t = torch.as_tensor(_DeviceDoubles(buf, count), device=dev)
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                comm.all_reduce(t)
+            return 0
+        except Exception:            # no exception may cross the C frames above
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = CB(reduce)
+    return KwyComm(comm.rank, comm.world, cb, None), (cb, comm)
+
+
+def fit_one_call(X, n_components, max_iter=100, tol=1e-3, reg_covar=1e-6, random_state=0, device_index=0, ctx=None,
+                 distributed=False):
     """The fit of one rank's rows through the library's single entry point `kwy_gmm_fit_dev` (the control flow of this
     module in C++, for binders without a Python driver).  X: (n, D) numpy array or float64 device tensor; an integer
-    `random_state`.  Returns a GaussianMixtureHIP carrying the fitted attributes."""
+    `random_state`.  distributed=True: `kwy_gmm_fit_comm_dev` with torch.distributed's default group as the
+    communicator -- X is this rank's shard and every rank returns the model of all rows.
+    Returns a GaussianMixtureHIP carrying the fitted attributes."""
     import ctypes
     import torch
     from .. import _lib
@@ -444,10 +485,19 @@ def fit_one_call(X, n_components, max_iter=100, tol=1e-3, reg_covar=1e-6, random
     g.weights_, g.means_, g.covariances_ = np.empty(M), np.empty((M, D)), np.empty((M, D, D))
     it, conv, kit, lb = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
     torch.cuda.synchronize(dev)
-    _lib.check(ctx, _lib.lib.kwy_gmm_fit_dev(ctx.handle, _lib.c_vp(Xd.data_ptr()), n, D, M, int(max_iter), float(tol),
-                                             float(reg_covar), int(random_state), _lib.ptr(g.weights_),
-                                             _lib.ptr(g.means_), _lib.ptr(g.covariances_), ctypes.byref(it),
-                                             ctypes.byref(lb), ctypes.byref(conv), ctypes.byref(kit)))
+    kc, alive = library_comm(device_index) if distributed else (None, ())
+    if kc is None:
+        _lib.check(ctx, _lib.lib.kwy_gmm_fit_dev(ctx.handle, _lib.c_vp(Xd.data_ptr()), n, D, M, int(max_iter), float(tol),
+                                                 float(reg_covar), int(random_state), _lib.ptr(g.weights_),
+                                                 _lib.ptr(g.means_), _lib.ptr(g.covariances_), ctypes.byref(it),
+                                                 ctypes.byref(lb), ctypes.byref(conv), ctypes.byref(kit)))
+    else:
+        _lib.check(ctx, _lib.lib.kwy_gmm_fit_comm_dev(ctx.handle, _lib.c_vp(Xd.data_ptr()), n, D, M, int(max_iter),
+                                                      float(tol), float(reg_covar), int(random_state),
+                                                      ctypes.cast(ctypes.pointer(kc), ctypes.c_void_p), _lib.ptr(g.weights_),
+                                                      _lib.ptr(g.means_), _lib.ptr(g.covariances_), ctypes.byref(it),
+                                                      ctypes.byref(lb), ctypes.byref(conv), ctypes.byref(kit)))
+    del alive
     g.n_iter_, g.lower_bound_, g.converged_, g.kmeans_n_iter_ = it.value, lb.value, bool(conv.value), kit.value
     return g
 

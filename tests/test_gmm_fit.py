@@ -394,3 +394,104 @@ def test_single_call_fit_matches_driver_and_sklearn(n, D, M, seed):
     assert np.allclose(one.covariances_, drv.covariances_, rtol=1e-8, atol=1e-12)
     assert np.allclose(one.means_, ref.means_, rtol=1e-6, atol=1e-8)
     assert np.allclose(one.covariances_, ref.covariances_, rtol=1e-5, atol=1e-8)
+
+
+def _comm_worker(rank, world, port, q, backend):
+    """one rank of the C-entry fit: kwy_gmm_fit_comm_dev with torch.distributed's group as the communicator"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP, fit_one_call
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if backend == 'nccl':
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    c = TWO_RANK_HIP
+    X = make_data(c['n'], c['D'], 6, seed=c['seed'])
+    cut = [0, c['cut'], c['n']] if world == 2 else [0, c['n']]
+    shard = np.ascontiguousarray(X[cut[rank]:cut[rank + 1]])
+    g = fit_one_call(shard, c['M'], max_iter=c['max_iter'], random_state=c['seed'], distributed=True)
+    # the Python driver (HipStats + Comm) under the same process group
+    d = GaussianMixtureHIP(n_components=c['M'], random_state=c['seed'], max_iter=c['max_iter'], device_index=0).fit(shard)
+    q.put((rank, g.n_iter_, g.lower_bound_, g.weights_, g.means_, g.covariances_, g.kmeans_n_iter_,
+           d.n_iter_, d.lower_bound_, d.means_, d.kmeans_n_iter_))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_comm_workers(world, backend):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _check_against_one_rank(res):
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
+    c = TWO_RANK_HIP
+    X = make_data(c['n'], c['D'], 6, seed=c['seed'])
+    one = GaussianMixtureHIP(n_components=c['M'], random_state=c['seed'], max_iter=c['max_iter']).fit(X)
+    for (_, it, lb, w, m, cv, kit, dit, dlb, dm, dkit) in res:
+        assert it == dit == one.n_iter_ and kit == dkit == one.kmeans_n_iter_
+        assert abs(lb - one.lower_bound_) <= 1e-9 * abs(lb) and abs(dlb - one.lower_bound_) <= 1e-9 * abs(lb)
+        assert np.allclose(w, one.weights_, rtol=1e-9) and np.allclose(m, one.means_, rtol=1e-8, atol=1e-11)
+        assert np.allclose(cv, one.covariances_, rtol=1e-7, atol=1e-10)
+        assert np.allclose(dm, one.means_, rtol=1e-8, atol=1e-11)
+    return one
+
+
+@pytest.mark.gpu
+def test_c_entry_fit_two_ranks_share_one_gpu():
+    """kwy_gmm_fit_comm_dev (the multi-rank fit as ONE C call, the communicator an all-reduce callback) run by two
+    processes on cuda:0 over uneven shards (gloo carries the callback's reductions): both ranks return the same model,
+    the model of the Python driver under the same group, of a one-rank fit of all rows, and of scikit-learn."""
+    res = _run_comm_workers(2, 'gloo')
+    (_, it0, lb0, w0, m0, c0, kit0, *_), (_, it1, lb1, w1, m1, c1, kit1, *_) = res
+    assert it0 == it1 and kit0 == kit1 and lb0 == lb1
+    assert np.array_equal(w0, w1) and np.array_equal(m0, m1) and np.array_equal(c0, c1)
+    _check_against_one_rank(res)
+    c = TWO_RANK_HIP
+    ref = sklearn_fit(make_data(c['n'], c['D'], 6, seed=c['seed']), c['M'], seed=c['seed'], max_iter=c['max_iter'])
+    assert ref.n_iter_ == it0 and np.allclose(ref.means_, m0, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_fit_under_rccl_world_size_one():
+    """RCCL itself under the fit: a world-size-1 'nccl' process group on cuda:0 (the one GPU of the test box).  The
+    Python driver (HipStats + Comm: device tensors, the fit's own stream current around the collectives) and the C entry
+    (kwy_gmm_fit_comm_dev, whose callback ends in ncclAllReduce on the library's stream) both equal the fit without a
+    process group.  Runs in a child process: the group must exist before the first collective and die with it."""
+    res = _run_comm_workers(1, 'nccl')
+    _check_against_one_rank(res)
+
+
+@pytest.mark.gpu
+def test_c_entry_relocates_two_empty_clusters_like_the_driver():
+    """two clusters emptied in the same Lloyd iteration: the C entry and the Python driver pair the farthest rows with
+    the empty clusters in the same order (largest distance first; scikit-learn's argpartition leaves that order
+    unspecified, so its labels may differ there -- documented in kwy_fit_driver.hip)"""
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP, fit_one_call
+    rng = np.random.default_rng(4)
+    # 30 tight far-apart blobs of 3 points and 8 centres: k-means++ on so few distinct regions leaves several
+    # clusters empty along the way for some seeds
+    hits = 0
+    for seed in range(12):
+        X = np.repeat(rng.standard_normal((10, 6)) * 20, 40, axis=0) + rng.standard_normal((400, 6)) * 1e-3
+        one = fit_one_call(X, 16, max_iter=3, random_state=seed)
+        drv = GaussianMixtureHIP(n_components=16, random_state=seed, max_iter=3, reg_covar=1e-6).fit(X)
+        assert one.kmeans_n_iter_ == drv.kmeans_n_iter_ and one.n_iter_ == drv.n_iter_
+        assert np.allclose(one.means_, drv.means_, rtol=1e-9, atol=1e-9)
+        hits += 1
+    assert hits == 12
