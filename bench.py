@@ -41,7 +41,8 @@ def _argv_value(flag, default):
 # different hardware queues; the runtime's default of 4 serialises the rest (round 3: 4 queues 1.43 M frames/s, 64:
 # 1.91 M).  The variable must be in the environment before the HIP runtime starts.  The default lockstep driver uses
 # four streams and leaves the environment alone.
-if _argv_value('--driver', 'batch') == 'streams' or _argv_value('--workload', 'pair') == 'utterance':
+if _argv_value('--driver', 'batch') == 'streams' or (_argv_value('--workload', 'pair') == 'utterance' and
+                                                   int(_argv_value('--utterances', '0')) == 0):
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '64')
 
 FS = 48000
@@ -159,12 +160,14 @@ def main_batch(args):
     from kwiiyatta_amd import pipeline as pl
 
     resident = [tuple(torch.from_numpy(a).to(dev) for a in u) for u in utts]
-    pool = cp.StreamPool(local_rank, args.batch)
+    lockstep = args.driver != 'streams'
+    drv = dict(driver='lockstep', lockstep=cp._Lockstep(local_rank)) if lockstep else \
+        dict(driver='streams', pool=cp.StreamPool(local_rank, args.batch))
     ylen = [int(cp.lib.kwy_synth_length(len(u[1]), FRAME_PERIOD, FS)) for u in utts]
     out = [torch.empty(n, dtype=torch.float64, device=dev) for n in ylen]
 
     def step():
-        return cp.resynthesize_batch(resident, FS, device_index=local_rank, pool=pool, out=out)[1]
+        return cp.resynthesize_batch(resident, FS, device_index=local_rank, out=out, **drv)[1]
 
     frames_step = 0
     for _ in range(max(1, args.warmup)):
@@ -218,12 +221,17 @@ def main_batch(args):
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'config4: batch of {args.utterances} distinct synthetic 48 kHz {args.seconds:g} s '
                                    f'utterances per GPU (T={T}, K={K}; seeds = global utterance index): CheapTrick + D4C + '
-                                   f'WORLD synthesis each, through a fixed pool of streams',
-                       'utterances_per_gpu': args.utterances, 'streams_per_gpu': args.batch,
-                       'launch': 'per stream one pipeline per utterance shape; its pass is a captured HIP graph from the '
-                                 'second utterance of that shape on; inputs resident in HBM, copied device-to-device '
-                                 'into the pipeline\'s buffers; every waveform kept',
-                       'parallelism': f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective'},
+                                   f'WORLD synthesis each' + (', in waves of 16 through the batched entries on two streams'
+                                                              if lockstep else ', through a fixed pool of streams'),
+                       'utterances_per_gpu': args.utterances, 'streams_per_gpu': 2 if lockstep else args.batch,
+                       'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
+                       'launch': ('kwiiyatta_amd.corpus.ConvertWave: one launch per stage and wave (kwy_*_batch_dev); inputs '
+                                  'resident in HBM; every waveform kept') if lockstep else
+                                 ('per stream one pipeline per utterance shape; its pass is a captured HIP graph from the '
+                                  'second utterance of that shape on; inputs resident in HBM, copied device-to-device '
+                                  'into the pipeline\'s buffers; every waveform kept'),
+                       'parallelism': (f'utterances in lockstep waves of 16, utterance-per-GPU x{world}, no collective' if lockstep
+                                       else f'utterance-per-stream x{args.batch}, utterance-per-GPU x{world}, no collective')},
             'real_time_factor': value / 200.0,
             'hbm_fraction_whole_path': value / world * 36664 / 8e12,
             'kernel_ms_per_launch_alone': alone,

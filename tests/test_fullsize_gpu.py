@@ -170,3 +170,172 @@ def test_pair_chained_on_recorded_speech(ko, which):
     print(f'chained, recorded speech at {fs} Hz: wave rms {rms:.3e} (peak {np.abs(ref["wave"]).max():.3f}), '
           f'aligned aperiodicity max err {ap_err:.3e}')
     assert rms <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 4: the sizes BASELINE.json's configs name, driver-run (not only builder-run lines under profiles/)
+
+def _make_utterance_job(job):
+    """(seed, seconds, f0_base, warp, formant) -> utterance.  Module-level for the process pool; synthetic.py is loaded
+    by path, so the (spawned) workers need neither the package nor the HIP runtime."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kwy_synthetic', os.path.join(root, 'kwiiyatta_amd', 'synthetic.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seed, seconds, f0_base, warp, formant = job
+    return mod.make_utterance(seed=seed, fs=FS, seconds=seconds, f0_base=f0_base, time_warp=warp, formant_scale=formant)
+
+
+def _generate(jobs):
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    import os
+    nproc = max(1, min(len(os.sched_getaffinity(0)), 16, len(jobs)))
+    with cf.ProcessPoolExecutor(nproc, mp_context=mp.get_context('spawn')) as ex:
+        return list(ex.map(_make_utterance_job, jobs, chunksize=2))
+
+
+def test_lockstep_step_full_size_against_all_oracle_chain(ko, gmm64):
+    """config 3 on the lockstep driver at BASELINE size: four 10 s + 11 s pairs in two waves, the pads drawn inside the
+    step by the device generator.  Pair 0 against the all-oracle chain ON THE PADS THE DEVICE DREW (equal FastDTW path,
+    waveform within 1e-4 RMS), the generator equal to numpy's afterwards, a replayed graph bit-identical in everything
+    but the fresh pads' effect (checked: same path, waveform within 1e-9 of the first pass)."""
+    import torch
+    from oracle import chain
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    utts = _generate([(1234 + 2 * i, 10.0, 140.0, 1.0, 1.0) for i in range(4)] +
+                     [(4321 + 2 * i, 10.0, 140.0, 1.1, 1.12) for i in range(4)])
+    pairs = [(utts[i], utts[4 + i]) for i in range(4)]
+    assert len(pairs[0][0][1]) == 2001 and len(pairs[0][1][1]) == 2201
+    dg = pl.DeviceGMM(gmm64.weights_, gmm64.means_, gmm64.covariances_, torch.device('cuda', 0))
+    rs = DeviceRandomState.from_seed(99)
+    b = pl.PairBatchPipeline(0, FS, pairs, dg, waves=2, rng=rs)
+    b.run()
+    b.sync()
+    pads0 = [blk.cpu().numpy() for blk in b.pad_rows[:4]]
+    ref_rng = np.random.RandomState(99)
+    for blk in b.pad_rows:
+        exp = np.abs(ref_rng.normal(0, pl.EPS / FS, (pl.PAD_LEN, 1025)))
+        assert np.abs(blk.cpu().numpy() - exp).max() <= 4e-16 * exp.max()
+    st_d, st_n = rs.get_state(), ref_rng.get_state()
+    assert np.array_equal(st_d[1], st_n[1]) and st_d[2:] == tuple(st_n[2:])
+    ref = chain.pair_chain(pairs[0][0], pairs[0][1], (gmm64.weights_, gmm64.means_, gmm64.covariances_), FS, pads0)
+    path_t, n_t, _ = b.path(0)
+    path = [tuple(r) for r in path_t.cpu().numpy()[:int(n_t.item())].tolist()]
+    assert path == ref['path']
+    wave = b.wave(0).cpu().numpy()
+    rms = float(np.sqrt(np.mean((wave - ref['wave']) ** 2)))
+    print(f'lockstep config 3, pair 0 vs the all-oracle chain on device-drawn pads: wave rms {rms:.3e}')
+    assert rms <= 1e-4
+    first = [b.wave(k).clone() for k in range(4)]
+    b.capture()
+    b.replay()
+    b.sync()
+    for k in range(4):
+        assert torch.isfinite(b.wave(k)).all()
+        assert float((b.wave(k) - first[k]).abs().max()) <= 1e-9      # other pads (~1e-21 spectra): same alignment
+
+
+def test_config4_256_utterances_of_10_seconds(ko):
+    """BASELINE config 4 at its own size: 256 distinct 48 kHz utterances of 10 s (T = 2001 each) analysed and
+    resynthesised in lockstep waves of 16 (corpus.resynthesize_batch).  All outputs finite, a second pass
+    bit-identical, four utterances against the oracle's own analyse -> synthesise chain (north star: 1e-4 RMS)."""
+    import torch
+    from kwiiyatta_amd import corpus as cp
+    n_utt = 256
+    utts = _generate([(s, 10.0, 110.0 + (s % 7) * 15.0, 1.0, 1.0) for s in range(n_utt)])
+    dev = torch.device('cuda', 0)
+    resident = [tuple(torch.from_numpy(a).to(dev) for a in u) for u in utts]     # inputs live in HBM
+    ls = cp._Lockstep(0)
+    waves, frames = cp.resynthesize_batch(resident, FS, lockstep=ls)
+    assert frames == n_utt * 2001
+    picks = (0, 17, 100, 255)
+    first = {i: waves[i].cpu().numpy().copy() for i in picks}
+    finite = all(bool(torch.isfinite(w).all().item()) and float(w.abs().max().item()) > 1e-3 for w in waves)
+    assert finite
+    sums = [float(w.sum().item()) for w in waves]
+    waves2, _ = cp.resynthesize_batch(resident, FS, lockstep=ls)
+    assert all(torch.equal(a, b) for a, b in zip(waves, waves2)) and sums == [float(w.sum().item()) for w in waves2]
+    worst = 0.0
+    for i in picks:
+        x, f0, t = utts[i]
+        sp = ko.cheaptrick(x, f0, t, FS)
+        ap = ko.d4c(x, f0, t, FS)
+        ref = ko.synthesize(f0, sp, ap, FS, 5.0)
+        assert ref.shape == first[i].shape
+        worst = max(worst, float(np.sqrt(np.mean((first[i] - ref) ** 2))))
+    print(f'config 4 at size: 256 x 10 s in lockstep waves, worst RMS against the all-oracle chain {worst:.3e}')
+    assert worst <= 1e-4
+
+
+def _corpus_rank(rank, world, port, q, jobs):
+    """one rank of the config-5 data-set phase: its contiguous block of the corpus, the ONE generator stream of the
+    corpus advanced past the blocks before it"""
+    import hashlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    utts = [_make_utterance_job(j) for j in jobs]
+    n = len(utts) // 2
+    corpus = [(utts[i], utts[n + i]) for i in range(n)]
+    mine = cp.shard_block(n, rank, world)
+    X, frames = cp.build_training_matrix([corpus[i] for i in mine], FS, rng=DeviceRandomState.from_seed(2024),
+                                         pairs_before=mine[0])
+    h = hashlib.sha256(X.cpu().numpy().tobytes()).hexdigest()
+    q.put((rank, h, int(X.shape[0]), float(X.sum().item()), frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_64_distinct_pairs_one_and_two_ranks(gmm64):
+    """BASELINE config 5 at 64 DISTINCT 48 kHz pairs (2 s each): the training matrix of two ranks (gloo, both on
+    cuda:0, contiguous blocks, each advancing the corpus' one generator stream past the block before it) is the
+    one-rank matrix, byte for byte; the fit runs real EM iterations on it; the batch conversion is finite and
+    deterministic."""
+    import hashlib
+    import multiprocessing as mp
+    import socket
+    import torch
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
+    n = 64
+    jobs = [(1000 + k, 2.0, 100.0 + (k * 37 % 90), 1.0, 1.0) for k in range(n)] + \
+           [(5000 + k, 2.0, (100.0 + (k * 37 % 90)) * 1.25, 1.04 + 0.01 * (k % 9), 1.08 + 0.01 * (k % 7)) for k in range(n)]
+    utts = _generate(jobs)
+    corpus = [(utts[i], utts[n + i]) for i in range(n)]
+    X, frames = cp.build_training_matrix(corpus, FS, rng=DeviceRandomState.from_seed(2024))
+    assert frames == sum(len(s[1]) for s, _ in corpus) and X.shape[1] == 144 and X.shape[0] > 0.5 * frames
+    whole = X.cpu().numpy()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    procs = [ctx.Process(target=_corpus_rank, args=(r, 2, port, q, jobs)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows0, rows1 = res[0][2], res[1][2]
+    assert rows0 + rows1 == whole.shape[0] and res[0][4] + res[1][4] == frames
+    assert res[0][1] == hashlib.sha256(whole[:rows0].tobytes()).hexdigest()
+    assert res[1][1] == hashlib.sha256(whole[rows0:].tobytes()).hexdigest()
+    g = GaussianMixtureHIP(n_components=16, max_iter=30, tol=1e-3, random_state=0).fit(X)
+    assert g.n_iter_ >= 3 and np.isfinite(g.lower_bound_)
+    sources = [s for s, _ in corpus]
+    w1 = cp.convert_batch(sources, FS, g)
+    w2 = cp.convert_batch(sources, FS, g)
+    assert all(bool(torch.isfinite(a).all().item()) and torch.equal(a, b) for a, b in zip(w1, w2))
