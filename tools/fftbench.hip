@@ -6,6 +6,176 @@
 #include <vector>
 #include "../kwiiyatta_amd/csrc/kwy_device.hpp"
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4 experiment, measured and NOT adopted: a wave-local 2048-point transform with two
+// workgroup barriers instead of seven.  Alone it is 10-12 % faster than the in-place radix-8 transform at the
+// occupancies of the D4C kernels (1436 vs 1624 ns per transform and CU at three workgroups per CU, 1370 vs 1521 at
+// four); inside k_d4c_body / k_d4c_bands / k_d4c_lovetrain it changed nothing (bands -1 %, LoveTrain -2 %) or cost
+// (body +4.5 %: 84 bytes per lane of spills at its register cap) -- the barrier stalls of one workgroup's transform
+// are already covered by the other resident workgroups' non-FFT phases.
+// ------------------------------------------------- wave-local FFT (round 4): 2048 points, 256 threads
+// The in-place transform above meets at a workgroup barrier twice per radix-8 pass: seven barriers for 2048 points, and
+// with three or four workgroups per CU the wavefronts spend a third of their cycles waiting.  Here the four wavefronts
+// of the workgroup each transform ONE 512-point subsequence on their own -- x[w + 4 m], decimation in time across the
+// wavefronts -- three radix-8 stages whose operands change lanes through the wavefront's PRIVATE quarter of the
+// buffer (the LDS executes one wavefront's instructions in order: no barrier), and only the closing radix-4 stage
+// across the wavefronts needs the workgroup: TWO barriers per transform.
+//
+//   stage 1   lane l, slot t holds f[l + 64 t]: 8-point DFT over the slots, times W512^(l t')
+//   stage 2   (lane a + 8 b, slot t') -> (lane a + 8 t', slot b); DFT over b, times W64^(a b')
+//   stage 3   (lane a + 8 t', slot b') -> (lane b' + 8 t', slot a); DFT over a: F[64 a' + 8 b' + t'],
+//             times W2048^(w k') for the radix-4 across the wavefronts
+//   tail      X[k' + 512 q] = sum_w (-i)^(w q) G_w[k'], in place
+//
+// Layouts (complex indices; a wavefront's region is 516 entries: the four spare ones keep the producers' stores and the
+// tail off each other's banks):
+//   input    packed point n at region n & 3, entry 64 (n >> 8) + ((n >> 2) & 63)      kwy_fftw_in()
+//   output   X[k] at region k >> 9, entry (k & 511) ^ ((k >> 3) & 7)                  kwy_fftw_at()
+// Every store and load below is free of bank conflicts (b128: 16 lanes per cycle over 16 x 16 bytes).
+#define KWY_FFTW_REGION 516
+#define KWY_FFTW_ENTRIES (4 * KWY_FFTW_REGION)       // complex entries of the buffer (2048-point transform)
+__device__ __forceinline__ int kwy_fftw_in(int n) {              // packed complex point n of the input
+  return KWY_FFTW_REGION * (n & 3) + 64 * (n >> 8) + ((n >> 2) & 63);
+}
+__device__ __forceinline__ int kwy_fftw_in_real(int i) {         // real sample i (packed two per point): index in doubles
+  return 2 * kwy_fftw_in(i >> 1) + (i & 1);
+}
+__device__ __forceinline__ int kwy_fftw_at(int k) {              // bin k of the output
+  return KWY_FFTW_REGION * (k >> 9) + ((k & 511) ^ ((k >> 3) & 7));
+}
+struct kwy_fftw_tw { kwy_c b1, b2, b3, cw; };
+// twH: exp(-2 pi i k / 2048), k < 2048
+__device__ __forceinline__ kwy_fftw_tw kwy_fftw_twiddles(const kwy_c *__restrict__ twH) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  kwy_fftw_tw t;
+  t.b1 = twH[4 * l];                                    // W512^l
+  t.b2 = twH[32 * (l & 7)];                             // W64^(l & 7)
+  t.b3 = twH[(w * (8 * (l & 7) + (l >> 3))) & 2047];    // W2048^(w (8 b' + t')), lane = b' + 8 t'
+  t.cw = twH[64 * __builtin_amdgcn_readfirstlane(w)];   // W2048^(64 w): the same for the whole wavefront (scalar registers)
+  return t;
+}
+__device__ __forceinline__ kwy_c kwy_opaque_c(kwy_c v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y));
+  return v;
+}
+// a[m] *= base^m (m = 1..7), the powers formed by multiplication
+__device__ __forceinline__ void kwy_fftw_scale(kwy_c (&a)[8], kwy_c w1) {
+  const kwy_c w2 = cmulf(w1, w1), w4 = cmulf(w2, w2);
+  const kwy_c w3 = cmulf(w1, w2), w5 = cmulf(w4, w1), w6 = cmulf(w4, w2);
+  const kwy_c w7 = cmulf(w4, w3);
+  a[1] = cmulf(w1, a[1]); a[2] = cmulf(w2, a[2]); a[3] = cmulf(w3, a[3]); a[4] = cmulf(w4, a[4]);
+  a[5] = cmulf(w5, a[5]); a[6] = cmulf(w6, a[6]); a[7] = cmulf(w7, a[7]);
+}
+// orders this wavefront's LDS stores before its following LDS loads (for the compiler; the hardware keeps the order)
+__device__ __forceinline__ void kwy_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Forward transform of 2048 packed points (256 threads).  z: KWY_FFTW_ENTRIES entries, input in the kwy_fftw_in layout
+// and complete (a barrier between the producers' stores and this call); output in the kwy_fftw_at layout; ends with a
+// barrier.  Unnormalised.
+// everything behind stage 1's butterfly: a[t'] = the 8-point DFT over the slots of this lane
+__device__ __forceinline__ void kwy_fftw_2048_rest(kwy_c *z, const kwy_fftw_tw &tw, kwy_c (&a)[8]) {
+  const int tid = kwy_tid_opaque();
+  const int l = tid & 63, w = tid >> 6;
+  kwy_c *R = z + KWY_FFTW_REGION * w;
+  kwy_fftw_scale(a, kwy_opaque_c(tw.b1));
+  {
+    const int la = l & 7, lb = l >> 3;           // lane = a + 8 b
+#pragma unroll
+    for (int t = 0; t < 8; ++t) R[64 * lb + ((la + 8 * t) ^ (8 * (lb & 1)))] = a[t];
+  }
+  kwy_wave_lds_sync();
+  // ---- stage 2: lane = a + 8 t', slots b
+#pragma unroll
+  for (int s = 0; s < 8; ++s) a[s] = R[64 * s + (l ^ (8 * (s & 1)))];
+  kwy_dft8<false>(a);
+  kwy_fftw_scale(a, kwy_opaque_c(tw.b2));
+  {
+    const int la = l & 7, lt = l >> 3;           // lane = a + 8 t'
+#pragma unroll
+    for (int b = 0; b < 8; ++b) R[64 * la + ((b + 8 * lt) ^ la)] = a[b];
+  }
+  kwy_wave_lds_sync();
+  // ---- stage 3: lane = b' + 8 t', slots a
+#pragma unroll
+  for (int s = 0; s < 8; ++s) a[s] = R[64 * s + (l ^ s)];
+  kwy_dft8<false>(a);
+  {
+    // G[k'] = W2048^(w k') F[k'], k' = 64 a' + 8 b' + t': b3 times cw^a'
+    kwy_c p = kwy_opaque_c(tw.b3);
+    const kwy_c c = kwy_opaque_c(tw.cw);
+    const int lb = l & 7, lt = l >> 3;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      R[64 * m + 8 * lb + (lt ^ lb)] = cmulf(p, a[m]);
+      p = cmulf(p, c);
+    }
+  }
+  __syncthreads();
+  // ---- the radix-4 across the wavefronts, in place: two butterflies per thread
+  kwy_c g[2][4];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int k = tid + 256 * it;
+    const int e = k ^ ((k >> 3) & 7);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[it][q] = z[KWY_FFTW_REGION * q + e];
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int k = tid + 256 * it;
+    const int e = k ^ ((k >> 3) & 7);
+    const kwy_c apc = cadd(g[it][0], g[it][2]), amc = csub(g[it][0], g[it][2]);
+    const kwy_c bpd = cadd(g[it][1], g[it][3]), jb = kwy_rot90<false>(csub(g[it][1], g[it][3]));
+    z[e] = cadd(apc, bpd);
+    z[KWY_FFTW_REGION + e] = cadd(amc, jb);
+    z[2 * KWY_FFTW_REGION + e] = csub(apc, bpd);
+    z[3 * KWY_FFTW_REGION + e] = csub(amc, jb);
+  }
+  __syncthreads();
+}
+__device__ inline void kwy_fftw_2048(kwy_c *z, const kwy_fftw_tw &tw) {
+  const int tid = kwy_tid_opaque();
+  const kwy_c *R = z + KWY_FFTW_REGION * (tid >> 6);
+  kwy_c a[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) a[t] = R[64 * t + (tid & 63)];
+  kwy_dft8<false>(a);
+  kwy_fftw_2048_rest(z, tw, a);
+}
+// The same transform of an input that is zero from point 257 on, handed over in registers: thread (w, l) supplies
+// point n = w + 4 l in f0, thread 0 also point 256 in f1 (zero elsewhere).  Stage 1's butterfly is a copy -- nothing is
+// read, and no barrier is needed in front, as long as the buffer is free.
+__device__ inline void kwy_fftw_2048_sparse(kwy_c *z, const kwy_fftw_tw &tw, kwy_c f0, kwy_c f1) {
+  kwy_c a[8];
+  if (kwy_tid_opaque() == 0) {
+    a[0] = f0; a[1] = f1;
+#pragma unroll
+    for (int m = 2; m < 8; ++m) a[m] = {0.0, 0.0};
+    kwy_dft8<false>(a);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) a[m] = f0;
+  }
+  kwy_fftw_2048_rest(z, tw, a);
+}
+// bin k of the REAL transform whose packed half-length transform kwy_fftw_2048 left in z (cf. kwy_rfft_bin2_w:
+// twice the bin, w = exp(-2 pi i k / 4096))
+__device__ __forceinline__ kwy_c kwy_fftw_rbin2(const kwy_c *z, int k, kwy_c w) {
+  constexpr int H = 2048;
+  if (k == 0) return {2.0 * (z[0].x + z[0].y), 0.0};
+  if (k == H) return {2.0 * (z[0].x - z[0].y), 0.0};
+  const kwy_c A = z[kwy_fftw_at(k)];
+  const kwy_c Bc = z[kwy_fftw_at(H - k)];
+  const kwy_c B = {Bc.x, -Bc.y};
+  const double er = A.x + B.x, ei = A.y + B.y;
+  const double dr = A.x - B.x, di = A.y - B.y;
+  return {__builtin_fma(dr, w.y, __builtin_fma(di, w.x, er)), __builtin_fma(-dr, w.x, __builtin_fma(di, w.y, ei))};
+}
+
+
 // Baseline for the comparison: the two-buffer radix-4 Stockham transform the
 // kernels used before kwy_fft_inplace replaced it.
 // One Stockham radix-4 pass over H points: x -> y, sub-transform stride s.
@@ -86,12 +256,41 @@ __global__ __launch_bounds__(NT) void k_fft(const kwy_c *__restrict__ tw, double
   for (int it = 0; it < reps; ++it) {
     if (VAR == 0) { kwy_fft_inplace<LOG2H, NT, false>(A, tw); r = A; }
     if (VAR == 1) { r = kwy_fft_lds<false, NT>(A, B2, LOG2H, tw); }
+    if constexpr (VAR == 2) { kwy_fftw_2048(A, kwy_fftw_twiddles(tw)); r = A; }
   }
   long long t1 = clock64();
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
   double acc = 0;
   for (int i = threadIdx.x; i < H; i += NT) acc += r[i].x + r[i].y;
   if (acc == 12345.678) out[blockIdx.x] = acc;
+}
+
+// the wave-local transform against the in-place one on the same input: max |difference| over the bins
+__global__ __launch_bounds__(256) void k_check(const kwy_c *__restrict__ tw, double *out) {
+  extern __shared__ double smem[];
+  kwy_c *A = (kwy_c *)smem;
+  kwy_c *B2 = A + 2049;
+  for (int i = threadIdx.x; i < 2048; i += 256) {
+    const kwy_c v = {sin(0.37 * i + blockIdx.x) * 3.0 + (i % 7), cos(1.3 * i) - 0.01 * i};
+    A[i] = v;
+    B2[kwy_fftw_in(i)] = v;
+  }
+  __syncthreads();
+  kwy_fft_inplace<11, 256, false>(A, tw);
+  kwy_fftw_2048(B2, kwy_fftw_twiddles(tw));
+  double e = 0.0, m = 0.0;
+  for (int k = threadIdx.x; k < 2048; k += 256) {
+    const kwy_c a = A[k], b = B2[kwy_fftw_at(k)];
+    e = fmax(e, fmax(fabs(a.x - b.x), fabs(a.y - b.y)));
+    m = fmax(m, fmax(fabs(a.x), fabs(a.y)));
+  }
+  __shared__ double se[256], sm[256];
+  se[threadIdx.x] = e; sm[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 256; ++i) { e = fmax(e, se[i]); m = fmax(m, sm[i]); }
+    out[2 * blockIdx.x] = e; out[2 * blockIdx.x + 1] = m;
+  }
 }
 
 template <int LOG2H, int NT, int VAR>
@@ -118,6 +317,13 @@ int main() {
   std::vector<kwy_c> h(H);
   for (int k = 0; k < H; ++k) { double a = -2.0 * M_PI * k / H; h[k].x = cos(a); h[k].y = sin(a); }
   kwy_c *tw; CK(hipMalloc(&tw, sizeof(kwy_c) * H)); CK(hipMemcpy(tw, h.data(), sizeof(kwy_c) * H, hipMemcpyHostToDevice));
+  {
+    double *out; CK(hipMalloc(&out, 16 * 4));
+    CK(hipFuncSetAttribute((const void *)k_check, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    hipLaunchKernelGGL(k_check, dim3(4), dim3(256), 80 * 1024, 0, tw, out);
+    double h8[8]; CK(hipMemcpy(h8, out, 64, hipMemcpyDeviceToHost));
+    for (int b = 0; b < 4; ++b) printf("check block %d: max |wave-local - in-place| = %.3e (max |X| = %.3e)\n", b, h8[2 * b], h8[2 * b + 1]);
+  }
   const int grid = 2048, reps = 20;
   size_t one = sizeof(kwy_c) * (H + 1), two = 2 * one;
   run<11, 512, 0>("inplace r8 NT512, 1 WG/CU (lds 100K)", tw, 100 * 1024, grid, reps);
@@ -125,6 +331,10 @@ int main() {
   run<11, 512, 0>("inplace r8 NT512, 4 WG/CU (lds 33K)", tw, one, grid, reps);
   run<11, 256, 0>("inplace r8 NT256, 2 WG/CU (lds 70K)", tw, 70 * 1024, grid, reps);
   run<11, 256, 0>("inplace r8 NT256, 4 WG/CU (lds 33K)", tw, one, grid, reps);
+  run<11, 256, 0>("inplace r8 NT256, 3 WG/CU (lds 51K)", tw, 51 * 1024, grid, reps);
+  run<11, 256, 2>("wave-local NT256, 2 WG/CU (lds 70K)", tw, 70 * 1024, grid, reps);
+  run<11, 256, 2>("wave-local NT256, 3 WG/CU (lds 51K)", tw, 51 * 1024, grid, reps);
+  run<11, 256, 2>("wave-local NT256, 4 WG/CU (lds 33K)", tw, sizeof(kwy_c) * KWY_FFTW_ENTRIES + 64, grid, reps);
   run<11, 512, 1>("pingpong r4 NT512, 1 WG/CU (lds 100K)", tw, 100 * 1024, grid, reps);
   run<11, 512, 1>("pingpong r4 NT512, 2 WG/CU (lds 70K)", tw, 70 * 1024, grid, reps);
   run<11, 256, 1>("pingpong r4 NT256, 2 WG/CU (lds 70K)", tw, 70 * 1024, grid, reps);
