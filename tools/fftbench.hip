@@ -176,6 +176,110 @@ __device__ __forceinline__ kwy_c kwy_fftw_rbin2(const kwy_c *z, int k, kwy_c w) 
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// (Measured, round 4, and NOT adopted either: 883 ns per transform and CU against the in-place transform's 809 at five
+// workgroups per CU, 955 against 953 at three -- radix-8 passes with half the lanes idle still beat five radix-4
+// stages with all lanes busy: fewer twiddle products and fewer LDS round trips per point.)
+// 1024 points on 256 threads.  The in-place radix-8 transform has 128 butterflies per pass there: two of the four
+// wavefronts -- two of the CU's four SIMDs -- sit the passes out.  The wave-local form gives every lane one radix-4
+// butterfly per stage: four stages inside a wavefront (its 256-point subsequence x[w + 4 m], operands changing lanes
+// through the wavefront's own quarter of the buffer, no barrier), then the radix-4 across the wavefronts.
+// Drop-in: natural order in and out, `tw` = exp(-2 pi i k / 1024), k < 128 (the table the callers keep in LDS).
+//   lane l = a + 4 b + 16 c, slot t: m = l + 64 t
+//   stage 1  DFT over t, times W256^(l t')            -> (lane a + 4 b + 16 t', slot c)
+//   stage 2  DFT over c, times W64^((a + 4 b) c')     -> (lane a + 4 c' + 16 t', slot b)
+//   stage 3  DFT over b, times W16^(a b')             -> (lane b' + 4 c' + 16 t', slot a)
+//   stage 4  DFT over a: F[64 a' + 16 b' + 4 c' + t'], times W1024^(w k')
+__device__ __forceinline__ kwy_c fftw_tw1024(const kwy_c *__restrict__ tw, int i) {   // exp(-2 pi i i / 1024), i < 1024
+  return kwy_tw_octant(tw[i & 127], i >> 7);
+}
+template <bool INV>
+__device__ __forceinline__ void fftw_dft4(kwy_c (&a)[4]) {
+  const kwy_c apc = cadd(a[0], a[2]), amc = csub(a[0], a[2]);
+  const kwy_c bpd = cadd(a[1], a[3]), jb = kwy_rot90<INV>(csub(a[1], a[3]));
+  a[0] = cadd(apc, bpd); a[1] = cadd(amc, jb); a[2] = csub(apc, bpd); a[3] = csub(amc, jb);
+}
+template <bool INV>
+__device__ __forceinline__ void fftw_scale4(kwy_c (&a)[4], kwy_c w1) {
+  if (INV) w1.y = -w1.y;
+  const kwy_c w2 = cmulf(w1, w1), w3 = cmulf(w1, w2);
+  a[1] = cmulf(w1, a[1]); a[2] = cmulf(w2, a[2]); a[3] = cmulf(w3, a[3]);
+}
+__device__ __forceinline__ void fftw_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool INV>
+__device__ inline void kwy_fftw_1024(kwy_c *z, const kwy_c *__restrict__ tw) {
+  const int tid = kwy_tid_opaque();
+  const int l = tid & 63, w = tid >> 6;
+  kwy_c *R = z + 256 * w;
+  kwy_c a[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a[t] = z[w + 4 * l + 256 * t];       // (the one access with a bank conflict: 4-way)
+  __syncthreads();                                                 // every wavefront has its inputs: the regions are free
+  // ---- stage 1
+  fftw_dft4<INV>(a);
+  fftw_scale4<INV>(a, fftw_tw1024(tw, 4 * l));
+  {
+    const int ab = l & 15, c = l >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) R[64 * c + ab + 16 * t] = a[t];
+  }
+  fftw_wave_sync();
+  // ---- stage 2: lane = a + 4 b + 16 t', slots c
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a[s] = R[64 * s + l];
+  fftw_dft4<INV>(a);
+  fftw_scale4<INV>(a, fftw_tw1024(tw, 16 * (l & 15)));
+  {
+    const int la = l & 3, lb = (l >> 2) & 3, lt = l >> 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) R[64 * lb + ((la + 4 * c + 16 * lt) ^ (4 * lb))] = a[c];
+  }
+  fftw_wave_sync();
+  // ---- stage 3: lane = a + 4 c' + 16 t', slots b
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a[s] = R[64 * s + (l ^ (4 * s))];
+  fftw_dft4<INV>(a);
+  fftw_scale4<INV>(a, fftw_tw1024(tw, 64 * (l & 3)));
+  {
+    const int la = l & 3, lc = (l >> 2) & 3, lt = l >> 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) R[64 * la + ((b + 4 * lc + 16 * lt) ^ la)] = a[b];
+  }
+  fftw_wave_sync();
+  // ---- stage 4: lane = b' + 4 c' + 16 t', slots a
+#pragma unroll
+  for (int s = 0; s < 4; ++s) a[s] = R[64 * s + (l ^ s)];
+  fftw_dft4<INV>(a);
+  {
+    // G[k'] = W1024^(w k') F[k'], k' = 64 a' + 16 b' + 4 c' + t'
+    const int lb = l & 3, lc = (l >> 2) & 3, lt = l >> 4;
+    kwy_c p = fftw_tw1024(tw, w * (16 * lb + 4 * lc + lt));
+    kwy_c c = fftw_tw1024(tw, 64 * w);
+    if (INV) { p.y = -p.y; c.y = -c.y; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      R[64 * m + 16 * lb + 4 * lc + (lt ^ lb)] = cmulf(p, a[m]);      // entry k' ^ ((k' >> 4) & 3)
+      p = cmulf(p, c);
+    }
+  }
+  __syncthreads();
+  // ---- the radix-4 across the wavefronts: X[k' + 256 q], natural order
+  {
+    const int e = tid ^ ((tid >> 4) & 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = z[256 * q + e];
+  }
+  fftw_dft4<INV>(a);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) z[256 * q + tid] = a[q];
+  __syncthreads();
+}
+
 // Baseline for the comparison: the two-buffer radix-4 Stockham transform the
 // kernels used before kwy_fft_inplace replaced it.
 // One Stockham radix-4 pass over H points: x -> y, sub-transform stride s.
@@ -257,6 +361,8 @@ __global__ __launch_bounds__(NT) void k_fft(const kwy_c *__restrict__ tw, double
     if (VAR == 0) { kwy_fft_inplace<LOG2H, NT, false>(A, tw); r = A; }
     if (VAR == 1) { r = kwy_fft_lds<false, NT>(A, B2, LOG2H, tw); }
     if constexpr (VAR == 2) { kwy_fftw_2048(A, kwy_fftw_twiddles(tw)); r = A; }
+    if constexpr (VAR == 3) { kwy_fftw_1024<false>(A, tw); r = A; }
+    if constexpr (VAR == 4) { kwy_fftw_1024<true>(A, tw); r = A; }
   }
   long long t1 = clock64();
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
@@ -281,6 +387,34 @@ __global__ __launch_bounds__(256) void k_check(const kwy_c *__restrict__ tw, dou
   double e = 0.0, m = 0.0;
   for (int k = threadIdx.x; k < 2048; k += 256) {
     const kwy_c a = A[k], b = B2[kwy_fftw_at(k)];
+    e = fmax(e, fmax(fabs(a.x - b.x), fabs(a.y - b.y)));
+    m = fmax(m, fmax(fabs(a.x), fabs(a.y)));
+  }
+  __shared__ double se[256], sm[256];
+  se[threadIdx.x] = e; sm[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 256; ++i) { e = fmax(e, se[i]); m = fmax(m, sm[i]); }
+    out[2 * blockIdx.x] = e; out[2 * blockIdx.x + 1] = m;
+  }
+}
+
+template <bool INV>
+__global__ __launch_bounds__(256) void k_check1024(const kwy_c *__restrict__ tw, double *out) {
+  extern __shared__ double smem[];
+  kwy_c *A = (kwy_c *)smem;
+  kwy_c *B2 = A + 1025;
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const kwy_c v = {sin(0.37 * i + blockIdx.x) * 3.0 + (i % 7), cos(1.3 * i) - 0.01 * i};
+    A[i] = v;
+    B2[i] = v;
+  }
+  __syncthreads();
+  kwy_fft_inplace<10, 256, INV>(A, tw);
+  kwy_fftw_1024<INV>(B2, tw);
+  double e = 0.0, m = 0.0;
+  for (int k = threadIdx.x; k < 1024; k += 256) {
+    const kwy_c a = A[k], b = B2[k];
     e = fmax(e, fmax(fabs(a.x - b.x), fabs(a.y - b.y)));
     m = fmax(m, fmax(fabs(a.x), fabs(a.y)));
   }
@@ -324,7 +458,28 @@ int main() {
     double h8[8]; CK(hipMemcpy(h8, out, 64, hipMemcpyDeviceToHost));
     for (int b = 0; b < 4; ++b) printf("check block %d: max |wave-local - in-place| = %.3e (max |X| = %.3e)\n", b, h8[2 * b], h8[2 * b + 1]);
   }
+  kwy_c *tw10;
+  {
+    std::vector<kwy_c> h10(1024);
+    for (int k = 0; k < 1024; ++k) { double a = -2.0 * M_PI * k / 1024; h10[k].x = cos(a); h10[k].y = sin(a); }
+    CK(hipMalloc(&tw10, sizeof(kwy_c) * 1024)); CK(hipMemcpy(tw10, h10.data(), sizeof(kwy_c) * 1024, hipMemcpyHostToDevice));
+    double *out; CK(hipMalloc(&out, 16 * 4));
+    double h8[8];
+    CK(hipFuncSetAttribute((const void *)k_check1024<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
+    hipLaunchKernelGGL(k_check1024<false>, dim3(4), dim3(256), 40 * 1024, 0, tw10, out);
+    CK(hipMemcpy(h8, out, 64, hipMemcpyDeviceToHost));
+    for (int b = 0; b < 2; ++b) printf("check 1024 fwd block %d: max |wave-local - in-place| = %.3e (max |X| = %.3e)\n", b, h8[2 * b], h8[2 * b + 1]);
+    CK(hipFuncSetAttribute((const void *)k_check1024<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
+    hipLaunchKernelGGL(k_check1024<true>, dim3(4), dim3(256), 40 * 1024, 0, tw10, out);
+    CK(hipMemcpy(h8, out, 64, hipMemcpyDeviceToHost));
+    for (int b = 0; b < 2; ++b) printf("check 1024 inv block %d: max |wave-local - in-place| = %.3e (max |X| = %.3e)\n", b, h8[2 * b], h8[2 * b + 1]);
+  }
   const int grid = 2048, reps = 20;
+  run<10, 256, 0>("1024: inplace r8 NT256, 5 WG/CU (lds 29K)", tw10, 29 * 1024, 2560, reps);
+  run<10, 256, 3>("1024: wave-local NT256, 5 WG/CU (lds 29K)", tw10, 29 * 1024, 2560, reps);
+  run<10, 256, 4>("1024: wave-local inverse, 5 WG/CU (lds 29K)", tw10, 29 * 1024, 2560, reps);
+  run<10, 256, 0>("1024: inplace r8 NT256, 3 WG/CU (lds 51K)", tw10, 51 * 1024, 2304, reps);
+  run<10, 256, 3>("1024: wave-local NT256, 3 WG/CU (lds 51K)", tw10, 51 * 1024, 2304, reps);
   size_t one = sizeof(kwy_c) * (H + 1), two = 2 * one;
   run<11, 512, 0>("inplace r8 NT512, 1 WG/CU (lds 100K)", tw, 100 * 1024, grid, reps);
   run<11, 512, 0>("inplace r8 NT512, 2 WG/CU (lds 70K)", tw, 70 * 1024, grid, reps);
