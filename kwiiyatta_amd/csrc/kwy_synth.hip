@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "kwy_internal.hpp"
@@ -1418,20 +1419,29 @@ extern "C" int kwy_synth_render_dev(kwy_ctx *ctx, const void *plan, int64_t T, c
   return synth_render(ctx, syn_plan_carve(const_cast<void *>(plan), y_length), sp, ap, p, log2n, y);
 }
 
-// The rendering of several utterances in one pass of launches (include/kwy.h).
+// The rendering of several utterances (include/kwy.h).  A pass of launches takes SYN_RENDER_GROUP utterances -- four
+// 10 s utterances are ~9 000 pulses: a dozen rounds of the chip's resident workgroups -- and the passes of a call share
+// ONE pool of response slots (the launches of a stream run one after the other: a pass's responses are dead when the
+// next pass writes its own).  Until round 4 a call held the slots of all its utterances at once: 116 MB per 10 s
+// utterance, 3.7 GB for the 32 pairs of the benchmark; now 0.46 GB per context whatever the number of utterances.
+#define SYN_RENDER_GROUP 4
 extern "C" int kwy_synth_render_batch_dev(kwy_ctx *ctx, const kwy_synth_job *jobs, int count, int fft_size,
                                           double frame_period_ms, int fs, double sp_mul) {
   if (!ctx) return KWY_EINVAL;
   if (!jobs || count < 0) { ctx->err = "synth_render_batch: bad argument"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
-  size_t bytes = 0;
+  size_t bytes = 0, group = 0;
+  int in_group = 0;
   for (int j = 0; j < count; ++j) {
     const kwy_synth_job &q = jobs[j];
     KWY_TRY(syn_check(ctx, q.spectrogram, q.f0_length, q.spectrogram, q.aperiodicity, fft_size, frame_period_ms, fs,
                       q.y_length, q.y));
     if (!q.plan) { ctx->err = "synth_render_batch: bad argument"; return KWY_EINVAL; }
-    bytes += syn_render_scratch_bytes(q.y_length, fft_size, fs);
+    if (q.y_length < 2 || q.f0_length < 2) continue;
+    group += syn_render_scratch_bytes(q.y_length, fft_size, fs);
+    if (++in_group == SYN_RENDER_GROUP) { bytes = std::max(bytes, group); group = 0; in_group = 0; }
   }
+  bytes = std::max(bytes, group);
   KWY_TRY(kwy_arena_begin(ctx, bytes));
   syn_batch batch;
   batch.n = 0;
@@ -1447,7 +1457,11 @@ extern "C" int kwy_synth_render_batch_dev(kwy_ctx *ctx, const kwy_synth_job *job
     }
     KWY_TRY(syn_fill_view(ctx, syn_plan_carve(const_cast<void *>(q.plan), q.y_length), q.spectrogram, q.aperiodicity, p,
                           q.y, &batch.u[batch.n]));
-    if (++batch.n == KWY_BATCH_MAX) { KWY_TRY(syn_launch(ctx, batch, log2n)); batch.n = 0; }
+    if (++batch.n == SYN_RENDER_GROUP) {
+      KWY_TRY(syn_launch(ctx, batch, log2n));
+      batch.n = 0;
+      ctx->arena_off = 0;               // the next pass takes the same slots
+    }
   }
   if (batch.n > 0) KWY_TRY(syn_launch(ctx, batch, log2n));
   return KWY_OK;
