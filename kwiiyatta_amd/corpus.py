@@ -88,6 +88,10 @@ class TrainPair:
                 self.stream.wait_event(silence_ready)
             self.silence = [s if torch.is_tensor(s) else torch.from_numpy(np.ascontiguousarray(s)).to(self.dev)
                             for s in silence]
+            # tensors made on other streams (the upload helper's, the generator's) are used on this one: the allocator
+            # must not hand their memory out again while this stream's work on them is still queued
+            for t_ in (self.src.x, self.src.f0, self.src.t, self.tgt.x, self.tgt.f0, self.tgt.t, *self.silence):
+                t_.record_stream(self.stream)
         self.frames = self.src.T
         self.n_rows = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.joint = None
@@ -417,6 +421,13 @@ class ConvertPipeline(_Graphed):
 
     def sync(self):
         self.ctx.sync()
+
+    def contexts(self):
+        """(a captured pass also holds addresses of the generator's scratch arena)"""
+        cs = [self.ctx]
+        if self.mcep_fs is not None and self.rng is not None and self.rng.ctx is not self.ctx:
+            cs.append(self.rng.ctx)
+        return cs
 
 
 class ConvertWave:

@@ -863,7 +863,8 @@ static int soft_core(kwy_ctx *ctx, const double *x, int64_t T, int D, int M, con
   const size_t lds_prep = sizeof(double) * 3 * D * D;
   const size_t lds_logp = sizeof(double) * (size_t)(ml_np(D) + ML_TILE) * (ml_kp(D) + 1);
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024 || D > 192 || M > 256) {
-    ctx->err = "gmm_convert_frames: feature dimension (<= 128 per side) or mixture count (<= 256) too large";
+    // (3 D^2 doubles of LDS for the preparation: 160 KB hold D <= 82)
+    ctx->err = "gmm_convert_frames: feature dimension (<= 82 per side) or mixture count (<= 256) too large";
     return KWY_EINVAL;
   }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
