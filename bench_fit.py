@@ -25,6 +25,9 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo lets '
                                                        'several ranks share one GPU when rehearsing the launch)')
+    ap.add_argument('--force-group', action='store_true',
+                    help='initialise the process group even for ONE rank (a world-size-1 \'nccl\' group: RCCL itself under '
+                         'the fit\'s collectives on a one-GPU box)')
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -32,8 +35,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
+    grouped = world > 1 or args.force_group
+    if grouped:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29549')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -51,7 +58,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     torch.cuda.set_stream(st.stream)           # the fit's stream: kernels, driver ops and collectives
@@ -103,8 +110,9 @@ def main():
                                                'diagonal add 10 % issued work); peak = 1024 SIMDs x 32 flop/cycle x '
                                                '2.4 GHz, measured 75.4 with tools/mfma_f64_bench.hip; k_fit_cov: '
                                                'cov_tflops / peak'},
+                          'process_group': (dist.get_backend() + f', world size {world}') if grouped else None,
                           'all_reduce_bytes_per_iteration': 8 * (M * (D + 1) + M * D * D + 1)}))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -420,7 +420,7 @@ class PairBatchPipeline(_Graphed):
     Outputs per pair k: `wave(k)`; equal to PairPipeline's bit for bit given the same pads."""
 
     def __init__(self, device_index, fs, pairs, gmm, order=24, radius=32, frame_period=5.0, waves=2, rng=None,
-                 silence=None, rng_place='side', serial=False):
+                 silence=None, rng_place='side', serial=False, max_wave=16):
         self.dev = torch.device('cuda', device_index)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
@@ -434,7 +434,7 @@ class PairBatchPipeline(_Graphed):
         self.rng_place = rng_place
         pairs = list(pairs)
         nw = max(1, min(int(waves), len(pairs)))
-        while (len(pairs) + nw - 1) // nw > 16:        # a wave is one launch of the batched entries
+        while (len(pairs) + nw - 1) // nw > max_wave:  # (16: a wave is one launch of the batched entries)
             nw += 1
         per = (len(pairs) + nw - 1) // nw
         self.stream = torch.cuda.Stream(device=self.dev)

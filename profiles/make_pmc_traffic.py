@@ -49,7 +49,10 @@ def main():
                                  'hbm_bytes_per_launch_raw': (fetch[k] + write[k]) * 1024,
                                  'hbm_bytes_per_launch_fetch_doubled': (2 * fetch[k] + write[k]) * 1024}
     here = os.path.dirname(os.path.abspath(__file__))
-    rnd = sys.argv[3] if len(sys.argv) > 3 else 'r3'
+    rnd = sys.argv[3] if len(sys.argv) > 3 else 'r4'
+    if len(sys.argv) > 4:          # frames per analysis launch of the profiled command (r4: 16 utterances = 33 616)
+        out['frames_per_launch'] = int(sys.argv[4])
+        out['command'] = sys.argv[5] if len(sys.argv) > 5 else out['command']
     json.dump(out, open(os.path.join(here, f'{rnd}_pmc_traffic.json'), 'w'), indent=1)
     print(json.dumps(out['kernels'], indent=1))
 

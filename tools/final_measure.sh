@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-end measurement set (run on the GPU box through gpurun, in two calls: `final_measure.sh a` then `... b`;
+# round-end measurement set (run on the GPU box through gpurun, in three calls: `final_measure.sh a`, `... b`, `... c`;
 # each stays under gpurun's 20-minute limit)
 R=$GRAFT_REPO_ROOT
 O=${KWY_MEASURE_OUT:-$R/gpurun_out/final}
@@ -7,38 +7,40 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 set -e
 PART=${1:-a}
+SERIAL="python $R/bench.py --driver serial --batch 16 --steps 2 --warmup 1 --no-graph --no-variants --no-cpu-baseline"
 if [ "$PART" = a ]; then
   KWY_KAT_DUMP=$O/kat_envelopes timeout -k 10 900 python -m pytest $R/tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
   python -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1
   python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
-  python $R/bench.py --batch 16 --no-cpu-baseline --no-pcie-variant > $O/bench_b16.json 2>/dev/null
-  python $R/bench.py --batch 64 --steps 5 --no-cpu-baseline --no-pcie-variant > $O/bench_b64.json 2>/dev/null
-  python $R/bench.py --batch 1 --steps 5 --no-cpu-baseline --no-pcie-variant > $O/bench_b1.json 2>/dev/null
+  python $R/bench.py --batch 16 --waves 1 --no-cpu-baseline > $O/bench_b16.json 2>/dev/null
+  python $R/bench.py --batch 64 --steps 10 --no-cpu-baseline > $O/bench_b64.json 2>/dev/null
+  python $R/bench.py --batch 1 --waves 1 --steps 20 --no-cpu-baseline --no-variants > $O/bench_b1.json 2>/dev/null
+  python $R/bench.py --driver serial --no-cpu-baseline --no-variants > $O/bench_serial.json 2>/dev/null
+  python $R/bench.py --driver streams --no-cpu-baseline > $O/bench_streams.json 2>/dev/null
   python $R/bench.py --workload utterance --batch 1 > $O/bench_utt_b1.json 2>/dev/null
-  python $R/bench.py --workload utterance --batch 16 --no-cpu-baseline > $O/bench_utt_b16.json 2>/dev/null
-  python $R/bench.py --workload utterance --utterances 256 --batch 16 --steps 3 --warmup 1 > $O/bench_config4.json 2> $O/bench_config4.err
+  python $R/bench.py --workload utterance --utterances 256 --steps 3 --warmup 1 > $O/bench_config4.json 2> $O/bench_config4.err
+  echo done > $O/DONE_A
+elif [ "$PART" = b ]; then
   python $R/bench_fit.py > $O/bench_fit.json 2>/dev/null
   python $R/bench_corpus.py > $O/bench_corpus.json 2> $O/bench_corpus.err
-  python $R/bench_corpus.py --max-iter 100 > $O/bench_corpus_ref_em.json 2>/dev/null
-  python $R/bench_corpus.py --pads host > $O/bench_corpus_hostpads.json 2>/dev/null
+  python $R/bench_corpus.py --em-iters 10 > $O/bench_corpus_em10.json 2>/dev/null
+  python $R/bench_corpus.py --driver streams --distinct 8 --em-iters 10 > $O/bench_corpus_streams.json 2>/dev/null
   # the N-rank paths rehearsed on this one GPU: two ranks, gloo for the collectives, started by torchrun from the shell
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
     $R/bench_fit.py --backend gloo --frames 200000 > $O/bench_fit_2rank_gloo.json 2> $O/bench_fit_2rank_gloo.err
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 \
-    $R/bench_corpus.py --backend gloo --pairs 64 --seconds 2 > $O/bench_corpus_2rank_gloo.json 2> $O/bench_corpus_2rank_gloo.err
-  python $R/bench_corpus.py --pairs 64 --seconds 2 > $O/bench_corpus_1rank_64.json 2>/dev/null
+    $R/bench_corpus.py --backend gloo --pairs 64 --seconds 2 --em-iters 10 > $O/bench_corpus_2rank_gloo.json 2> $O/bench_corpus_2rank_gloo.err
+  python $R/bench_corpus.py --pairs 64 --seconds 2 --em-iters 10 > $O/bench_corpus_1rank_64.json 2>/dev/null
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29543 \
-    $R/bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --no-cpu-baseline --no-pcie-variant > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
-  echo done > $O/DONE_A
+    $R/bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --no-cpu-baseline --no-variants > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
+  # RCCL itself: a one-rank 'nccl' group on the one GPU
+  python $R/bench_fit.py --backend nccl --force-group > $O/bench_fit_1rank_nccl.json 2> $O/bench_fit_1rank_nccl.err
+  echo done > $O/DONE_B
 else
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b32 -- python $R/bench.py --no-cpu-baseline --no-pcie-variant > $O/stats_pair_b32.log 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b1 -- python $R/bench.py --batch 1 --steps 5 --no-cpu-baseline --no-pcie-variant > $O/stats_pair_b1.log 2>&1
-  # one pair on ONE stream: the analysis kernels take both utterances per launch (4 202 frames), alone on the chip --
-  # the launch `roofline.avg_launch_ms` of the bench line is about
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pair_b1_single -- python $R/bench.py --batch 1 --side-stream off --steps 5 --no-cpu-baseline --no-pcie-variant > $O/stats_pair_b1_single.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --workload utterance --batch 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+  KWY_MEASURE_OUT=$O/prof_step bash $R/tools/prof_step.sh
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $SERIAL > $O/pmc_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $SERIAL > $O/pmc_write.log 2>&1
   KWY_MEASURE_OUT=$O/pmc_sq bash $R/tools/pmc_sq.sh
   bash $R/tools/prof_fit.sh
-  echo done > $O/DONE_B
+  echo done > $O/DONE_C
 fi
