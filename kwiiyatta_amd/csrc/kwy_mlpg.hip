@@ -176,18 +176,22 @@ typedef double ml_v4f64 __attribute__((ext_vector_type(4)));
 __host__ __device__ static inline int ml_kp(int D) { return (D + 3) & ~3; }
 __host__ __device__ static inline int ml_np(int D) { return (D + 15) & ~15; }
 
-__global__ __launch_bounds__(KWY_THREADS) void k_gmm_logp(const double *__restrict__ X, ml_dims dm,
+// NW wavefronts per workgroup, 16 frames each (round 4: eight where the LDS allows -- a workgroup fills a CU alone, so
+// its wavefronts are all the latency hiding there is: 0.68 -> see DESIGN.md section 5 for a wave of 35 216 frames)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_gmm_logp(const double *__restrict__ X, ml_dims dm,
                                                          const double *__restrict__ model,
                                                          double *__restrict__ logp) {
   extern __shared__ double smem[];
   const int D = dm.D, Kp = ml_kp(D), NP = ml_np(D), ZS = Kp + 1;
   double *Zs = smem;             // NP x ZS
-  double *dts = Zs + NP * ZS;    // ML_TILE x ZS
+  constexpr int TILE = 16 * NW;
+  double *dts = Zs + NP * ZS;    // TILE x ZS
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.y;
   const double *mod = model + (size_t)m * ml_model_stride(D);
   const double *mZ = mod, *mux = mod + 2 * D * D;
   const double cst = mod[2 * D * D + 3 * D];
-  for (int jb = 4 * wv; jb < NP; jb += 4 * KWY_WAVES) {  // four rows per wavefront and step, loads batched
+  for (int jb = 4 * wv; jb < NP; jb += 4 * NW) {  // four rows per wavefront and step, loads batched
     double z0[4], z1[4];
     const int i0 = lane, i1 = lane + 64;
 #pragma unroll
@@ -207,9 +211,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_gmm_logp(const double *__restri
     }
   }
   const int ar = lane & 15, ak = lane >> 4;
-  const int64_t ntiles = (dm.T + ML_TILE - 1) / ML_TILE;
+  const int64_t ntiles = (dm.T + TILE - 1) / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t t0 = tile * ML_TILE;
+    const int64_t t0 = tile * TILE;
     __syncthreads();  // the previous tile has been consumed (and Zs is complete)
     // every wavefront stages the 16 frames it multiplies itself
     {
@@ -749,11 +753,31 @@ static size_t ml_scratch_bytes(int64_t T, int d, int M, int n = 1) {
 }
 
 // frame-tile walkers per mixture: enough workgroups for every CU (one fits per CU), not more than tiles
-static int ml_logp_splits(int64_t T, int M) {
-  const int64_t ntiles = (T + ML_TILE - 1) / ML_TILE;
+static int ml_logp_waves(int D) {      // wavefronts per workgroup of k_gmm_logp: eight if Z_m and 128 frames fit the LDS
+  return sizeof(double) * (size_t)(ml_np(D) + 128) * (ml_kp(D) + 1) <= 150 * 1024 ? 8 : 4;
+}
+static size_t ml_logp_lds(int D) {
+  return sizeof(double) * (size_t)(ml_np(D) + 16 * ml_logp_waves(D)) * (ml_kp(D) + 1);
+}
+static int ml_logp_splits(int64_t T, int M, int D) {
+  const int tile = 16 * ml_logp_waves(D);
+  const int64_t ntiles = (T + tile - 1) / tile;
   int64_t s = (256 + M - 1) / M;
   if (s > ntiles) s = ntiles;
   return (int)(s < 1 ? 1 : s);
+}
+
+static int ml_launch_logp(kwy_ctx *ctx, const double *X, const ml_dims &dm, const double *model, double *logp) {
+  const size_t lds = ml_logp_lds(dm.D);
+  const dim3 grid((unsigned)ml_logp_splits(dm.T, dm.M, dm.D), dm.M);
+  if (ml_logp_waves(dm.D) == 8) {
+    KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp<8>, grid, dim3(512), lds, ctx->stream, X, dm, model, logp));
+  } else {
+    KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp<4>, grid, dim3(256), lds, ctx->stream, X, dm, model, logp));
+  }
+  return KWY_OK;
 }
 
 // chunks of the partitioned solve of a T-row system: 64/d per wavefront, at least 16 rows each
@@ -805,10 +829,9 @@ static int mlpg_batch_core(kwy_ctx *ctx, ml_batch &bt, const int64_t *Ts, int d,
   *status_out = status;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
   size_t lds_prep = sizeof(double) * 3 * D * D;
-  size_t lds_logp = sizeof(double) * (size_t)(ml_np(D) + ML_TILE) * (ml_kp(D) + 1);
+  size_t lds_logp = ml_logp_lds(D);
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024) { ctx->err = "gmm_mlpg: feature dimension too large"; return KWY_EINVAL; }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
-  KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
   const int cpw = 64 / d;
   const size_t lds_solve = sizeof(double) * ((size_t)d * 2 * (Pmax - 1) * 5 + 8);
   if (lds_solve > 160 * 1024) { ctx->err = "gmm_mlpg: static dimension too large"; return KWY_EINVAL; }
@@ -819,8 +842,7 @@ static int mlpg_batch_core(kwy_ctx *ctx, ml_batch &bt, const int64_t *Ts, int d,
                        diff, model, status);
   const unsigned ge = (unsigned)((T * d + 255) / 256);
   hipLaunchKernelGGL(k_delta, dim3(ge), dim3(256), 0, ctx->stream, bt, dm, X);
-  KWY_PROF(ctx, "k_gmm_logp", hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)ml_logp_splits(T, M), M), dim3(KWY_THREADS), lds_logp,
-                     ctx->stream, X, dm, model, logp));
+  KWY_TRY(ml_launch_logp(ctx, X, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_cond, dim3((unsigned)T), dim3(128), 0, ctx->stream, X, dm, model, logp, E, Dv, mix);
   hipLaunchKernelGGL(k_mlpg_build, dim3(ge), dim3(256), 0, ctx->stream, E, Dv, bt, dm, band);
   KWY_PROF(ctx, "k_mlpg_chunks", hipLaunchKernelGGL(k_mlpg_chunks, dim3((unsigned)((Pmax + cpw - 1) / cpw), n), dim3(64), 0, ctx->stream,
@@ -861,18 +883,16 @@ static int soft_core(kwy_ctx *ctx, const double *x, int64_t T, int D, int M, con
   *status_out = status;
   KWY_HIP(hipMemsetAsync(status, 0, sizeof(int) * 16, ctx->stream));
   const size_t lds_prep = sizeof(double) * 3 * D * D;
-  const size_t lds_logp = sizeof(double) * (size_t)(ml_np(D) + ML_TILE) * (ml_kp(D) + 1);
+  const size_t lds_logp = ml_logp_lds(D);
   if (lds_prep > 160 * 1024 || lds_logp > 160 * 1024 || D > 192 || M > 256) {
     // (3 D^2 doubles of LDS for the preparation: 160 KB hold D <= 82)
     ctx->err = "gmm_convert_frames: feature dimension (<= 82 per side) or mixture count (<= 256) too large";
     return KWY_EINVAL;
   }
   KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep));
-  KWY_HIP(hipFuncSetAttribute((const void *)k_gmm_logp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_logp));
   hipLaunchKernelGGL(k_gmm_prep, dim3(M), dim3(KWY_THREADS), lds_prep, ctx->stream, weights, means, covs, D, diff, model,
                      status);
-  hipLaunchKernelGGL(k_gmm_logp, dim3((unsigned)ml_logp_splits(T, M), M), dim3(KWY_THREADS), lds_logp, ctx->stream, x, dm,
-                     model, logp);
+  KWY_TRY(ml_launch_logp(ctx, x, dm, model, logp));
   hipLaunchKernelGGL(k_gmm_soft, dim3((unsigned)T), dim3(128), 0, ctx->stream, x, dm, model, logp, y);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
