@@ -2,7 +2,8 @@
 """Benchmark of kwiiyatta's per-utterance conversion hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: the process starts N ranks itself, one per GPU (bench_launch.py), unless it already runs under
+     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step = one pass of the hot path over one batch of synthetic 48 kHz utterance
 pairs that are already resident in HBM.  Default workload = BASELINE config 3:
@@ -50,13 +51,6 @@ FRAME_PERIOD = 5.0
 # counter summaries of the current kernels (tools/final_measure.sh + tools/collect_profiles.sh)
 PMC_TRAFFIC, PMC_SQ = 'r4_pmc_traffic.json', 'r4_pmc_sq_summary.json'
 METRIC = 'frames/sec end-to-end analyse->align->convert->synth, 48 kHz 5 ms hop'
-
-
-def make_pair(index, seconds):
-    from kwiiyatta_amd.synthetic import make_utterance
-    src = make_utterance(seed=1234 + 2 * index, fs=FS, seconds=seconds)
-    tgt = make_utterance(seed=4321 + 2 * index, fs=FS, seconds=seconds, time_warp=1.1, formant_scale=1.12)
-    return src, tgt
 
 
 def pair_silence(index, K=1025):
@@ -118,34 +112,44 @@ def cpu_baseline_pair(src, tgt, gmm, silence, budget_s=25.0):
 
 
 def _make_utterance_job(job):
-    """(seed, seconds) -> utterance; module-level so that a process pool can run it.  synthetic.py is loaded by path:
-    the workers need neither the package nor the HIP runtime."""
+    """(seed, seconds[, keyword arguments of make_utterance]) -> utterance; module-level so that a process pool can
+    run it.  synthetic.py is loaded by path: the workers need neither the package nor the HIP runtime."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('kwy_synthetic', os.path.join(ROOT, 'kwiiyatta_amd', 'synthetic.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    seed, seconds = job
-    return mod.make_utterance(seed=seed, fs=FS, seconds=seconds, f0_base=110.0 + (seed % 7) * 15.0)
+    seed, seconds = job[0], job[1]
+    kw = job[2] if len(job) > 2 else {'f0_base': 110.0 + (seed % 7) * 15.0}
+    return mod.make_utterance(seed=seed, fs=FS, seconds=seconds, **kw)
 
 
-def main_batch(args):
-    """BASELINE config 4: a batch of `--utterances` distinct synthetic 48 kHz utterances per GPU (256 on one GPU =
-    the configuration's whole batch; seeds = global utterance index), analysed and resynthesised through a fixed pool
-    of `--batch` streams -- many more utterances than streams, inputs resident in HBM, one frame = 5 ms of audio.
-    Reference flow: kwiiyatta/resynthesize_voice.py:46-79 per file."""
+def host_generate(jobs):
+    """The synthetic signals of `jobs` (see _make_utterance_job), made by a pool of FRESH worker processes (spawn: no
+    torch, no HIP) on the host cores this rank may use.  Call before the process touches the GPU where possible."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    if not jobs:
+        return []
+    nproc = max(1, min(len(os.sched_getaffinity(0)), 16, len(jobs)))
+    if nproc == 1:
+        return [_make_utterance_job(j) for j in jobs]
+    with cf.ProcessPoolExecutor(nproc, mp_context=mp.get_context('spawn')) as ex:
+        return list(ex.map(_make_utterance_job, jobs, chunksize=max(1, min(4, len(jobs) // nproc))))
+
+
+def pair_jobs(index, seconds):
+    """the two generator jobs of pair `index` (source: 10 s; target: the same schedule warped to 11 s with shifted formants)"""
+    return [(1234 + 2 * index, seconds, {}), (4321 + 2 * index, seconds, {'time_warp': 1.1, 'formant_scale': 1.12})]
+
+
+def init_group(args):
+    """(rank, local_rank, world, dev, rdev): the rank's place as torch.distributed.run / bench_launch set it, the
+    process group started (RCCL under `nccl`), the device chosen."""
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    seeds = [rank + world * i for i in range(args.utterances)]
-    # host-side signal generation first, in worker processes, before this process touches the GPU
-    import concurrent.futures as cf
-    import multiprocessing as mp
-    nproc = max(1, min(len(os.sched_getaffinity(0)), 16, len(seeds)))
-    with cf.ProcessPoolExecutor(nproc, mp_context=mp.get_context('spawn')) as ex:
-        utts = list(ex.map(_make_utterance_job, [(sd, args.seconds) for sd in seeds], chunksize=4))
-
-    import torch
-    import torch.distributed as dist
     local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -155,10 +159,39 @@ def main_batch(args):
             dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    rdev = dev if args.backend == 'nccl' else torch.device('cpu')
-    from kwiiyatta_amd import corpus as cp
-    from kwiiyatta_amd import pipeline as pl
+    rdev = dev if args.backend == 'nccl' else torch.device('cpu')   # where the timing reductions live
+    return rank, local_rank, world, dev, rdev
 
+
+def reduce_ranks(rank, world, rdev, seconds, frames):
+    """MAX of the elapsed time, SUM of the frames, the number of ranks that answered (a SUM of ones over the group:
+    `ranks_seen`) and every rank's own frames per second of its own elapsed time."""
+    if world == 1:
+        return seconds, float(frames), 1, [frames / seconds]
+    import torch
+    import torch.distributed as dist
+    tt = torch.tensor([seconds], dtype=torch.float64, device=rdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    v = torch.zeros(world + 2, dtype=torch.float64, device=rdev)
+    v[0], v[1], v[2 + rank] = float(frames), 1.0, frames / seconds
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    v = v.cpu().tolist()
+    return float(tt.item()), v[0], int(round(v[1])), v[2:]
+
+
+def config4_seeds(total, rank, world):
+    """BASELINE config 4 shards ONE batch of `total` utterances round-robin: rank r takes r, r + W, ... (the
+    reference's per-file loop, /root/reference/kwiiyatta/convert_voice.py:17-32); seed = global index."""
+    return list(range(rank, total, world))
+
+
+def config4_measure(args, grp, utts, steps, warmup):
+    """Time `steps` passes of this rank's share of the config-4 batch (analyse + resynthesise every utterance, in
+    lockstep waves of 16 or through a stream pool) under the contract's protocol.  Returns a dict (all ranks)."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world, dev, rdev = grp
+    from kwiiyatta_amd import corpus as cp
     resident = [tuple(torch.from_numpy(a).to(dev) for a in u) for u in utts]
     lockstep = args.driver != 'streams'
     drv = dict(driver='lockstep', lockstep=cp._Lockstep(local_rank)) if lockstep else \
@@ -167,34 +200,51 @@ def main_batch(args):
     out = [torch.empty(n, dtype=torch.float64, device=dev) for n in ylen]
 
     def step():
-        return cp.resynthesize_batch(resident, FS, device_index=local_rank, out=out, **drv)[1]
+        return cp.resynthesize_batch(resident, FS, device_index=local_rank, out=out, **drv)[1] if resident else 0
 
     frames_step = 0
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         frames_step = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
-    frames_total = float(frames_step * args.steps)
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-        ft = torch.tensor([frames_total], dtype=torch.float64, device=rdev)
-        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
-        frames_total = float(ft.item())
+    el, frames_total, ranks_seen, per_rank = reduce_ranks(rank, world, rdev, el, float(frames_step * steps))
     finite = all(bool(torch.isfinite(w).all().item()) for w in out)
     first = [w.clone() for w in out]
     step()
     torch.cuda.synchronize()
     identical = all(torch.equal(a, b) for a, b in zip(first, out))
+    return {'seconds': el, 'frames_total': frames_total, 'ranks_seen': ranks_seen, 'per_rank_frames_per_s': per_rank,
+            'finite': finite, 'identical': identical, 'lockstep': lockstep, 'first': first, 'out': out}
+
+
+def main_batch(args):
+    """BASELINE config 4: ONE batch of `--utterances` distinct synthetic 48 kHz utterances (256 = the configuration's
+    batch; seeds = global utterance index) sharded round-robin over the ranks, analysed and resynthesised in lockstep
+    waves of 16 (or through a fixed pool of `--batch` streams) -- inputs resident in HBM, one frame = 5 ms of audio.
+    Strong scaling: the batch is fixed, a rank takes 1/N of it.
+    Reference flow: kwiiyatta/resynthesize_voice.py:46-79 per file."""
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    seeds = config4_seeds(args.utterances, rank, world)
+    # host-side signal generation first, in worker processes, before this process touches the GPU
+    utts = host_generate([(sd, args.seconds) for sd in seeds])
+
+    import torch
+    import torch.distributed as dist
+    grp = init_group(args)
+    rank, local_rank, world, dev, rdev = grp
+    from kwiiyatta_amd import pipeline as pl
+    m = config4_measure(args, grp, utts, args.steps, args.warmup)
+    el, frames_total, finite, identical, lockstep, first = (m['seconds'], m['frames_total'], m['finite'], m['identical'],
+                                                             m['lockstep'], m['first'])
     if rank == 0:
         # the D4C stage (dominant whole-chip kernels) of one utterance alone, HIP events on its stream
         lone = pl.UtterancePipeline(local_rank, FS, utts[0])
@@ -218,12 +268,14 @@ def main_batch(args):
         res = {
             'metric': METRIC, 'value': value, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1000.0 * el / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'config4: batch of {args.utterances} distinct synthetic 48 kHz {args.seconds:g} s '
-                                   f'utterances per GPU (T={T}, K={K}; seeds = global utterance index): CheapTrick + D4C + '
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'ranks_seen': m['ranks_seen'], 'per_rank_frames_per_s': m['per_rank_frames_per_s'],
+            'config': {'workload': f'config4: ONE batch of {args.utterances} distinct synthetic 48 kHz {args.seconds:g} s '
+                                   f'utterances sharded round-robin over the ranks (T={T}, K={K}; seeds = global utterance index): CheapTrick + D4C + '
                                    f'WORLD synthesis each' + (', in waves of 16 through the batched entries on two streams'
                                                               if lockstep else ', through a fixed pool of streams'),
-                       'utterances_per_gpu': args.utterances, 'streams_per_gpu': 2 if lockstep else args.batch,
+                       'utterances_total': args.utterances, 'utterances_this_rank': len(utts),
+                       'streams_per_gpu': 2 if lockstep else args.batch,
                        'GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
                        'launch': ('kwiiyatta_amd.corpus.ConvertWave: one launch per stage and wave (kwy_*_batch_dev); inputs '
                                   'resident in HBM; every waveform kept') if lockstep else
@@ -265,30 +317,27 @@ def main_lockstep(args):
     <= 16 through the batched entries of include/kwy.h, the step one HIP graph on four streams; the pad spectra of
     every pair are drawn INSIDE the step from numpy's legacy generator continued on the device (what `align` does per
     call: /root/reference/kwiiyatta/vocoder/feature.py:19-41, world.py:158-161)."""
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    serial = args.driver == 'serial'
+    # ---- host-side signal generation first, in fresh worker processes, before this process touches the GPU
+    mine = list(range(rank, world * args.batch, world))       # = parallel.shard_indices: pair i belongs to rank i % W
+    nbase = min(len(mine), args.distinct)      # distinct host-generated signal pairs (default: every pair of the batch)
+    c4_total = 0 if (serial or args.config4 == 'off') else args.config4_utterances
+    c4_seeds = config4_seeds(c4_total, rank, world)
+    made = host_generate(sum((pair_jobs(mine[i], args.seconds) for i in range(nbase)), []) +
+                         [(sd, args.seconds) for sd in c4_seeds])
+    base = [(made[2 * i], made[2 * i + 1]) for i in range(nbase)]
+    c4_utts = made[2 * nbase:]
+
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(args.backend)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    rdev = dev if args.backend == 'nccl' else torch.device('cpu')   # where the timing reductions live
+    grp = init_group(args)
+    rank, local_rank, world, dev, rdev = grp
 
     from kwiiyatta_amd import pipeline as pl
     from kwiiyatta_amd.backend.nprandom import DeviceRandomState
-    from kwiiyatta_amd.parallel import shard_indices
 
-    serial = args.driver == 'serial'
-    mine = shard_indices(world * args.batch, rank, world)
-    nbase = min(len(mine), args.distinct)      # distinct host-generated signal pairs, reused round-robin
-    base = [make_pair(mine[i], args.seconds) for i in range(nbase)]
     gmm = pl.synthetic_gmm(order=24, components=args.components, seed=0)
     dgmm = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev)
     pairs = [base[i % nbase] for i in range(len(mine))]
@@ -333,14 +382,18 @@ def main_lockstep(args):
         step = pipe.run
     for _ in range(args.warmup):
         step()
-    el = timed(step, args.steps)
-    frames_rank = pipe.frames * args.steps
+    sync_all()
     if world > 1:
-        ft = torch.tensor([float(frames_rank)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
-        frames_total = float(ft.item())
-    else:
-        frames_total = float(frames_rank)
+        dist.barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    if world > 1:
+        dist.barrier()
+    el_own = time.perf_counter() - t0
+    el, frames_total, ranks_seen, per_rank = reduce_ranks(rank, world, rdev, el_own, float(pipe.frames * args.steps))
     value = frames_total / el
 
     # One more (untimed) pass with the generator's state read before it: numpy, set to that state, must draw the same
@@ -408,6 +461,24 @@ def main_lockstep(args):
                                          'two service streams, two staging slots each way '
                                          '(kwiiyatta_amd.pipeline.BatchHostFeeder); never `value`'}
         del feeder
+
+    # ---- BASELINE config 4 beside config 3 (every rank takes part): ONE batch of 256 distinct utterances sharded
+    #      round-robin over the ranks (strong scaling), analyse + resynthesise in lockstep waves of 16
+    config4 = None
+    if c4_total:
+        m4 = config4_measure(args, grp, c4_utts, args.config4_steps, 2)
+        v4 = m4['frames_total'] / m4['seconds']
+        config4 = {'metric': METRIC, 'value': v4, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.config4_steps,
+                   'ms_per_step': 1000.0 * m4['seconds'] / args.config4_steps, 'scaling': 'strong',
+                   'ranks_seen': m4['ranks_seen'], 'per_rank_frames_per_s': m4['per_rank_frames_per_s'],
+                   'real_time_factor': v4 / 200.0,
+                   'config': {'workload': f'config4: ONE batch of {c4_total} distinct synthetic 48 kHz {args.seconds:g} s utterances '
+                                          'sharded round-robin over the ranks (seed = global utterance index): CheapTrick + '
+                                          'D4C + WORLD synthesis each, in lockstep waves of 16 (kwiiyatta_amd.corpus.ConvertWave), '
+                                          'inputs resident in HBM, every waveform kept',
+                              'utterances_total': c4_total, 'utterances_this_rank': len(c4_utts)},
+                   'checks': {'all_outputs_finite': m4['finite'], 'second_pass_bit_identical': m4['identical']}}
+        del m4
 
     if rank == 0:
         K = pipe.K
@@ -517,6 +588,9 @@ def main_lockstep(args):
             'with_pcie': variants.get('with_pcie'),
             'parity': None,
             'distinct_pairs_per_gpu': nbase,
+            'ranks_seen': ranks_seen,
+            'per_rank_frames_per_s': per_rank,
+            'config4': config4,
             'cpu_baseline': None,
         }
         if not args.no_cpu_baseline and world == 1:
@@ -558,7 +632,15 @@ def main():
     ap_.add_argument('--waves', type=int, default=2, help='lockstep driver: waves of <= 16 pairs side by side')
     ap_.add_argument('--no-variants', action='store_true', help='lockstep driver: skip the pads-replayed and PCIe variants')
     ap_.add_argument('--no-cpu-baseline', action='store_true')
-    ap_.add_argument('--distinct', type=int, default=8, help='distinct synthetic signal pairs per rank (cycled over the batch)')
+    ap_.add_argument('--distinct', type=int, default=32,
+                     help='distinct synthetic signal pairs per rank (cycled over the batch when fewer than --batch; made '
+                          'by a pool of host processes before the GPU is touched)')
+    ap_.add_argument('--config4', choices=['on', 'off'], default='on',
+                     help='pair workload, lockstep driver: after config 3 also time BASELINE config 4 (ONE batch of '
+                          '--config4-utterances distinct utterances sharded round-robin over the ranks) and report it '
+                          'as the `config4` object of the line')
+    ap_.add_argument('--config4-utterances', type=int, default=256)
+    ap_.add_argument('--config4-steps', type=int, default=3)
     ap_.add_argument('--no-pcie-variant', action='store_true',
                      help='skip the second timed loop that uploads the waveforms and downloads the result inside the step')
     ap_.add_argument('--side-stream', choices=['auto', 'on', 'off'], default='auto',
@@ -574,6 +656,8 @@ def main():
     ap_.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL; gloo lets '
                                                         'several ranks share one GPU when rehearsing the launch)')
     args = ap_.parse_args()
+    import bench_launch
+    bench_launch.maybe_launch(args.gpus)     # --gpus N > 1 outside a rank: become the launcher of N ranks (never returns)
 
     args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.batch == 1)
     if args.workload == 'utterance' and args.utterances > 0:
@@ -583,29 +667,20 @@ def main():
             args.batch = 16
         return main_lockstep(args)
 
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    # global utterance indices of this rank (weak scaling: `batch` per rank); signals made before the GPU is touched
+    mine = list(range(rank, world * args.batch, world))
+    nbase = min(len(mine), args.distinct)      # distinct host-generated signal pairs, reused round-robin
+    made = host_generate(sum((pair_jobs(mine[i], args.seconds) for i in range(nbase)), []))
+    base = [(made[2 * i], made[2 * i + 1]) for i in range(nbase)]
+
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(args.backend)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    rdev = dev if args.backend == 'nccl' else torch.device('cpu')   # where the timing reductions live
+    rank, local_rank, world, dev, rdev = init_group(args)
 
     from kwiiyatta_amd import pipeline as pl
-    from kwiiyatta_amd.parallel import shard_indices
 
-    # global utterance indices of this rank (weak scaling: `batch` per rank)
-    mine = shard_indices(world * args.batch, rank, world)
-    nbase = min(len(mine), args.distinct)      # distinct host-generated signal pairs, reused round-robin
-    base = [make_pair(mine[i], args.seconds) for i in range(nbase)]
     gmm = pl.synthetic_gmm(order=24, components=args.components, seed=0) if args.workload == 'pair' else None
     dgmm = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, dev) if gmm is not None else None
 

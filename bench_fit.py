@@ -3,8 +3,9 @@
 feature matrix (n ~ 5e5 frames x 144, 64 full-covariance components).
 
     python bench_fit.py [--frames N] [--iters K]                      one GPU
-    python -m torch.distributed.run --nproc-per-node G bench_fit.py   G GPUs: frames sharded,
-                                                                     statistics all-reduced (RCCL)
+    python bench_fit.py --gpus G                                      G GPUs (G ranks started by bench_launch.py, or
+                                                                     run under torch.distributed.run): frames
+                                                                     sharded, statistics all-reduced (RCCL)
 Prints one JSON line with the time per EM iteration (strong scaling: total frames fixed)."""
 import argparse
 import json
@@ -19,6 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1, help='N > 1 outside a rank: start N ranks, one per GPU')
     ap.add_argument('--frames', type=int, default=500000)
     ap.add_argument('--dim', type=int, default=144)
     ap.add_argument('--components', type=int, default=64)
@@ -29,6 +31,8 @@ def main():
                     help='initialise the process group even for ONE rank (a world-size-1 \'nccl\' group: RCCL itself under '
                          'the fit\'s collectives on a one-GPU box)')
     args = ap.parse_args()
+    import bench_launch
+    bench_launch.maybe_launch(args.gpus)     # --gpus N > 1 outside a rank: become the launcher of N ranks (never returns)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
@@ -90,6 +94,7 @@ def main():
         m_step()
     barrier()
     el = time.perf_counter() - t0
+    ranks_seen = int(round(float(comm.all_reduce(torch.ones(1, dtype=torch.float64, device=st.X.device)).item()))) if grouped else 1
     if rank == 0:
         lp, n1 = st.ctx.profile_read('k_fit_logprob')
         cv, n2 = st.ctx.profile_read('k_fit_cov')
@@ -99,7 +104,7 @@ def main():
         lp_tf = flops / (lp_ms * 1e-3) / 1e12 if n1 else None
         cv_tf = flops / (cv_ms * 1e-3) / 1e12 if n2 else None
         print(json.dumps({'metric': 'EM iteration time, full-covariance GMM fit', 'value': el / args.iters * 1e3,
-                          'unit': 'ms/iteration', 'n_gpus': world, 'frames_total': n_local * world, 'dim': D,
+                          'unit': 'ms/iteration', 'n_gpus': world, 'ranks_seen': ranks_seen, 'frames_total': n_local * world, 'dim': D,
                           'components': M, 'higher_is_better': False, 'scaling': 'strong', 'dtype': 'f64',
                           'kmeans_init_ms': km_s * 1e3, 'kmeans_lloyd_iterations': km_iters,
                           'k_fit_logprob_ms': lp_ms, 'k_fit_cov_ms': cv_ms,
