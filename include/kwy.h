@@ -134,6 +134,29 @@ int kwy_dio(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, double f0_f
 int kwy_stonemask(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
                   const double *temporal_positions, const double *f0, int64_t f0_length,
                   double *refined_f0);
+/* The f0 track without the host (round 5): what Analyzer.extract_f0 does in front of every analysis,
+ * kwiiyatta/vocoder/world.py:33-41, on DEVICE pointers, enqueued on the context's stream and not synchronised; the
+ * batch forms take the utterances of a wave in one pass of launches (<= 16 per pass), as kwy_cheaptrick_batch_dev
+ * does.  Every job's result equals the host entry's bit for bit (the host entries run the same pass on staged copies).
+ * status (one int32 on the device per utterance, or NULL): cleared by the call, set to 1 when an engine's
+ * zero-crossing buffer overflowed (kwy_dio reports that as KWY_EHIP); a driver reads the words back once per wave. */
+typedef struct kwy_f0_job {
+  const double *x;               /* waveform, x_length samples */
+  int64_t x_length;
+  double *temporal_positions;    /* kwy_dio_frames(fs, x_length, frame_period_ms) frame times [s], written */
+  double *f0;                    /* as many f0 values, written */
+  int32_t *status;               /* see above; may be NULL */
+} kwy_f0_job;
+int kwy_dio_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, double f0_floor, double f0_ceil,
+                double channels_in_octave, double frame_period_ms, int speed, double allowed_range,
+                double *temporal_positions, double *f0, int32_t *status);
+int kwy_dio_batch_dev(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, int fs, double f0_floor, double f0_ceil,
+                      double channels_in_octave, double frame_period_ms, int speed, double allowed_range);
+int kwy_stonemask_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
+                      const double *temporal_positions, const double *f0, int64_t f0_length,
+                      double *refined_f0);
+/* utterances[i].out: the refined f0 (f0_length values); .f0: the initial track */
+int kwy_stonemask_batch_dev(kwy_ctx *ctx, const kwy_utterance *utterances, int count, int fs);
 
 /* ---- WORLD synthesis ------------------------------------------------------------ */
 /* pyworld.synthesize(f0, sp, ap, fs, frame_period)   kwiiyatta/vocoder/world.py:86-92
@@ -180,6 +203,26 @@ typedef struct kwy_synth_job {
 } kwy_synth_job;
 int kwy_synth_render_batch_dev(kwy_ctx *ctx, const kwy_synth_job *jobs, int count, int fft_size,
                                double frame_period_ms, int fs, double sp_mul);
+
+/* The post-step of a synthesised waveform and its 16-bit PCM, for a batch of waveforms in device memory:
+ *   Synthesizer.synthesize(normalize=True): wavdata.normalize(None); normalize_data() on the first `frame_len`
+ *     1 ms pieces                                     kwiiyatta/vocoder/abc/synthesizer.py:11-20
+ *   Wavdata.save(normalize=True): data -= mean; normalize_data(data, peak_lv); (data * 2**15).astype(np.int16)
+ *                                                     kwiiyatta/wavfile.py:8-29
+ * normalize_synth / normalize_save: the two `normalize` flags; piece_ceiling / save_ceiling: 10 ** (peak_lv / 10) of
+ * the two calls (save_ceiling NaN: peak_lv=None, mean removal only).  The samples equal the host path's exactly
+ * (numpy's chunked pairwise mean is reproduced).  y is not modified; a wave downloads 2 bytes per sample.  Enqueued on
+ * the context's stream, not synchronised.  KWY_EINVAL where the reference's loop would fail (a piece beyond the end). */
+typedef struct kwy_finish_job {
+  const double *y;      /* y_length samples (kwy_synthesize's output) */
+  int64_t y_length;
+  int64_t frame_len;    /* frames of the feature the waveform was rendered from */
+  int16_t *pcm;         /* y_length samples, written */
+} kwy_finish_job;
+int kwy_finish_pcm16_batch_dev(kwy_ctx *ctx, const kwy_finish_job *jobs, int count, int fs, int normalize_synth,
+                               double piece_ceiling, int normalize_save, double save_ceiling);
+/* bytes of the context's scratch arena one waveform of that length needs in the call above (kwy_ctx_reserve) */
+int64_t kwy_finish_scratch_bytes(int64_t y_length);
 
 /* ---- mel-cepstrum ---------------------------------------------------------------- */
 /* pysptk.sp2mc(spec, order, alpha) row-wise          kwiiyatta/vocoder/mcep.py:71

@@ -84,6 +84,12 @@ SIGNATURES = {
     'kwy_dio': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_dbl,
                         c_vp, c_vp]),
     'kwy_stonemask': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp]),
+    'kwy_dio_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_dbl, c_vp, c_vp, c_vp]),
+    'kwy_dio_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_int, c_dbl]),
+    'kwy_stonemask_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp]),
+    'kwy_stonemask_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int]),
+    'kwy_finish_pcm16_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_dbl, c_int, c_dbl]),
+    'kwy_finish_scratch_bytes': (c_i64, [c_i64]),
     'kwy_synthesize': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_i64,
                                c_vp]),
     'kwy_synthesize_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl,
@@ -222,6 +228,10 @@ PadJob = _job_struct('PadJob', 'kwy_pad_job', [('f0', c_vp), ('n', c_i64), ('f0_
 TrainJob = _job_struct('TrainJob', 'kwy_train_job',
                        [('path', c_vp), ('path_len', c_vp), ('feat_x', c_vp), ('feat_y', c_vp), ('mc_x', c_vp), ('mc_y', c_vp),
                         ('x_length', c_i64), ('y_length', c_i64), ('n_rows', c_vp)])
+F0Job = _job_struct('F0Job', 'kwy_f0_job: the DIO f0 track of one utterance',
+                   [('x', c_vp), ('x_length', c_i64), ('temporal_positions', c_vp), ('f0', c_vp), ('status', c_vp)])
+FinishJob = _job_struct('FinishJob', 'kwy_finish_job: post-step + 16-bit PCM of one synthesised waveform',
+                        [('y', c_vp), ('y_length', c_i64), ('frame_len', c_i64), ('pcm', c_vp)])
 SynthPlanJob = _job_struct('SynthPlanJob', 'kwy_synth_plan_job: the pulse placement of one utterance',
                            [('f0', c_vp), ('f0_length', c_i64), ('y_length', c_i64), ('plan', c_vp)])
 

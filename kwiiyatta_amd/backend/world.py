@@ -125,3 +125,27 @@ def stonemask(x, f0, temporal_positions, fs, ctx=None):
     _lib.check(ctx, lib.kwy_stonemask(ctx.handle, ptr(x), len(x), int(fs), ptr(t), ptr(f0), len(f0),
                                       ptr(out)))
     return out
+
+
+# ---- the f0 track of a batch of utterances without the host (device tensors; round 5) -------------------------------
+def dio_frames(fs, x_length, frame_period=default_frame_period):
+    return int(lib.kwy_dio_frames(int(fs), int(x_length), float(frame_period)))
+
+
+def dio_batch_dev(ctx, waves, fs, t_out, f0_out, status=None, f0_floor=default_f0_floor, f0_ceil=default_f0_ceil,
+                  channels_in_octave=2.0, frame_period=default_frame_period, speed=1, allowed_range=0.1):
+    """pyworld.dio for every waveform of `waves` (float64 device tensors), enqueued on the context's stream and not
+    synchronised.  t_out / f0_out: per utterance a device tensor of dio_frames(...) values; status: an int32 device
+    tensor with one word per utterance (non-zero afterwards: zero-crossing buffer overflow), or None."""
+    rows = [(x, x.numel(), t, f, (status[i:i + 1] if status is not None else 0))
+            for i, (x, t, f) in enumerate(zip(waves, t_out, f0_out))]
+    jobs = _lib.job_array(_lib.F0Job, rows)
+    _lib.check(ctx, lib.kwy_dio_batch_dev(ctx.handle, jobs, len(rows), int(fs), float(f0_floor), float(f0_ceil),
+                                          float(channels_in_octave), float(frame_period), int(speed),
+                                          float(allowed_range)))
+
+
+def stonemask_batch_dev(ctx, waves, t, f0, fs, out):
+    """pyworld.stonemask for every utterance (device tensors), one grid over all frames; not synchronised"""
+    arr = _lib.utterance_array(list(zip(waves, t, f0, out)))
+    _lib.check(ctx, lib.kwy_stonemask_batch_dev(ctx.handle, arr, len(arr), int(fs)))

@@ -3,8 +3,8 @@ files) and convert wav files with it.  Command line and outputs of the reference
 for every input <name>.wav a <name>.diff.wav (the input waveform through the differential MLSA filter) and a
 <name>.synth.wav (WORLD synthesis from the converted mel-cepstrum).  Additions: `--no-diffvc` skips the first;
 `--converter-model FILE` keeps the trained converter between runs; `--batch` renders the .synth.wav outputs of all
-input files through the HBM-resident batch path (kwiiyatta_amd.corpus.convert_batch: one stream per file in flight,
-features never leave the GPU) instead of file by file."""
+input files through the HBM-resident batch path (kwiiyatta_amd.corpus.convert_batch: waves of 16 files in lockstep,
+wav in -> 16-bit PCM out on the device) instead of file by file."""
 import pathlib
 
 OUTPUTS = (('diff', True), ('synth', False))          # suffix, differential?
@@ -22,9 +22,24 @@ def convert(conf, converter, src_path, diffvc=True):
     return rendered.synthesize()
 
 
+class _Pcm16:
+    """the 16-bit samples of a finished waveform as the batch path hands them over: `save` writes them as they are
+    (what Wavdata.save(normalize=True) would write for the waveform -- kwy_finish_pcm16_batch_dev)"""
+
+    def __init__(self, fs, pcm):
+        self.fs, self.pcm = fs, pcm
+
+    def save(self, wav):
+        from scipy.io import wavfile
+        wavfile.write(wav, self.fs, self.pcm)
+
+
 def convert_synth_batch(conf, converter, paths):
-    """{path: Wavdata} of the .synth.wav outputs.  Files whose sampling rate or frame period differ from the
-    converter's go through `convert` one by one (the batch path has no resampling stage)."""
+    """{path: object with .save(file)} of the .synth.wav outputs.  Files whose sampling rate or frame period differ
+    from the converter's go through `convert` one by one (the batch path has no resampling stage).  The others go
+    through the device WAV IN -> PCM OUT: f0 (DIO + StoneMask), analysis, conversion, synthesis, the post-step of
+    `synthesize` and `save`'s normalisation and 16-bit truncation all run on the GPU (corpus.convert_batch(pcm=True));
+    the host reads the wav files and writes 2 bytes per sample."""
     import kwiiyatta_amd as k
     from . import corpus
     from .converter.delta import DeltaFeatureConverter
@@ -39,11 +54,11 @@ def convert_synth_batch(conf, converter, paths):
             batch.append((path, a))
     if batch:
         fs = batch[0][1].fs
-        triples = [(a.wavdata.data, a.f0, a._timeaxis) for _, a in batch]      # f0: DIO + StoneMask on the GPU
-        waves = corpus.convert_batch(triples, fs, converter.gmm, order=converter.order,
-                                     frame_period=float(batch[0][1].frame_period))
-        for (path, a), w in zip(batch, waves):
-            out[path] = k.Synthesizer.finish(k.Wavdata(fs, w.cpu().numpy()), a.frame_len)
+        waves = [a.wavdata.data for _, a in batch]
+        _, pcms = corpus.convert_batch(waves, fs, converter.gmm, order=converter.order,
+                                       frame_period=float(batch[0][1].frame_period), pcm=True)
+        for (path, a), p in zip(batch, pcms):
+            out[path] = _Pcm16(fs, p.cpu().numpy())
     return out
 
 

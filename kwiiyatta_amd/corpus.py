@@ -434,10 +434,18 @@ class ConvertWave:
     """<= 16 utterances analysed and rendered in lockstep (the batched entries of include/kwy.h on two streams): with a
     prepared GMM model the mel-cepstra are converted in between (convert_voice.convert(diffvc=False) of every file,
     /root/reference/kwiiyatta/convert_voice.py:35-46), without one the features are resynthesised as they are
-    (resynthesize_voice.py:46-79, BASELINE config 4).  Utterances of any lengths; `wave[i]` are views of one block."""
+    (resynthesize_voice.py:46-79, BASELINE config 4).  Utterances of any lengths; `wave[i]` are views of one block.
 
-    def __init__(self, ls, fs, utterances, gmm=None, order=24, frame_period=5.0):
+    An utterance is an (x, f0, t) triple, or a bare waveform (numpy array / device tensor): then its f0 track is
+    extracted inside the wave -- DIO + StoneMask on the device (kwy_dio_batch_dev, kwy_stonemask_batch_dev:
+    Analyzer.extract_f0, /root/reference/kwiiyatta/vocoder/world.py:33-41) -- and `f0_status` holds one word per
+    utterance to read back (non-zero: DIO's zero-crossing buffer overflowed).  pcm=True: the post-step and the 16-bit
+    samples on the device as well (kwy_finish_pcm16_batch_dev: vocoder/abc/synthesizer.py:11-20, wavfile.py:8-29):
+    `pcm[i]` int16 views, 2 bytes per sample to download."""
+
+    def __init__(self, ls, fs, utterances, gmm=None, order=24, frame_period=5.0, pcm=False):
         self.ls, self.fs, self.order, self.frame_period = ls, int(fs), int(order), float(frame_period)
+        self.wav_in = len(utterances) > 0 and not isinstance(utterances[0], (tuple, list))
         dev = ls.dev
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
         self.K = K = self.fft // 2 + 1
@@ -448,18 +456,36 @@ class ConvertWave:
         f64 = dict(dtype=torch.float64, device=dev)
         with torch.cuda.stream(ls.main):
             self.model = gmm.model(diff=False) if gmm is not None else None
-            us = [_resident(u, dev, (ls.main, ls.side)) for u in utterances]
-            self.x, self.f0, self.t = ([u[k] for u in us] for k in range(3))
-            self.T = [len(v) for v in self.f0]
-            off = np.concatenate(([0], np.cumsum(self.T))).astype(np.int64)
-            self.rows = int(off[-1])
             cut = lambda a, o, i: a[int(o[i]):int(o[i + 1])]  # noqa: E731
+            if self.wav_in:
+                self.x = [_resident((u,), dev, (ls.main, ls.side))[0] for u in utterances]
+                self.T = [int(lib.kwy_dio_frames(self.fs, v.numel(), self.frame_period)) for v in self.x]
+                off = np.concatenate(([0], np.cumsum(self.T))).astype(np.int64)
+                blocks = [torch.empty(int(off[-1]), **f64) for _ in range(3)]
+                self.t, self.f0_dio, self.f0 = ([cut(b, off, i) for i in range(n)] for b in blocks)
+                self.f0_status = torch.zeros(n, dtype=torch.int32, device=dev)
+                self.j_dio = _lib.job_array(_lib.F0Job, [(self.x[i], self.x[i].numel(), self.t[i], self.f0_dio[i],
+                                                          self.f0_status[i:i + 1]) for i in range(n)])
+                self.j_sm = _lib.utterance_array([(self.x[i], self.t[i], self.f0_dio[i], self.f0[i]) for i in range(n)])
+            else:
+                us = [_resident(u, dev, (ls.main, ls.side)) for u in utterances]
+                self.x, self.f0, self.t = ([u[k] for u in us] for k in range(3))
+                self.T = [len(v) for v in self.f0]
+                off = np.concatenate(([0], np.cumsum(self.T))).astype(np.int64)
+                self.f0_status = None
+            self.rows = int(off[-1])
             self.sp_all = torch.empty((self.rows, K), **f64)
             self.ap_all = torch.empty((self.rows, K), **f64)
             self.ylen = [int(lib.kwy_synth_length(t, self.frame_period, self.fs)) for t in self.T]
             yo = np.concatenate(([0], np.cumsum(self.ylen))).astype(np.int64)
             self.wave_all = torch.empty(int(yo[-1]), **f64)
             self.wave = [cut(self.wave_all, yo, i) for i in range(n)]
+            self.pcm = None
+            if pcm:
+                self.pcm_all = torch.zeros(int(yo[-1]), dtype=torch.int16, device=dev)
+                self.pcm = [cut(self.pcm_all, yo, i) for i in range(n)]
+                self.j_fin = _lib.job_array(_lib.FinishJob, [(self.wave[i], self.ylen[i], self.T[i], self.pcm[i])
+                                                             for i in range(n)])
             self.plan = [torch.empty(int(lib.kwy_synth_plan_bytes(y)), dtype=torch.uint8, device=dev) for y in self.ylen]
             sp = [cut(self.sp_all, off, i) for i in range(n)]
             ap = [cut(self.ap_all, off, i) for i in range(n)]
@@ -479,6 +505,11 @@ class ConvertWave:
 
     def run(self):
         ls, fs, fft, K, order, n = self.ls, self.fs, self.fft, self.K, self.order, self.n
+        if self.wav_in:
+            with torch.cuda.stream(ls.main):
+                _lib.check(ls.ctx, lib.kwy_dio_batch_dev(ls.ctx.handle, self.j_dio, n, fs, 71.0, 800.0, 2.0,
+                                                         self.frame_period, 1, 0.1))
+                _lib.check(ls.ctx, lib.kwy_stonemask_batch_dev(ls.ctx.handle, self.j_sm, n, fs))
         ls.side.wait_stream(ls.main)
         with torch.cuda.stream(ls.side):
             hs = ls.side_ctx.handle
@@ -494,22 +525,34 @@ class ConvertWave:
                 chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), self.rows, order, self.alpha, fft, _p(self.sp_conv)))
             ls.main.wait_stream(ls.side)
             chk(lib.kwy_synth_render_batch_dev(h, self.j_render, n, fft, self.frame_period, fs, float(fs)))
+            if self.pcm is not None:
+                from .pipeline import PIECE_CEILING
+                chk(lib.kwy_finish_pcm16_batch_dev(h, self.j_fin, n, fs, 1, PIECE_CEILING, 1, PIECE_CEILING))
 
 
-def _lockstep_batch(utterances, fs, device_index, gmm, order, frame_period, ls, keep, wave_size=16):
-    """utterances in waves of `wave_size` through ConvertWave; keep(i, waveform view) on the main stream"""
+def _lockstep_batch(utterances, fs, device_index, gmm, order, frame_period, ls, keep, wave_size=16, pcm=False):
+    """utterances in waves of `wave_size` through ConvertWave; keep(i, waveform view[, pcm view]) on the main stream.
+    Bare waveforms get their f0 on the device; the DIO status words of all waves are read back ONCE at the end."""
     ls = ls if ls is not None else _Lockstep(device_index)
-    held = []
+    held, status = [], []
     for w0 in range(0, len(utterances), wave_size):
-        wv = ConvertWave(ls, fs, utterances[w0:w0 + wave_size], gmm=gmm, order=order, frame_period=frame_period)
+        wv = ConvertWave(ls, fs, utterances[w0:w0 + wave_size], gmm=gmm, order=order, frame_period=frame_period, pcm=pcm)
         wv.run()
         with torch.cuda.stream(ls.main):
             for i in range(wv.n):
-                keep(w0 + i, wv.wave[i])
+                if pcm:
+                    keep(w0 + i, wv.wave[i], wv.pcm[i])
+                else:
+                    keep(w0 + i, wv.wave[i])
+        if wv.f0_status is not None:
+            status.append(wv.f0_status)
         held.append(wv)
         while len(held) > 2:
             held.pop(0)
     ls.sync()
+    if status and bool(torch.cat(status).any().item()):
+        bad = torch.nonzero(torch.cat(status)).flatten().tolist()
+        raise RuntimeError(f'dio: zero-crossing buffer overflow in utterance(s) {bad} (signal too noisy for the band filters)')
     return ls
 
 
@@ -826,8 +869,10 @@ def _stream_batch(make_pipeline, utterances, pool, shapes_per_stream, keep):
 
 
 def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16, pool=None,
-                  shapes_per_stream=4, driver=None, lockstep=None):
+                  shapes_per_stream=4, driver=None, lockstep=None, pcm=False):
     """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors).
+    Lockstep driver only: an utterance may be a bare waveform (its f0 is then extracted on the device), and pcm=True
+    returns (waveforms, int16 tensors of the post-processed samples) -- wav in, 16-bit PCM out without the host.
     driver='lockstep' (default): waves of 16 utterances through the batched entries on two streams (`ConvertWave`);
     'streams': round 3's utterance-per-stream driver, see `_stream_batch` for its scheduling."""
     dev = torch.device('cuda', device_index)
@@ -835,10 +880,14 @@ def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.
     out = [None] * len(utterances)
     driver = driver or ('streams' if pool is not None else 'lockstep')     # (a caller's pool asks for the stream driver)
     if driver == 'lockstep':
-        def keep_view(i, w):
-            out[i] = w                     # (a view of its wave's block, which lives as long as the views)
-        _lockstep_batch(utterances, fs, device_index, dg, order, frame_period, lockstep, keep_view)
-        return out
+        pcms = [None] * len(utterances)
+
+        def keep_view(i, w, p=None):
+            out[i], pcms[i] = w, p         # (views of their wave's blocks, which live as long as the views)
+        _lockstep_batch(utterances, fs, device_index, dg, order, frame_period, lockstep, keep_view, pcm=pcm)
+        return (out, pcms) if pcm else out
+    if pcm or (len(utterances) and not isinstance(utterances[0], (tuple, list))):
+        raise ValueError('convert_batch: wav-in utterances and pcm=True need the lockstep driver')
     if pool is None:
         pool = StreamPool(device_index, streams)
 

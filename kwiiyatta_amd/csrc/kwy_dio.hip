@@ -3,14 +3,22 @@
 // Replaces pyworld.dio / pyworld.stonemask (reference call sites
 // kwiiyatta/vocoder/world.py:35-40; WORLD dio.cpp / stonemask.cpp as shipped with
 // pyworld 0.2.8).  SURVEY.md ranks this producer of the f0 track as 8(f)-1: it
-// sits in front of the timed hot path, and is here so that wav-in analysis
-// needs no CPU numerics at all.
+// sits in front of the hot path, and is here so that wav-in analysis needs no CPU
+// numerics and -- round 5 -- no trip over the host either: kwy_dio_batch_dev /
+// kwy_stonemask_batch_dev take device pointers for up to 16 utterances per pass
+// of launches and do not synchronise.
 //
-// DIO on the CPU filters the whole signal with FFTs of ~2^19 points (a 50 Hz
-// low-cut, then one Nuttall low-pass per half-octave band).  All filters are
-// short FIRs (<= 1921 taps), so here they are direct, LDS-tiled convolutions --
-// embarrassingly parallel and free of the big-FFT round trips.  Then, per band:
-// the four zero-crossing interval tracks (ordered stream compaction), their
+// DIO on the CPU filters the whole signal with FFTs of ~2^19 points: a 50 Hz
+// low-cut, then one Nuttall low-pass per half-octave band.  Both are short FIRs
+// (1921 and <= 956 taps at 48 kHz), so the filtered signal of band b is ONE
+// linear convolution of the centred signal with h_b = lowcut * nuttall_b.  Round
+// 1-4 evaluated the two stages as direct LDS-tiled convolutions (2.3 G
+// multiply-adds per 10 s utterance: as long as the whole analysis); now a
+// workgroup takes a block of 8192 samples, transforms it ONCE (real FFT in LDS,
+// the spectrum stays in registers) and multiplies it with each band's
+// precomputed filter spectrum: overlap-save, 8 transforms per 5 317 outputs of
+// all 7 bands instead of 20 k multiply-adds per output.  Then, per band: the
+// four zero-crossing interval tracks (ordered stream compaction), their
 // interpolation onto the frame times, the candidate / score per frame; finally
 // the best-candidate contour and WORLD's four-step contour repair.
 //
@@ -19,6 +27,7 @@
 // twiddle table an FFT would use.
 #include <math.h>
 
+#include <complex>
 #include <vector>
 
 #include "kwy_internal.hpp"
@@ -27,74 +36,114 @@
 #define DIO_MAXVAL 100000.0
 #define DIO_CUTOFF 50.0
 #define DIO_MAX_BANDS 16
-#define DIO_CONV_OUT 1024   // outputs per convolution workgroup (4 per thread)
+#define DIO_LOG2H 12                 // the overlap-save transform: N = 8192 reals = 4096 packed complex
+#define DIO_H (1 << DIO_LOG2H)
+#define DIO_N (2 * DIO_H)
+#define DIO_NT 512                   // threads of the filter kernel: one radix-8 butterfly per thread and pass
+#define DIO_PARTS 256                // partial sums of the mean
+
+// ---- one pass of launches over <= KWY_BATCH_MAX utterances -------------------------------------------
+// Everything a kernel needs travels by value in this struct (no descriptor in device memory: capturable in a HIP
+// graph).  Scratch: one block per utterance at scratch + u * stride, laid out for the LONGEST utterance of the pass.
+struct dio_utt {
+  const double *x;      // n samples
+  double *tpos, *f0;    // T frame times / f0 values (written)
+  int *status;          // one word: set to 1 when an engine's zero-crossing buffer overflowed
+  int n, T;
+};
+
+struct dio_plan {
+  int count, nbands;
+  int ny_max, T_max, ntiles_max, cap_max;   // layout extents
+  int half, V;                              // Lh + 2 max_hal (the longest combined filter is 2 half taps); outputs per block
+  double fs, f0_floor, f0_ceil, frame_period, allowed_range;
+  double boundary[DIO_MAX_BANDS];
+  const kwy_c *G;                           // [nbands][DIO_H + 1]: filter spectra / N, band delays equalised
+  char *scratch;
+  int64_t stride;
+  int64_t off_part, off_filt, off_cnt, off_nedges, off_fine, off_cand, off_score, off_w1, off_w2, off_idx;
+  dio_utt u[KWY_BATCH_MAX];
+  template <class T>
+  __device__ __forceinline__ T *at(int utt, int64_t off) const { return (T *)(scratch + utt * stride + off); }
+};
 
 // ---- signal preparation ---------------------------------------------------------------
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_sum(const double *__restrict__ x, int n,
-                                                        double *__restrict__ partial) {
+// partial sums of an utterance's samples (grid: DIO_PARTS x count); the mean is their sum in index order / (n + 1):
+// x[n] = 0 is part of the average, as upstream
+__global__ __launch_bounds__(KWY_THREADS) void k_dio_sum(dio_plan P) {
   __shared__ double red[8];
+  const int utt = blockIdx.y;
+  const double *__restrict__ x = P.u[utt].x;
+  const int n = P.u[utt].n;
   double s = 0.0;
   for (int i = blockIdx.x * KWY_THREADS + threadIdx.x; i < n; i += gridDim.x * KWY_THREADS) s += x[i];
   s = kwy_block_sum(s, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) {
+    P.at<double>(utt, P.off_part)[blockIdx.x] = s;
+    if (blockIdx.x == 0) *P.u[utt].status = 0;
+  }
 }
 
-// y[m] = x[m] - mean on [0, ny) (x[n] = 0 is part of the average, as upstream), 0 elsewhere;
-// stored with an offset of E zeros on both sides.
-__global__ void k_dio_center(const double *__restrict__ x, int n, int ny, int E,
-                             const double *__restrict__ partial, int nparts, double *__restrict__ y) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x - E;
-  if (m >= ny + E) return;
-  double mean = 0.0;
-  for (int i = 0; i < nparts; ++i) mean += partial[i];
-  mean /= ny;
-  double v = 0.0;
-  if (m >= 0 && m < ny) v = (m < n ? x[m] : 0.0) - mean;
-  y[m + E] = v;
-}
-
-// out[m] = sum_{k=0}^{ntaps-1} taps[k] * in[m + shift - k]   for m in [m0, m1)
-// `in` and `out` are stored with offsets in_off / out_off; reads outside
-// [in_lo, in_hi) return 0.
-struct conv_desc {
-  int ntaps, shift, m0, m1, in_lo, in_hi, in_off, out_off;
-  int64_t taps_off, out_stride;
-};
-
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_conv(const double *__restrict__ in,
-                                                         const double *__restrict__ taps_all,
-                                                         const conv_desc *__restrict__ descs,
-                                                         double *__restrict__ out_all) {
+// Overlap-save block `blockIdx.x` of utterance `blockIdx.y`: outputs i0 .. i0 + V - 1 of every band.
+//   y[m]       = x[m] - mean on [0, ny) (x[n] = 0), 0 elsewhere
+//   filt_b[i]  = sum_c h_b[c] y[i + D_b - c],  h_b = lowcut * nuttall_b,  D_b = Lh + 2 hal_b
+// (upstream: ylc = lowcut filter of y, then the band's Nuttall window over ylc; both "same"-centred).  The segment
+// seg[q] = y[i0 - half + 1 + q], q < N, is transformed once; G_b carries h_b delayed by 2 (max_hal - hal_b), so that
+// for every band output i sits at q = i - i0 + 2 half - 1, free of wrap-around for q >= 2 half - 1.
+__global__ __launch_bounds__(DIO_NT, 4) void k_dio_filter(dio_plan P, const kwy_c *__restrict__ twH,
+                                                         const kwy_c *__restrict__ twN) {
+  constexpr int H = DIO_H, N = DIO_N, NT = DIO_NT;
   extern __shared__ double smem[];
-  const conv_desc d = descs[blockIdx.y];
-  const int base = d.m0 + blockIdx.x * DIO_CONV_OUT;
-  if (base >= d.m1) return;
-  double *tp = smem;               // ntaps
-  double *seg = smem + d.ntaps;    // DIO_CONV_OUT + ntaps - 1 input samples
-  const double *taps = taps_all + d.taps_off;
-  for (int k = threadIdx.x; k < d.ntaps; k += KWY_THREADS) tp[k] = taps[k];
-  // seg[q] = in[base + shift - (ntaps-1) + q]
-  const int seg_n = DIO_CONV_OUT + d.ntaps - 1;
-  const int first = base + d.shift - (d.ntaps - 1);
-  for (int q = threadIdx.x; q < seg_n; q += KWY_THREADS) {
-    int idx = first + q;
-    seg[q] = (idx >= d.in_lo && idx < d.in_hi) ? in[idx + d.in_off] : 0.0;
+  kwy_c *z = (kwy_c *)smem;              // H + 1 complex
+  kwy_c *twl = z + (H + 1);              // exp(-2 pi i k / H), k < H/8
+  double *sh = (double *)(twl + H / 8);  // DIO_PARTS + 1
+  const int tid = threadIdx.x, utt = blockIdx.y;
+  const int n = P.u[utt].n, ny = n + 1;
+  const int i0 = blockIdx.x * P.V;
+  if (i0 >= ny) return;
+  const double *__restrict__ x = P.u[utt].x;
+  if (tid < DIO_PARTS) sh[tid] = P.at<double>(utt, P.off_part)[tid];
+  for (int i = tid; i < H / 8; i += NT) twl[i] = twH[i];
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0;
+    for (int i = 0; i < DIO_PARTS; ++i) m += sh[i];
+    sh[DIO_PARTS] = m / ny;
   }
   __syncthreads();
-  double *out = out_all + d.out_stride * blockIdx.y;
-  // thread t computes outputs base + t + 256*r, r < 4
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const int t = threadIdx.x;
-  for (int k = 0; k < d.ntaps; ++k) {
-    const double c = tp[k];
-    const int q = t + (d.ntaps - 1) - k;
+  const double mean = sh[DIO_PARTS];
+  double *A = (double *)z;
+  const int s0 = i0 - P.half + 1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += c * seg[q + KWY_THREADS * r];
+  for (int j = 0; j < N / NT; ++j) {
+    const int q = tid + NT * j, m = s0 + q;
+    double v = 0.0;
+    if (m >= 0 && m < ny) v = (m < n ? x[m] : 0.0) - mean;
+    A[q] = v;
   }
+  __syncthreads();
+  const kwy_c twb = twN[tid];
+  kwy_rfft_inplace<DIO_LOG2H, NT>(z, twl, twb, twN);
+  kwy_c X[H / NT];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int m = base + t + KWY_THREADS * r;
-    if (m < d.m1) out[m + d.out_off] = acc[r];
+  for (int r = 0; r < H / NT; ++r) X[r] = z[tid + NT * r];
+  const double xh = z[H].x;
+  __syncthreads();
+  const int first = 2 * P.half - 1;
+  double *filt = P.at<double>(utt, P.off_filt);
+  for (int b = 0; b < P.nbands; ++b) {
+    const kwy_c *__restrict__ G = P.G + (size_t)b * (H + 1);
+#pragma unroll
+    for (int r = 0; r < H / NT; ++r) z[tid + NT * r] = cmulf(G[tid + NT * r], X[r]);
+    if (tid == 0) z[H] = {G[H].x * xh, 0.0};
+    kwy_irfft_inplace<DIO_LOG2H, NT>(z, twl, twb, twN);
+    double *o = filt + (int64_t)b * P.ny_max;
+#pragma unroll
+    for (int j = 0; j < N / NT; ++j) {
+      const int q = tid + NT * j, i = i0 + q - first;
+      if (q >= first && i < ny) o[i] = A[q];
+    }
+    __syncthreads();
   }
 }
 
@@ -135,12 +184,12 @@ __device__ __forceinline__ int dio_block_exscan(int v, int *sh, int *total) {
   return woff + (inc - v);
 }
 
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_count(const double *__restrict__ filt,
-                                                             int64_t fstride, int ny, int ntiles,
-                                                             int *__restrict__ cnt) {
+// grids: (tiles of the longest utterance, engines, utterances); tiles beyond an utterance's end count nothing
+__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_count(dio_plan P) {
   __shared__ int sh[KWY_WAVES];
-  const int e = blockIdx.y, band = e >> 2, kind = e & 3;
-  const double *f = filt + fstride * band;
+  const int e = blockIdx.y, band = e >> 2, kind = e & 3, utt = blockIdx.z;
+  const int ny = P.u[utt].n + 1;
+  const double *f = P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band;
   const int len = kind < 2 ? ny : ny - 1;
   const int base = blockIdx.x * DIO_ZC_TILE + threadIdx.x * DIO_ZC_PER_THREAD;
   int c = 0;
@@ -148,14 +197,14 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_count(const double *__re
   for (int j = 0; j < DIO_ZC_PER_THREAD; ++j) c += dio_is_edge(f, kind, base + j, len) ? 1 : 0;
   int tot;
   (void)dio_block_exscan(c, sh, &tot);
-  if (threadIdx.x == 0) cnt[e * ntiles + blockIdx.x] = tot;
+  if (threadIdx.x == 0) P.at<int>(utt, P.off_cnt)[e * P.ntiles_max + blockIdx.x] = tot;
 }
 
-// exclusive scan of every engine's tile counts (one block per engine)
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_scan(int *__restrict__ cnt, int ntiles,
-                                                            int *__restrict__ nedges) {
+// exclusive scan of every engine's tile counts (one block per engine and utterance)
+__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_scan(dio_plan P) {
   __shared__ int tot[KWY_THREADS];
-  int *c = cnt + blockIdx.x * ntiles;
+  const int utt = blockIdx.y, ntiles = P.ntiles_max;
+  int *c = P.at<int>(utt, P.off_cnt) + blockIdx.x * ntiles;
   const int t = threadIdx.x;
   const int chunk = (ntiles + KWY_THREADS - 1) / KWY_THREADS;
   const int b0 = t * chunk, b1 = min(ntiles, b0 + chunk);
@@ -166,28 +215,27 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_scan(int *__restrict__ c
   if (t == 0) {
     int acc = 0;
     for (int i = 0; i < KWY_THREADS; ++i) { int v = tot[i]; tot[i] = acc; acc += v; }
-    nedges[blockIdx.x] = acc;
+    P.at<int>(utt, P.off_nedges)[blockIdx.x] = acc;
   }
   __syncthreads();
   run = tot[t];
   for (int i = b0; i < b1; ++i) { int v = c[i]; c[i] = run; run += v; }
 }
 
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_emit(const double *__restrict__ filt,
-                                                            int64_t fstride, int ny, int ntiles,
-                                                            const int *__restrict__ cnt, int cap,
-                                                            double *__restrict__ fine, int *__restrict__ status) {
+__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_emit(dio_plan P) {
   __shared__ int sh[KWY_WAVES];
-  const int e = blockIdx.y, band = e >> 2, kind = e & 3;
-  const double *f = filt + fstride * band;
+  const int e = blockIdx.y, band = e >> 2, kind = e & 3, utt = blockIdx.z;
+  const int ny = P.u[utt].n + 1, cap = ny / 8 + 64;
+  const double *f = P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band;
   const int len = kind < 2 ? ny : ny - 1;
   const int base = blockIdx.x * DIO_ZC_TILE + threadIdx.x * DIO_ZC_PER_THREAD;
+  if (blockIdx.x * DIO_ZC_TILE >= len) return;       // (uniform) nothing of this utterance in the tile
   int c = 0;
 #pragma unroll
   for (int j = 0; j < DIO_ZC_PER_THREAD; ++j) c += dio_is_edge(f, kind, base + j, len) ? 1 : 0;
   int tot;
-  int pos = cnt[e * ntiles + blockIdx.x] + dio_block_exscan(c, sh, &tot);
-  double *o = fine + (int64_t)e * cap;
+  int pos = P.at<int>(utt, P.off_cnt)[e * P.ntiles_max + blockIdx.x] + dio_block_exscan(c, sh, &tot);
+  double *o = P.at<double>(utt, P.off_fine) + (int64_t)e * P.cap_max;
 #pragma unroll
   for (int j = 0; j < DIO_ZC_PER_THREAD; ++j) {
     const int i = base + j;
@@ -196,7 +244,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_emit(const double *__res
         const double a = dio_sig(f, kind, i), b = dio_sig(f, kind, i + 1);
         o[pos] = (i + 1) - a / (b - a);
       } else {
-        atomicExch(status, 1);
+        atomicExch(P.u[utt].status, 1);
       }
       ++pos;
     }
@@ -222,39 +270,36 @@ __device__ inline double dio_interp(const double *__restrict__ fe, int n, double
   return ya + s * (yb - ya);
 }
 
-struct dio_params {
-  int ny, T, nbands, cap;
-  double fs, f0_floor, f0_ceil, frame_period, allowed_range;
-  double boundary[DIO_MAX_BANDS];
-};
-
-__global__ void k_dio_candidates(const double *__restrict__ fine, const int *__restrict__ nedges,
-                                 dio_params p, double *__restrict__ cand, double *__restrict__ score) {
+// grid: (frames of the longest utterance / 256, bands, utterances)
+__global__ void k_dio_candidates(dio_plan P) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = blockIdx.y;
-  if (j >= p.T) return;
-  const int *ne = nedges + 4 * b;
+  const int b = blockIdx.y, utt = blockIdx.z;
+  const int T = P.u[utt].T;
+  if (j >= T) return;
+  const int cap = (P.u[utt].n + 1) / 8 + 64;
+  const int *ne = P.at<int>(utt, P.off_nedges) + 4 * b;
+  const double *fine = P.at<double>(utt, P.off_fine);
   double c = 0.0, sc = DIO_MAXVAL;
   // every engine needs at least 3 interval points (count - 2 > 0)
   if (ne[0] - 1 > 2 && ne[1] - 1 > 2 && ne[2] - 1 > 2 && ne[3] - 1 > 2) {
-    const double xi = j * p.frame_period / 1000.0;
+    const double xi = j * P.frame_period / 1000.0;
     double v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      v[k] = dio_interp(fine + (int64_t)(4 * b + k) * p.cap, min(ne[k], p.cap) - 1, p.fs, xi);
+      v[k] = dio_interp(fine + (int64_t)(4 * b + k) * P.cap_max, min(ne[k], cap) - 1, P.fs, xi);
     c = (v[0] + v[1] + v[2] + v[3]) / 4.0;
     sc = sqrt(((v[0] - c) * (v[0] - c) + (v[1] - c) * (v[1] - c) + (v[2] - c) * (v[2] - c) +
                (v[3] - c) * (v[3] - c)) / 3.0);
-    const double bf = p.boundary[b];
-    if (c > bf || c < bf / 2.0 || c > p.f0_ceil || c < p.f0_floor) { c = 0.0; sc = DIO_MAXVAL; }
+    const double bf = P.boundary[b];
+    if (c > bf || c < bf / 2.0 || c > P.f0_ceil || c < P.f0_floor) { c = 0.0; sc = DIO_MAXVAL; }
   }
-  cand[(int64_t)b * p.T + j] = c;
-  score[(int64_t)b * p.T + j] = sc / (c + DIO_SAFE);
+  P.at<double>(utt, P.off_cand)[(int64_t)b * P.T_max + j] = c;
+  P.at<double>(utt, P.off_score)[(int64_t)b * P.T_max + j] = sc / (c + DIO_SAFE);
 }
 
 // ---- best contour + WORLD FixF0Contour (one workgroup) -----------------------------------------
 __device__ inline double dio_select_best(double current_f0, double past_f0, const double *__restrict__ cand,
-                                         int nb, int T, int idx, double allowed_range) {
+                                         int nb, int T /* row stride */, int idx, double allowed_range) {
   const double reference_f0 = (current_f0 * 3.0 - past_f0) / 2.0;
   double minimum_error = fabs(reference_f0 - cand[idx]);
   double best = cand[idx];
@@ -266,19 +311,21 @@ __device__ inline double dio_select_best(double current_f0, double past_f0, cons
   return best;
 }
 
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_fix(const double *__restrict__ cand,
-                                                        const double *__restrict__ score, dio_params p,
-                                                        double *__restrict__ w1, double *__restrict__ w2,
-                                                        int *__restrict__ idxbuf, double *__restrict__ tpos,
-                                                        double *__restrict__ f0) {
-  const int T = p.T, nb = p.nbands, tid = threadIdx.x;
-  __shared__ int s_pos, s_neg;
+// one workgroup per utterance
+__global__ __launch_bounds__(KWY_THREADS) void k_dio_fix(dio_plan p) {
+  const int utt = blockIdx.x;
+  const int T = p.u[utt].T, Ts = p.T_max, nb = p.nbands, tid = threadIdx.x;
+  const double *__restrict__ cand = p.at<double>(utt, p.off_cand);
+  const double *__restrict__ score = p.at<double>(utt, p.off_score);
+  double *__restrict__ w1 = p.at<double>(utt, p.off_w1), *__restrict__ w2 = p.at<double>(utt, p.off_w2);
+  int *__restrict__ idxbuf = p.at<int>(utt, p.off_idx);
+  double *__restrict__ tpos = p.u[utt].tpos, *__restrict__ f0 = p.u[utt].f0;
   for (int i = tid; i < T; i += KWY_THREADS) {
     tpos[i] = i * p.frame_period / 1000.0;
     f0[i] = 0.0;
     double tmp = score[i], best = cand[i];
     for (int j = 1; j < nb; ++j)
-      if (tmp > score[(int64_t)j * T + i]) { tmp = score[(int64_t)j * T + i]; best = cand[(int64_t)j * T + i]; }
+      if (tmp > score[(int64_t)j * Ts + i]) { tmp = score[(int64_t)j * Ts + i]; best = cand[(int64_t)j * Ts + i]; }
     w1[i] = best;  // best_f0_contour
   }
   __syncthreads();
@@ -317,7 +364,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_fix(const double *__restric
     for (int i = 0; i < nc; ++i) {
       int limit = i == nc - 1 ? T - 1 : negative_index[i + 1];
       for (int j = negative_index[i]; j < limit; ++j) {
-        f0[j + 1] = dio_select_best(f0[j], f0[j - 1], cand, nb, T, j + 1, p.allowed_range);
+        f0[j + 1] = dio_select_best(f0[j], f0[j - 1], cand, nb, Ts, j + 1, p.allowed_range);
         if (f0[j + 1] == 0) break;
       }
     }
@@ -325,25 +372,34 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_fix(const double *__restric
     for (int i = pc - 1; i >= 0; --i) {
       int limit = i == 0 ? 1 : positive_index[i - 1];
       for (int j = positive_index[i]; j > limit; --j) {
-        f0[j - 1] = dio_select_best(f0[j], f0[j + 1], cand, nb, T, j - 1, p.allowed_range);
+        f0[j - 1] = dio_select_best(f0[j], f0[j + 1], cand, nb, Ts, j - 1, p.allowed_range);
         if (f0[j - 1] == 0) break;
       }
     }
-    s_pos = pc; s_neg = nc;
   }
 }
 
 // ---- StoneMask ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(KWY_THREADS) void k_stonemask(const double *__restrict__ x, int x_length, int fs,
-                                                          const double *__restrict__ tpos,
-                                                          const double *__restrict__ f0in,
-                                                          const kwy_c *const *__restrict__ tw_tables,
-                                                          double *__restrict__ out) {
+struct sm_view {
+  const double *x, *tpos, *f0in;
+  double *out;
+  int x_length;
+};
+typedef kwy_batch<sm_view> sm_batch;
+struct sm_tables { const kwy_c *t[20]; };   // t[l]: exp(-2 pi i k / 2^l)
+
+// one workgroup per frame of every utterance of the batch
+__global__ __launch_bounds__(KWY_THREADS) void k_stonemask(sm_batch batch, int fs, sm_tables tw_tables) {
   __shared__ double red[8];
   __shared__ double res[32];
   const int tid = threadIdx.x;
-  const int64_t frame = blockIdx.x;
-  const double initial_f0 = f0in[frame];
+  const int utt = batch.find(blockIdx.x);
+  const int64_t frame = (int)blockIdx.x - batch.start[utt];
+  const double *__restrict__ x = batch.u[utt].x;
+  const double *__restrict__ tpos = batch.u[utt].tpos;
+  double *__restrict__ out = batch.u[utt].out;
+  const int x_length = batch.u[utt].x_length;
+  const double initial_f0 = batch.u[utt].f0in[frame];
   if (initial_f0 <= 40.0 || initial_f0 > fs / 12.0) {
     if (tid == 0) out[frame] = 0.0;
     return;
@@ -354,7 +410,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_stonemask(const double *__restr
   const int len = 2 * half + 1;
   const int log2n = 2 + (int)(log(half * 2.0 + 1.0) / 0.69314718055994529);
   const int N = 1 << log2n;
-  const kwy_c *tw = tw_tables[log2n];
+  const kwy_c *tw = tw_tables.t[log2n];
   const double base_time0 = (double)(-half) / fs;
   const int basic_index = kwy_matlab_round((pos + base_time0) * fs + 0.001);
   auto mainw = [&](int i) {
@@ -437,120 +493,244 @@ static void nuttall_host(int n, double *y) {
 
 static inline int mround(double x) { return x > 0 ? (int)(x + 0.5) : (int)(x - 0.5); }
 
-extern "C" int kwy_dio(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, double f0_floor,
-                       double f0_ceil, double channels_in_octave, double frame_period_ms, int speed,
-                       double allowed_range, double *temporal_positions, double *f0) {
-  if (!ctx) return KWY_EINVAL;
-  if (!x || !temporal_positions || !f0 || x_length <= 0 || x_length > 0x3fffffff || fs <= 0 ||
-      !(f0_floor > 0) || !(f0_ceil > f0_floor) || !(channels_in_octave > 0) || !(frame_period_ms > 0)) {
+// in-place radix-2 FFT of N = 2^k points on the host (the filter spectra are built once per parameter set)
+static void host_fft(std::vector<std::complex<double>> &a) {
+  const size_t n = a.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  std::vector<std::complex<double>> w(n / 2);
+  for (size_t k = 0; k < n / 2; ++k) {
+    const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+    w[k] = {(double)cosl(ang), (double)sinl(ang)};
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t step = n / len;
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < len / 2; ++k) {
+        const std::complex<double> u = a[i + k], v = a[i + k + len / 2] * w[k * step];
+        a[i + k] = u + v;
+        a[i + k + len / 2] = u - v;
+      }
+  }
+}
+
+struct dio_filters {
+  int nbands, Lh, max_hal;
+  double boundary[DIO_MAX_BANDS];
+  const kwy_c *G;
+};
+
+// The band filters' spectra for (fs, f0_floor, f0_ceil, channels_in_octave), cached per context:
+// G_b[k] = DFT_N(lowcut)[k] * DFT_N(nuttall_b delayed by 2 (max_hal - hal_b))[k] / N,  k <= N/2
+static int dio_get_filters(kwy_ctx *ctx, int fs, double f0_floor, double f0_ceil, double channels_in_octave,
+                           dio_filters *out) {
+  dio_filters f;
+  f.nbands = 1 + (int)(log(f0_ceil / f0_floor) / 0.69314718055994529 * channels_in_octave);
+  if (f.nbands > DIO_MAX_BANDS) { ctx->err = "dio: too many bands"; return KWY_EINVAL; }
+  for (int i = 0; i < f.nbands; ++i) f.boundary[i] = f0_floor * pow(2.0, (i + 1) / channels_in_octave);
+  f.Lh = mround((double)fs / DIO_CUTOFF);
+  const int Nlc = 2 * f.Lh + 1;
+  std::vector<int> hal(f.nbands);
+  f.max_hal = 0;
+  for (int b = 0; b < f.nbands; ++b) {
+    hal[b] = mround(fs / f.boundary[b] / 2.0);
+    if (hal[b] < 1) { ctx->err = "dio: band too high for this sampling rate"; return KWY_EINVAL; }
+    f.max_hal = hal[b] > f.max_hal ? hal[b] : f.max_hal;
+  }
+  if (2 * (f.Lh + 2 * f.max_hal) > DIO_N - 1024) {
+    ctx->err = "dio: filters too long for this sampling rate / f0 floor (the overlap-save block is 8192 samples)";
+    return KWY_EINVAL;
+  }
+  char key[160];
+  snprintf(key, sizeof(key), "dio:%d:%.17g:%.17g:%.17g", fs, f0_floor, f0_ceil, channels_in_octave);
+  auto it = ctx->d_mats.find(key);
+  if (it == ctx->d_mats.end()) {
+    const int N = DIO_N, H = DIO_H;
+    std::vector<std::complex<double>> lc(N, 0.0), nu(N);
+    {
+      // DesignLowCutFilter: -(Hanning)/sum, centre tap + 1
+      std::vector<double> g(Nlc);
+      double sum = 0.0;
+      for (int i = 1; i <= Nlc; ++i) { g[i - 1] = 0.5 - 0.5 * cos(i * 2.0 * KWY_PI / (Nlc + 1)); sum += g[i - 1]; }
+      for (int i = 0; i < Nlc; ++i) g[i] = -g[i] / sum;
+      g[f.Lh] += 1.0;
+      for (int i = 0; i < Nlc; ++i) lc[i] = g[i];
+    }
+    host_fft(lc);
+    std::vector<kwy_c> G((size_t)f.nbands * (H + 1));
+    std::vector<double> nt;
+    for (int b = 0; b < f.nbands; ++b) {
+      nt.assign(4 * hal[b], 0.0);
+      nuttall_host(4 * hal[b], nt.data());
+      std::fill(nu.begin(), nu.end(), std::complex<double>(0.0, 0.0));
+      const int delay = 2 * (f.max_hal - hal[b]);
+      for (int j = 0; j < 4 * hal[b]; ++j) nu[delay + j] = nt[j];
+      host_fft(nu);
+      for (int k = 0; k <= H; ++k) {
+        const std::complex<double> v = lc[k] * nu[k] / (double)N;
+        G[(size_t)b * (H + 1) + k] = {v.real(), v.imag()};
+      }
+    }
+    double *d = nullptr;
+    KWY_HIP(hipMalloc((void **)&d, sizeof(kwy_c) * G.size()));
+    KWY_HIP(hipMemcpy(d, G.data(), sizeof(kwy_c) * G.size(), hipMemcpyHostToDevice));
+    it = ctx->d_mats.emplace(key, d).first;
+  }
+  f.G = (const kwy_c *)it->second;
+  *out = f;
+  return KWY_OK;
+}
+
+// lays out one utterance block for the extents in p (ny_max, T_max, ...) and returns its size
+static size_t dio_layout(dio_plan &p) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += kwy_pad(bytes); return (int64_t)o; };
+  const int nengines = 4 * p.nbands;
+  p.off_part = take(sizeof(double) * DIO_PARTS);
+  p.off_filt = take(sizeof(double) * (size_t)p.ny_max * p.nbands);
+  p.off_cnt = take(sizeof(int) * (size_t)nengines * p.ntiles_max);
+  p.off_nedges = take(sizeof(int) * nengines);
+  p.off_fine = take(sizeof(double) * (size_t)nengines * p.cap_max);
+  p.off_cand = take(sizeof(double) * (size_t)p.nbands * p.T_max);
+  p.off_score = take(sizeof(double) * (size_t)p.nbands * p.T_max);
+  p.off_w1 = take(sizeof(double) * p.T_max);
+  p.off_w2 = take(sizeof(double) * p.T_max);
+  p.off_idx = take(sizeof(int) * 2 * (size_t)p.T_max);
+  p.stride = (int64_t)off;
+  return off;
+}
+
+// parameter checks, the cached filter spectra, and the plan (layout for utterances of up to n_max samples)
+static int dio_prepare(kwy_ctx *ctx, int fs, double f0_floor, double f0_ceil, double channels_in_octave,
+                       double frame_period_ms, int speed, double allowed_range, int64_t n_max, dio_plan *out,
+                       size_t *block) {
+  if (fs <= 0 || !(f0_floor > 0) || !(f0_ceil > f0_floor) || !(channels_in_octave > 0) || !(frame_period_ms > 0) ||
+      n_max <= 0 || n_max > 0x3fffffff) {
     ctx->err = "dio: bad argument";
     return KWY_EINVAL;
   }
   if (speed != 1) { ctx->err = "dio: only speed=1 (pyworld's default, the value kwiiyatta uses) is implemented"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
-  const int n = (int)x_length, ny = n + 1;
-  const int T = (int)kwy_dio_frames(fs, x_length, frame_period_ms);
-  dio_params p;
-  p.nbands = 1 + (int)(log(f0_ceil / f0_floor) / 0.69314718055994529 * channels_in_octave);
-  if (p.nbands > DIO_MAX_BANDS) { ctx->err = "dio: too many bands"; return KWY_EINVAL; }
-  for (int i = 0; i < p.nbands; ++i) p.boundary[i] = f0_floor * pow(2.0, (i + 1) / channels_in_octave);
-  p.ny = ny; p.T = T; p.fs = fs; p.f0_floor = f0_floor; p.f0_ceil = f0_ceil;
-  p.frame_period = frame_period_ms; p.allowed_range = allowed_range;
+  dio_filters f;
+  KWY_TRY(dio_get_filters(ctx, fs, f0_floor, f0_ceil, channels_in_octave, &f));
+  dio_plan p;
+  p.count = 0;
+  p.nbands = f.nbands;
+  for (int i = 0; i < DIO_MAX_BANDS; ++i) p.boundary[i] = i < f.nbands ? f.boundary[i] : 0.0;
+  p.G = f.G;
+  p.half = f.Lh + 2 * f.max_hal;
+  p.V = DIO_N - 2 * p.half + 1;
+  p.fs = fs; p.f0_floor = f0_floor; p.f0_ceil = f0_ceil; p.frame_period = frame_period_ms;
+  p.allowed_range = allowed_range;
+  p.ny_max = (int)n_max + 1;
+  p.T_max = (int)kwy_dio_frames(fs, n_max, frame_period_ms);
+  p.ntiles_max = (p.ny_max + DIO_ZC_TILE - 1) / DIO_ZC_TILE;
+  p.cap_max = p.ny_max / 8 + 64;
+  p.scratch = nullptr;
+  *block = dio_layout(p);
+  *out = p;
+  return KWY_OK;
+}
 
-  // filters: low-cut (centred, 2*Lh+1 taps) and one Nuttall low-pass per band
-  const int Lh = mround((double)fs / DIO_CUTOFF);
-  const int Nlc = 2 * Lh + 1;
-  std::vector<int> hal(p.nbands);
-  int max_hal = 0;
-  size_t ntaps_total = Nlc;
-  for (int b = 0; b < p.nbands; ++b) {
-    hal[b] = mround(fs / p.boundary[b] / 2.0);
-    if (hal[b] < 1) { ctx->err = "dio: band too high for this sampling rate"; return KWY_EINVAL; }
-    max_hal = hal[b] > max_hal ? hal[b] : max_hal;
-    ntaps_total += 4 * hal[b];
+// One pass of launches over jobs[0 .. count), count <= KWY_BATCH_MAX (device pointers); scratch: `count` blocks of
+// the plan's stride; a job without a status word gets spare[u].
+static int dio_pass(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, dio_plan p, char *scratch, int *spare) {
+  p.count = count;
+  p.scratch = scratch;
+  for (int u = 0; u < KWY_BATCH_MAX; ++u) {
+    if (u < count) {
+      const kwy_f0_job &q = jobs[u];
+      p.u[u] = dio_utt{q.x, q.temporal_positions, q.f0, q.status ? (int *)q.status : spare + u, (int)q.x_length,
+                       (int)kwy_dio_frames((int)p.fs, q.x_length, p.frame_period)};
+    } else {
+      p.u[u] = dio_utt{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    }
   }
-  const int E = (Lh > 2 * max_hal ? Lh : 2 * max_hal) + 8;  // zero margin kept around y / ylc
-  std::vector<double> taps(ntaps_total);
-  {
-    // DesignLowCutFilter: -(Hanning)/sum, centre tap + 1
-    double sum = 0.0;
-    for (int i = 1; i <= Nlc; ++i) { taps[i - 1] = 0.5 - 0.5 * cos(i * 2.0 * KWY_PI / (Nlc + 1)); sum += taps[i - 1]; }
-    for (int i = 0; i < Nlc; ++i) taps[i] = -taps[i] / sum;
-    taps[Lh] += 1.0;
-  }
-  std::vector<conv_desc> descs(1 + p.nbands);
-  const int64_t ylen = (int64_t)ny + 2 * E;
-  // desc 0: ylc[m] = sum_k g[k-Lh] y[m - (k - Lh)], m in [-E, ny+E)
-  descs[0] = {Nlc, Lh, -E, ny + E, -E, ny + E, E, E, 0, 0};
-  size_t toff = Nlc;
-  for (int b = 0; b < p.nbands; ++b) {
-    nuttall_host(4 * hal[b], taps.data() + toff);
-    // filtered[i] = sum_j nutt[j] * ylc[i + 2 hal - j], i in [0, ny)
-    descs[1 + b] = {4 * hal[b], 2 * hal[b], 0, ny, -E, ny + E, E, 0, (int64_t)toff, (int64_t)ny};
-    toff += 4 * hal[b];
-  }
-  const int ntiles = (ny + DIO_ZC_TILE - 1) / DIO_ZC_TILE;
+  const kwy_c *twH, *twN;
+  KWY_TRY(kwy_get_twiddles(ctx, DIO_LOG2H, &twH));
+  KWY_TRY(kwy_get_twiddles(ctx, DIO_LOG2H + 1, &twN));
+  const size_t lds = sizeof(kwy_c) * (DIO_H + 1 + DIO_H / 8) + sizeof(double) * (DIO_PARTS + 8);
+  KWY_HIP(hipFuncSetAttribute((const void *)k_dio_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nengines = 4 * p.nbands;
-  const int cap = ny / 8 + 64;
-  p.cap = cap;
-
-  size_t need = kwy_pad(sizeof(double) * n) + 2 * kwy_pad(sizeof(double) * ylen) + kwy_pad(sizeof(double) * 1024) +
-                kwy_pad(sizeof(double) * ntaps_total) + kwy_pad(sizeof(conv_desc) * descs.size()) +
-                kwy_pad(sizeof(double) * (size_t)ny * p.nbands) + kwy_pad(sizeof(int) * (size_t)nengines * ntiles) +
-                kwy_pad(sizeof(int) * nengines) + kwy_pad(sizeof(double) * (size_t)nengines * cap) +
-                2 * kwy_pad(sizeof(double) * (size_t)p.nbands * T) + 4 * kwy_pad(sizeof(double) * T) +
-                kwy_pad(sizeof(int) * 2 * T) + kwy_pad(64);
-  KWY_TRY(kwy_arena_begin(ctx, need));
-  double *dx = kwy_arena<double>(ctx, n);
-  double *dy = kwy_arena<double>(ctx, ylen), *dylc = kwy_arena<double>(ctx, ylen);
-  double *dpart = kwy_arena<double>(ctx, 1024);
-  double *dtaps = kwy_arena<double>(ctx, ntaps_total);
-  conv_desc *ddesc = (conv_desc *)kwy_arena_alloc(ctx, sizeof(conv_desc) * descs.size());
-  double *dfilt = kwy_arena<double>(ctx, (size_t)ny * p.nbands);
-  int *dcnt = kwy_arena<int>(ctx, (size_t)nengines * ntiles);
-  int *dnedges = kwy_arena<int>(ctx, nengines);
-  double *dfine = kwy_arena<double>(ctx, (size_t)nengines * cap);
-  double *dcand = kwy_arena<double>(ctx, (size_t)p.nbands * T), *dscore = kwy_arena<double>(ctx, (size_t)p.nbands * T);
-  double *dw1 = kwy_arena<double>(ctx, T), *dw2 = kwy_arena<double>(ctx, T);
-  double *dt = kwy_arena<double>(ctx, T), *df0 = kwy_arena<double>(ctx, T);
-  int *didx = kwy_arena<int>(ctx, 2 * T);
-  int *dstatus = kwy_arena<int>(ctx, 16);
-  if (!dx || !dy || !dylc || !dpart || !dtaps || !ddesc || !dfilt || !dcnt || !dnedges || !dfine || !dcand ||
-      !dscore || !dw1 || !dw2 || !dt || !df0 || !didx || !dstatus) {
-    ctx->err = "dio: scratch arena too small";
-    return KWY_ENOMEM;
-  }
-  KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
-  KWY_HIP(hipMemcpyAsync(dtaps, taps.data(), sizeof(double) * ntaps_total, hipMemcpyHostToDevice, ctx->stream));
-  KWY_HIP(hipMemcpyAsync(ddesc, descs.data(), sizeof(conv_desc) * descs.size(), hipMemcpyHostToDevice, ctx->stream));
-  KWY_HIP(hipMemsetAsync(dstatus, 0, sizeof(int) * 16, ctx->stream));
-
-  const int nparts = 256;
-  hipLaunchKernelGGL(k_dio_sum, dim3(nparts), dim3(KWY_THREADS), 0, ctx->stream, dx, n, dpart);
-  hipLaunchKernelGGL(k_dio_center, dim3((unsigned)((ylen + 255) / 256)), dim3(256), 0, ctx->stream, dx, n, ny, E,
-                     dpart, nparts, dy);
+  const unsigned nblocks = (unsigned)((p.ny_max + p.V - 1) / p.V);
+  hipLaunchKernelGGL(k_dio_sum, dim3(DIO_PARTS, count), dim3(KWY_THREADS), 0, ctx->stream, p);
+  KWY_PROF(ctx, "k_dio_filter", hipLaunchKernelGGL(k_dio_filter, dim3(nblocks, count), dim3(DIO_NT), lds, ctx->stream,
+                                                   p, twH, twN));
   {
-    size_t lds = sizeof(double) * (Nlc + DIO_CONV_OUT + Nlc);
-    // 96 kHz: 3841 low-cut taps -> 70 KB; the CU has 160 KB
-    KWY_HIP(hipFuncSetAttribute((const void *)k_dio_conv, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    if (lds > 152 * 1024) { ctx->err = "dio: low-cut filter too long for this sampling rate"; return KWY_EINVAL; }
-    hipLaunchKernelGGL(k_dio_conv, dim3((unsigned)((ylen + DIO_CONV_OUT - 1) / DIO_CONV_OUT), 1), dim3(KWY_THREADS),
-                       lds, ctx->stream, dy, dtaps, ddesc, dylc);
-    size_t lds2 = sizeof(double) * (4 * max_hal + DIO_CONV_OUT + 4 * max_hal);
-    if (lds2 > 64 * 1024) { ctx->err = "dio: band filter too long for this sampling rate"; return KWY_EINVAL; }
-    hipLaunchKernelGGL(k_dio_conv, dim3((unsigned)((ny + DIO_CONV_OUT - 1) / DIO_CONV_OUT), p.nbands),
-                       dim3(KWY_THREADS), lds2, ctx->stream, dylc, dtaps, ddesc + 1, dfilt);
+    kwy_prof_scope ps_(ctx, "k_dio_zc");
+    hipLaunchKernelGGL(k_dio_zc_count, dim3(p.ntiles_max, nengines, count), dim3(KWY_THREADS), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_dio_zc_scan, dim3(nengines, count), dim3(KWY_THREADS), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_dio_zc_emit, dim3(p.ntiles_max, nengines, count), dim3(KWY_THREADS), 0, ctx->stream, p);
   }
-  hipLaunchKernelGGL(k_dio_zc_count, dim3(ntiles, nengines), dim3(KWY_THREADS), 0, ctx->stream, dfilt, (int64_t)ny,
-                     ny, ntiles, dcnt);
-  hipLaunchKernelGGL(k_dio_zc_scan, dim3(nengines), dim3(KWY_THREADS), 0, ctx->stream, dcnt, ntiles, dnedges);
-  hipLaunchKernelGGL(k_dio_zc_emit, dim3(ntiles, nengines), dim3(KWY_THREADS), 0, ctx->stream, dfilt, (int64_t)ny,
-                     ny, ntiles, dcnt, cap, dfine, dstatus);
-  hipLaunchKernelGGL(k_dio_candidates, dim3((T + 255) / 256, p.nbands), dim3(256), 0, ctx->stream, dfine, dnedges,
-                     p, dcand, dscore);
-  hipLaunchKernelGGL(k_dio_fix, dim3(1), dim3(KWY_THREADS), 0, ctx->stream, dcand, dscore, p, dw1, dw2, didx, dt,
-                     df0);
+  KWY_PROF(ctx, "k_dio_candidates", hipLaunchKernelGGL(k_dio_candidates, dim3((p.T_max + 255) / 256, p.nbands, count),
+                                                       dim3(256), 0, ctx->stream, p));
+  KWY_PROF(ctx, "k_dio_fix", hipLaunchKernelGGL(k_dio_fix, dim3(count), dim3(KWY_THREADS), 0, ctx->stream, p));
   KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+// pyworld.dio for `count` utterances (device pointers, not synchronised): passes of <= KWY_BATCH_MAX utterances
+extern "C" int kwy_dio_batch_dev(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, int fs, double f0_floor,
+                                 double f0_ceil, double channels_in_octave, double frame_period_ms, int speed,
+                                 double allowed_range) {
+  if (!ctx) return KWY_EINVAL;
+  if (!jobs || count < 1) { ctx->err = "dio: bad argument"; return KWY_EINVAL; }
+  int64_t n_max = 0;
+  for (int i = 0; i < count; ++i) {
+    const kwy_f0_job &q = jobs[i];
+    if (!q.x || !q.temporal_positions || !q.f0 || q.x_length <= 0 || q.x_length > 0x3fffffff) {
+      ctx->err = "dio: bad argument";
+      return KWY_EINVAL;
+    }
+    n_max = q.x_length > n_max ? q.x_length : n_max;
+  }
+  dio_plan p;
+  size_t block;
+  KWY_TRY(dio_prepare(ctx, fs, f0_floor, f0_ceil, channels_in_octave, frame_period_ms, speed, allowed_range, n_max,
+                      &p, &block));
+  const int per_pass = count < KWY_BATCH_MAX ? count : KWY_BATCH_MAX;
+  KWY_TRY(kwy_arena_begin(ctx, block * per_pass + kwy_pad(sizeof(int) * KWY_BATCH_MAX)));
+  char *scratch = (char *)kwy_arena_alloc(ctx, block * per_pass);
+  int *spare = kwy_arena<int>(ctx, KWY_BATCH_MAX);
+  if (!scratch || !spare) { ctx->err = "dio: scratch arena too small"; return KWY_ENOMEM; }
+  // (the passes of a call share the scratch: they run one after the other on the context's stream)
+  for (int i0 = 0; i0 < count; i0 += KWY_BATCH_MAX)
+    KWY_TRY(dio_pass(ctx, jobs + i0, count - i0 < KWY_BATCH_MAX ? count - i0 : KWY_BATCH_MAX, p, scratch, spare));
+  return KWY_OK;
+}
+
+extern "C" int kwy_dio_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, double f0_floor, double f0_ceil,
+                           double channels_in_octave, double frame_period_ms, int speed, double allowed_range,
+                           double *temporal_positions, double *f0, int32_t *status) {
+  const kwy_f0_job job = {x, x_length, temporal_positions, f0, status};
+  return kwy_dio_batch_dev(ctx, &job, 1, fs, f0_floor, f0_ceil, channels_in_octave, frame_period_ms, speed,
+                           allowed_range);
+}
+
+// host pointers: the same pass on staged copies (a batch of one), synchronous
+extern "C" int kwy_dio(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, double f0_floor,
+                       double f0_ceil, double channels_in_octave, double frame_period_ms, int speed,
+                       double allowed_range, double *temporal_positions, double *f0) {
+  if (!ctx) return KWY_EINVAL;
+  if (!x || !temporal_positions || !f0) { ctx->err = "dio: bad argument"; return KWY_EINVAL; }
+  dio_plan p;
+  size_t block;
+  KWY_TRY(dio_prepare(ctx, fs, f0_floor, f0_ceil, channels_in_octave, frame_period_ms, speed, allowed_range, x_length,
+                      &p, &block));
+  const int64_t T = p.T_max;
+  KWY_TRY(kwy_arena_begin(ctx, block + kwy_pad(sizeof(double) * x_length) + 2 * kwy_pad(sizeof(double) * T) +
+                                   kwy_pad(sizeof(int) * KWY_BATCH_MAX)));
+  char *scratch = (char *)kwy_arena_alloc(ctx, block);
+  double *dx = kwy_arena<double>(ctx, x_length), *dt = kwy_arena<double>(ctx, T), *df0 = kwy_arena<double>(ctx, T);
+  int *dstatus = kwy_arena<int>(ctx, KWY_BATCH_MAX);
+  if (!scratch || !dx || !dt || !df0 || !dstatus) { ctx->err = "dio: scratch arena too small"; return KWY_ENOMEM; }
+  KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * x_length, hipMemcpyHostToDevice, ctx->stream));
+  const kwy_f0_job job = {dx, x_length, dt, df0, nullptr};
+  KWY_TRY(dio_pass(ctx, &job, 1, p, scratch, dstatus));
   int hstatus = 0;
   KWY_HIP(hipMemcpyAsync(temporal_positions, dt, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipMemcpyAsync(f0, df0, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
@@ -558,6 +738,62 @@ extern "C" int kwy_dio(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, 
   KWY_HIP(hipStreamSynchronize(ctx->stream));
   if (hstatus != 0) { ctx->err = "dio: zero-crossing buffer overflow (signal too noisy for the band filters)"; return KWY_EHIP; }
   return KWY_OK;
+}
+
+// ---- StoneMask entries ---------------------------------------------------------------------------------
+static int sm_tables_for(kwy_ctx *ctx, int fs, sm_tables *tabs) {
+  // twiddle tables for every FFT size a frame may ask for (f0 in (40, fs/12])
+  const int max_half = (int)(1.5 * fs / 40.0 + 1.0);
+  const int max_log2 = 2 + (int)(log(max_half * 2.0 + 1.0) / 0.69314718055994529);
+  if (max_log2 >= 20) { ctx->err = "stonemask: sampling rate too high"; return KWY_EINVAL; }
+  for (int l = 0; l < 20; ++l) tabs->t[l] = nullptr;
+  for (int l = 2; l <= max_log2; ++l) KWY_TRY(kwy_get_twiddles(ctx, l, &tabs->t[l]));
+  return KWY_OK;
+}
+
+static int sm_launch(kwy_ctx *ctx, const kwy_utterance *utts, int count, int fs, const sm_tables &tabs) {
+  for (int i0 = 0; i0 < count; i0 += KWY_BATCH_MAX) {
+    sm_batch b;
+    b.n = count - i0 < KWY_BATCH_MAX ? count - i0 : KWY_BATCH_MAX;
+    b.start[0] = 0;
+    for (int u = 0; u < b.n; ++u) {
+      const kwy_utterance &q = utts[i0 + u];
+      b.u[u] = sm_view{q.x, q.temporal_positions, q.f0, q.out, (int)q.x_length};
+      b.start[u + 1] = b.start[u] + (int)q.f0_length;
+    }
+    KWY_PROF(ctx, "k_stonemask", hipLaunchKernelGGL(k_stonemask, dim3((unsigned)b.start[b.n]), dim3(KWY_THREADS), 0,
+                                                    ctx->stream, b, fs, tabs));
+    KWY_HIP(hipGetLastError());
+  }
+  return KWY_OK;
+}
+
+// pyworld.stonemask for `count` utterances (device pointers; kwy_utterance.out = the refined f0, f0_length values);
+// one grid over all frames of <= KWY_BATCH_MAX utterances, not synchronised
+extern "C" int kwy_stonemask_batch_dev(kwy_ctx *ctx, const kwy_utterance *utts, int count, int fs) {
+  if (!ctx) return KWY_EINVAL;
+  if (!utts || count < 1 || fs <= 0) { ctx->err = "stonemask: bad argument"; return KWY_EINVAL; }
+  int64_t frames = 0;
+  for (int i = 0; i < count; ++i) {
+    const kwy_utterance &q = utts[i];
+    if (!q.x || !q.temporal_positions || !q.f0 || !q.out || q.x_length <= 0 || q.x_length > 0x7fffffff ||
+        q.f0_length <= 0) {
+      ctx->err = "stonemask: bad argument";
+      return KWY_EINVAL;
+    }
+    frames += q.f0_length;
+  }
+  if (frames > 0x7fffffff) { ctx->err = "stonemask: too many frames"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  sm_tables tabs;
+  KWY_TRY(sm_tables_for(ctx, fs, &tabs));
+  return sm_launch(ctx, utts, count, fs, tabs);
+}
+
+extern "C" int kwy_stonemask_dev(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
+                                 const double *f0, int64_t T, double *refined_f0) {
+  const kwy_utterance u = {x, x_length, t, f0, T, refined_f0};
+  return kwy_stonemask_batch_dev(ctx, &u, 1, fs);
 }
 
 extern "C" int kwy_stonemask(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
@@ -568,24 +804,18 @@ extern "C" int kwy_stonemask(kwy_ctx *ctx, const double *x, int64_t x_length, in
     return KWY_EINVAL;
   }
   KWY_HIP(hipSetDevice(ctx->device));
-  // twiddle tables for every FFT size a frame may ask for (f0 in (40, fs/12])
-  const int max_half = (int)(1.5 * fs / 40.0 + 1.0);
-  const int max_log2 = 2 + (int)(log(max_half * 2.0 + 1.0) / 0.69314718055994529);
-  if (max_log2 >= 20) { ctx->err = "stonemask: sampling rate too high"; return KWY_EINVAL; }
-  std::vector<const kwy_c *> tabs(20, nullptr);
-  for (int l = 2; l <= max_log2; ++l) KWY_TRY(kwy_get_twiddles(ctx, l, &tabs[l]));
+  sm_tables tabs;
+  KWY_TRY(sm_tables_for(ctx, fs, &tabs));
   size_t bx = kwy_pad(sizeof(double) * x_length), bt = kwy_pad(sizeof(double) * T);
-  KWY_TRY(kwy_arena_begin(ctx, bx + 3 * bt + kwy_pad(sizeof(void *) * 20)));
+  KWY_TRY(kwy_arena_begin(ctx, bx + 3 * bt));
   double *dx = kwy_arena<double>(ctx, x_length), *dt = kwy_arena<double>(ctx, T);
   double *df0 = kwy_arena<double>(ctx, T), *dout = kwy_arena<double>(ctx, T);
-  const kwy_c **dtabs = (const kwy_c **)kwy_arena_alloc(ctx, sizeof(void *) * 20);
+  if (!dx || !dt || !df0 || !dout) { ctx->err = "stonemask: scratch arena too small"; return KWY_ENOMEM; }
   KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * x_length, hipMemcpyHostToDevice, ctx->stream));
   KWY_HIP(hipMemcpyAsync(dt, t, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
   KWY_HIP(hipMemcpyAsync(df0, f0, sizeof(double) * T, hipMemcpyHostToDevice, ctx->stream));
-  KWY_HIP(hipMemcpyAsync(dtabs, tabs.data(), sizeof(void *) * 20, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_stonemask, dim3((unsigned)T), dim3(KWY_THREADS), 0, ctx->stream, dx, (int)x_length, fs, dt,
-                     df0, dtabs, dout);
-  KWY_HIP(hipGetLastError());
+  const kwy_utterance u = {dx, x_length, dt, df0, T, dout};
+  KWY_TRY(sm_launch(ctx, &u, 1, fs, tabs));
   KWY_HIP(hipMemcpyAsync(refined_f0, dout, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipStreamSynchronize(ctx->stream));
   return KWY_OK;

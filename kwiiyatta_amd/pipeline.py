@@ -34,6 +34,7 @@ EPS = 2.220446049250313e-16
 SAFE_GUARD_MINIMUM = 1e-12
 PAD_LEN = 100
 POWER_WEIGHT, POWER_THRESHOLD, VUV_WEIGHT = 9.4, 1.636, 9.0
+PIECE_CEILING = float(np.power(10, -1 / 10))          # normalize_data's default peak_lv = -1 (kwiiyatta/wavfile.py:8-12)
 
 
 def _p(t):
@@ -317,13 +318,22 @@ class _Wave:
             self.side = torch.cuda.Stream(device=dev)
             self.side_ctx = _lib.Context(dev.index, stream=self.side.cuda_stream)
         sides = [s for pair in pairs for s in pair]               # source 0, target 0, source 1, ...
+        wav_in = owner.wav_in
+        sides = [(s,) if wav_in and not isinstance(s, (tuple, list)) else s for s in sides]
         self.N = [len(s[0]) for s in sides]
-        self.T = [len(s[1]) for s in sides]
+        # wav in: the frame grid is DIO's (kwy_dio_frames), the f0 track is extracted inside the step
+        self.T = [int(lib.kwy_dio_frames(fs, len(s[0]), owner.frame_period)) for s in sides] if wav_in else \
+            [len(s[1]) for s in sides]
         self.Tp = [t + 2 * PAD_LEN for t in self.T]
         cat = lambda k: torch.from_numpy(np.concatenate([np.ascontiguousarray(s[k], dtype=np.float64)  # noqa: E731
                                                          for s in sides])).to(dev)
         with torch.cuda.stream(self.stream):
-            self.x_all, self.f0_all, self.t_all = cat(0), cat(1), cat(2)
+            self.x_all = cat(0)
+            if wav_in:
+                self.t_all = torch.empty(int(sum(self.T)), **f64)
+                self.f0_all = torch.empty(int(sum(self.T)), **f64)        # DIO's track, before the refinement
+            else:
+                self.f0_all, self.t_all = cat(1), cat(2)
             rows = int(sum(self.Tp))
             self.sp_pad = torch.zeros((rows, K), **f64)
             self.ap_pad = torch.full((rows, K), 1 - SAFE_GUARD_MINIMUM, **f64)
@@ -345,8 +355,17 @@ class _Wave:
             self.mc_p = [cut(self.mc_pad, po, i) for i in range(ns)]
             self.f0_p = [cut(self.f0_pad, po, i) for i in range(ns)]
             self.feat_p = [cut(self.feat, po, i) for i in range(ns)]
-            for i in range(ns):
-                self.f0_p[i][PAD_LEN:PAD_LEN + self.T[i]] = self.f0[i]
+            if wav_in:
+                # StoneMask writes the refined track straight into the padded f0 rows; every consumer reads it there
+                self.f0_dio = self.f0
+                self.f0 = [self.f0_p[i][PAD_LEN:PAD_LEN + self.T[i]] for i in range(ns)]
+                self.f0_status = torch.zeros(ns, dtype=torch.int32, device=dev)
+                self.j_dio = _lib.job_array(_lib.F0Job, [(self.x[i], self.N[i], self.t[i], self.f0_dio[i],
+                                                          self.f0_status[i:i + 1]) for i in range(ns)])
+                self.j_sm = _lib.utterance_array([(self.x[i], self.t[i], self.f0_dio[i], self.f0[i]) for i in range(ns)])
+            else:
+                for i in range(ns):
+                    self.f0_p[i][PAD_LEN:PAD_LEN + self.T[i]] = self.f0[i]
             # pad rows in the reference's order of draws: source head, source tail, target head, target tail
             self.pad_rows = [blk for i in range(ns) for blk in (self.sp_p[i][:PAD_LEN], self.sp_p[i][PAD_LEN + self.T[i]:])]
             # per pair, on the target's time axis
@@ -362,6 +381,11 @@ class _Wave:
             yo = np.concatenate(([0], np.cumsum(self.ylen)))
             self.wave_all = torch.empty(int(yo[-1]), **f64)
             self.wave = [cut(self.wave_all, yo, k) for k in range(self.n)]
+            if owner.pcm:         # the post-step and the 16-bit samples on the device (kwy_finish_pcm16_batch_dev)
+                self.pcm_all = torch.zeros(int(yo[-1]), dtype=torch.int16, device=dev)
+                self.pcm = [cut(self.pcm_all, yo, k) for k in range(self.n)]
+                self.j_fin = _lib.job_array(_lib.FinishJob, [(self.wave[k], self.ylen[k], Tt[k], self.pcm[k])
+                                                             for k in range(self.n)])
             cap = [self.Tp[2 * k] + self.Tp[2 * k + 1] + 2 for k in range(self.n)]
             self.path = [torch.zeros((c, 2), dtype=torch.int32, device=dev) for c in cap]
             self.path_len = torch.zeros(self.n, dtype=torch.int64, device=dev)
@@ -417,11 +441,18 @@ class PairBatchPipeline(_Graphed):
     fork: 30.0), 'own' (the generator's own stream as a fifth branch of the graph: 31.8).
     serial: everything on ONE stream, kernel after kernel (for per-kernel timing).
 
+    wav_in: the pairs are bare waveforms (or (x, ...) tuples whose f0 is ignored): DIO + StoneMask of both sides run at
+    the head of every wave (kwy_dio_batch_dev, kwy_stonemask_batch_dev: Analyzer.extract_f0,
+    kwiiyatta/vocoder/world.py:33-41), the refined track going straight into the padded f0 rows.  pcm: the post-step
+    and the int16 samples of every waveform at the end of the wave (kwy_finish_pcm16_batch_dev:
+    vocoder/abc/synthesizer.py:11-20 + wavfile.py:8-29), `pcm(k)`.
+
     Outputs per pair k: `wave(k)`; equal to PairPipeline's bit for bit given the same pads."""
 
     def __init__(self, device_index, fs, pairs, gmm, order=24, radius=32, frame_period=5.0, waves=2, rng=None,
-                 silence=None, rng_place='side', serial=False, max_wave=16):
+                 silence=None, rng_place='side', serial=False, max_wave=16, wav_in=False, pcm=False):
         self.dev = torch.device('cuda', device_index)
+        self.wav_in, self.pcm = bool(wav_in), bool(pcm)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
         self.K = self.fft // 2 + 1
@@ -461,6 +492,14 @@ class PairBatchPipeline(_Graphed):
         w, i = self.where[k]
         return self.waves[w].wave[i]
 
+    def pcm16(self, k):
+        w, i = self.where[k]
+        return self.waves[w].pcm[i]
+
+    def f0_status(self):
+        """wav_in: the DIO status words of all utterances (one read-back; non-zero = zero-crossing overflow)"""
+        return torch.cat([wv.f0_status for wv in self.waves]).cpu().numpy()
+
     def path(self, k):
         """(path, path_len, dist) device tensors of pair k"""
         w, i = self.where[k]
@@ -494,11 +533,22 @@ class PairBatchPipeline(_Graphed):
                 wv.side.wait_stream(origin)
         for wv in self.waves:
             h, hs, n = wv.ctx.handle, wv.side_ctx.handle, wv.n
+            f0_done = None
+            if self.wav_in:
+                with torch.cuda.stream(wv.stream):
+                    _lib.check(wv.ctx, lib.kwy_dio_batch_dev(h, wv.j_dio, 2 * n, fs, 71.0, 800.0, 2.0, self.frame_period,
+                                                             1, 0.1))
+                    _lib.check(wv.ctx, lib.kwy_stonemask_batch_dev(h, wv.j_sm, 2 * n, fs))
+                    if wv.side is not wv.stream:
+                        f0_done = torch.cuda.Event()
+                        f0_done.record(wv.stream)
             with torch.cuda.stream(wv.side):
                 if self.rng is not None and self.rng_place == 'side' and wv is self.waves[0]:
                     self.rng.abs_normal_blocks(EPS / fs, self.pad_rows, ctx=wv.side_ctx)
                     pads = torch.cuda.Event()
                     pads.record(wv.side)
+                if f0_done is not None:
+                    wv.side.wait_event(f0_done)
                 _lib.check(wv.side_ctx, lib.kwy_d4c_batch_dev(hs, wv.j_ap, 2 * n, fs, 0.85, fft))
                 ap_done = torch.cuda.Event()
                 ap_done.record(wv.side)
@@ -520,6 +570,8 @@ class PairBatchPipeline(_Graphed):
                 chk(lib.kwy_mc2sp_dev(h, _p(wv.mc_conv), wv.arows, order, self.alpha, fft, _p(wv.sp_conv)))
                 wv.stream.wait_stream(wv.side)                      # join: the plans are there
                 chk(lib.kwy_synth_render_batch_dev(h, wv.j_render, n, fft, self.frame_period, fs, float(fs)))
+                if self.pcm:
+                    chk(lib.kwy_finish_pcm16_batch_dev(h, wv.j_fin, n, fs, 1, PIECE_CEILING, 1, PIECE_CEILING))
         with torch.cuda.stream(origin):
             for wv in self.waves:
                 if wv.stream is not origin:
