@@ -343,7 +343,9 @@ def main_lockstep(args):
     pairs = [base[i % nbase] for i in range(len(mine))]
     seed = 1000 + rank
     rng = DeviceRandomState.from_seed(seed, device_index=local_rank)
-    pipe = pl.PairBatchPipeline(local_rank, FS, pairs, dgmm, waves=1 if serial else args.waves, rng=rng, serial=serial)
+    wav = args.workload == 'wav'            # wav in -> int16 out: DIO + StoneMask and the post-step inside the step
+    pipe = pl.PairBatchPipeline(local_rank, FS, pairs, dgmm, waves=1 if serial else args.waves, rng=rng, serial=serial,
+                                wav_in=wav, pcm=wav)
     torch.cuda.synchronize()
 
     def sync_all():
@@ -425,7 +427,8 @@ def main_lockstep(args):
     #      cannot be recorded inside a captured graph here), the library's events around its tracked kernels
     names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_d4c_bands', 'k_syn_phase', 'k_syn_pulse', 'k_syn_ola', 'k_sp2mc',
              'k_mc2sp', 'k_dtw_dist', 'k_dtw_values', 'k_dtw_codes', 'k_dtw_trace', 'k_dtw_small', 'k_gmm_logp', 'k_mlpg_chunks',
-             'k_mlpg_finish', 'k_np_words', 'k_np_jump', 'k_np_words_seg', 'k_np_emit']
+             'k_mlpg_finish', 'k_np_words', 'k_np_jump', 'k_np_words_seg', 'k_np_emit', 'k_dio_filter', 'k_dio_zc',
+             'k_dio_candidates', 'k_dio_fix', 'k_stonemask', 'k_finish']
     pipe.profile(True)
     for _ in range(min(args.steps, 3)):
         pipe.run()
@@ -461,6 +464,36 @@ def main_lockstep(args):
                                          'two service streams, two staging slots each way '
                                          '(kwiiyatta_amd.pipeline.BatchHostFeeder); never `value`'}
         del feeder
+        if not wav:
+            # the same step from WAVEFORMS to 16-bit samples: f0 extraction (DIO + StoneMask of both sides) at the head
+            # of every wave, the post-step of synthesize/save and the int16 truncation at its end
+            pw = pl.PairBatchPipeline(local_rank, FS, pairs, dgmm, waves=args.waves, wav_in=True, pcm=True,
+                                      rng=DeviceRandomState.from_seed(seed + 500, device_index=local_rank))
+            stepw = pw.run
+            if args.graph:
+                pw.run(); pw.sync()
+                pw.capture()
+                stepw = pw.replay
+            for _ in range(3):
+                stepw()
+            pw.sync()
+            torch.cuda.synchronize()
+            elp = timed(stepw, args.steps, pw.sync)
+            f0_dev = pw.waves[0].f0[0].cpu().numpy()
+            f0_gen = np.asarray(pairs[0][0][1])
+            both = (f0_dev > 0) & (f0_gen > 0)
+            variants['wav_in_pcm_out'] = {
+                'ms_per_step': 1000.0 * elp / args.steps, 'frames_per_s_rank': pw.frames * args.steps / elp,
+                'ratio_to_value': (pw.frames * args.steps / elp) / (pipe.frames * args.steps / el_own),
+                'dio_status_words_nonzero': int(np.count_nonzero(pw.f0_status())),
+                'f0_vs_generating_contour': {'voicing_agreement': float(np.mean((f0_dev > 0) == (f0_gen > 0))),
+                                             'median_rel_diff_voiced': float(np.median(np.abs(f0_dev[both] - f0_gen[both]) / f0_gen[both]))
+                                             if both.any() else None},
+                'pcm_peak': int(pw.pcm16(0).abs().max().item()),
+                'note': 'the same pairs from WAVEFORMS to int16: kwy_dio_batch_dev + kwy_stonemask_batch_dev of both sides at '
+                        'the head of every wave (the f0 tracks are no longer given), kwy_finish_pcm16_batch_dev at its end; '
+                        '`bench.py --workload wav` runs this as the main measurement with per-kernel times'}
+            del pw
 
     # ---- BASELINE config 4 beside config 3 (every rank takes part): ONE batch of 256 distinct utterances sharded
     #      round-robin over the ranks (strong scaling), analyse + resynthesise in lockstep waves of 16
@@ -485,7 +518,7 @@ def main_lockstep(args):
         hop = FS * FRAME_PERIOD / 1000.0
         # the kernels with the GPU to themselves: ONE wave (<= 16 pairs) on ONE stream, kernel after kernel
         lone_pairs = pairs[:min(16, len(pairs))]
-        lone = pipe if serial else pl.PairBatchPipeline(local_rank, FS, lone_pairs, dgmm, waves=1, serial=True,
+        lone = pipe if serial else pl.PairBatchPipeline(local_rank, FS, lone_pairs, dgmm, waves=1, serial=True, wav_in=wav, pcm=wav,
                                                         rng=DeviceRandomState.from_seed(7, device_index=local_rank))
         lone.run(); lone.sync()
         lone.profile(True)
@@ -562,9 +595,11 @@ def main_lockstep(args):
             'warmup': args.warmup, 'ms_per_step': 1000.0 * el / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {
-                'workload': ('config3: 48 kHz source (10 s, T=2001) + target (11 s, T=2201) pairs: CheapTrick+D4C of '
+                'workload': ('config3: 48 kHz source (10 s, T=2001) + target (11 s, T=2201) pairs: ' +
+                             ('f0 by DIO+StoneMask of both (wav in), ' if wav else '') + 'CheapTrick+D4C of '
                              'both, pad with freshly drawn silent spectra, sp2mc, FastDTW(radius 32) align, GMM(%d comp, '
-                             'D=144)+MLPG convert, mc2sp, WORLD synthesis' % args.components),
+                             'D=144)+MLPG convert, mc2sp, WORLD synthesis' % args.components +
+                             (', post-step + int16 (pcm out)' if wav else '')),
                 'pairs_per_gpu': args.batch, 'source_frames_per_pair': pipe.waves[0].T[0],
                 'driver': 'one stream, kernel after kernel (--driver serial)' if serial else
                           'lockstep: %d waves of <= 16 pairs, two streams per wave, batched entries (one grid per stage and '
@@ -586,6 +621,7 @@ def main_lockstep(args):
             'draws_check': draws_equal,
             'pads_replayed': variants.get('pads_replayed'),
             'with_pcie': variants.get('with_pcie'),
+            'wav_in_pcm_out': variants.get('wav_in_pcm_out'),
             'parity': None,
             'distinct_pairs_per_gpu': nbase,
             'ranks_seen': ranks_seen,
@@ -595,7 +631,11 @@ def main_lockstep(args):
         }
         if not args.no_cpu_baseline and world == 1:
             # the CPU chain on the very pads the device drew for pair 0 in the last timed pass
-            out['cpu_baseline'], ref = cpu_baseline_pair(base[0][0], base[0][1], gmm, pads0)
+            src0, tgt0 = base[0]
+            if wav:     # the CPU chain starts from the waveforms too: the oracle's own DIO + StoneMask tracks
+                from oracle import oracle as ko
+                src0, tgt0 = ((u[0], ko.stonemask(u[0], *ko.dio(u[0], FS), FS), u[2]) for u in (src0, tgt0))
+            out['cpu_baseline'], ref = cpu_baseline_pair(src0, tgt0, gmm, pads0)
             out['parity'] = {
                 'wave_rms_vs_cpu_chain': float(np.sqrt(np.mean((wave0 - ref['wave']) ** 2))),
                 'wave_peak': float(np.abs(ref['wave']).max()),
@@ -619,7 +659,9 @@ def main():
                           'work run 5 %% slower -- clocks, first touches -- whatever the code does)')
     ap_.add_argument('--batch', type=int, default=32, help='utterance pairs per GPU per step')
     ap_.add_argument('--seconds', type=float, default=10.0, help='source utterance length')
-    ap_.add_argument('--workload', choices=['pair', 'utterance'], default='pair')
+    ap_.add_argument('--workload', choices=['pair', 'utterance', 'wav'], default='pair',
+                     help='pair: BASELINE config 3 with the f0 tracks given (the headline); wav: the same from waveforms to '
+                          '16-bit samples (DIO + StoneMask and the post-step inside the step); utterance: configs 2 / 4')
     ap_.add_argument('--utterances', type=int, default=0,
                      help='with --workload utterance: BASELINE config 4 -- this many DISTINCT utterances per GPU and step '
                           '(seeds = global utterance index, 256 = the configuration\'s batch on one GPU) through a fixed '
@@ -662,7 +704,7 @@ def main():
     args.side_stream = args.side_stream == 'on' or (args.side_stream == 'auto' and args.batch == 1)
     if args.workload == 'utterance' and args.utterances > 0:
         return main_batch(args)
-    if args.workload == 'pair' and args.driver != 'streams':
+    if args.workload in ('pair', 'wav') and args.driver != 'streams':
         if args.driver == 'serial' and args.batch > 16:
             args.batch = 16
         return main_lockstep(args)

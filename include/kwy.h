@@ -443,7 +443,12 @@ int kwy_gmm_fit_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, int 
  * -- and all ranks return the same model (that of a one-rank fit of the concatenated rows, up to the rounding of the
  * sums).  What is exchanged: per k-means++ centre the shard totals, <= 8 candidate rows and potentials; per Lloyd
  * iteration M (D + 1) + 1 doubles; per EM iteration M (D + 1) and M D D doubles and the log-likelihood.  comm == NULL:
- * kwy_gmm_fit_dev.  The library does not link RCCL: the callback is the caller's. */
+ * kwy_gmm_fit_dev.  The library does not link RCCL: the callback is the caller's.
+ * Errors: what can go wrong on ONE rank -- its arguments (every rank needs n >= 1 rows: an empty shard is an error),
+ * its allocations -- is the first quantity the ranks exchange, so either every rank fits or every rank returns an
+ * error (the failing ones their own code, the others KWY_EINVAL "another rank failed its set-up"); nobody is left
+ * waiting in a collective.  A failure of the callback itself (non-zero return, e.g. an exception in a Python
+ * binder) cannot be agreed on and is fatal for the whole group: the caller must tear the group down. */
 typedef struct kwy_comm {
   int rank, world;
   int (*all_reduce_sum)(void *user, double *device_buffer, int64_t count, void *stream);   /* 0 = success */

@@ -50,7 +50,20 @@ class DeviceRandomState:
             self.stream = torch.cuda.ExternalStream(lib.kwy_ctx_stream(ctx.handle), device=self.dev)
         self.ctx = ctx
         self.state = torch.empty(_BYTES, dtype=torch.uint8, device=self.dev)
+        self._foreign = False      # a draw was enqueued on another context's stream (or inside a graph that replays it)
         self.set_state(state)
+
+    def _join_foreign(self):
+        """Draws enqueued through another context (`abs_normal_blocks(ctx=...)`: a driver's stream, possibly captured
+        into a HIP graph that is replayed on yet another stream) read and write `self.state` outside the generator's
+        own stream.  Before the generator's stream touches the state again the device is drained: the only order
+        that holds for every such stream, replayed graphs included."""
+        if self._foreign:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('DeviceRandomState: the state was last used on another context\'s stream; it cannot '
+                                   'be joined from inside a stream capture')
+            torch.cuda.synchronize(self.dev)
+            self._foreign = False
 
     @classmethod
     def from_global(cls, **kwargs):
@@ -61,12 +74,15 @@ class DeviceRandomState:
         return cls(np.random.RandomState(seed).get_state(), **kwargs)
 
     def set_state(self, state):
+        self._join_foreign()
         with torch.cuda.stream(self.stream):
             self.state.copy_(torch.from_numpy(_pack(state)))
         self.stream.synchronize()
 
     def get_state(self):
-        """numpy's state tuple after everything enqueued so far (synchronises the generator's stream)"""
+        """numpy's state tuple after everything enqueued so far -- on the generator's own stream and, when draws went
+        through other contexts (`abs_normal_blocks(ctx=...)`), on the whole device (synchronises)"""
+        self._join_foreign()
         with torch.cuda.stream(self.stream):
             host = self.state.cpu()
         self.stream.synchronize()
@@ -88,6 +104,7 @@ class DeviceRandomState:
             out = torch.empty(size, dtype=torch.float64, device=self.dev)
         elif out.dtype != torch.float64 or not out.is_contiguous() or out.device != self.dev:
             raise ValueError('out must be a contiguous float64 tensor on the generator\'s device')
+        self._join_foreign()
         _lib.check(self.ctx, lib.kwy_np_normal_dev(self.ctx.handle, c_vp(self.state.data_ptr()), float(loc), float(scale),
                                                    int(bool(absolute)), out.numel(), c_vp(out.data_ptr())))
         return out
@@ -101,7 +118,11 @@ class DeviceRandomState:
         batch in pair order: one layout of the generator's words for all of them).
         ctx: enqueue on this library context's stream instead of the generator's own (a driver that wants the draw in
         line with its other work; it then also orders the draw against other users of the generator)."""
-        ctx = self.ctx if ctx is None else ctx
+        if ctx is None or ctx is self.ctx:
+            ctx = self.ctx
+            self._join_foreign()
+        else:
+            self._foreign = True
         n_each = outs[0].numel()
         for t in outs:
             if t.dtype != torch.float64 or not t.is_contiguous() or t.device != self.dev or t.numel() != n_each:
@@ -116,6 +137,7 @@ class DeviceRandomState:
         self.stream.synchronize()
 
     def record_event(self):
+        self._join_foreign()
         ev = torch.cuda.Event()
         ev.record(self.stream)
         return ev

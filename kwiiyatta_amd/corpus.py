@@ -726,27 +726,38 @@ def _build_training_matrix_lockstep(pairs, fs, device_index, order, radius, fram
             X = torch.empty((cap_rows, 6 * order), dtype=torch.float64, device=dev)
             cursor = torch.zeros(1, dtype=torch.int64, device=dev)
         prev, held = None, []
+        worst = torch.zeros(1, dtype=torch.int64, device=dev)      # min over all pairs' n_rows: < 0 = a pair was dropped
+
+        def close(wave):
+            wave.finish(X, cursor, pads)
+            with torch.cuda.stream(ls.main):
+                torch.minimum(worst, wave.n_rows.min().reshape(1), out=worst)
         for w0 in range(0, len(pairs), wave_pairs):
             chunk = [uploads.get() for _ in range(len(pairs[w0:w0 + wave_pairs]))]
             wave = TrainWave(ls, fs, chunk, order=order, radius=radius, frame_period=frame_period)
             wave.analyse()                     # enqueued BEFORE the host waits for the previous wave's lengths
             if prev is not None:
-                prev.finish(X, cursor, pads)
+                close(prev)
                 held.append(prev)
             frames += wave.frames
             prev = wave
             while len(held) > 2:
                 held.pop(0)                    # (its buffers: all uses are ordered on the main stream before reuse)
-        prev.finish(X, cursor, pads)
+        close(prev)
         with torch.cuda.stream(ls.main):
-            n_rows = int(cursor.item())
+            n_rows, dropped = (int(v) for v in torch.cat((cursor, worst)).tolist())     # ONE read-back
         ls.sync()
+        if dropped < 0:
+            # k_tr_rows_place marks a pair that did not fit behind the cursor with -1 - rows and drops it; the capacity
+            # above (one row per frame of both sides) bounds every pair's rows, so this is a bug, never a data property
+            raise RuntimeError(f'training matrix: a pair of {-1 - dropped} rows did not fit the capacity of {cap_rows}')
     finally:
         if ahead is not None:
             ahead.stop()
         uploads.stop()
     torch.cuda.current_stream(dev).synchronize()
-    return X[:n_rows], frames
+    # (a view would keep the whole capacity block alive: twice the rows actually used, or more)
+    return (X[:n_rows].clone() if n_rows * 4 < cap_rows * 3 else X[:n_rows]), frames
 
 
 def _build_training_matrix_streams(pairs, fs, device_index=0, order=24, radius=32, frame_period=5.0, streams=16,

@@ -324,6 +324,12 @@ __global__ __launch_bounds__(KWY_THREADS) void k_copy(double2 *__restrict__ dst,
   if (dst1 && blockIdx.x == 0 && threadIdx.x == 0) *dst1 = *src1;        // the odd eighth byte group
 }
 
+// buffers that are only 8-byte aligned (a staging offset behind an odd number of samples): one double per lane
+__global__ __launch_bounds__(KWY_THREADS) void k_copy8(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * KWY_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * KWY_THREADS + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 // ================================================================ C ABI: context
 extern "C" {
 
@@ -335,8 +341,12 @@ int kwy_copy_dev(kwy_ctx *ctx, void *dst, const void *src, int64_t bytes) {
   }
   if (bytes == 0) return KWY_OK;
   KWY_HIP(hipSetDevice(ctx->device));
-  if (((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) {      // 8-byte aligned only: plain doubles through the same kernel
-    KWY_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  if (((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) {      // 8-byte aligned only: a kernel too, one double per lane
+    const int64_t n = bytes / 8;
+    int64_t g8 = (n + KWY_THREADS * 8 - 1) / (KWY_THREADS * 8);
+    g8 = g8 < 1 ? 1 : (g8 > 4096 ? 4096 : g8);
+    hipLaunchKernelGGL(k_copy8, dim3((unsigned)g8), dim3(KWY_THREADS), 0, ctx->stream, (double *)dst, (const double *)src, n);
+    KWY_HIP(hipGetLastError());
     return KWY_OK;
   }
   const int64_t n2 = bytes / 16;

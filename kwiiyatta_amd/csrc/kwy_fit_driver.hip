@@ -105,16 +105,29 @@ extern "C" int kwy_gmm_fit_comm_dev(kwy_ctx *ctx, const double *X, int64_t n, in
                                     int *converged_out, int *kmeans_iter_out) {
   if (!ctx) return KWY_EINVAL;
   const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
-  if (!X || !weights || !means || !covs || n < 1 || M < 1 || M > 256 || D < 1 || D > 160 || max_iter < 1 ||
-      world < 1 || rank < 0 || rank >= world || (world > 1 && !comm->all_reduce_sum)) {
-    ctx->err = "gmm_fit: bad argument (needs n >= 1 rows per rank, M <= 256, D <= 160)";
+  // What every rank can check about the GROUP comes first: without a usable communicator nothing can be agreed on.
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !comm->all_reduce_sum)) {
+    ctx->err = "gmm_fit: bad communicator";
     return KWY_EINVAL;
   }
-  const int n_trials = 2 + (int)log((double)M);
-  if (n_trials > 8) { ctx->err = "gmm_fit: more than 8 k-means++ candidates per centre (M > 403)"; return KWY_EINVAL; }
+  // Everything that can fail on ONE rank only -- its arguments (an empty shard: n < 1), its allocations -- is collected
+  // in rc_local and becomes the FIRST exchanged quantity below, so that all ranks leave with an error together
+  // instead of one returning while its peers wait in the next all-reduce.  (A failure of the communicator's
+  // callback itself, e.g. a Python exception in it, cannot be agreed on: it is fatal for the whole group.)
+  int rc_local = KWY_OK;
+  if (!X || !weights || !means || !covs || n < 1 || M < 1 || M > 256 || D < 1 || D > 160 || max_iter < 1) {
+    ctx->err = "gmm_fit: bad argument (needs n >= 1 rows per rank, M <= 256, D <= 160)";
+    rc_local = KWY_EINVAL;
+  }
+  const int n_trials = 2 + (int)log((double)(M > 0 ? M : 1));
+  if (rc_local == KWY_OK && n_trials > 8) {
+    ctx->err = "gmm_fit: more than 8 k-means++ candidates per centre (M > 403)";
+    rc_local = KWY_EINVAL;
+  }
+  if (world == 1 && rc_local != KWY_OK) return rc_local;
   FIT_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const size_t nn = (size_t)n;
+  const size_t nn = (size_t)(n > 0 ? n : 0);
 
   DevBuf<double> resp, ll, stats, sxx, dmeans, dweights, dcovs, Xc, xsq, closest, newd, pots, csums, total, shift2;
   DevBuf<double> centers, centers_new, cand, vals, cs, meanv, owndist, gath, lohi, pack;
@@ -122,18 +135,23 @@ extern "C" int kwy_gmm_fit_comm_dev(kwy_ctx *ctx, const double *X, int64_t n, in
   DevBuf<int32_t> pick32, labels;
   DevBuf<unsigned long long> changed;
   DevBuf<int> status;
-  const size_t nchunks = (size_t)kwy_km_chunks(n);
-  const size_t nstats = (size_t)M * (D + 1);
-  FIT_HIP(resp.alloc(nn * M)); FIT_HIP(ll.alloc((nn + 255) / 256)); FIT_HIP(stats.alloc(nstats + 1));
-  FIT_HIP(sxx.alloc((size_t)M * D * D)); FIT_HIP(dmeans.alloc((size_t)M * D)); FIT_HIP(dweights.alloc(M));
-  FIT_HIP(dcovs.alloc((size_t)M * D * D)); FIT_HIP(Xc.alloc(nn * D)); FIT_HIP(xsq.alloc(nn)); FIT_HIP(closest.alloc(nn));
-  FIT_HIP(newd.alloc(8 * nn)); FIT_HIP(pots.alloc(8)); FIT_HIP(csums.alloc(nchunks)); FIT_HIP(total.alloc(1));
-  FIT_HIP(shift2.alloc(M)); FIT_HIP(centers.alloc((size_t)M * D)); FIT_HIP(centers_new.alloc((size_t)M * D));
-  FIT_HIP(cand.alloc(8 * (size_t)D)); FIT_HIP(vals.alloc(8)); FIT_HIP(cs.alloc(2 * (size_t)D)); FIT_HIP(meanv.alloc(D));
-  FIT_HIP(pick.alloc(8)); FIT_HIP(pick32.alloc(8)); FIT_HIP(labels.alloc(nn)); FIT_HIP(changed.alloc(1));
-  FIT_HIP(status.alloc(4)); FIT_HIP(gath.alloc((size_t)world + 2)); FIT_HIP(lohi.alloc(2));
-  FIT_HIP(hipMemsetAsync(status.p, 0, sizeof(int) * 4, st));
-  FIT_HIP(hipMemsetAsync(labels.p, 0xff, sizeof(int32_t) * nn, st));     // -1: every label "changes" in the first pass
+  const size_t nchunks = rc_local == KWY_OK ? (size_t)kwy_km_chunks(n) : 1;
+  const size_t nstats = (size_t)(M > 0 ? M : 1) * ((D > 0 ? D : 1) + 1);
+  FIT_HIP(gath.alloc((size_t)world + 2));           // (the buffer of the agreement itself: its failure is fatal)
+  auto setup = [&]() -> int {
+    FIT_HIP(resp.alloc(nn * M)); FIT_HIP(ll.alloc((nn + 255) / 256)); FIT_HIP(stats.alloc(nstats + 1));
+    FIT_HIP(sxx.alloc((size_t)M * D * D)); FIT_HIP(dmeans.alloc((size_t)M * D)); FIT_HIP(dweights.alloc(M));
+    FIT_HIP(dcovs.alloc((size_t)M * D * D)); FIT_HIP(Xc.alloc(nn * D)); FIT_HIP(xsq.alloc(nn)); FIT_HIP(closest.alloc(nn));
+    FIT_HIP(newd.alloc(8 * nn)); FIT_HIP(pots.alloc(8)); FIT_HIP(csums.alloc(nchunks)); FIT_HIP(total.alloc(1));
+    FIT_HIP(shift2.alloc(M)); FIT_HIP(centers.alloc((size_t)M * D)); FIT_HIP(centers_new.alloc((size_t)M * D));
+    FIT_HIP(cand.alloc(8 * (size_t)D)); FIT_HIP(vals.alloc(8)); FIT_HIP(cs.alloc(2 * (size_t)D)); FIT_HIP(meanv.alloc(D));
+    FIT_HIP(pick.alloc(8)); FIT_HIP(pick32.alloc(8)); FIT_HIP(labels.alloc(nn)); FIT_HIP(changed.alloc(1));
+    FIT_HIP(status.alloc(4)); FIT_HIP(lohi.alloc(2));
+    FIT_HIP(hipMemsetAsync(status.p, 0, sizeof(int) * 4, st));
+    FIT_HIP(hipMemsetAsync(labels.p, 0xff, sizeof(int32_t) * nn, st));     // -1: every label "changes" in the first pass
+    return KWY_OK;
+  };
+  if (rc_local == KWY_OK) rc_local = setup();
 
   auto d2h = [&](void *dst, const void *src, size_t bytes) -> int {
     FIT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
@@ -162,11 +180,22 @@ extern "C" int kwy_gmm_fit_comm_dev(kwy_ctx *ctx, const double *X, int64_t n, in
     return d2h(hgath.data(), gath.p, sizeof(double) * world);
   };
 
-  // ---------------------------------------------------------------- the rows of all ranks
+  // ---------------------------------------------------------------- the rows of all ranks, and whether all are ready
   {
-    const double mine = (double)n;
-    KWY_TRY(h2d(total.p, &mine, sizeof(double)));
-    KWY_TRY(all_gather(total.p));
+    // slot r: the rows of rank r; slot `world`: the number of ranks whose set-up failed
+    std::vector<double> mine((size_t)world + 1, 0.0);
+    mine[rank] = (double)(n > 0 ? n : 0);
+    mine[world] = rc_local != KWY_OK ? 1.0 : 0.0;
+    const std::string local_err = ctx->err;
+    KWY_TRY(h2d(gath.p, mine.data(), sizeof(double) * (world + 1)));
+    KWY_TRY(all_reduce(gath.p, (size_t)world + 1));
+    hgath.resize((size_t)world + 1);
+    KWY_TRY(d2h(hgath.data(), gath.p, sizeof(double) * (world + 1)));
+    if (hgath[world] > 0.0) {
+      if (rc_local != KWY_OK) { ctx->err = local_err; return rc_local; }
+      ctx->err = "gmm_fit: another rank failed its set-up (bad arguments, an empty shard or an allocation); no rank fits";
+      return KWY_EINVAL;
+    }
   }
   int64_t n_total = 0, row0 = 0;
   for (int r = 0; r < world; ++r) { const int64_t c = (int64_t)llround(hgath[r]); if (r < rank) row0 += c; n_total += c; }

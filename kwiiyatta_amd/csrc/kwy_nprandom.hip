@@ -74,6 +74,10 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_normal(np_state *__restrict_
   int r = 0;                          // words at the front of words[] that belong to the block before
   int64_t produced = 0;
   if (n <= 0) return;
+  if (base < 0) {                     // a poisoned state (k_np_advance): no draws, the poison stays
+    for (int64_t i = tid; i < n; i += KWY_THREADS) out[i] = __builtin_nan("");
+    return;
+  }
   if (st->has_gauss) {
     if (tid == 0) out[0] = emit(st->gauss);
     produced = 1;
@@ -309,7 +313,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_count(const np_state *__rest
   for (int j = 0; j < 4; ++j) {
     const int64_t a = (int64_t)blockIdx.x * NP_TILE + j * KWY_THREADS + threadIdx.x;
     double x1, x2, r2;
-    if (a < job.attempts && np_attempt(kbuf, pos, a, &x1, &x2, &r2)) ++c;
+    // (pos < 0: a poisoned state -- nothing is accepted, k_np_scan flags the shortage, k_np_emit writes NaN)
+    if (pos >= 0 && a < job.attempts && np_attempt(kbuf, pos, a, &x1, &x2, &r2)) ++c;
   }
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -348,6 +353,12 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_emit(np_state *__restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pos = st->pos;
   const int64_t first = info[0], need = info[1];
+  if (pos < 0) {      // poisoned by an earlier shortage: the outputs of this request are NaN, not stale or garbage pads
+    const int64_t stride = (int64_t)gridDim.x * KWY_THREADS;
+    for (int64_t o = (int64_t)blockIdx.x * KWY_THREADS + tid; o < job.n; o += stride)
+      job.outs[o / job.n_each][o % job.n_each] = __builtin_nan("");
+    return;
+  }
   const int64_t tile_base = (int64_t)((const uint64_t *)(info + 8))[blockIdx.x];
   if (tile_base >= need) return;
   double x1[4], x2[4], r2[4];
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_np_advance(np_state *__restrict
   // a shortage of attempts (the layout's margin is ~14 standard deviations): outputs are missing.  The state is
   // poisoned (pos = -1: no numpy state has it) so that whoever reads it back learns of it instead of a silent
   // divergence from numpy's stream.
-  if (info[3] != 0) { if (threadIdx.x == 0) { atomicExch(status, 1); st->pos = -1; } return; }
+  if (info[3] != 0 || st->pos < 0) { if (threadIdx.x == 0) { atomicExch(status, 1); st->pos = -1; } return; }
   const int64_t last = info[2];
   if (last < 0) return;                                  // nothing but the cached value was needed
   const int64_t g_last = (int64_t)st->pos + 4 * last + 3;    // stream index of the last word consumed

@@ -203,7 +203,7 @@ def test_finish_on_synthesised_speech():
     from kwiiyatta_amd import _lib
     a = k.analyze_wav(CLB_WAV)
     feat = k.feature(a)
-    wav = feat.synthesize(normalize=False)
+    wav = feat.Synthesizer.synthesize(feat, normalize=False)
     ctx = _lib.Context(0)
     got = _device_pcm(ctx, [np.ascontiguousarray(wav.data)], [feat.frame_len], wav.fs)[0]
     exp = _host_pcm(np.ascontiguousarray(wav.data), feat.frame_len, wav.fs)
