@@ -405,6 +405,22 @@ int kwy_mlsa_synthesis(kwy_ctx *ctx, const double *x, int64_t n, const double *b
                        double alpha, int pd, int hopsize, double *y);
 int kwy_mlsa_synthesis_dev(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int order,
                            double alpha, int pd, int hopsize, double *y);
+/* kwiiyatta.apply_mlsa_filter for a batch of signals (device pointers, not synchronised): what convert_voice.py writes
+ * as <name>.diff.wav for every file (kwiiyatta/convert_voice.py:19,39-40; filter/mlsa.py:9-30) -- pysptk.mc2b of the
+ * job's mel-cepstra (ignore_c0 != 0: with c0 taken as zero, filter/mlsa.py's `mcep.data[:, 0] = 0`), then the MLSA
+ * filter over the waveform, one wavefront per signal and all signals of the batch side by side in one launch (the
+ * recursion is serial in the sample: N signals occupy N compute units).  Every job's output equals kwy_mc2b_dev +
+ * kwy_mlsa_synthesis_dev bit for bit. */
+typedef struct kwy_mlsa_job {
+  const double *x;      /* x_length samples in */
+  int64_t x_length;
+  const double *mc;     /* T x (order + 1) mel-cepstra */
+  int64_t T;
+  double *y;            /* x_length samples out */
+} kwy_mlsa_job;
+int kwy_mlsa_filter_batch_dev(kwy_ctx *ctx, const kwy_mlsa_job *jobs, int count, int order, double alpha, int pd,
+                              int hopsize, int ignore_c0);
+
 
 /* ---- converter fit: EM building blocks --------------------------------------------------------
  * sklearn.mixture.GaussianMixture(covariance_type='full').fit as used at

@@ -159,6 +159,7 @@ SIGNATURES = {
     'kwy_mc2b_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_dbl, c_vp]),
     'kwy_mlsa_synthesis': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),
     'kwy_mlsa_synthesis_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_int, c_vp]),
+    'kwy_mlsa_filter_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_int, c_int, c_int]),
     'kwy_gmm_prepare_dev': (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_gmm_mlpg_model_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     'kwy_convert_mcep_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
@@ -230,6 +231,8 @@ TrainJob = _job_struct('TrainJob', 'kwy_train_job',
                         ('x_length', c_i64), ('y_length', c_i64), ('n_rows', c_vp)])
 F0Job = _job_struct('F0Job', 'kwy_f0_job: the DIO f0 track of one utterance',
                    [('x', c_vp), ('x_length', c_i64), ('temporal_positions', c_vp), ('f0', c_vp), ('status', c_vp)])
+MlsaJob = _job_struct('MlsaJob', 'kwy_mlsa_job: one signal through the MLSA filter of its mel-cepstra',
+                      [('x', c_vp), ('x_length', c_i64), ('mc', c_vp), ('T', c_i64), ('y', c_vp)])
 FinishJob = _job_struct('FinishJob', 'kwy_finish_job: post-step + 16-bit PCM of one synthesised waveform',
                         [('y', c_vp), ('y_length', c_i64), ('frame_len', c_i64), ('pcm', c_vp)])
 SynthPlanJob = _job_struct('SynthPlanJob', 'kwy_synth_plan_job: the pulse placement of one utterance',

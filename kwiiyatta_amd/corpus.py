@@ -441,10 +441,14 @@ class ConvertWave:
     Analyzer.extract_f0, /root/reference/kwiiyatta/vocoder/world.py:33-41) -- and `f0_status` holds one word per
     utterance to read back (non-zero: DIO's zero-crossing buffer overflowed).  pcm=True: the post-step and the 16-bit
     samples on the device as well (kwy_finish_pcm16_batch_dev: vocoder/abc/synthesizer.py:11-20, wavfile.py:8-29):
-    `pcm[i]` int16 views, 2 bytes per sample to download."""
+    `pcm[i]` int16 views, 2 bytes per sample to download.  diff=True (with a GMM): also the DIFFERENTIAL output of
+    every file -- the input waveform through the MLSA filter of the differential conversion, convert(diffvc=True),
+    /root/reference/kwiiyatta/convert_voice.py:19,39-40, filter/mlsa.py:9-30 -- as `wave_diff[i]` (and `pcm_diff[i]`:
+    Wavdata.save's normalisation only, a filtered waveform has no synthesis post-step)."""
 
-    def __init__(self, ls, fs, utterances, gmm=None, order=24, frame_period=5.0, pcm=False):
+    def __init__(self, ls, fs, utterances, gmm=None, order=24, frame_period=5.0, pcm=False, diff=False):
         self.ls, self.fs, self.order, self.frame_period = ls, int(fs), int(order), float(frame_period)
+        self.diff = bool(diff) and gmm is not None
         self.wav_in = len(utterances) > 0 and not isinstance(utterances[0], (tuple, list))
         dev = ls.dev
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
@@ -500,6 +504,23 @@ class ConvertWave:
                 self.j_conv = _lib.job_array(_lib.ConvertJob, [(cut(self.mc, off, i), self.T[i], cut(self.mc_conv, off, i))
                                                                for i in range(n)])
                 sp = [cut(self.sp_conv, off, i) for i in range(n)]
+            if self.diff:
+                self.model_diff = gmm.model(diff=True)
+                self.mc_diff = torch.empty((self.rows, order + 1), **f64)
+                self.j_conv_diff = _lib.job_array(_lib.ConvertJob, [(cut(self.mc, off, i), self.T[i], cut(self.mc_diff, off, i))
+                                                                    for i in range(n)])
+                xo = np.concatenate(([0], np.cumsum([v.numel() for v in self.x]))).astype(np.int64)
+                self.wave_diff_all = torch.empty(int(xo[-1]), **f64)
+                self.wave_diff = [cut(self.wave_diff_all, xo, i) for i in range(n)]
+                self.j_mlsa = _lib.job_array(_lib.MlsaJob, [(self.x[i], self.x[i].numel(), cut(self.mc_diff, off, i), self.T[i],
+                                                            self.wave_diff[i]) for i in range(n)])
+                self.hop = int(self.fs * (self.frame_period * 0.001))
+                self.pcm_diff = None
+                if pcm:
+                    self.pcm_diff_all = torch.zeros(int(xo[-1]), dtype=torch.int16, device=dev)
+                    self.pcm_diff = [cut(self.pcm_diff_all, xo, i) for i in range(n)]
+                    self.j_fin_diff = _lib.job_array(_lib.FinishJob, [(self.wave_diff[i], self.x[i].numel(), 0, self.pcm_diff[i])
+                                                                      for i in range(n)])
             self.j_render = _lib.synth_job_array([(self.plan[i], sp[i], ap[i], self.wave[i]) for i in range(n)])
         self.frames = int(sum(self.T))
 
@@ -525,22 +546,32 @@ class ConvertWave:
                 chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), self.rows, order, self.alpha, fft, _p(self.sp_conv)))
             ls.main.wait_stream(ls.side)
             chk(lib.kwy_synth_render_batch_dev(h, self.j_render, n, fft, self.frame_period, fs, float(fs)))
+            from .pipeline import PIECE_CEILING
             if self.pcm is not None:
-                from .pipeline import PIECE_CEILING
                 chk(lib.kwy_finish_pcm16_batch_dev(h, self.j_fin, n, fs, 1, PIECE_CEILING, 1, PIECE_CEILING))
+            if self.diff:
+                # the differential conversion of the same mel-cepstra, its filter over the INPUT waveforms: all
+                # utterances' recursions side by side (one wavefront each)
+                chk(lib.kwy_convert_mcep_batch_dev(h, self.j_conv_diff, n, order, self.gmm.M, _p(self.model_diff)))
+                chk(lib.kwy_mlsa_filter_batch_dev(h, self.j_mlsa, n, order, self.alpha, 4, self.hop, 1))
+                if self.pcm_diff is not None:
+                    chk(lib.kwy_finish_pcm16_batch_dev(h, self.j_fin_diff, n, fs, 0, PIECE_CEILING, 1, PIECE_CEILING))
 
 
-def _lockstep_batch(utterances, fs, device_index, gmm, order, frame_period, ls, keep, wave_size=16, pcm=False):
+def _lockstep_batch(utterances, fs, device_index, gmm, order, frame_period, ls, keep, wave_size=16, pcm=False, diff=False):
     """utterances in waves of `wave_size` through ConvertWave; keep(i, waveform view[, pcm view]) on the main stream.
     Bare waveforms get their f0 on the device; the DIO status words of all waves are read back ONCE at the end."""
     ls = ls if ls is not None else _Lockstep(device_index)
     held, status = [], []
     for w0 in range(0, len(utterances), wave_size):
-        wv = ConvertWave(ls, fs, utterances[w0:w0 + wave_size], gmm=gmm, order=order, frame_period=frame_period, pcm=pcm)
+        wv = ConvertWave(ls, fs, utterances[w0:w0 + wave_size], gmm=gmm, order=order, frame_period=frame_period, pcm=pcm,
+                         diff=diff)
         wv.run()
         with torch.cuda.stream(ls.main):
             for i in range(wv.n):
-                if pcm:
+                if diff:
+                    keep(w0 + i, wv.wave[i], wv.pcm[i] if pcm else None, wv.wave_diff[i], wv.pcm_diff[i] if pcm else None)
+                elif pcm:
                     keep(w0 + i, wv.wave[i], wv.pcm[i])
                 else:
                     keep(w0 + i, wv.wave[i])
@@ -880,10 +911,12 @@ def _stream_batch(make_pipeline, utterances, pool, shapes_per_stream, keep):
 
 
 def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.0, streams=16, pool=None,
-                  shapes_per_stream=4, driver=None, lockstep=None, pcm=False):
+                  shapes_per_stream=4, driver=None, lockstep=None, pcm=False, diff=False):
     """Convert this rank's utterances with the fitted mixture: list of waveforms (device tensors).
     Lockstep driver only: an utterance may be a bare waveform (its f0 is then extracted on the device), and pcm=True
-    returns (waveforms, int16 tensors of the post-processed samples) -- wav in, 16-bit PCM out without the host.
+    returns (waveforms, int16 tensors of the post-processed samples) -- wav in, 16-bit PCM out without the host;
+    diff=True appends the differential outputs (the inputs through the MLSA filter of the differential conversion,
+    convert_voice.py's .diff.wav): (waveforms, pcm or None, diff waveforms, diff pcm or None).
     driver='lockstep' (default): waves of 16 utterances through the batched entries on two streams (`ConvertWave`);
     'streams': round 3's utterance-per-stream driver, see `_stream_batch` for its scheduling."""
     dev = torch.device('cuda', device_index)
@@ -891,13 +924,15 @@ def convert_batch(utterances, fs, gmm, device_index=0, order=24, frame_period=5.
     out = [None] * len(utterances)
     driver = driver or ('streams' if pool is not None else 'lockstep')     # (a caller's pool asks for the stream driver)
     if driver == 'lockstep':
-        pcms = [None] * len(utterances)
+        pcms, dwav, dpcm = ([None] * len(utterances) for _ in range(3))
 
-        def keep_view(i, w, p=None):
-            out[i], pcms[i] = w, p         # (views of their wave's blocks, which live as long as the views)
-        _lockstep_batch(utterances, fs, device_index, dg, order, frame_period, lockstep, keep_view, pcm=pcm)
+        def keep_view(i, w, p=None, wd=None, pd=None):
+            out[i], pcms[i], dwav[i], dpcm[i] = w, p, wd, pd      # (views of their wave's blocks, which live as long as the views)
+        _lockstep_batch(utterances, fs, device_index, dg, order, frame_period, lockstep, keep_view, pcm=pcm, diff=diff)
+        if diff:
+            return out, (pcms if pcm else None), dwav, (dpcm if pcm else None)
         return (out, pcms) if pcm else out
-    if pcm or (len(utterances) and not isinstance(utterances[0], (tuple, list))):
+    if pcm or diff or (len(utterances) and not isinstance(utterances[0], (tuple, list))):
         raise ValueError('convert_batch: wav-in utterances and pcm=True need the lockstep driver')
     if pool is None:
         pool = StreamPool(device_index, streams)

@@ -30,24 +30,43 @@ __constant__ double c_pade[21] = {1.0,
                                   1.0, 0.4999273, 0.1067005, 0.01170221, 0.0005656279,
                                   1.0, 0.4999391, 0.1107098, 0.01369984, 0.0009564853, 0.00003041721};
 
-// b[m] = c[m]; b[i] = c[i] - a b[i+1]   (pysptk.mc2b, one thread per frame)
-__global__ void k_mc2b(const double *__restrict__ mc, int64_t T, int m, double a, double *__restrict__ b) {
+// One signal of a launch: the jobs travel by value in the kernel arguments (capturable, no descriptor in memory).
+#define MLSA_JOBS_MAX 64
+struct mlsa_job {
+  const double *x;    // n samples in
+  const double *mc;   // T x (m + 1): mel-cepstra (k_mc2b) -- or the filter coefficients b themselves (k_mlsa_filter)
+  double *b;          // T x (m + 1): filter coefficients (k_mc2b's output)
+  double *y;          // n samples out
+  int64_t n, T;
+};
+struct mlsa_jobs {
+  int count;
+  mlsa_job j[MLSA_JOBS_MAX];
+};
+
+// b[m] = c[m]; b[i] = c[i] - a b[i+1]   (pysptk.mc2b, one thread per frame); zero_c0: c[0] is taken as 0
+// (apply_mlsa_filter's `mcep.data[:, 0] = 0`: the filter changes the envelope's shape, not its power)
+__global__ void k_mc2b(mlsa_jobs J, int m, double a, int zero_c0) {
+  const mlsa_job q = J.j[blockIdx.y];
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
-  const double *c = mc + t * (m + 1);
-  double *o = b + t * (m + 1);
+  if (t >= q.T) return;
+  const double *c = q.mc + t * (m + 1);
+  double *o = q.b + t * (m + 1);
   double nxt = c[m];
   o[m] = nxt;
-  for (int i = m - 1; i >= 0; --i) { nxt = c[i] - a * nxt; o[i] = nxt; }
+  for (int i = m - 1; i >= 0; --i) { nxt = ((i == 0 && zero_c0) ? 0.0 : c[i]) - a * nxt; o[i] = nxt; }
 }
 
 // NB = number of 8-link blocks of the all-pass chain (links i = 2 .. 8 NB + 1 >= m; the coefficients
 // of the links behind m are zero).  The chain state lives in registers: the loops over links are
 // unrolled, SPTK's shift d[i] = d[i-1] becomes the register the new value is written to.
+// One wavefront (workgroup) per signal of the launch.
 template <int NB, int PD>
-__global__ __launch_bounds__(64) void k_mlsa_filter(const double *__restrict__ x, int64_t n,
-                                                   const double *__restrict__ b, int64_t T, int m, double a,
-                                                   int hop, double *__restrict__ y) {
+__global__ __launch_bounds__(64) void k_mlsa_filter(mlsa_jobs J, int m, double a, int hop) {
+  const double *__restrict__ x = J.j[blockIdx.x].x;
+  const double *__restrict__ b = J.j[blockIdx.x].b;
+  double *__restrict__ y = J.j[blockIdx.x].y;
+  const int64_t n = J.j[blockIdx.x].n, T = J.j[blockIdx.x].T;
   constexpr int pd = PD;
   constexpr int ML = 8 * NB;
   extern __shared__ double sm[];
@@ -176,38 +195,48 @@ static int mlsa_check(kwy_ctx *ctx, const void *x, int64_t n, const void *b, int
 }
 
 template <int NB>
-static int mlsa_launch(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int m, double a,
-                       int pd, int hop, double *y) {
+static int mlsa_launch(kwy_ctx *ctx, const mlsa_jobs &J, int m, double a, int pd, int hop) {
   const size_t lds = sizeof(double) * (2 * 72 + 2 * hop);
-  void (*kern)(const double *, int64_t, const double *, int64_t, int, double, int, double *) =
-      (pd == 4) ? k_mlsa_filter<NB, 4> : k_mlsa_filter<NB, 5>;
+  void (*kern)(mlsa_jobs, int, double, int) = (pd == 4) ? k_mlsa_filter<NB, 4> : k_mlsa_filter<NB, 5>;
   KWY_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_mlsa_filter", hipLaunchKernelGGL(kern, dim3(1), dim3(64), lds, ctx->stream, x, n, b, T, m, a, hop, y));
+  KWY_PROF(ctx, "k_mlsa_filter", hipLaunchKernelGGL(kern, dim3(J.count), dim3(64), lds, ctx->stream, J, m, a, hop));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
 
-static int mlsa_core(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int m, double a,
-                     int pd, int hop, double *y) {
+// the filters of J.count signals (J.j[].b: their coefficients), one workgroup each
+static int mlsa_core(kwy_ctx *ctx, const mlsa_jobs &J, int m, double a, int pd, int hop) {
   switch ((m - 1 + 7) / 8) {   // links 2..m in blocks of 8
-    case 1: return mlsa_launch<1>(ctx, x, n, b, T, m, a, pd, hop, y);
-    case 2: return mlsa_launch<2>(ctx, x, n, b, T, m, a, pd, hop, y);
-    case 3: return mlsa_launch<3>(ctx, x, n, b, T, m, a, pd, hop, y);
-    case 4: return mlsa_launch<4>(ctx, x, n, b, T, m, a, pd, hop, y);
-    case 5: return mlsa_launch<5>(ctx, x, n, b, T, m, a, pd, hop, y);
-    case 6: return mlsa_launch<6>(ctx, x, n, b, T, m, a, pd, hop, y);
-    case 7: return mlsa_launch<7>(ctx, x, n, b, T, m, a, pd, hop, y);
-    default: return mlsa_launch<8>(ctx, x, n, b, T, m, a, pd, hop, y);
+    case 1: return mlsa_launch<1>(ctx, J, m, a, pd, hop);
+    case 2: return mlsa_launch<2>(ctx, J, m, a, pd, hop);
+    case 3: return mlsa_launch<3>(ctx, J, m, a, pd, hop);
+    case 4: return mlsa_launch<4>(ctx, J, m, a, pd, hop);
+    case 5: return mlsa_launch<5>(ctx, J, m, a, pd, hop);
+    case 6: return mlsa_launch<6>(ctx, J, m, a, pd, hop);
+    case 7: return mlsa_launch<7>(ctx, J, m, a, pd, hop);
+    default: return mlsa_launch<8>(ctx, J, m, a, pd, hop);
   }
+}
+
+static mlsa_jobs mlsa_one(const double *x, int64_t n, const double *mc, double *b, int64_t T, double *y) {
+  mlsa_jobs J;
+  J.count = 1;
+  J.j[0] = mlsa_job{x, mc, b, y, n, T};
+  return J;
+}
+
+static int mc2b_launch(kwy_ctx *ctx, const mlsa_jobs &J, int64_t T_max, int order, double alpha, int zero_c0) {
+  hipLaunchKernelGGL(k_mc2b, dim3((unsigned)((T_max + 255) / 256), J.count), dim3(256), 0, ctx->stream, J, order, alpha,
+                     zero_c0);
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
 }
 
 extern "C" int kwy_mc2b_dev(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, double *b) {
   if (!ctx) return KWY_EINVAL;
   if (!mc || !b || T <= 0 || order < 1) { ctx->err = "mc2b: bad argument"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_mc2b, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, mc, T, order, alpha, b);
-  KWY_HIP(hipGetLastError());
-  return KWY_OK;
+  return mc2b_launch(ctx, mlsa_one(nullptr, 0, mc, b, T, nullptr), T, order, alpha, 0);
 }
 
 extern "C" int kwy_mc2b(kwy_ctx *ctx, const double *mc, int64_t T, int order, double alpha, double *b) {
@@ -228,7 +257,39 @@ extern "C" int kwy_mlsa_synthesis_dev(kwy_ctx *ctx, const double *x, int64_t n, 
                                       int order, double alpha, int pd, int hopsize, double *y) {
   KWY_TRY(mlsa_check(ctx, x, n, b, T, order, alpha, pd, hopsize, y));
   KWY_HIP(hipSetDevice(ctx->device));
-  return mlsa_core(ctx, x, n, b, T, order, alpha, pd, hopsize, y);
+  return mlsa_core(ctx, mlsa_one(x, n, nullptr, (double *)b, T, y), order, alpha, pd, hopsize);
+}
+
+// apply_mlsa_filter for a batch of signals (device pointers, not synchronised): mc2b of every job's mel-cepstra
+// (ignore_c0: with c0 taken as zero) into the context's scratch, then the filters, one wavefront per signal,
+// <= MLSA_JOBS_MAX signals per launch.  Every job equals kwy_mc2b_dev + kwy_mlsa_synthesis_dev bit for bit.
+extern "C" int kwy_mlsa_filter_batch_dev(kwy_ctx *ctx, const kwy_mlsa_job *jobs, int count, int order, double alpha,
+                                         int pd, int hopsize, int ignore_c0) {
+  if (!ctx) return KWY_EINVAL;
+  if (!jobs || count < 1) { ctx->err = "mlsa_filter_batch: bad argument"; return KWY_EINVAL; }
+  size_t need = 0;
+  for (int i = 0; i < count; ++i) {
+    const kwy_mlsa_job &q = jobs[i];
+    KWY_TRY(mlsa_check(ctx, q.x, q.x_length, q.mc, q.T, order, alpha, pd, hopsize, q.y));
+    need += kwy_pad(sizeof(double) * (size_t)q.T * (order + 1));
+  }
+  KWY_HIP(hipSetDevice(ctx->device));
+  KWY_TRY(kwy_arena_begin(ctx, need));
+  for (int i0 = 0; i0 < count; i0 += MLSA_JOBS_MAX) {
+    mlsa_jobs J;
+    J.count = count - i0 < MLSA_JOBS_MAX ? count - i0 : MLSA_JOBS_MAX;
+    int64_t T_max = 0;
+    for (int u = 0; u < J.count; ++u) {
+      const kwy_mlsa_job &q = jobs[i0 + u];
+      double *b = kwy_arena<double>(ctx, (size_t)q.T * (order + 1));
+      if (!b) { ctx->err = "mlsa_filter_batch: scratch arena too small"; return KWY_ENOMEM; }
+      J.j[u] = mlsa_job{q.x, q.mc, b, q.y, q.x_length, q.T};
+      T_max = q.T > T_max ? q.T : T_max;
+    }
+    KWY_TRY(mc2b_launch(ctx, J, T_max, order, alpha, ignore_c0 ? 1 : 0));
+    KWY_TRY(mlsa_core(ctx, J, order, alpha, pd, hopsize));
+  }
+  return KWY_OK;
 }
 
 extern "C" int kwy_mlsa_synthesis(kwy_ctx *ctx, const double *x, int64_t n, const double *b, int64_t T, int order,
@@ -241,7 +302,7 @@ extern "C" int kwy_mlsa_synthesis(kwy_ctx *ctx, const double *x, int64_t n, cons
   double *db = kwy_arena<double>(ctx, (size_t)T * (order + 1));
   KWY_HIP(hipMemcpyAsync(dx, x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
   KWY_HIP(hipMemcpyAsync(db, b, sizeof(double) * T * (order + 1), hipMemcpyHostToDevice, ctx->stream));
-  KWY_TRY(mlsa_core(ctx, dx, n, db, T, order, alpha, pd, hopsize, dy));
+  KWY_TRY(mlsa_core(ctx, mlsa_one(dx, n, nullptr, db, T, dy), order, alpha, pd, hopsize));
   KWY_HIP(hipMemcpyAsync(y, dy, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
   KWY_HIP(hipStreamSynchronize(ctx->stream));
   return KWY_OK;

@@ -527,28 +527,27 @@ class PairBatchPipeline(_Graphed):
                 pads = self.rng.record_event()
             elif self.rng is not None and self.rng_place == 'head':
                 self.rng.abs_normal_blocks(EPS / fs, self.pad_rows, ctx=self.ctx)
+            if self.wav_in:
+                # The f0 tracks of ALL waves first, on the origin stream, then the fork.  (With the extraction at the
+                # head of every wave's own stream -- forks of the graph at two different depths -- hipStreamEndCapture
+                # crashed on ROCm 7.2 as soon as there were two waves, whatever ran on the second one:
+                # scratch/capture_probe2.py.  The kernels are chip-wide anyway.)
+                c0 = self.waves[0].ctx
+                for wv in self.waves:
+                    _lib.check(c0, lib.kwy_dio_batch_dev(c0.handle, wv.j_dio, 2 * wv.n, fs, 71.0, 800.0, 2.0,
+                                                         self.frame_period, 1, 0.1))
+                    _lib.check(c0, lib.kwy_stonemask_batch_dev(c0.handle, wv.j_sm, 2 * wv.n, fs))
             for wv in self.waves:
                 if wv.stream is not origin:
                     wv.stream.wait_stream(origin)
                 wv.side.wait_stream(origin)
         for wv in self.waves:
             h, hs, n = wv.ctx.handle, wv.side_ctx.handle, wv.n
-            f0_done = None
-            if self.wav_in:
-                with torch.cuda.stream(wv.stream):
-                    _lib.check(wv.ctx, lib.kwy_dio_batch_dev(h, wv.j_dio, 2 * n, fs, 71.0, 800.0, 2.0, self.frame_period,
-                                                             1, 0.1))
-                    _lib.check(wv.ctx, lib.kwy_stonemask_batch_dev(h, wv.j_sm, 2 * n, fs))
-                    if wv.side is not wv.stream:
-                        f0_done = torch.cuda.Event()
-                        f0_done.record(wv.stream)
             with torch.cuda.stream(wv.side):
                 if self.rng is not None and self.rng_place == 'side' and wv is self.waves[0]:
                     self.rng.abs_normal_blocks(EPS / fs, self.pad_rows, ctx=wv.side_ctx)
                     pads = torch.cuda.Event()
                     pads.record(wv.side)
-                if f0_done is not None:
-                    wv.side.wait_event(f0_done)
                 _lib.check(wv.side_ctx, lib.kwy_d4c_batch_dev(hs, wv.j_ap, 2 * n, fs, 0.85, fft))
                 ap_done = torch.cuda.Event()
                 ap_done.record(wv.side)

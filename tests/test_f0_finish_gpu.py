@@ -236,3 +236,115 @@ def test_convert_batch_wav_in_pcm_out():
         assert np.array_equal(a, b), i
         assert np.isfinite(a).all() and np.abs(a).max() > 1e-3
         assert np.array_equal(p.cpu().numpy(), _host_pcm(a, len(triples[i][1]), fs)), i
+
+
+def test_mlsa_filter_batch_equals_single_calls():
+    """kwy_mlsa_filter_batch_dev (one wavefront per signal, all signals of a launch side by side; more jobs than one
+    launch holds) == kwy_mc2b_dev + kwy_mlsa_synthesis_dev per signal, bit for bit; with and without c0"""
+    import torch
+    from kwiiyatta_amd import _lib
+    from kwiiyatta_amd._lib import lib, c_vp
+    rng = np.random.default_rng(3)
+    order, alpha, hop, pd = 24, 0.55, 240, 4
+    ctx = _lib.Context(0)
+    jobs, single = [], []
+    keep = []
+    for i in range(70):
+        T = int(rng.integers(3, 60))
+        n = T * hop + int(rng.integers(-hop + 1, hop))
+        x = _dev(rng.standard_normal(n) * 0.3)
+        mc = _dev(rng.standard_normal((T, order + 1)) * 0.05)
+        y = torch.full((n,), 9.0, dtype=torch.float64, device='cuda')
+        keep.append((x, mc, y))
+        jobs.append((x, n, mc, T, y))
+    for ignore in (1, 0):
+        arr = _lib.job_array(_lib.MlsaJob, jobs)
+        _lib.check(ctx, lib.kwy_mlsa_filter_batch_dev(ctx.handle, arr, len(jobs), order, alpha, pd, hop, ignore))
+        ctx.sync()
+        for x, n, mc, T, y in jobs[::7]:
+            m2 = mc.clone()
+            if ignore:
+                m2[:, 0] = 0.0
+            b = torch.empty_like(m2)
+            y1 = torch.empty_like(y)
+            _lib.check(ctx, lib.kwy_mc2b_dev(ctx.handle, c_vp(m2.data_ptr()), T, order, alpha, c_vp(b.data_ptr())))
+            _lib.check(ctx, lib.kwy_mlsa_synthesis_dev(ctx.handle, c_vp(x.data_ptr()), n, c_vp(b.data_ptr()), T, order, alpha,
+                                                       pd, hop, c_vp(y1.data_ptr())))
+            ctx.sync()
+            assert torch.equal(y, y1)
+            assert bool(torch.isfinite(y).all())
+
+
+def test_convert_batch_diff_outputs():
+    """corpus.convert_batch(diff=True): the differential output of every file equals apply_mlsa_filter of the
+    differential conversion through the Python API's stages (same kernels, single calls) bit for bit, and its int16
+    samples equal Wavdata.save's"""
+    import torch
+    import kwiiyatta_amd as k
+    from kwiiyatta_amd import _lib, corpus, pipeline as pl
+    from kwiiyatta_amd._lib import lib, c_vp
+    an = [k.analyze_wav(p) for p in (CLB_WAV, SLT_WAV, CLB_WAV2)]
+    fs = an[0].fs
+    waves_in = [np.ascontiguousarray(a.wavdata.data) for a in an]
+    gmm = pl.synthetic_gmm(order=24, components=4, seed=2, n_frames=4000)
+    wav, pcm, dwav, dpcm = corpus.convert_batch(waves_in, fs, gmm, pcm=True, diff=True)
+    assert all(w is not None for w in wav) and all(p.dtype == torch.int16 for p in pcm)
+    dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, 'cuda:0')
+    ctx = _lib.Context(0)
+    for i, a in enumerate(an):
+        mc = torch.from_numpy(np.ascontiguousarray(a.mel_cepstrum.data)).cuda()
+        out = torch.empty_like(mc)
+        _lib.check(ctx, lib.kwy_convert_mcep_dev(ctx.handle, c_vp(mc.data_ptr()), len(mc), 24, dg.M,
+                                                 c_vp(dg.model(diff=True).data_ptr()), c_vp(out.data_ptr())))
+        ctx.sync()
+        rec = k.feature(a).mel_cepstrum
+        rec.data = out.cpu().numpy()
+        ref = k.apply_mlsa_filter(a.wavdata, rec)
+        got = dwav[i].cpu().numpy()
+        assert got.shape == ref.data.shape
+        assert np.abs(got - ref.data).max() <= 1e-12 * max(1.0, np.abs(ref.data).max())
+        assert np.array_equal(dpcm[i].cpu().numpy(), k.Wavdata(fs, got.copy())._pcm16(True, {}))
+
+
+def test_lockstep_pairs_wav_in_pcm_out_and_its_graph():
+    """PairBatchPipeline(wav_in=True, pcm=True), two waves: the f0 tracks extracted inside the step are the host
+    entries', every waveform equals the pipeline that is GIVEN those tracks bit for bit, the int16 samples equal the
+    host post-step of those waveforms, and the captured step (one HIP graph over four streams) replays to the same
+    samples."""
+    import torch
+    from kwiiyatta_amd import pipeline as pl
+    from kwiiyatta_amd.backend import world
+    from kwiiyatta_amd.synthetic import make_utterance
+    fs = 48000
+    raw = [(make_utterance(seed=20 + 2 * i, fs=fs, seconds=1.0 + 0.1 * i)[0],
+            make_utterance(seed=21 + 2 * i, fs=fs, seconds=1.2 + 0.05 * i, time_warp=1.1, formant_scale=1.1)[0]) for i in range(5)]
+    gmm = pl.synthetic_gmm(order=24, components=4, seed=0, n_frames=3000)
+    dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
+    rng = np.random.default_rng(0)
+    K = 1025
+    silence = [np.abs(rng.normal(0, pl.EPS / fs, (pl.PAD_LEN, K))) for _ in range(4 * len(raw))]
+    pw = pl.PairBatchPipeline(0, fs, raw, dg, waves=2, silence=silence, wav_in=True, pcm=True)
+    pw.run(); pw.sync()
+    assert not pw.f0_status().any()
+
+    def track(x):
+        f0c, t = world.dio(x, fs)
+        return (x, world.stonemask(x, f0c, t, fs), t)
+    given = [(track(a), track(b)) for a, b in raw]
+    wv0 = pw.waves[0]
+    assert np.array_equal(wv0.f0[0].cpu().numpy(), given[0][0][1]) and np.array_equal(wv0.t[1].cpu().numpy(), given[0][1][2])
+    pg = pl.PairBatchPipeline(0, fs, given, dg, waves=2, silence=silence)
+    pg.run(); pg.sync()
+    first = []
+    for k in range(len(raw)):
+        a, b = pw.wave(k).cpu().numpy(), pg.wave(k).cpu().numpy()
+        assert np.array_equal(a, b), k
+        pcm = pw.pcm16(k).cpu().numpy()
+        assert np.array_equal(pcm, _host_pcm(a, len(given[k][1][1]), fs)), k
+        first.append(pcm)
+    pw.capture()
+    for k in range(len(raw)):
+        pw.pcm16(k).zero_()
+    pw.replay(); pw.sync()
+    for k in range(len(raw)):
+        assert np.array_equal(pw.pcm16(k).cpu().numpy(), first[k]), k

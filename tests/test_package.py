@@ -325,14 +325,21 @@ def test_cli_converter_model_and_batch(kwiiyatta, request, tmp_path):
             fb, b = sio.read(tmp_path / 'b' / f'{name}.{kind}.wav')
             assert fa == fb and np.array_equal(a, b), (name, kind)
     if request.node.callspec.params['kwiiyatta'] == 'hip':
-        _run_cli(cv.main, ['--result-dir', str(tmp_path / 'c'), '--converter-model', str(model), '--batch',
+        # the batch path: wav in -> 16-bit PCM out on the device, both outputs of every file
+        _run_cli(cv.main, ['--result-dir', str(tmp_path / 'c'), '--converter-model', str(model), '--batch'] + inputs)
+        for name in ('arctic_a0008', 'arctic_a0009'):
+            for kind in ('synth', 'diff'):
+                _, a = sio.read(tmp_path / 'a' / f'{name}.{kind}.wav')
+                _, c = sio.read(tmp_path / 'c' / f'{name}.{kind}.wav')
+                assert a.shape == c.shape and c.dtype == np.int16
+                assert np.abs(a.astype(np.int64) - c.astype(np.int64)).max() <= 1, (name, kind)      # 16-bit samples
+        _run_cli(cv.main, ['--result-dir', str(tmp_path / 'd'), '--converter-model', str(model), '--batch',
                            '--no-diffvc'] + inputs)
         for name in ('arctic_a0008', 'arctic_a0009'):
-            _, a = sio.read(tmp_path / 'a' / f'{name}.synth.wav')
             _, c = sio.read(tmp_path / 'c' / f'{name}.synth.wav')
-            assert a.shape == c.shape
-            assert np.abs(a.astype(np.int64) - c.astype(np.int64)).max() <= 1, name      # 16-bit samples
-        assert not (tmp_path / 'c' / 'arctic_a0009.diff.wav').exists()
+            _, d = sio.read(tmp_path / 'd' / f'{name}.synth.wav')
+            assert np.array_equal(c, d)
+        assert not (tmp_path / 'd' / 'arctic_a0009.diff.wav').exists()
 
 
 def test_converter_stack_checks(kwiiyatta):
