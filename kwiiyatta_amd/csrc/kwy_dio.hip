@@ -61,7 +61,7 @@ struct dio_plan {
   const kwy_c *G;                           // [nbands][DIO_H + 1]: filter spectra / N, band delays equalised
   char *scratch;
   int64_t stride;
-  int64_t off_part, off_filt, off_cnt, off_nedges, off_fine, off_cand, off_score, off_w1, off_w2, off_idx;
+  int64_t off_part, off_filt, off_cnt, off_nedges, off_fine, off_cand, off_score, off_w1, off_w2, off_idx, off_trans;
   dio_utt u[KWY_BATCH_MAX];
   template <class T>
   __device__ __forceinline__ T *at(int utt, int64_t off) const { return (T *)(scratch + utt * stride + off); }
@@ -163,41 +163,59 @@ __device__ __forceinline__ bool dio_is_edge(const double *__restrict__ f, int ki
   return i < len - 1 && 0.0 < dio_sig(f, kind, i) && dio_sig(f, kind, i + 1) <= 0.0;
 }
 
-#define DIO_ZC_PER_THREAD 8
-#define DIO_ZC_TILE (KWY_THREADS * DIO_ZC_PER_THREAD)
+#define DIO_ZC_ROWS 8
+#define DIO_ZC_TILE (KWY_THREADS * DIO_ZC_ROWS)
 
-__device__ __forceinline__ int dio_block_exscan(int v, int *sh, int *total) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int inc = v;
+// One tile of DIO_ZC_TILE samples of ONE band, staged once in LDS (coalesced, two samples of halo), serves the
+// band's four engines.  Sample q = KWY_THREADS j + tid of the tile belongs to thread tid in row j: consecutive
+// lanes look at consecutive samples (no bank conflicts), and the order of the edges inside the tile is (row, wave,
+// lane) -- a wavefront's edges of a row are one ballot, their ranks one popcount.
+// (Rounds 1-4 ran one workgroup per (tile, ENGINE), every thread walking 8 consecutive samples straight from global
+// memory: 8 reads of the filtered signals per pass, 3.8 GB per 16 utterances and 2.2 ms; now 2 reads and LDS.)
+struct dio_zc_masks { unsigned long long m[4][DIO_ZC_ROWS]; };
+
+__device__ __forceinline__ void dio_zc_tile(const double *__restrict__ f, int ny, int tile0, double *tile,
+                                            dio_zc_masks &mk) {
+  const int tid = threadIdx.x;
+  for (int q = tid; q < DIO_ZC_TILE + 2; q += KWY_THREADS) tile[q] = (tile0 + q < ny) ? f[tile0 + q] : 0.0;
+  __syncthreads();
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int u = __shfl_up(inc, o);
-    if (lane >= o) inc += u;
+  for (int j = 0; j < DIO_ZC_ROWS; ++j) {
+    const int q = KWY_THREADS * j + tid, i = tile0 + q;
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) {
+      const int len = kind < 2 ? ny : ny - 1;
+      const bool e = i < len - 1 && 0.0 < dio_sig(tile, kind, q) && dio_sig(tile, kind, q + 1) <= 0.0;
+      mk.m[kind][j] = __ballot(e);
+    }
   }
-  __syncthreads();
-  if (lane == 63) sh[wv] = inc;
-  __syncthreads();
-  int woff = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < KWY_WAVES; ++i) { if (i < wv) woff += sh[i]; tot += sh[i]; }
-  *total = tot;
-  return woff + (inc - v);
 }
 
-// grids: (tiles of the longest utterance, engines, utterances); tiles beyond an utterance's end count nothing
+// grids: (tiles of the longest utterance, bands, utterances); tiles beyond an utterance's end count nothing
 __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_count(dio_plan P) {
-  __shared__ int sh[KWY_WAVES];
-  const int e = blockIdx.y, band = e >> 2, kind = e & 3, utt = blockIdx.z;
+  __shared__ double tile[DIO_ZC_TILE + 2];
+  __shared__ int wc[4][KWY_WAVES];
+  const int band = blockIdx.y, utt = blockIdx.z, tid = threadIdx.x;
   const int ny = P.u[utt].n + 1;
-  const double *f = P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band;
-  const int len = kind < 2 ? ny : ny - 1;
-  const int base = blockIdx.x * DIO_ZC_TILE + threadIdx.x * DIO_ZC_PER_THREAD;
-  int c = 0;
+  const int tile0 = blockIdx.x * DIO_ZC_TILE;
+  int *cnt = P.at<int>(utt, P.off_cnt);
+  if (tile0 >= ny) {      // (uniform)
+    if (tid < 4) cnt[(4 * band + tid) * P.ntiles_max + blockIdx.x] = 0;
+    return;
+  }
+  dio_zc_masks mk;
+  dio_zc_tile(P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band, ny, tile0, tile, mk);
+  if ((tid & 63) == 0) {
 #pragma unroll
-  for (int j = 0; j < DIO_ZC_PER_THREAD; ++j) c += dio_is_edge(f, kind, base + j, len) ? 1 : 0;
-  int tot;
-  (void)dio_block_exscan(c, sh, &tot);
-  if (threadIdx.x == 0) P.at<int>(utt, P.off_cnt)[e * P.ntiles_max + blockIdx.x] = tot;
+    for (int kind = 0; kind < 4; ++kind) {
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < DIO_ZC_ROWS; ++j) c += __popcll(mk.m[kind][j]);
+      wc[kind][tid >> 6] = c;
+    }
+  }
+  __syncthreads();
+  if (tid < 4) cnt[(4 * band + tid) * P.ntiles_max + blockIdx.x] = wc[tid][0] + wc[tid][1] + wc[tid][2] + wc[tid][3];
 }
 
 // exclusive scan of every engine's tile counts (one block per engine and utterance)
@@ -223,30 +241,44 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_scan(dio_plan P) {
 }
 
 __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_emit(dio_plan P) {
-  __shared__ int sh[KWY_WAVES];
-  const int e = blockIdx.y, band = e >> 2, kind = e & 3, utt = blockIdx.z;
+  __shared__ double tile[DIO_ZC_TILE + 2];
+  __shared__ int rc[4][DIO_ZC_ROWS * KWY_WAVES];      // edges per (kind, row, wave)
+  const int band = blockIdx.y, utt = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ny = P.u[utt].n + 1, cap = ny / 8 + 64;
-  const double *f = P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band;
-  const int len = kind < 2 ? ny : ny - 1;
-  const int base = blockIdx.x * DIO_ZC_TILE + threadIdx.x * DIO_ZC_PER_THREAD;
-  if (blockIdx.x * DIO_ZC_TILE >= len) return;       // (uniform) nothing of this utterance in the tile
-  int c = 0;
+  const int tile0 = blockIdx.x * DIO_ZC_TILE;
+  if (tile0 >= ny) return;       // (uniform) nothing of this utterance in the tile
+  dio_zc_masks mk;
+  dio_zc_tile(P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band, ny, tile0, tile, mk);
+  if (lane == 0) {
 #pragma unroll
-  for (int j = 0; j < DIO_ZC_PER_THREAD; ++j) c += dio_is_edge(f, kind, base + j, len) ? 1 : 0;
-  int tot;
-  int pos = P.at<int>(utt, P.off_cnt)[e * P.ntiles_max + blockIdx.x] + dio_block_exscan(c, sh, &tot);
-  double *o = P.at<double>(utt, P.off_fine) + (int64_t)e * P.cap_max;
+    for (int kind = 0; kind < 4; ++kind)
 #pragma unroll
-  for (int j = 0; j < DIO_ZC_PER_THREAD; ++j) {
-    const int i = base + j;
-    if (dio_is_edge(f, kind, i, len)) {
-      if (pos < cap) {
-        const double a = dio_sig(f, kind, i), b = dio_sig(f, kind, i + 1);
-        o[pos] = (i + 1) - a / (b - a);
-      } else {
-        atomicExch(P.u[utt].status, 1);
+      for (int j = 0; j < DIO_ZC_ROWS; ++j) rc[kind][j * KWY_WAVES + wv] = __popcll(mk.m[kind][j]);
+  }
+  __syncthreads();
+  const int *cnt = P.at<int>(utt, P.off_cnt);
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int kind = 0; kind < 4; ++kind) {
+    const int e = 4 * band + kind;
+    double *o = P.at<double>(utt, P.off_fine) + (int64_t)e * P.cap_max;
+    int pos = cnt[e * P.ntiles_max + blockIdx.x];        // edges of this engine in the tiles before
+#pragma unroll
+    for (int j = 0; j < DIO_ZC_ROWS; ++j) {
+      // edges of the tile before (row j, this wave): every (row, wave) slot in front of it
+      int before = 0;
+      for (int s_ = 0; s_ < j * KWY_WAVES + wv; ++s_) before += rc[kind][s_];
+      const unsigned long long m = mk.m[kind][j];
+      if ((m >> lane) & 1ull) {
+        const int at = pos + before + __popcll(m & below);
+        if (at < cap) {
+          const int q = KWY_THREADS * j + tid;
+          const double a = dio_sig(tile, kind, q), b = dio_sig(tile, kind, q + 1);
+          o[at] = (tile0 + q + 1) - a / (b - a);
+        } else {
+          atomicExch(P.u[utt].status, 1);
+        }
       }
-      ++pos;
     }
   }
 }
@@ -297,18 +329,51 @@ __global__ void k_dio_candidates(dio_plan P) {
   P.at<double>(utt, P.off_score)[(int64_t)b * P.T_max + j] = sc / (c + DIO_SAFE);
 }
 
-// ---- best contour + WORLD FixF0Contour (one workgroup) -----------------------------------------
-__device__ inline double dio_select_best(double current_f0, double past_f0, const double *__restrict__ cand,
-                                         int nb, int T /* row stride */, int idx, double allowed_range) {
+// ---- best contour + WORLD FixF0Contour -----------------------------------------------------------
+// SelectBestF0 of WORLD's contour repair: of the frame's candidates the one closest to the linear prediction
+// (3 current - past) / 2 (the first of equals), or none if it is further than allowed_range from it.  Returns the
+// candidate's band, 0xff for none.
+#define DIO_NONE 0xff
+__host__ __device__ static inline int dio_trans_row(int nb) { return (nb * (nb + 1) + 7) & ~7; }
+
+template <class CAND>
+__device__ __forceinline__ int dio_select_best(double current_f0, double past_f0, CAND cand, int nb, double allowed_range) {
   const double reference_f0 = (current_f0 * 3.0 - past_f0) / 2.0;
-  double minimum_error = fabs(reference_f0 - cand[idx]);
-  double best = cand[idx];
+  double minimum_error = fabs(reference_f0 - cand(0));
+  double best = cand(0);
+  int at = 0;
   for (int i = 1; i < nb; ++i) {
-    double err = fabs(reference_f0 - cand[(int64_t)i * T + idx]);
-    if (err < minimum_error) { minimum_error = err; best = cand[(int64_t)i * T + idx]; }
+    const double c = cand(i), err = fabs(reference_f0 - c);
+    if (err < minimum_error) { minimum_error = err; best = c; at = i; }
   }
-  if (fabs(1.0 - best / reference_f0) > allowed_range) return 0.0;
-  return best;
+  if (fabs(1.0 - best / reference_f0) > allowed_range) return DIO_NONE;
+  return at;
+}
+
+// The repair's steps 3 and 4 grow the voiced sections frame by frame, each new value chosen from the NEXT frame's
+// candidates given the two values before it -- which are themselves candidates of their frames (or 0).  So the walk
+// moves through a finite state space, (band of the current value, band of the value before it | none), and its
+// transitions can all be evaluated beforehand, in parallel: trans[dir][frame][a (nb + 1) + b] = the band chosen in
+// frame + 1 (dir 0) / frame - 1 (dir 1) when the current value is candidate a of `frame` and the one before it
+// candidate b of the frame behind (b = nb: 0).  The serial walk (k_dio_fix) is then one table look-up per frame
+// instead of seven comparisons and a division on its dependence chain (0.8 ms per 16 utterances before).
+// grid: (states of the longest utterance / 256, 2, utterances)
+__global__ __launch_bounds__(KWY_THREADS) void k_dio_trans(dio_plan p) {
+  const int utt = blockIdx.z, dir = blockIdx.y, nb = p.nbands, T = p.u[utt].T, Ts = p.T_max;
+  const int RS = dio_trans_row(nb), per = nb * (nb + 1);
+  const int64_t g = (int64_t)blockIdx.x * KWY_THREADS + threadIdx.x;
+  const int frame = (int)(g / per), st = (int)(g - (int64_t)frame * per);
+  if (frame >= T) return;
+  const int a = st / (nb + 1), b = st - a * (nb + 1);
+  const double *__restrict__ cand = p.at<double>(utt, p.off_cand);
+  const int behind = dir == 0 ? frame - 1 : frame + 1, ahead = dir == 0 ? frame + 1 : frame - 1;
+  int res = DIO_NONE;
+  if (ahead >= 0 && ahead < T) {
+    const double cur = cand[(int64_t)a * Ts + frame];
+    const double past = (b < nb && behind >= 0 && behind < T) ? cand[(int64_t)b * Ts + behind] : 0.0;
+    res = dio_select_best(cur, past, [&](int i) { return cand[(int64_t)i * Ts + ahead]; }, nb, p.allowed_range);
+  }
+  p.at<unsigned char>(utt, p.off_trans)[((int64_t)dir * Ts + frame) * RS + st] = (unsigned char)res;
 }
 
 // one workgroup per utterance
@@ -352,28 +417,86 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_fix(dio_plan p) {
     f0[i] = v;
   }
   __syncthreads();
-  // sections + steps 3 and 4: short, serial
-  if (tid == 0) {
-    int *positive_index = idxbuf, *negative_index = idxbuf + T;
-    int pc = 0, nc = 0;
-    for (int i = 1; i < T; ++i) {
-      if (f0[i] == 0 && f0[i - 1] != 0) negative_index[nc++] = i - 1;
-      else if (f0[i - 1] == 0 && f0[i] != 0) positive_index[pc++] = i;
+  // ---- the voiced sections' borders, in frame order: every thread looks at a stretch of frames, an exclusive scan
+  //      of the two counts places its finds (round 1-4: one thread walked all T frames through global memory, 1.5 ms)
+  __shared__ int sh2[2][KWY_WAVES];
+  __shared__ int s_tot[2];
+  int *positive_index = idxbuf, *negative_index = idxbuf + T;
+  {
+    const int chunk = (T - 1 + KWY_THREADS - 1) / KWY_THREADS;
+    const int i0 = 1 + tid * chunk, i1 = min(T, i0 + chunk);
+    int np_ = 0, nn_ = 0;
+    for (int i = i0; i < i1; ++i) {
+      const double a = f0[i - 1], b = f0[i];
+      if (b == 0 && a != 0) ++nn_;
+      else if (a == 0 && b != 0) ++np_;
     }
-    // step 3 (forward) in place on f0
-    for (int i = 0; i < nc; ++i) {
-      int limit = i == nc - 1 ? T - 1 : negative_index[i + 1];
-      for (int j = negative_index[i]; j < limit; ++j) {
-        f0[j + 1] = dio_select_best(f0[j], f0[j - 1], cand, nb, Ts, j + 1, p.allowed_range);
-        if (f0[j + 1] == 0) break;
-      }
+    const int lane = tid & 63, wv = tid >> 6;
+    int ip = np_, in_ = nn_;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(ip, o), un = __shfl_up(in_, o);
+      if (lane >= o) { ip += up; in_ += un; }
     }
-    // step 4 (backward)
-    for (int i = pc - 1; i >= 0; --i) {
-      int limit = i == 0 ? 1 : positive_index[i - 1];
-      for (int j = positive_index[i]; j > limit; --j) {
-        f0[j - 1] = dio_select_best(f0[j], f0[j + 1], cand, nb, Ts, j - 1, p.allowed_range);
-        if (f0[j - 1] == 0) break;
+    if (lane == 63) { sh2[0][wv] = ip; sh2[1][wv] = in_; }
+    __syncthreads();
+    int op = ip - np_, on = in_ - nn_;
+    for (int w = 0; w < wv; ++w) { op += sh2[0][w]; on += sh2[1][w]; }
+    if (tid == KWY_THREADS - 1) { s_tot[0] = op + np_; s_tot[1] = on + nn_; }
+    for (int i = i0; i < i1; ++i) {
+      const double a = f0[i - 1], b = f0[i];
+      if (b == 0 && a != 0) negative_index[on++] = i - 1;
+      else if (a == 0 && b != 0) positive_index[op++] = i;
+    }
+  }
+  __syncthreads();
+  // ---- steps 3 and 4: the sections grow along the candidates, serially.  ONE wavefront walks, all lanes in step
+  //      (every lane loads, decides and stores the same values: a lane always sees its own earlier stores), through
+  //      the transition tables of k_dio_trans: per frame one look-up in LDS, where the tables and the candidates of
+  //      64 frames at a time are staged (coalesced loads).
+  if (tid < 64) {
+    __shared__ double cc[DIO_MAX_BANDS][64];
+    __shared__ unsigned int tr[64 * (DIO_MAX_BANDS * (DIO_MAX_BANDS + 1) + 7) / 4 + 8];
+    const int lane = tid, RS = dio_trans_row(nb), nbp = nb + 1;
+    const unsigned char *__restrict__ trans = p.at<unsigned char>(utt, p.off_trans);
+    const int pc = s_tot[0], nc = s_tot[1];
+    for (int dir = 0; dir < 2; ++dir) {
+      int c0 = -64;
+      auto stage = [&](int idx) {            // frames [idx & ~63, +64): candidates and this direction's transitions
+        c0 = idx & ~63;
+        for (int b = 0; b < nb; ++b) cc[b][lane] = (c0 + lane < T) ? cand[(int64_t)b * Ts + c0 + lane] : 0.0;
+        const unsigned int *src = (const unsigned int *)(trans + ((int64_t)dir * Ts + c0) * RS);   // RS % 8 == 0
+        const int words = min(64, T - c0) * RS / 4;
+        for (int q = lane; q < words; q += 64) tr[q] = src[q];
+      };
+      // the band whose candidate of `frame` equals v (v is one of them, or 0: none)
+      auto band_of = [&](double v, int frame) -> int {
+        if (v == 0.0) return nb;
+        for (int b = 0; b < nb; ++b)
+          if (cand[(int64_t)b * Ts + frame] == v) return b;
+        return nb;
+      };
+      const int sections = dir == 0 ? nc : pc;
+      for (int k = 0; k < sections; ++k) {
+        // step 3 (dir 0): sections in frame order, forward from their last frame up to the next section's last;
+        // step 4 (dir 1): sections from the last to the first, backward from their first frame
+        const int i = dir == 0 ? k : pc - 1 - k;
+        const int step = dir == 0 ? 1 : -1;
+        const int j0 = dir == 0 ? negative_index[i] : positive_index[i];
+        const int limit = dir == 0 ? (i == nc - 1 ? T - 1 : negative_index[i + 1]) : (i == 0 ? 1 : positive_index[i - 1]);
+        int a = band_of(f0[j0], j0), b = band_of(f0[j0 - step], j0 - step);
+        for (int j = j0; dir == 0 ? j < limit : j > limit; j += step) {
+          const int nx = j + step;
+          if ((j & ~63) != c0) stage(j);
+          int n = DIO_NONE;
+          if (a < nb) n = ((const unsigned char *)tr)[(j - c0) * RS + a * nbp + b];
+          if ((nx & ~63) != c0) stage(nx);      // (the new value is a candidate of frame nx)
+          const double v = n == DIO_NONE ? 0.0 : cc[n][nx - c0];
+          f0[nx] = v;
+          if (v == 0) break;
+          b = a;
+          a = n;
+        }
       }
     }
   }
@@ -390,7 +513,7 @@ struct sm_tables { const kwy_c *t[20]; };   // t[l]: exp(-2 pi i k / 2^l)
 
 // one workgroup per frame of every utterance of the batch
 __global__ __launch_bounds__(KWY_THREADS) void k_stonemask(sm_batch batch, int fs, sm_tables tw_tables) {
-  __shared__ double red[8];
+  __shared__ double part[KWY_WAVES][24];
   __shared__ double res[32];
   const int tid = threadIdx.x;
   const int utt = batch.find(blockIdx.x);
@@ -413,18 +536,34 @@ __global__ __launch_bounds__(KWY_THREADS) void k_stonemask(sm_batch batch, int f
   const kwy_c *tw = tw_tables.t[log2n];
   const double base_time0 = (double)(-half) / fs;
   const int basic_index = kwy_matlab_round((pos + base_time0) * fs + 0.001);
-  auto mainw = [&](int i) {
-    double tmp = (basic_index + i - 1.0) / fs - pos;
-    return 0.42 + 0.5 * cos(2.0 * KWY_PI * tmp / wlt) + 0.08 * cos(4.0 * KWY_PI * tmp / wlt);
-  };
+  // WORLD's window: mainw(i) = 0.42 + 0.5 cos(th_i) + 0.08 cos(2 th_i), th_i = 2 pi ((basic_index + i - 1) / fs - pos)
+  // / wlt, and its difference window -(mainw(i+1) - mainw(i-1)) / 2.  One sincos per sample serves both: the
+  // neighbours' angles differ by the constant step dth, so with c+- = cos(th +- dth)
+  //     mainw(i+1) - mainw(i-1) = 0.5 (c+ - c-) + 0.16 (c+^2 - c-^2) = -sin th sin dth (1 + 0.64 cos th cos dth)
+  // (rounds 1-4 evaluated six cosines per sample and pass: 0.98 ms per 32 utterances, as much as CheapTrick.)
   const double fsd = (double)fs;
+  double sd, cd;
+  sincos(2.0 * KWY_PI / (fsd * wlt), &sd, &cd);
+  auto mainw_of = [](double c) { return 0.42 + 0.5 * c + 0.08 * (2.0 * c * c - 1.0); };
   double f0_try = initial_f0;
   double mean_f0 = 0.0;
   for (int pass = 0; pass < 2; ++pass) {
     const int nh = pass == 0 ? 2 : min((int)(fsd / 2.0 / initial_f0), 6);
     int bins[6];
 #pragma unroll
-    for (int h = 0; h < 6; ++h) bins[h] = min(kwy_matlab_round(f0_try * N / fsd * (h + 1)), N / 2);
+    for (int h = 0; h < 6; ++h)
+      bins[h] = __builtin_amdgcn_readfirstlane(min(kwy_matlab_round(f0_try * N / fsd * (h + 1)), N / 2));
+    // the bins' twiddles exp(-2 pi i bin i / N) at i = tid + 256 r: the first from the table, the others by rotation
+    // with the (uniform) factor of 256 samples
+    kwy_c wh[6], ws[6];
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+      wh[h] = ws[h] = kwy_c{1.0, 0.0};
+      if (h < nh) {
+        wh[h] = tw[(int)(((int64_t)bins[h] * tid) & (N - 1))];
+        ws[h] = tw[(int)(((int64_t)bins[h] * KWY_THREADS) & (N - 1))];
+      }
+    }
     // accumulate main/diff spectra at the nh bins
     double acc[24];
 #pragma unroll
@@ -432,28 +571,35 @@ __global__ __launch_bounds__(KWY_THREADS) void k_stonemask(sm_batch batch, int f
     for (int i = tid; i < len; i += KWY_THREADS) {
       const int idx = max(0, min(x_length - 1, basic_index + i - 1));
       const double xv = x[idx];
-      const double mw = mainw(i);
+      double st, ct;
+      sincos(2.0 * KWY_PI * ((basic_index + i - 1.0) / fs - pos) / wlt, &st, &ct);
+      const double mw = mainw_of(ct);
       double dw;
-      if (i == 0) dw = -mainw(1) / 2.0;
-      else if (i == len - 1) dw = mainw(len - 2) / 2.0;
-      else dw = -(mainw(i + 1) - mainw(i - 1)) / 2.0;
+      if (i == 0) dw = -mainw_of(ct * cd - st * sd) / 2.0;
+      else if (i == len - 1) dw = mainw_of(ct * cd + st * sd) / 2.0;
+      else dw = st * sd * (1.0 + 0.64 * ct * cd) / 2.0;
       const double a = xv * mw, b = xv * dw;
 #pragma unroll
       for (int h = 0; h < 6; ++h) {
         if (h < nh) {
-          const kwy_c w = tw[(int)(((int64_t)bins[h] * i) & (N - 1))];
+          const kwy_c w = wh[h];
           acc[4 * h + 0] += a * w.x; acc[4 * h + 1] += a * w.y;
           acc[4 * h + 2] += b * w.x; acc[4 * h + 3] += b * w.y;
+          wh[h] = cmulf(w, ws[h]);
         }
       }
     }
+    // all sums with ONE workgroup barrier: every wavefront reduces its 4 nh values by lane shifts and leaves them in
+    // LDS, then the four partial sums are added in wave order (rounds 1-4: 24 block reductions of two barriers each)
 #pragma unroll
     for (int q = 0; q < 24; ++q) {
       if (q < 4 * nh) {
-        double v = kwy_block_sum(acc[q], red);
-        if (tid == 0) res[q] = v;
+        const double v = kwy_wave_sum(acc[q]);
+        if ((tid & 63) == 0) part[tid >> 6][q] = v;
       }
     }
+    __syncthreads();
+    if (tid < 4 * nh) res[tid] = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
     __syncthreads();
     // FixF0 (all threads compute the same scalars)
     double numerator = 0.0, denominator = 0.0;
@@ -600,6 +746,7 @@ static size_t dio_layout(dio_plan &p) {
   p.off_w1 = take(sizeof(double) * p.T_max);
   p.off_w2 = take(sizeof(double) * p.T_max);
   p.off_idx = take(sizeof(int) * 2 * (size_t)p.T_max);
+  p.off_trans = take(2 * (size_t)p.T_max * dio_trans_row(p.nbands));
   p.stride = (int64_t)off;
   return off;
 }
@@ -662,13 +809,19 @@ static int dio_pass(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, dio_plan p,
                                                    p, twH, twN));
   {
     kwy_prof_scope ps_(ctx, "k_dio_zc");
-    hipLaunchKernelGGL(k_dio_zc_count, dim3(p.ntiles_max, nengines, count), dim3(KWY_THREADS), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_dio_zc_count, dim3(p.ntiles_max, p.nbands, count), dim3(KWY_THREADS), 0, ctx->stream, p);
     hipLaunchKernelGGL(k_dio_zc_scan, dim3(nengines, count), dim3(KWY_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(k_dio_zc_emit, dim3(p.ntiles_max, nengines, count), dim3(KWY_THREADS), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_dio_zc_emit, dim3(p.ntiles_max, p.nbands, count), dim3(KWY_THREADS), 0, ctx->stream, p);
   }
   KWY_PROF(ctx, "k_dio_candidates", hipLaunchKernelGGL(k_dio_candidates, dim3((p.T_max + 255) / 256, p.nbands, count),
                                                        dim3(256), 0, ctx->stream, p));
-  KWY_PROF(ctx, "k_dio_fix", hipLaunchKernelGGL(k_dio_fix, dim3(count), dim3(KWY_THREADS), 0, ctx->stream, p));
+  {
+    kwy_prof_scope ps_(ctx, "k_dio_fix");
+    const int64_t states = (int64_t)p.T_max * p.nbands * (p.nbands + 1);
+    hipLaunchKernelGGL(k_dio_trans, dim3((unsigned)((states + KWY_THREADS - 1) / KWY_THREADS), 2, count), dim3(KWY_THREADS),
+                       0, ctx->stream, p);
+    hipLaunchKernelGGL(k_dio_fix, dim3(count), dim3(KWY_THREADS), 0, ctx->stream, p);
+  }
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
