@@ -90,13 +90,14 @@ __device__ inline void d4c_dc_correction(double *P, double *S, double cf0, int f
 // pass are issued together: k_d4c_body 0.343 ms against 0.333 ms per launch of two utterances.  The kernel is bound
 // by instruction issue, the other resident workgroups already cover the LDS latency of these loops, and the
 // predicated unrolled forms issue more instructions.)
+// kmax: only out[0 .. kmax] are wanted (the mirrored fill and the prefix sum stop where those bins stop reading)
 template <int NT>
 __device__ inline void d4c_linear_smoothing(const double *in, double *out, double *S, double *tot,
-                                            double width, int fs, int N) {
+                                            double width, int fs, int N, int kmax) {
   const int H = N / 2;
   int boundary = (int)(width * N / fs) + 1;
   if (boundary > H / 2) boundary = H / 2;  // LDS guard; outside WORLD's domain anyway
-  const int L = H + boundary * 2 + 1;
+  const int L = min(H + boundary * 2 + 1, kmax + boundary * 2 + 4);
   for (int i = threadIdx.x; i < L; i += NT) {
     double m;
     if (i < boundary) m = in[boundary - i];
@@ -108,7 +109,7 @@ __device__ inline void d4c_linear_smoothing(const double *in, double *out, doubl
   kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
   const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
-  for (int k = threadIdx.x; k <= H; k += NT) {
+  for (int k = threadIdx.x; k <= min(H, kmax); k += NT) {
     double fa = (double)k / N * fs - width / 2.0;
     double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     fa += width;
@@ -126,7 +127,7 @@ struct d4c_view {
   uint64_t *offs_b;     // T + 1: scratch of the body scan
   uint64_t *offs3;      // 3 T: stream positions of the body's three windows per frame, relative to offs_lt[T]
   double *ap0;          // T: LoveTrain's voicing measure
-  double *dvbuf;        // T x (H + 1): static group delay, body -> bands
+  double *dvbuf;        // T x dv_stride: static group delay (the bins the band windows read), body -> bands
   int x_length, T;
 };
 typedef kwy_batch<d4c_view> d4c_batch;
@@ -280,6 +281,8 @@ __global__ __launch_bounds__(NT) void k_d4c_lovetrain(
 // ------------------------------------------------------------------ general body
 struct d4c_params {
   int fs, K, fft_size, nbands, window_length;
+  int dv_len;       // bins of the static group delay the band windows read: [0, dv_len) -- 1537 of 2049 at 48 kHz
+  int dv_stride;    // row stride of dvbuf (dv_len rounded up to an even count)
   double threshold;
 };
 
@@ -373,11 +376,11 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, i
 
 // WORLD LinearSmoothing as above, but out[k] = in[k] - smoothed[k] (the last step of the static group delay)
 template <int NT>
-__device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot, double width, int fs, int N) {
+__device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot, double width, int fs, int N, int kmax) {
   const int H = N / 2;
   int boundary = (int)(width * N / fs) + 1;
   if (boundary > H / 2) boundary = H / 2;
-  const int L = H + boundary * 2 + 1;
+  const int L = min(H + boundary * 2 + 1, kmax + boundary * 2 + 4);
   for (int i = threadIdx.x; i < L; i += NT) {
     double m;
     if (i < boundary) m = io[boundary - i];
@@ -389,7 +392,7 @@ __device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot,
   kwy_block_cumsum<NT>(S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
   const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
-  for (int k = threadIdx.x; k <= H; k += NT) {
+  for (int k = threadIdx.x; k <= min(H, kmax); k += NT) {
     double fa = (double)k / N * fs - width / 2.0;
     double low = d4c_interp1q_inv(origin, inv_dfi, S, L, fa);
     fa += width;
@@ -519,38 +522,71 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
 
   D4C_STAMP(1);
   // ---- static centroid: two temporal centroids at pos -+ 0.25/f0, each Re(X2 conj X1) of the
-  //      normalised window (X1) and the window times its sample index (X2)
-  double cen[RK];
+  //      normalised window a (X1) and the window times its sample index, b = a (i + 1) (X2).
+  // Round 5: the two REAL sequences travel as ONE complex sequence c = a + j b.  Its N-point transform Z splits into
+  // the H-point transforms of the even and the odd samples, Z[k] = E[k] + W^k O[k], Z[H + k] = E[k] - W^k O[k], and
+  //     Re(X2[k] conj X1[k]) = Im(Z[k] Z[N - k]) / 2
+  // (X1 = (Z[k] + conj Z[N-k]) / 2, X2 = (Z[k] - conj Z[N-k]) / 2j): a thread that holds E and O at k = p and H - p
+  // forms bins p and H - p with two complex products -- instead of four even/odd extractions of packed real
+  // transforms (two per bin and transform) followed by the product.  Same two H-point transforms per centroid.
+  // Pairs (p, H - p), p = tid + NT r < H/2, live in registers; the self-paired bin H/2 is thread 0's, through two
+  // LDS slots (a fifth register set for one bin would tip the kernel into scratch).
+  constexpr int RP = (H / 2 + NT - 1) / NT;
+  double cen_lo[RP], cen_hi[RP];
+  double *mid = coarse;            // [0..1]: E[H/2], [2]: the centroid sum of bin H/2  (the band values' slots: unused here)
   {
     double av[E];
     for (int which = 0; which < 2; ++which) {
       const int tid = kwy_tid_opaque();
       double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
       d4c_frame_window<N, NT>(x, x_length, p, cf0, cpos, D4C_BLACKMAN, which == 0 ? dpos0 : dpos1, rs, poly, e, jtab, Bd, true, red, av);
+      __syncthreads();      // (the window code keeps per-thread values in Bd until here)
+      // even samples: z[m] = a[2m] + j b[2m] -- sample i = tid + NT r has the parity of tid
+      if (!(tid & 1)) {
 #pragma unroll
-      for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];   // each thread overwrites the draws it consumed
+        for (int r = 0; r < E; ++r) { const int i = tid + NT * r; Bd[i] = av[r]; Bd[i + 1] = av[r] * (i + 1.0); }
+      }
       __syncthreads();
       D4C_STAMP(2 + which * 2);
       kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
-      kwy_c X1[RK];
+      kwy_c Ek[RP], Eh[RP];
 #pragma unroll
-      for (int r = 0; r < RK; ++r) {
-        const int k = tid + NT * r;
-        X1[r] = k <= H ? kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r)) : kwy_c{0.0, 0.0};
+      for (int r = 0; r < RP; ++r) {
+        const int pp = tid + NT * r;
+        Ek[r] = Eh[r] = kwy_c{0.0, 0.0};
+        if (pp < H / 2) { Ek[r] = B[pp]; Eh[r] = B[(H - pp) & (H - 1)]; }     // (p = 0: E[H] = E[0])
       }
+      if (tid == 0) { mid[0] = B[H / 2].x; mid[1] = B[H / 2].y; }
       __syncthreads();
+      if (tid & 1) {
 #pragma unroll
-      for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r] * (tid + NT * r + 1.0);
+        for (int r = 0; r < E; ++r) { const int i = tid + NT * r; Bd[i - 1] = av[r]; Bd[i] = av[r] * (i + 1.0); }
+      }
       __syncthreads();
       kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
 #pragma unroll
-      for (int r = 0; r < RK; ++r) {
-        const int k = tid + NT * r;
-        if (k <= H) {
-          const kwy_c X2 = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
-          const double v = __builtin_fma(X2.x, X1[r].x, X1[r].y * X2.y);
-          cen[r] = which == 0 ? v : cen[r] + v;
+      for (int r = 0; r < RP; ++r) {
+        const int pp = tid + NT * r;
+        if (pp < H / 2) {
+          const kwy_c w = kwy_tw_hex(d4c_opaque(twb), HEX * r);            // W^p = exp(-2 pi i p / N)
+          const kwy_c Ok = B[pp], Oh = B[(H - pp) & (H - 1)];
+          const kwy_c t = cmulf(w, Ok);                                     // W^p O[p]
+          const kwy_c u = cmulf(kwy_c{-w.x, w.y}, Oh);                      // W^(H-p) O[H-p] = -conj(W^p) O[H-p]
+          const kwy_c zp = cadd(Ek[r], t), zhp = csub(Ek[r], t);            // Z[p], Z[H + p]
+          const kwy_c zq = cadd(Eh[r], u), znp = csub(Eh[r], u);            // Z[H - p], Z[N - p]
+          // 2 Im(Z[k] Z[N-k]) = 4 Re(X2 conj X1): the scale of the "times two" bins the power spectrum uses
+          const double lo = 2.0 * __builtin_fma(zp.x, znp.y, zp.y * znp.x);
+          const double hi = 2.0 * __builtin_fma(zq.x, zhp.y, zq.y * zhp.x);
+          cen_lo[r] = which == 0 ? lo : cen_lo[r] + lo;
+          cen_hi[r] = which == 0 ? hi : cen_hi[r] + hi;
         }
+      }
+      if (tid == 0) {     // bin H/2: W^(H/2) = -i, Z[H/2] = E + t, Z[N - H/2] = Z[H + H/2] = E - t
+        const kwy_c Em = {mid[0], mid[1]}, Om = B[H / 2];
+        const kwy_c t = {Om.y, -Om.x};
+        const kwy_c za = cadd(Em, t), zb = csub(Em, t);
+        const double v = 2.0 * __builtin_fma(za.x, zb.y, za.y * zb.x);
+        mid[2] = which == 0 ? v : mid[2] + v;
       }
       __syncthreads();
       D4C_STAMP(3 + which * 2);
@@ -587,22 +623,28 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   D4C_STAMP(9);
   // ---- static group delay: the centroid sum moves into A0
 #pragma unroll
-  for (int r = 0; r < RK; ++r)
-    if (tid + NT * r <= H) Dv[tid + NT * r] = cen[r];
+  for (int r = 0; r < RP; ++r) {
+    const int pp = tid + NT * r;
+    if (pp < H / 2) { Dv[pp] = cen_lo[r]; Dv[H - pp] = cen_hi[r]; }
+  }
+  if (tid == 0) Dv[H / 2] = mid[2];
   __syncthreads();
   d4c_dc_correction<NT>(Dv, S, cf0, p.fs, N);
 #pragma unroll
   for (int r = 0; r < RK; ++r)
     if (tid + NT * r <= H) Dv[tid + NT * r] = Dv[tid + NT * r] / pv[r];
   __syncthreads();
-  d4c_linear_smoothing<NT>(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N);
-  d4c_subtract_smoothed<NT>(Dv, S, tot, cf0, p.fs, N);
+  // (only bins [0, dv_len) of the result are ever read -- by the band windows; the second smoothing of those bins
+  // reads its input up to two of its own half-widths further)
+  const int kdv = p.dv_len - 1;
+  d4c_linear_smoothing<NT>(Dv, Dv, S, tot, cf0 / 2.0, p.fs, N, kdv + 2 * ((int)(cf0 * N / p.fs) + 1) + 4);
+  d4c_subtract_smoothed<NT>(Dv, S, tot, cf0, p.fs, N, kdv);
 
   D4C_STAMP(10);
   // ---- hand the static group delay to the band items (k_d4c_bands): one row of H+1 doubles per frame
   {
-    double *dv = dvbuf + (size_t)frame * (H + 1);
-    for (int k = tid; k <= H; k += NT) dv[k] = Dv[k];
+    double *dv = dvbuf + (size_t)frame * p.dv_stride;
+    for (int k = tid; k < p.dv_len; k += NT) dv[k] = Dv[k];
   }
   D4C_STAMP(15);
 #undef D4C_STAMP
@@ -651,7 +693,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   kwy_c tw4[4];
   kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
   const kwy_c twb = twN[tid];
-  const double *Dv = dvbuf + (size_t)frame * (H + 1);
+  const double *Dv = dvbuf + (size_t)frame * p.dv_stride;
 
   const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
   const int half_window_length = p.window_length / 2;
@@ -819,9 +861,26 @@ static int d4c_fft_size(int fs) {
   return (int)pow(2.0, 1.0 + (int)(log(4.0 * fs / D4C_FLOOR_F0 + 1) / 0.69314718055994529));
 }
 
+static int d4c_nbands(int fs) {
+  double lim = fs / 2.0 - D4C_FREQ_INTERVAL;
+  if (lim > D4C_UPPER_LIMIT) lim = D4C_UPPER_LIMIT;
+  const int nb = (int)(lim / D4C_FREQ_INTERVAL);
+  return nb < 0 ? 0 : nb;
+}
+
+// The band windows (2 hw + 1 taps around bin (int)(3000 (b + 1) N / fs), hw = (int)(3000 N / fs)) read the bins
+// [0, (int)(3000 nbands N / fs) + hw] of the static group delay: 1537 of 2049 at 48 kHz.
+static int d4c_dv_len(int fs, int n4, int nbands) {
+  if (nbands <= 0) return 0;
+  const int hw = (int)(D4C_FREQ_INTERVAL * n4 / fs);
+  const int len = (int)(D4C_FREQ_INTERVAL * nbands * n4 / fs) + hw + 1;
+  return len < n4 / 2 + 1 ? len : n4 / 2 + 1;
+}
+
 static size_t d4c_scratch_bytes(int64_t T, int fs) {
-  const size_t H = (size_t)d4c_fft_size(fs) / 2;
-  return kwy_pad(sizeof(double) * (size_t)T * (H + 1)) + 2 * kwy_pad(sizeof(uint64_t) * (T + 1)) +
+  const int n4 = d4c_fft_size(fs);
+  const size_t stride = (size_t)((d4c_dv_len(fs, n4, d4c_nbands(fs)) + 1) & ~1);
+  return kwy_pad(sizeof(double) * (size_t)T * (stride > 0 ? stride : 2)) + 2 * kwy_pad(sizeof(uint64_t) * (T + 1)) +
          kwy_pad(sizeof(uint64_t) * 3 * T) + kwy_pad(sizeof(double) * T);
 }
 
@@ -845,6 +904,8 @@ static int d4c_core(kwy_ctx *ctx, d4c_batch &b, int fs, double threshold, int ff
   if (p.nbands < 0) p.nbands = 0;
   if (p.nbands > 5) { ctx->err = "d4c: too many bands"; return KWY_EINVAL; }
   p.window_length = (int)(D4C_FREQ_INTERVAL * n4 / fs) * 2 + 1;
+  p.dv_len = d4c_dv_len(fs, n4, p.nbands);
+  p.dv_stride = (p.dv_len + 1) & ~1;
   p.threshold = threshold;
 
   b.start[0] = 0;
@@ -855,7 +916,7 @@ static int d4c_core(kwy_ctx *ctx, d4c_batch &b, int fs, double threshold, int ff
     v.offs_b = kwy_arena<uint64_t>(ctx, T + 1);
     v.offs3 = kwy_arena<uint64_t>(ctx, 3 * T);
     v.ap0 = kwy_arena<double>(ctx, T);
-    v.dvbuf = kwy_arena<double>(ctx, T * (n4 / 2 + 1));
+    v.dvbuf = kwy_arena<double>(ctx, T * (size_t)(p.dv_stride > 0 ? p.dv_stride : 2));
     if (!v.dvbuf || !v.offs_lt || !v.offs_b || !v.offs3 || !v.ap0) { ctx->err = "d4c: scratch arena too small"; return KWY_ENOMEM; }
     b.start[u + 1] = b.start[u] + v.T;
   }

@@ -339,3 +339,44 @@ def test_config5_64_distinct_pairs_one_and_two_ranks(gmm64):
     w1 = cp.convert_batch(sources, FS, g)
     w2 = cp.convert_batch(sources, FS, g)
     assert all(bool(torch.isfinite(a).all().item()) and torch.equal(a, b) for a, b in zip(w1, w2))
+
+
+def test_config5_at_the_size_the_baseline_names():
+    """BASELINE config 5 at ITS size: 503 distinct 48 kHz pairs of 5 s (an atr503-sized parallel corpus), M = 64, the
+    reference's stopping rule (GaussianMixture(max_iter=100, tol=1e-3), /root/reference/kwiiyatta/converter/gmm.py:14-26).
+    Too large for an oracle run, so properties: the training matrix of two independent builds is the same bytes
+    (SHA-256) with the same row count; the fit converges under the rule; the batch conversion of 64 sources is finite,
+    audible and bit-identical on a second pass.  (~25 s of host signal generation in a process pool first.)"""
+    import hashlib
+    import torch
+    from kwiiyatta_amd import corpus as cp
+    from kwiiyatta_amd.backend.nprandom import DeviceRandomState
+    from kwiiyatta_amd.converter.gmm_fit import GaussianMixtureHIP
+    n = 503
+    jobs = [(1000 + k, 5.0, 100.0 + (k * 37 % 90), 1.0, 1.0) for k in range(n)] + \
+           [(5000 + k, 5.0, (100.0 + (k * 37 % 90)) * (1.25 + 0.01 * (k % 11)), 1.04 + 0.01 * (k % 9), 1.08 + 0.01 * (k % 7))
+            for k in range(n)]
+    utts = _generate(jobs)
+    corpus = [(utts[i], utts[n + i]) for i in range(n)]
+    ls = cp._Lockstep(0)
+    X, frames = cp.build_training_matrix(corpus, FS, rng=DeviceRandomState.from_seed(1234), driver='lockstep', lockstep=ls)
+    assert frames == sum(len(s[1]) for s, _ in corpus) == n * 1001
+    assert X.shape[1] == 144 and 0.5 * frames < X.shape[0] < 2 * frames
+    h1 = hashlib.sha256(X.cpu().numpy().tobytes()).hexdigest()
+    X2, _ = cp.build_training_matrix(corpus, FS, rng=DeviceRandomState.from_seed(1234), driver='lockstep', lockstep=ls)
+    assert X2.shape == X.shape and hashlib.sha256(X2.cpu().numpy().tobytes()).hexdigest() == h1
+    del X2
+    assert bool(torch.isfinite(X).all().item())
+    g = GaussianMixtureHIP(n_components=64, max_iter=100, tol=1e-3, random_state=0).fit(X)
+    print(f'config 5 at size: {X.shape[0]} rows, {g.kmeans_n_iter_} Lloyd + {g.n_iter_} EM iterations, '
+          f'lower bound {g.lower_bound_:.6f}, converged {g.converged_}')
+    assert g.converged_ and 2 <= g.n_iter_ <= 100 and np.isfinite(g.lower_bound_)
+    assert np.all(np.isfinite(g.means_)) and abs(float(np.sum(g.weights_)) - 1.0) < 1e-9
+    del X
+    sources = [s for s, _ in corpus[:64]]
+    w1 = cp.convert_batch(sources, FS, g, lockstep=ls)
+    sums = [float(w.abs().max().item()) for w in w1]
+    keep = [w.clone() for w in w1]
+    w2 = cp.convert_batch(sources, FS, g, lockstep=ls)
+    assert all(bool(torch.isfinite(a).all().item()) and torch.equal(a, b) for a, b in zip(keep, w2))
+    assert min(sums) > 1e-3
