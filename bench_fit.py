@@ -77,7 +77,7 @@ def main():
     def m_step():
         s = comm.all_reduce(st.sums())
         st.means_from(s)
-        c = comm.all_reduce(st.cov())
+        c = comm.all_reduce(st.cov(s))
         st.finalize(s, c, 1e-6)
 
     def e_step():

@@ -438,6 +438,13 @@ int kwy_gmm_em_sums_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, 
 int kwy_gmm_em_means_dev(kwy_ctx *ctx, const double *stats, int D, int M, double *means);
 int kwy_gmm_em_cov_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
                        const double *means, double *sxx /* M x D x D */);
+/* the same with the (globally reduced) sums of kwy_gmm_em_sums_dev at hand (stats; NULL = kwy_gmm_em_cov_dev): a
+ * frame whose responsibility for a mixture is below 2^-70 of that mixture's mass nk is left out of its covariance
+ * sum -- all such frames together weigh less than n 2^-70 of the mixture, below the rounding of nk itself for
+ * n <= 2^25 -- which lets the kernel skip the matrix products of the (many) frames that do not belong to a
+ * component.  kwy_gmm_em_cov_dev skips below 2^-200 only. */
+int kwy_gmm_em_cov_stats_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
+                             const double *means, const double *stats, double *sxx);
 int kwy_gmm_em_finalize_dev(kwy_ctx *ctx, const double *stats, const double *sxx, int D, int M,
                             double reg_covar, double *weights, double *covs);
 int kwy_gmm_em_scratch_bytes(int64_t n, int D, int M, int64_t *bytes);

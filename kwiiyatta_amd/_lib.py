@@ -116,6 +116,7 @@ SIGNATURES = {
     'kwy_gmm_em_sums_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     'kwy_gmm_em_means_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     'kwy_gmm_em_cov_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'kwy_gmm_em_cov_stats_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'kwy_gmm_em_finalize_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_dbl, c_vp, c_vp]),
     'kwy_gmm_fit_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_dbl, c_dbl, ctypes.c_uint32, c_vp, c_vp, c_vp,
                                 ctypes.POINTER(c_int), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

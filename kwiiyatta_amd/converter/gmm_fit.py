@@ -157,10 +157,12 @@ class HipStats:
         self._chk(self._lib.lib.kwy_gmm_em_means_dev(self.ctx.handle, self._p(stats), self.D, self.M,
                                                      self._p(self.means)))
 
-    def cov(self):
-        """(M, D, D) local sum r (x - mu)(x - mu)' around self.means, device tensor."""
-        self._chk(self._lib.lib.kwy_gmm_em_cov_dev(self.ctx.handle, self._p(self.X), self.n, self.D, self.M,
-                                                   self._p(self.resp), self._p(self.means), self._p(self.sxx)))
+    def cov(self, stats=None):
+        """(M, D, D) local sum r (x - mu)(x - mu)' around self.means, device tensor.  stats: the (globally reduced)
+        sums of `sums()` -- frames below 2^-70 of a mixture's mass are then left out of its sum (kwy_gmm_em_cov_stats_dev)."""
+        self._chk(self._lib.lib.kwy_gmm_em_cov_stats_dev(self.ctx.handle, self._p(self.X), self.n, self.D, self.M,
+                                                         self._p(self.resp), self._p(self.means),
+                                                         self._p(stats) if stats is not None else None, self._p(self.sxx)))
         return self.sxx
 
     def finalize(self, stats, sxx, reg_covar):
@@ -403,7 +405,7 @@ def _em_fit(stats, n_total, max_iter, tol, reg_covar, verbose):
     def m_step():
         s = comm.all_reduce(stats.sums())
         stats.means_from(s)
-        c = comm.all_reduce(stats.cov())
+        c = comm.all_reduce(stats.cov(s))
         stats.finalize(s, c, reg_covar)
 
     m_step()                                    # initialisation from the hard assignments

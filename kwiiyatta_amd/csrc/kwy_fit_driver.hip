@@ -366,7 +366,7 @@ extern "C" int kwy_gmm_fit_comm_dev(kwy_ctx *ctx, const double *X, int64_t n, in
     KWY_TRY(kwy_gmm_em_sums_dev(ctx, X, n, D, M, resp.p, stats.p));
     KWY_TRY(all_reduce(stats.p, nstats));
     KWY_TRY(kwy_gmm_em_means_dev(ctx, stats.p, D, M, dmeans.p));
-    KWY_TRY(kwy_gmm_em_cov_dev(ctx, X, n, D, M, resp.p, dmeans.p, sxx.p));
+    KWY_TRY(kwy_gmm_em_cov_stats_dev(ctx, X, n, D, M, resp.p, dmeans.p, stats.p, sxx.p));
     KWY_TRY(all_reduce(sxx.p, (size_t)M * D * D));
     return kwy_gmm_em_finalize_dev(ctx, stats.p, sxx.p, D, M, reg_covar, dweights.p, dcovs.p);
   };

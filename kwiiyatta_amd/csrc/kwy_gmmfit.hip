@@ -331,6 +331,8 @@ __global__ void k_fit_reduce(const double *__restrict__ part, int nchunks, int64
 // every register an architectural VGPR.  Workgroups are numbered so that the 64 that run together on
 // one XCD (2 per CU) are the mixtures of one row split and share its frames in that XCD's L2.
 #define FIT_COV_TILE 32
+#define FIT_R_MIN 6.223015277861142e-61      // 2^-200
+#define FIT_R_REL 8.470329472543003e-22      // 2^-70
 constexpr int fit_blk_row(int e) { int I = 0; while ((I + 1) * (I + 2) / 2 <= e) ++I; return I; }
 constexpr int fit_blk_col(int e) { return e - fit_blk_row(e) * (fit_blk_row(e) + 1) / 2; }
 constexpr int fit_blk_lo(int nblk, int w) { return (nblk * (nblk + 1) / 2) * w / 4; }
@@ -352,12 +354,19 @@ __device__ __forceinline__ void fit_static_for(F &&f) {
 
 template <int NBLK, int W, int CMAX>
 __device__ __forceinline__ void fit_cov_tile(const double *__restrict__ tile, const double *__restrict__ rt, int ZS,
-                                             int ar, int ak, fit_v4f64 (&acc)[CMAX]) {
+                                             int ar, int ak, double r_min, fit_v4f64 (&acc)[CMAX]) {
   constexpr int E0 = fit_blk_lo(NBLK, W), E1 = fit_blk_lo(NBLK, W + 1);
 #pragma unroll 2
   for (int ks = 0; ks < FIT_COV_TILE / 4; ++ks) {
     const double *drow = tile + (4 * ks + ak) * ZS + ar;
     const double rr = rt[4 * ks + ak];
+    // Four frames whose responsibilities for this mixture are all below r_min add nothing the covariance can hold: the
+    // step's operand loads and matrix instructions are skipped, uniformly for the wavefront.  r_min = 2^-200 always
+    // (n <= 2^31 such terms against nk >= 10 eps change an entry by less than 2^-90 |x - mu|^2), and 2^-70 of the
+    // mixture's own mass nk when the caller hands the sums over (the skipped terms then weigh less than n 2^-70 of
+    // the mixture: with n <= 2^25 frames below the rounding of nk itself).  A fitted mixture in D = 144 is SPARSE in
+    // this sense -- most frames belong to one or two of the 64 components.
+    if (__ballot(rr >= r_min) == 0) continue;
     double dv[NBLK], av[NBLK];
     fit_static_for<0, NBLK>([&](auto bc) {
       constexpr int b = decltype(bc)::value;
@@ -392,6 +401,7 @@ template <int NBLK>
 __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__restrict__ X, const double *__restrict__ resp,
                                                            int64_t n, int D, int M, int nsplit,
                                                            const double *__restrict__ means,
+                                                           const double *__restrict__ stats,
                                                            double *__restrict__ cpart) {
   constexpr int NP = 16 * NBLK, ZS = NP + 1, CMAX = (NBLK * (NBLK + 1) / 2 + 3) / 4;
   constexpr int ROWS = FIT_COV_TILE / 4;   // rows of a tile staged by one wavefront
@@ -413,6 +423,7 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
   const int64_t rows = (n + nsplit - 1) / nsplit;
   const int64_t r0 = split * rows, r1 = min(n, r0 + rows);
   const double *mu = means + (size_t)m * D;
+  const double r_min = fmax(FIT_R_MIN, stats ? stats[(size_t)m * (D + 1)] * FIT_R_REL : 0.0);
   double muv[FIT_LP_COLS];
 #pragma unroll
   for (int c = 0; c < FIT_LP_COLS; ++c) muv[c] = (lane + 64 * c < D) ? mu[lane + 64 * c] : 0.0;
@@ -453,10 +464,10 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
       fetch(b0 + FIT_COV_TILE);   // in flight during the MFMAs below
       const double *tile = ds + buf * FIT_COV_TILE * ZS, *rt = rs + buf * FIT_COV_TILE;
       switch (wv) {
-        case 0: fit_cov_tile<NBLK, 0, CMAX>(tile, rt, ZS, ar, ak, acc); break;
-        case 1: fit_cov_tile<NBLK, 1, CMAX>(tile, rt, ZS, ar, ak, acc); break;
-        case 2: fit_cov_tile<NBLK, 2, CMAX>(tile, rt, ZS, ar, ak, acc); break;
-        default: fit_cov_tile<NBLK, 3, CMAX>(tile, rt, ZS, ar, ak, acc); break;
+        case 0: fit_cov_tile<NBLK, 0, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
+        case 1: fit_cov_tile<NBLK, 1, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
+        case 2: fit_cov_tile<NBLK, 2, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
+        default: fit_cov_tile<NBLK, 3, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
       }
       stage(buf ^ 1);             // last read two tiles ago, before the previous barrier
       __syncthreads();
@@ -659,16 +670,23 @@ static int fit_cov_splits(int64_t n, int M) {
 
 template <int NBLK>
 static int fit_cov_launch(kwy_ctx *ctx, const double *X, const double *resp, int64_t n, int D, int M,
-                          const double *means, double *cpart, int nsplit) {
+                          const double *means, const double *stats, double *cpart, int nsplit) {
   const size_t lds = sizeof(double) * (2 * (size_t)FIT_COV_TILE * (16 * NBLK + 1) + 2 * FIT_COV_TILE);
   KWY_HIP(hipFuncSetAttribute((const void *)k_fit_cov<NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<NBLK>, dim3((unsigned)(M * nsplit)), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, nsplit, means, cpart));
+  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<NBLK>, dim3((unsigned)(M * nsplit)), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, nsplit, means, stats, cpart));
   return KWY_OK;
 }
 
 // sxx[m] = sum_t r[t][m] (x_t - mu_m)(x_t - mu_m)'    (local shard; full D x D per mixture)
 extern "C" int kwy_gmm_em_cov_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
                                   const double *means, double *sxx) {
+  return kwy_gmm_em_cov_stats_dev(ctx, X, n, D, M, resp, means, nullptr, sxx);
+}
+
+// ... with the (globally reduced) sums of kwy_gmm_em_sums_dev: frames whose responsibility is below 2^-70 of the
+// mixture's mass are left out (see fit_cov_tile)
+extern "C" int kwy_gmm_em_cov_stats_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
+                                        const double *means, const double *stats, double *sxx) {
   KWY_TRY(fit_check(ctx, n, D, M));
   if (!X || !resp || !means || !sxx) { ctx->err = "gmm_em_cov: null pointer"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
@@ -678,16 +696,16 @@ extern "C" int kwy_gmm_em_cov_dev(kwy_ctx *ctx, const double *X, int64_t n, int 
   double *cpart = kwy_arena<double>(ctx, (size_t)nsplit * len);
   if (!cpart) { ctx->err = "gmm_em_cov: scratch"; return KWY_ENOMEM; }
   switch ((D + 15) / 16) {
-    case 1: KWY_TRY(fit_cov_launch<1>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 2: KWY_TRY(fit_cov_launch<2>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 3: KWY_TRY(fit_cov_launch<3>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 4: KWY_TRY(fit_cov_launch<4>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 5: KWY_TRY(fit_cov_launch<5>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 6: KWY_TRY(fit_cov_launch<6>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 7: KWY_TRY(fit_cov_launch<7>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 8: KWY_TRY(fit_cov_launch<8>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    case 9: KWY_TRY(fit_cov_launch<9>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
-    default: KWY_TRY(fit_cov_launch<10>(ctx, X, resp, n, D, M, means, cpart, nsplit)); break;
+    case 1: KWY_TRY(fit_cov_launch<1>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 2: KWY_TRY(fit_cov_launch<2>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 3: KWY_TRY(fit_cov_launch<3>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 4: KWY_TRY(fit_cov_launch<4>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 5: KWY_TRY(fit_cov_launch<5>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 6: KWY_TRY(fit_cov_launch<6>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 7: KWY_TRY(fit_cov_launch<7>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 8: KWY_TRY(fit_cov_launch<8>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 9: KWY_TRY(fit_cov_launch<9>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    default: KWY_TRY(fit_cov_launch<10>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
   }
   hipLaunchKernelGGL(k_fit_reduce_sym, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, cpart, nsplit, D,
                      M, sxx);

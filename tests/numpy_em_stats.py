@@ -64,7 +64,7 @@ class NumpyStats:
         stats = stats.numpy()
         self.means = stats[:, 1:] / (stats[:, :1] + 10 * np.finfo(np.float64).eps)
 
-    def cov(self):
+    def cov(self, stats=None):
         out = np.empty((self.M, self.D, self.D))
         for m in range(self.M):
             diff = self.X - self.means[m]
