@@ -111,6 +111,15 @@ typedef struct kwy_utterance {
 } kwy_utterance;
 int kwy_cheaptrick_batch_dev(kwy_ctx *ctx, const kwy_utterance *utterances, int count, int fs, double q1,
                              double f0_floor, int fft_size, double out_div);
+/* CheapTrick and sp2mc in one, for consumers that only need the mel-cepstrum (the alignment, the conversion):
+ *   Analyzer.extract_spectrum_envelope + MelCepstrum of it        kwiiyatta/vocoder/world.py:43-52, mcep.py:68-71
+ * CheapTrick's last steps are: lifter the cepstrum, transform back, exp; sp2mc's first: log, transform to the
+ * cepstrum.  The fused form keeps the liftered cepstrum and applies pysptk's frequency transform to it directly (an
+ * f64 matrix product): no K-bin envelope row is written or read.  utterances[i].out: f0_length x (order + 1)
+ * mel-cepstral coefficients, equal to kwy_sp2mc_dev(kwy_cheaptrick_dev(...)) up to the rounding of the skipped
+ * exp / log round trip (1e-12 relative in the tests).  order <= 63. */
+int kwy_cheaptrick_mcep_batch_dev(kwy_ctx *ctx, const kwy_utterance *utterances, int count, int fs, double q1,
+                                  double f0_floor, int fft_size, double out_div, int order, double alpha);
 
 /* pyworld.d4c(x, f0, t, fs, threshold, fft_size)     kwiiyatta/vocoder/world.py:55
  * out: T x (fft_size/2+1). */

@@ -78,6 +78,7 @@ SIGNATURES = {
     'kwy_cheaptrick_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_dbl,
                                    c_int, c_dbl, c_vp]),
     'kwy_cheaptrick_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl]),
+    'kwy_cheaptrick_mcep_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_dbl, c_int, c_dbl, c_int, c_dbl]),
     'kwy_d4c_batch_dev': (c_int, [c_vp, c_vp, c_int, c_int, c_dbl, c_int]),
     'kwy_d4c': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_int, c_vp]),
     'kwy_d4c_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_dbl, c_int, c_vp]),

@@ -22,9 +22,14 @@
 // one utterance of a launch
 struct ct_view {
   const double *x, *tpos, *f0;
-  double *out;
+  double *out;           // T x K spectral envelope -- or, in the mel-cepstrum form, T x (order + 1) coefficients
   uint64_t *offsets;     // T + 1: stream position of every frame's first draw (WORLD reseeds per call: 0 for frame 0)
   int x_length, T;
+};
+// the mel-cepstrum form (k_cheaptrick<.., true> + k_cep2mc): the liftered cepstra of all frames of the launch
+struct ct_mcep {
+  double *cep;           // (frames of the launch) x ncs, in workgroup order
+  int ncut, ncs;         // cepstral coefficients the frequency transform reads; row length (ncut rounded up to 4)
 };
 typedef kwy_batch<ct_view> ct_batch;
 
@@ -50,10 +55,16 @@ __device__ __forceinline__ double ct_interp1q(double x0, double shift, const dou
   return __builtin_fma(dy, frac, y0);
 }
 
-template <int LOG2N>
+// MCEP: stop at the liftered cepstrum.  The smoothed log-envelope is log P[n] = sum_k c[k] cos(2 pi k n / N) over the
+// symmetric cepstrum c the lifter leaves in the buffer -- exactly the cepstrum pysptk.sp2mc would recover from the
+// envelope with an inverse transform of its logarithm (kwiiyatta/vocoder/mcep.py:68-71).  A consumer that only wants
+// the mel-cepstrum therefore needs neither this kernel's last transform, its exp and its K-bin row, nor sp2mc's
+// logarithm and transform of that row: the first ncut coefficients (c[0] halved, minus log(out_div) for the
+// division of world.py:50) go to a scratch row and k_cep2mc applies the frequency transform as a matrix product.
+template <int LOG2N, bool MCEP>
 __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
     ct_batch batch, int fs, double q1, double f0_floor_eff, kwy_randn_src rs, const uint4 *__restrict__ poly,
-    const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN, double out_div) {
+    const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN, double out_div, ct_mcep mcep) {
   constexpr int N = 1 << LOG2N;
   constexpr int H = N / 2;
   constexpr int K = H + 1;
@@ -265,9 +276,21 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
           sl = ls / th;
           cl = (1.0 - 2.0 * q1) + 2.0 * q1 * (1.0 - 2.0 * ls * ls);
         }
-        Cx[k] = {Cx[k].x * sl * cl / N, 0.0};
+        const double cv = Cx[k].x * sl * cl / N;
+        if constexpr (MCEP) {
+          if (k < mcep.ncs) {
+            double *crow = mcep.cep + (size_t)blockIdx.x * mcep.ncs;
+            crow[k] = k >= mcep.ncut ? 0.0 : (k == 0 ? (cv - log(out_div)) / 2.0 : cv);
+          }
+        } else {
+          Cx[k] = {cv, 0.0};
+        }
       }
     }
+  }
+  if constexpr (MCEP) {
+    for (int k = H + 1 + tid; k < mcep.ncs; k += KWY_THREADS) mcep.cep[(size_t)blockIdx.x * mcep.ncs + k] = 0.0;   // row padding
+    return;
   }
   kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(bufA, twl, twb, twN);
   const double *wr = (const double *)bufA;
@@ -279,8 +302,46 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   }
 }
 
-template <int LOG2N>
-static int launch_ct(kwy_ctx *ctx, const ct_batch &b, int fs, double q1, double floor_eff, double out_div) {
+// mc[t][j] = sum_n cep[t][n] F[n][j]: pysptk's frequency transform (freqt) of the cepstra as an f64 matrix product, one
+// wavefront per 16 frames (v_mfma_f64_16x16x4_f64; A = 16 frames x 4 cepstral indices, B = F, 16 coefficients per
+// block).  F: [ncut][64] (kwy_mcep.hip), L2-resident.  Row t of the launch belongs to the utterance batch.find(t).
+typedef double ct_v4f64 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(KWY_THREADS) void k_cep2mc(ct_batch batch, ct_mcep mcep, int order,
+                                                       const double *__restrict__ F) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ar = lane & 15, ak = lane >> 4;
+  const int rows = batch.start[batch.n];
+  const int t0 = ((int)blockIdx.x * KWY_WAVES + wv) * 16;
+  if (t0 >= rows) return;
+  const int nblk = (order + 16) / 16;                  // 16-coefficient blocks: <= 4
+  const double *__restrict__ crow = mcep.cep + (size_t)min(t0 + ar, rows - 1) * mcep.ncs;
+  ct_v4f64 acc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) acc[b] = ct_v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int ks = 0; ks < mcep.ncs / 4; ++ks) {
+    const int n = 4 * ks + ak;
+    const double a = crow[n];
+    const double *__restrict__ frow = F + (size_t)min(n, mcep.ncut - 1) * 64 + ar;    // (rows beyond ncut: a == 0)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < nblk) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, frow[16 * b], acc[b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int t = t0 + ak + 4 * r;
+    if (t >= rows) continue;
+    int u = 0;
+    while (u + 1 < batch.n && t >= batch.start[u + 1]) ++u;
+    double *o = batch.u[u].out + (size_t)(t - batch.start[u]) * (order + 1);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < nblk && 16 * b + ar <= order) o[16 * b + ar] = acc[b][r];
+  }
+}
+
+template <int LOG2N, bool MCEP>
+static int launch_ct(kwy_ctx *ctx, const ct_batch &b, int fs, double q1, double floor_eff, double out_div, ct_mcep mcep) {
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
   constexpr int C = (N + K + KWY_THREADS - 1) / KWY_THREADS;
   const kwy_c *twH, *twN;
@@ -290,10 +351,10 @@ static int launch_ct(kwy_ctx *ctx, const ct_batch &b, int fs, double q1, double 
   KWY_TRY(kwy_get_poly_multi(ctx, C, KWY_THREADS, &poly));
   size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) + sizeof(double) * (K + 1 + 8 + KWY_THREADS) +
                sizeof(uint32_t) * KWY_EBASE_WORDS;
-  KWY_HIP(hipFuncSetAttribute((const void *)k_cheaptrick<LOG2N>,
+  KWY_HIP(hipFuncSetAttribute((const void *)k_cheaptrick<LOG2N, MCEP>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_cheaptrick", hipLaunchKernelGGL(k_cheaptrick<LOG2N>, dim3((unsigned)b.start[b.n]), dim3(KWY_THREADS), lds,
-                     ctx->stream, b, fs, q1, floor_eff, kwy_randn(ctx), poly, twH, twN, out_div));
+  KWY_PROF(ctx, "k_cheaptrick", hipLaunchKernelGGL((k_cheaptrick<LOG2N, MCEP>), dim3((unsigned)b.start[b.n]), dim3(KWY_THREADS), lds,
+                     ctx->stream, b, fs, q1, floor_eff, kwy_randn(ctx), poly, twH, twN, out_div, mcep));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
@@ -303,8 +364,12 @@ static size_t ct_scratch_bytes(int64_t T) {
 }
 
 // device-pointer core for up to KWY_BATCH_MAX utterances (b.u[].offsets are filled in here from the arena, which must
-// already have room: ct_scratch_bytes per utterance)
-static int cheaptrick_core(kwy_ctx *ctx, ct_batch &b, int fs, double q1, int fft_size, double out_div) {
+// already have room: ct_scratch_bytes per utterance).  mc_order >= 0: the mel-cepstrum form (b.u[].out: T x
+// (mc_order + 1)); the arena then also holds the launch's cepstra (ct_mcep_bytes).
+static size_t ct_mcep_bytes(int64_t frames, int ncs) { return kwy_pad(sizeof(double) * (size_t)frames * ncs); }
+
+static int cheaptrick_core(kwy_ctx *ctx, ct_batch &b, int fs, double q1, int fft_size, double out_div, int mc_order = -1,
+                           double mc_alpha = 0.0) {
   const int log2n = kwy_ilog2(fft_size);
   if ((1 << log2n) != fft_size || log2n < 9 || log2n > 12) {
     ctx->err = "cheaptrick: fft_size must be a power of two in [512, 4096]";
@@ -320,12 +385,33 @@ static int cheaptrick_core(kwy_ctx *ctx, ct_batch &b, int fs, double q1, int fft
   }
   hipLaunchKernelGGL(k_ct_scan, dim3(b.n), dim3(KWY_THREADS), 0, ctx->stream, b, fs, floor_eff, K);
   KWY_HIP(hipGetLastError());
-  switch (log2n) {
-    case 9: return launch_ct<9>(ctx, b, fs, q1, floor_eff, out_div);
-    case 10: return launch_ct<10>(ctx, b, fs, q1, floor_eff, out_div);
-    case 11: return launch_ct<11>(ctx, b, fs, q1, floor_eff, out_div);
-    default: return launch_ct<12>(ctx, b, fs, q1, floor_eff, out_div);
+  if (mc_order < 0) {
+    const ct_mcep none = {nullptr, 0, 0};
+    switch (log2n) {
+      case 9: return launch_ct<9, false>(ctx, b, fs, q1, floor_eff, out_div, none);
+      case 10: return launch_ct<10, false>(ctx, b, fs, q1, floor_eff, out_div, none);
+      case 11: return launch_ct<11, false>(ctx, b, fs, q1, floor_eff, out_div, none);
+      default: return launch_ct<12, false>(ctx, b, fs, q1, floor_eff, out_div, none);
+    }
   }
+  const double *F;
+  ct_mcep mcep;
+  KWY_TRY(kwy_get_sp2mc_matrix(ctx, fft_size, mc_order, mc_alpha, &F, &mcep.ncut));
+  if (mcep.ncut > K) mcep.ncut = K;
+  mcep.ncs = (mcep.ncut + 3) & ~3;
+  mcep.cep = kwy_arena<double>(ctx, (size_t)b.start[b.n] * mcep.ncs);
+  if (!mcep.cep) { ctx->err = "cheaptrick: scratch arena too small"; return KWY_ENOMEM; }
+  switch (log2n) {
+    case 9: KWY_TRY((launch_ct<9, true>(ctx, b, fs, q1, floor_eff, out_div, mcep))); break;
+    case 10: KWY_TRY((launch_ct<10, true>(ctx, b, fs, q1, floor_eff, out_div, mcep))); break;
+    case 11: KWY_TRY((launch_ct<11, true>(ctx, b, fs, q1, floor_eff, out_div, mcep))); break;
+    default: KWY_TRY((launch_ct<12, true>(ctx, b, fs, q1, floor_eff, out_div, mcep))); break;
+  }
+  const unsigned tiles = (unsigned)((b.start[b.n] + 15) / 16);
+  KWY_PROF(ctx, "k_cep2mc", hipLaunchKernelGGL(k_cep2mc, dim3((tiles + KWY_WAVES - 1) / KWY_WAVES), dim3(KWY_THREADS), 0,
+                                               ctx->stream, b, mcep, mc_order, F));
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
 }
 
 static int cheaptrick_one(kwy_ctx *ctx, const double *x, int64_t x_length, int fs, const double *t,
@@ -384,6 +470,40 @@ extern "C" int kwy_cheaptrick_batch_dev(kwy_ctx *ctx, const kwy_utterance *utts,
       b.u[u] = ct_view{q.x, q.temporal_positions, q.f0, q.out, nullptr, (int)q.x_length, (int)q.f0_length};
     }
     KWY_TRY(cheaptrick_core(ctx, b, fs, q1, fft_size, out_div));
+  }
+  return KWY_OK;
+}
+
+// CheapTrick + sp2mc in one: the mel-cepstra of `count` utterances (device pointers, not synchronised) for a consumer
+// that does not need the envelopes themselves -- Analyzer.extract_spectrum_envelope followed by `.mel_cepstrum`
+// (kwiiyatta/vocoder/world.py:43-52, vocoder/mcep.py:68-71).  utts[i].out: f0_length x (order + 1).
+extern "C" int kwy_cheaptrick_mcep_batch_dev(kwy_ctx *ctx, const kwy_utterance *utts, int count, int fs, double q1,
+                                             double f0_floor, int fft_size, double out_div, int order, double alpha) {
+  if (!ctx) return KWY_EINVAL;
+  if (!utts || count < 1 || order < 1 || order > 63 || !(fabs(alpha) < 1.0) || !(out_div > 0)) {
+    ctx->err = "cheaptrick_mcep_batch: bad argument (order 1..63)";
+    return KWY_EINVAL;
+  }
+  size_t scratch = 0;
+  int64_t frames = 0;
+  for (int i = 0; i < count; ++i) {
+    const kwy_utterance &q = utts[i];
+    KWY_TRY(ct_check(ctx, q.x, q.x_length, fs, q.temporal_positions, q.f0, q.f0_length, q.out, &fft_size, f0_floor));
+    scratch += ct_scratch_bytes(q.f0_length);
+    frames += q.f0_length;
+  }
+  if (frames > 0x7fffffff) { ctx->err = "cheaptrick_mcep_batch: too many frames"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  // (the cepstra rows are at most K + 3 doubles; the passes of a call run one after the other but keep their own rows)
+  KWY_TRY(kwy_arena_begin(ctx, scratch + ct_mcep_bytes(frames, fft_size / 2 + 4) + 4096 * ((count + KWY_BATCH_MAX - 1) / KWY_BATCH_MAX)));
+  for (int i0 = 0; i0 < count; i0 += KWY_BATCH_MAX) {
+    ct_batch b;
+    b.n = count - i0 < KWY_BATCH_MAX ? count - i0 : KWY_BATCH_MAX;
+    for (int u = 0; u < b.n; ++u) {
+      const kwy_utterance &q = utts[i0 + u];
+      b.u[u] = ct_view{q.x, q.temporal_positions, q.f0, q.out, nullptr, (int)q.x_length, (int)q.f0_length};
+    }
+    KWY_TRY(cheaptrick_core(ctx, b, fs, q1, fft_size, out_div, order, alpha));
   }
   return KWY_OK;
 }

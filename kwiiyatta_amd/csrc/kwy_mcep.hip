@@ -201,7 +201,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_mc2sp_mfma(const double *__rest
 }
 
 // ---- host side ----------------------------------------------------------------------
-static int get_sp2mc_matrix(kwy_ctx *ctx, int N, int order, double alpha, const double **out, int *ncut) {
+int kwy_get_sp2mc_matrix(kwy_ctx *ctx, int N, int order, double alpha, const double **out, int *ncut) {
   char key[96];
   snprintf(key, sizeof(key), "sp2mc:%d:%d:%.17g", N, order, alpha);
   std::string cnt_key = std::string(key) + ":ncut";
@@ -379,7 +379,7 @@ extern "C" int kwy_sp2mc_dev(kwy_ctx *ctx, const double *sp, int64_t T, int K, i
   if (l == 0) return launch_sp2mc_dense(ctx, sp, T, K, order, alpha, mc);
   const double *F;
   int ncut;
-  KWY_TRY(get_sp2mc_matrix(ctx, 1 << l, order, alpha, &F, &ncut));
+  KWY_TRY(kwy_get_sp2mc_matrix(ctx, 1 << l, order, alpha, &F, &ncut));
   switch (l) {
     case 9: return launch_sp2mc<9>(ctx, sp, T, order, F, ncut, mc);
     case 10: return launch_sp2mc<10>(ctx, sp, T, order, F, ncut, mc);

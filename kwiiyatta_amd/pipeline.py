@@ -335,7 +335,9 @@ class _Wave:
             else:
                 self.f0_all, self.t_all = cat(1), cat(2)
             rows = int(sum(self.Tp))
-            self.sp_pad = torch.zeros((rows, K), **f64)
+            fused = owner.fused_mcep
+            if not fused:
+                self.sp_pad = torch.zeros((rows, K), **f64)
             self.ap_pad = torch.full((rows, K), 1 - SAFE_GUARD_MINIMUM, **f64)
             self.f0_pad = torch.zeros(rows, **f64)
             self.mc_pad = torch.empty((rows, order + 1), **f64)
@@ -348,9 +350,10 @@ class _Wave:
             self.x = [cut(self.x_all, xo, i) for i in range(ns)]
             self.f0 = [cut(self.f0_all, to, i) for i in range(ns)]
             self.t = [cut(self.t_all, to, i) for i in range(ns)]
-            self.sp = [cut(self.sp_pad, po, i, PAD_LEN, PAD_LEN) for i in range(ns)]      # the un-padded middle parts
             self.ap = [cut(self.ap_pad, po, i, PAD_LEN, PAD_LEN) for i in range(ns)]
-            self.sp_p = [cut(self.sp_pad, po, i) for i in range(ns)]
+            if not fused:
+                self.sp = [cut(self.sp_pad, po, i, PAD_LEN, PAD_LEN) for i in range(ns)]      # the un-padded middle parts
+                self.sp_p = [cut(self.sp_pad, po, i) for i in range(ns)]
             self.ap_p = [cut(self.ap_pad, po, i) for i in range(ns)]
             self.mc_p = [cut(self.mc_pad, po, i) for i in range(ns)]
             self.f0_p = [cut(self.f0_pad, po, i) for i in range(ns)]
@@ -367,7 +370,20 @@ class _Wave:
                 for i in range(ns):
                     self.f0_p[i][PAD_LEN:PAD_LEN + self.T[i]] = self.f0[i]
             # pad rows in the reference's order of draws: source head, source tail, target head, target tail
-            self.pad_rows = [blk for i in range(ns) for blk in (self.sp_p[i][:PAD_LEN], self.sp_p[i][PAD_LEN + self.T[i]:])]
+            if not fused:
+                self.pad_rows = [blk for i in range(ns) for blk in (self.sp_p[i][:PAD_LEN], self.sp_p[i][PAD_LEN + self.T[i]:])]
+            else:
+                # No envelope rows at all: CheapTrick hands over mel-cepstra (kwy_cheaptrick_mcep_batch_dev) straight into
+                # the padded rows' middle parts; the pad SPECTRA live in one block of their own, their mel-cepstra
+                # (sp2mc over 2 x 100 rows per side) are copied to the rows around
+                self.pads_sp = torch.zeros((2 * ns * PAD_LEN, K), **f64)
+                self.pads_mc = torch.empty((2 * ns * PAD_LEN, order + 1), **f64)
+                self.pad_rows = [self.pads_sp[b * PAD_LEN:(b + 1) * PAD_LEN] for b in range(2 * ns)]
+                self.pad_idx = torch.arange(PAD_LEN, dtype=torch.int32, device=dev)
+                pm = lambda b: self.pads_mc[b * PAD_LEN:(b + 1) * PAD_LEN]  # noqa: E731
+                self.j_padmc = _lib.job_array(_lib.GatherJob, [row for i in range(ns) for row in (
+                    (pm(2 * i), PAD_LEN, self.pad_idx, PAD_LEN, self.mc_p[i][:PAD_LEN]),
+                    (pm(2 * i + 1), PAD_LEN, self.pad_idx, PAD_LEN, self.mc_p[i][PAD_LEN + self.T[i]:]))])
             # per pair, on the target's time axis
             Tt = [self.T[2 * k + 1] for k in range(self.n)]
             self.Tt = Tt
@@ -396,7 +412,8 @@ class _Wave:
             one = lambda a, k: a[k:k + 1]  # noqa: E731
             J = _lib.job_array
             both = range(ns)
-            self.j_env = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], self.sp[i]) for i in both])
+            self.j_env = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i],
+                                                self.mc_p[i][PAD_LEN:PAD_LEN + self.T[i]] if fused else self.sp[i]) for i in both])
             self.j_ap = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], self.ap[i]) for i in both])
             self.j_feat = J(_lib.AlignJob, [(self.mc_p[i], self.f0_p[i], self.Tp[i], self.feat_p[i]) for i in both])
             self.j_dtw = J(_lib.DtwJob, [(self.feat_p[2 * k], self.Tp[2 * k], self.feat_p[2 * k + 1], self.Tp[2 * k + 1],
@@ -447,12 +464,17 @@ class PairBatchPipeline(_Graphed):
     and the int16 samples of every waveform at the end of the wave (kwy_finish_pcm16_batch_dev:
     vocoder/abc/synthesizer.py:11-20 + wavfile.py:8-29), `pcm(k)`.
 
-    Outputs per pair k: `wave(k)`; equal to PairPipeline's bit for bit given the same pads."""
+    fused_mcep (default): CheapTrick hands over mel-cepstra (kwy_cheaptrick_mcep_batch_dev: its liftered cepstrum
+    through pysptk's frequency transform -- no envelope row is written, no sp2mc re-reads it); only the pad spectra go
+    through sp2mc.  False: the two calls of the reference's stages, bit-equal to PairPipeline.
+
+    Outputs per pair k: `wave(k)`; with fused_mcep=False equal to PairPipeline's bit for bit given the same pads, with
+    it within the rounding of one exp / log round trip (same DTW path in the tests, waveforms within 1e-9)."""
 
     def __init__(self, device_index, fs, pairs, gmm, order=24, radius=32, frame_period=5.0, waves=2, rng=None,
-                 silence=None, rng_place='side', serial=False, max_wave=16, wav_in=False, pcm=False):
+                 silence=None, rng_place='side', serial=False, max_wave=16, wav_in=False, pcm=False, fused_mcep=True):
         self.dev = torch.device('cuda', device_index)
-        self.wav_in, self.pcm = bool(wav_in), bool(pcm)
+        self.wav_in, self.pcm, self.fused_mcep = bool(wav_in), bool(pcm), bool(fused_mcep)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
         self.K = self.fft // 2 + 1
@@ -554,10 +576,17 @@ class PairBatchPipeline(_Graphed):
                 _lib.check(wv.side_ctx, lib.kwy_synth_plan_batch_dev(hs, wv.j_plan, n, fft, self.frame_period, fs))
             with torch.cuda.stream(wv.stream):
                 chk = lambda rc, c=wv.ctx: _lib.check(c, rc)  # noqa: E731
-                chk(lib.kwy_cheaptrick_batch_dev(h, wv.j_env, 2 * n, fs, -0.15, 71.0, fft, float(fs)))
-                if pads is not None:
-                    wv.stream.wait_event(pads)
-                chk(lib.kwy_sp2mc_dev(h, _p(wv.sp_pad), wv.rows, K, order, self.alpha, _p(wv.mc_pad)))
+                if self.fused_mcep:
+                    chk(lib.kwy_cheaptrick_mcep_batch_dev(h, wv.j_env, 2 * n, fs, -0.15, 71.0, fft, float(fs), order, self.alpha))
+                    if pads is not None:
+                        wv.stream.wait_event(pads)
+                    chk(lib.kwy_sp2mc_dev(h, _p(wv.pads_sp), wv.pads_sp.shape[0], K, order, self.alpha, _p(wv.pads_mc)))
+                    chk(lib.kwy_gather_rows_batch_dev(h, wv.j_padmc, 4 * n, order + 1))
+                else:
+                    chk(lib.kwy_cheaptrick_batch_dev(h, wv.j_env, 2 * n, fs, -0.15, 71.0, fft, float(fs)))
+                    if pads is not None:
+                        wv.stream.wait_event(pads)
+                    chk(lib.kwy_sp2mc_dev(h, _p(wv.sp_pad), wv.rows, K, order, self.alpha, _p(wv.mc_pad)))
                 chk(lib.kwy_align_features_batch_dev(h, wv.j_feat, 2 * n, order + 1, POWER_WEIGHT, POWER_THRESHOLD,
                                                      VUV_WEIGHT))
                 chk(lib.kwy_fastdtw_batch_dev(h, wv.j_dtw, n, order + 2, self.radius))

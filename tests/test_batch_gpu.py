@@ -228,7 +228,7 @@ def test_pair_batch_pipeline_equals_pair_pipelines():
     K = 1025
     rng = np.random.default_rng(1)
     silence = [np.abs(rng.standard_normal((pl.PAD_LEN, K))) * pl.EPS / fs for _ in range(4 * len(pairs))]
-    b = pl.PairBatchPipeline(0, fs, pairs, dg, waves=2, silence=silence)
+    b = pl.PairBatchPipeline(0, fs, pairs, dg, waves=2, silence=silence, fused_mcep=False)   # the reference's two stages
     assert len(b.waves) == 2
     b.run()
     b.sync()
@@ -261,7 +261,7 @@ def test_pair_batch_pipeline_draws_its_pads_like_align():
     gmm = pl.synthetic_gmm(order=24, components=8, seed=0, n_frames=4000)
     dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
     rs = DeviceRandomState.from_seed(4242)
-    b = pl.PairBatchPipeline(0, fs, pairs, dg, waves=2, rng=rs)
+    b = pl.PairBatchPipeline(0, fs, pairs, dg, waves=2, rng=rs, fused_mcep=False)
     b.run()
     b.sync()
     rs.sync()
@@ -289,3 +289,55 @@ def test_pair_batch_pipeline_draws_its_pads_like_align():
         ref2.normal(0, 1.0, (pl.PAD_LEN, K))
     st_dev, st_np = rs.get_state(), ref2.get_state()
     assert np.array_equal(st_dev[1], st_np[1]) and st_dev[2:] == tuple(st_np[2:])
+
+
+def test_cheaptrick_mcep_entry_and_fused_lockstep_step():
+    """kwy_cheaptrick_mcep_batch_dev (CheapTrick's liftered cepstrum through pysptk's frequency transform, no envelope
+    row in between) against the two calls it replaces: the oracle's sp2mc(cheaptrick(x) / fs) within 1e-12 of the
+    coefficients' scale, more utterances than one launch holds; and the lockstep step built on it against the step
+    that runs the two stages: same FastDTW paths, mel-cepstra within 1e-12, waveforms within 1e-9."""
+    import torch
+    from oracle import oracle as ko
+    from kwiiyatta_amd import _lib, pipeline as pl
+    from kwiiyatta_amd._lib import lib
+    from kwiiyatta_amd.backend import sptk
+    from kwiiyatta_amd.synthetic import make_utterance
+    fs, order = 48000, 24
+    alpha = sptk.mcepalpha(fs)
+    utts = [make_utterance(seed=40 + i, fs=fs, seconds=0.3 + 0.07 * i, f0_base=100.0 + 9 * i) for i in range(18)]
+    ctx = _lib.Context(0)
+    dev = [tuple(_dev(a) for a in u) for u in utts]
+    outs = [torch.full((len(u[1]), order + 1), float('nan'), dtype=torch.float64, device='cuda') for u in utts]
+    arr = _lib.utterance_array([(d[0], d[2], d[1], o) for d, o in zip(dev, outs)])
+    _lib.check(ctx, lib.kwy_cheaptrick_mcep_batch_dev(ctx.handle, arr, len(utts), fs, -0.15, 71.0, 2048, float(fs), order, alpha))
+    ctx.sync()
+    for i in (0, 5, 17):
+        x, f0, t = utts[i]
+        ref = ko.sp2mc(np.ascontiguousarray(ko.cheaptrick(x, f0, t, fs) / fs), order, alpha)
+        got = outs[i].cpu().numpy()
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (i, np.abs(got - ref).max())
+    pairs = _pairs(5, fs)
+    gmm = pl.synthetic_gmm(order=24, components=8, seed=0, n_frames=4000)
+    dg = pl.DeviceGMM(gmm.weights_, gmm.means_, gmm.covariances_, torch.device('cuda', 0))
+    rng = np.random.default_rng(2)
+    silence = [np.abs(rng.standard_normal((pl.PAD_LEN, 1025))) * pl.EPS / fs for _ in range(4 * len(pairs))]
+    a = pl.PairBatchPipeline(0, fs, pairs, dg, waves=2, silence=silence)                     # fused (default)
+    b = pl.PairBatchPipeline(0, fs, pairs, dg, waves=2, silence=silence, fused_mcep=False)
+    for p in (a, b):
+        p.run()
+        p.sync()
+    for wa, wb in zip(a.waves, b.waves):
+        ma, mb = wa.mc_pad.cpu().numpy(), wb.mc_pad.cpu().numpy()
+        assert np.abs(ma - mb).max() <= 1e-12 * np.abs(mb).max()
+    for k in range(len(pairs)):
+        pa, na, da = a.path(k)
+        pb, nb, db = b.path(k)
+        assert int(na.item()) == int(nb.item()) and torch.equal(pa[:int(na.item())], pb[:int(nb.item())])
+        assert float((a.wave(k) - b.wave(k)).abs().max()) <= 1e-9
+    first = [a.wave(k).clone() for k in range(len(pairs))]
+    a.capture()
+    a.replay()
+    a.sync()
+    for k in range(len(pairs)):
+        assert torch.equal(a.wave(k), first[k])
