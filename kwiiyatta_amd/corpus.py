@@ -478,7 +478,9 @@ class ConvertWave:
                 off = np.concatenate(([0], np.cumsum(self.T))).astype(np.int64)
                 self.f0_status = None
             self.rows = int(off[-1])
-            self.sp_all = torch.empty((self.rows, K), **f64)
+            # (with a GMM nothing reads the analysed envelopes but sp2mc: CheapTrick hands over mel-cepstra instead,
+            # kwy_cheaptrick_mcep_batch_dev)
+            self.sp_all = torch.empty((self.rows, K), **f64) if gmm is None else None
             self.ap_all = torch.empty((self.rows, K), **f64)
             self.ylen = [int(lib.kwy_synth_length(t, self.frame_period, self.fs)) for t in self.T]
             yo = np.concatenate(([0], np.cumsum(self.ylen))).astype(np.int64)
@@ -491,14 +493,15 @@ class ConvertWave:
                 self.j_fin = _lib.job_array(_lib.FinishJob, [(self.wave[i], self.ylen[i], self.T[i], self.pcm[i])
                                                              for i in range(n)])
             self.plan = [torch.empty(int(lib.kwy_synth_plan_bytes(y)), dtype=torch.uint8, device=dev) for y in self.ylen]
-            sp = [cut(self.sp_all, off, i) for i in range(n)]
+            if gmm is not None:
+                assert gmm.D2 == 6 * order
+                self.mc = torch.empty((self.rows, order + 1), **f64)
+            sp = [cut(self.sp_all if gmm is None else self.mc, off, i) for i in range(n)]
             ap = [cut(self.ap_all, off, i) for i in range(n)]
             self.j_env = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], sp[i]) for i in range(n)])
             self.j_ap = _lib.utterance_array([(self.x[i], self.t[i], self.f0[i], ap[i]) for i in range(n)])
             self.j_plan = _lib.job_array(_lib.SynthPlanJob, [(self.f0[i], self.T[i], self.ylen[i], self.plan[i]) for i in range(n)])
             if gmm is not None:
-                assert gmm.D2 == 6 * order
-                self.mc = torch.empty((self.rows, order + 1), **f64)
                 self.mc_conv = torch.empty((self.rows, order + 1), **f64)
                 self.sp_conv = torch.empty((self.rows, K), **f64)
                 self.j_conv = _lib.job_array(_lib.ConvertJob, [(cut(self.mc, off, i), self.T[i], cut(self.mc_conv, off, i))
@@ -539,9 +542,10 @@ class ConvertWave:
         with torch.cuda.stream(ls.main):
             h = ls.ctx.handle
             chk = lambda rc: _lib.check(ls.ctx, rc)  # noqa: E731
-            chk(lib.kwy_cheaptrick_batch_dev(h, self.j_env, n, fs, -0.15, 71.0, fft, float(fs)))
-            if self.gmm is not None:
-                chk(lib.kwy_sp2mc_dev(h, _p(self.sp_all), self.rows, K, order, self.alpha, _p(self.mc)))
+            if self.gmm is None:
+                chk(lib.kwy_cheaptrick_batch_dev(h, self.j_env, n, fs, -0.15, 71.0, fft, float(fs)))
+            else:
+                chk(lib.kwy_cheaptrick_mcep_batch_dev(h, self.j_env, n, fs, -0.15, 71.0, fft, float(fs), order, self.alpha))
                 chk(lib.kwy_convert_mcep_batch_dev(h, self.j_conv, n, order, self.gmm.M, _p(self.model)))
                 chk(lib.kwy_mc2sp_dev(h, _p(self.mc_conv), self.rows, order, self.alpha, fft, _p(self.sp_conv)))
             ls.main.wait_stream(ls.side)

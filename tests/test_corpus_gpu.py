@@ -334,8 +334,10 @@ def test_lockstep_drivers_equal_the_stream_drivers(corpus):
     utts = [s for s, _ in corpus] + [t for _, t in corpus] + [corpus[0][0]] * 11      # 19: more than one wave, ragged
     w1 = cp.convert_batch(utts, FS, g, order=ORDER, driver='lockstep')
     w2 = cp.convert_batch(utts, FS, g, order=ORDER, driver='streams', streams=2)
+    # (the lockstep driver takes its mel-cepstra from CheapTrick's liftered cepstrum, kwy_cheaptrick_mcep_batch_dev, the
+    # stream driver from sp2mc of the envelope: equal up to the rounding of one exp / log round trip)
     for u, v in zip(w1, w2):
-        assert torch.equal(u, v)
+        assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-9 * max(1.0, float(v.abs().max()))
     r1, f1 = cp.resynthesize_batch(utts, FS, driver='lockstep')
     r2, f2 = cp.resynthesize_batch(utts, FS, driver='streams', streams=2)
     assert f1 == f2
