@@ -16,11 +16,13 @@
 // multiply-adds per 10 s utterance: as long as the whole analysis); now a
 // workgroup takes a block of 8192 samples, transforms it ONCE (real FFT in LDS,
 // the spectrum stays in registers) and multiplies it with each band's
-// precomputed filter spectrum: overlap-save, 8 transforms per 5 317 outputs of
-// all 7 bands instead of 20 k multiply-adds per output.  Then, per band: the
-// four zero-crossing interval tracks (ordered stream compaction), their
-// interpolation onto the frame times, the candidate / score per frame; finally
-// the best-candidate contour and WORLD's four-step contour repair.
+// precomputed filter spectrum: overlap-save, 8 transforms per 5 315 outputs of
+// all 7 bands instead of 20 k multiply-adds per output.  The filtered signals
+// never reach memory: the same workgroup finds the zero crossings of its block
+// (four interval tracks per band) while the block is in LDS and leaves them as
+// short lists, which a tiny kernel strings together in order.  Then per band
+// the tracks' interpolation onto the frame times, the candidate / score per
+// frame; finally the best-candidate contour and WORLD's four-step contour repair.
 //
 // StoneMask: one workgroup per frame; the two windowed spectra are only needed
 // at <= 6 harmonic bins, so they are evaluated as direct DFT sums with the same
@@ -54,18 +56,35 @@ struct dio_utt {
 
 struct dio_plan {
   int count, nbands;
-  int ny_max, T_max, ntiles_max, cap_max;   // layout extents
+  int ny_max, T_max, ntiles_max, cap_max;   // layout extents (ntiles_max: filter blocks of the longest utterance)
+  int cap_block;                            // edges one filter block may leave per engine
   int half, V;                              // Lh + 2 max_hal (the longest combined filter is 2 half taps); outputs per block
   double fs, f0_floor, f0_ceil, frame_period, allowed_range;
   double boundary[DIO_MAX_BANDS];
   const kwy_c *G;                           // [nbands][DIO_H + 1]: filter spectra / N, band delays equalised
   char *scratch;
   int64_t stride;
-  int64_t off_part, off_filt, off_cnt, off_nedges, off_fine, off_cand, off_score, off_w1, off_w2, off_idx, off_trans;
+  int64_t off_part, off_lists, off_cnt, off_nedges, off_fine, off_cand, off_score, off_w1, off_w2, off_idx, off_trans;
   dio_utt u[KWY_BATCH_MAX];
   template <class T>
   __device__ __forceinline__ T *at(int utt, int64_t off) const { return (T *)(scratch + utt * stride + off); }
 };
+
+// ---- zero-crossing engines -------------------------------------------------------------
+// engine e = 4*band + kind; kind 0: f, 1: -f, 2: f[i+1]-f[i], 3: f[i]-f[i+1]
+__device__ __forceinline__ double dio_sig(const double *__restrict__ f, int kind, int i) {
+  switch (kind) {
+    case 0: return f[i];
+    case 1: return -f[i];
+    case 2: return -f[i] - (-f[i + 1]);
+    default: return -(-f[i] - (-f[i + 1]));
+  }
+}
+
+__device__ __forceinline__ bool dio_is_edge(const double *__restrict__ f, int kind, int i, int len) {
+  // negative-going point between samples i and i+1 of the engine's signal (edge index i+1)
+  return i < len - 1 && 0.0 < dio_sig(f, kind, i) && dio_sig(f, kind, i + 1) <= 0.0;
+}
 
 // ---- signal preparation ---------------------------------------------------------------
 // partial sums of an utterance's samples (grid: DIO_PARTS x count); the mean is their sum in index order / (n + 1):
@@ -96,11 +115,16 @@ __global__ __launch_bounds__(DIO_NT, 4) void k_dio_filter(dio_plan P, const kwy_
   extern __shared__ double smem[];
   kwy_c *z = (kwy_c *)smem;              // H + 1 complex
   kwy_c *twl = z + (H + 1);              // exp(-2 pi i k / H), k < H/8
-  double *sh = (double *)(twl + H / 8);  // DIO_PARTS + 1
+  double *sh = (double *)(twl + H / 8);  // DIO_PARTS + 8
+  int (*zc)[128] = (int (*)[128])(sh + DIO_PARTS + 8);     // [4][128]: edges per (engine of the band, row, wavefront)
   const int tid = threadIdx.x, utt = blockIdx.y;
   const int n = P.u[utt].n, ny = n + 1;
   const int i0 = blockIdx.x * P.V;
-  if (i0 >= ny) return;
+  if (i0 >= ny) {       // (uniform) a block behind this utterance's end: no edges
+    int *cnt0 = P.at<int>(utt, P.off_cnt);
+    for (int e_ = tid; e_ < 4 * P.nbands; e_ += NT) cnt0[e_ * P.ntiles_max + blockIdx.x] = 0;
+    return;
+  }
   const double *__restrict__ x = P.u[utt].x;
   if (tid < DIO_PARTS) sh[tid] = P.at<double>(utt, P.off_part)[tid];
   for (int i = tid; i < H / 8; i += NT) twl[i] = twH[i];
@@ -130,95 +154,86 @@ __global__ __launch_bounds__(DIO_NT, 4) void k_dio_filter(dio_plan P, const kwy_
   const double xh = z[H].x;
   __syncthreads();
   const int first = 2 * P.half - 1;
-  double *filt = P.at<double>(utt, P.off_filt);
+  const int wv = tid >> 6, lane = tid & 63;
+  const int rows = (P.V + NT - 1) / NT;                    // <= DIO_ZROWS
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int *cnt = P.at<int>(utt, P.off_cnt);
   for (int b = 0; b < P.nbands; ++b) {
     const kwy_c *__restrict__ G = P.G + (size_t)b * (H + 1);
 #pragma unroll
     for (int r = 0; r < H / NT; ++r) z[tid + NT * r] = cmulf(G[tid + NT * r], X[r]);
     if (tid == 0) z[H] = {G[H].x * xh, 0.0};
     kwy_irfft_inplace<DIO_LOG2H, NT>(z, twl, twb, twN);
-    double *o = filt + (int64_t)b * P.ny_max;
+    // ---- the block's zero crossings, straight from LDS: fl[li] = filtered sample i0 + li, li < V + 2 (the block
+    //      OWNS li < V; the two samples behind them are its own values too, so every edge is decided exactly once,
+    //      on one set of numbers).  Pass 1 counts per (engine, row, wavefront) by ballots, a scan orders the slots,
+    //      pass 2 evaluates the same tests again and writes the edges to the block's list.
+    const double *fl = A + first;
+    // the four engines' tests on one triple of samples: f, -f, and the differences d(li) = f[li+1] - f[li] (formed as
+    // the engines' own expression -f[li] - (-f[li+1])), d(li+1)
+    auto edges = [&](int li, bool (&e)[4]) {
+      const int i = i0 + li;
+      const bool own = li < P.V;
+      const double f0_ = fl[min(li, P.V + 1)], f1_ = fl[min(li + 1, P.V + 1)], f2_ = fl[min(li + 2, P.V + 1)];
+      const double d0 = -f0_ - (-f1_), d1 = -f1_ - (-f2_);
+      e[0] = own && i < ny - 1 && 0.0 < f0_ && f1_ <= 0.0;
+      e[1] = own && i < ny - 1 && 0.0 < -f0_ && -f1_ <= 0.0;
+      e[2] = own && i < ny - 2 && 0.0 < d0 && d1 <= 0.0;
+      e[3] = own && i < ny - 2 && 0.0 < -d0 && -d1 <= 0.0;
+    };
+    unsigned int rows_with_edges = 0;      // (uniform per wavefront) rows in which this wavefront found any edge
+    for (int j = 0; j < rows; ++j) {
+      bool e[4];
+      edges(tid + NT * j, e);
+      unsigned long long any = 0;
 #pragma unroll
-    for (int j = 0; j < N / NT; ++j) {
-      const int q = tid + NT * j, i = i0 + q - first;
-      if (q >= first && i < ny) o[i] = A[q];
+      for (int kind = 0; kind < 4; ++kind) {
+        const unsigned long long m = __ballot(e[kind]);
+        any |= m;
+        if (lane == 0) zc[kind][j * (NT / 64) + wv] = __popcll(m);
+      }
+      if (any) rows_with_edges |= 1u << j;
+    }
+    __syncthreads();
+    if (wv < 4) {                        // wavefront k: exclusive scan of engine k's <= 128 slots, two per lane
+      const int nslot = rows * (NT / 64);
+      const int v0 = 2 * lane < nslot ? zc[wv][2 * lane] : 0, v1 = 2 * lane + 1 < nslot ? zc[wv][2 * lane + 1] : 0;
+      int inc = v0 + v1;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+      }
+      zc[wv][2 * lane] = inc - v0 - v1;
+      zc[wv][2 * lane + 1] = inc - v1;
+      if (lane == 63) cnt[(4 * b + wv) * P.ntiles_max + blockIdx.x] = min(inc, P.cap_block);
+    }
+    __syncthreads();
+    double *lists = P.at<double>(utt, P.off_lists);
+    for (int j = 0; j < rows; ++j) {
+      if (!((rows_with_edges >> j) & 1u)) continue;
+      const int li = tid + NT * j;
+      bool e[4];
+      edges(li, e);
+#pragma unroll
+      for (int kind = 0; kind < 4; ++kind) {
+        const unsigned long long m = __ballot(e[kind]);
+        if (e[kind]) {
+          const int at = zc[kind][j * (NT / 64) + wv] + __popcll(m & below);
+          if (at < P.cap_block) {
+            const double a = dio_sig(fl, kind, li), c = dio_sig(fl, kind, li + 1);
+            lists[((int64_t)(4 * b + kind) * P.ntiles_max + blockIdx.x) * P.cap_block + at] = (i0 + li + 1) - a / (c - a);
+          } else {
+            atomicExch(P.u[utt].status, 1);
+          }
+        }
+      }
     }
     __syncthreads();
   }
 }
 
-// ---- zero-crossing engines -------------------------------------------------------------
-// engine e = 4*band + kind; kind 0: f, 1: -f, 2: f[i+1]-f[i], 3: f[i]-f[i+1]
-__device__ __forceinline__ double dio_sig(const double *__restrict__ f, int kind, int i) {
-  switch (kind) {
-    case 0: return f[i];
-    case 1: return -f[i];
-    case 2: return -f[i] - (-f[i + 1]);
-    default: return -(-f[i] - (-f[i + 1]));
-  }
-}
-
-__device__ __forceinline__ bool dio_is_edge(const double *__restrict__ f, int kind, int i, int len) {
-  // negative-going point between samples i and i+1 of the engine's signal (edge index i+1)
-  return i < len - 1 && 0.0 < dio_sig(f, kind, i) && dio_sig(f, kind, i + 1) <= 0.0;
-}
-
-#define DIO_ZC_ROWS 8
-#define DIO_ZC_TILE (KWY_THREADS * DIO_ZC_ROWS)
-
-// One tile of DIO_ZC_TILE samples of ONE band, staged once in LDS (coalesced, two samples of halo), serves the
-// band's four engines.  Sample q = KWY_THREADS j + tid of the tile belongs to thread tid in row j: consecutive
-// lanes look at consecutive samples (no bank conflicts), and the order of the edges inside the tile is (row, wave,
-// lane) -- a wavefront's edges of a row are one ballot, their ranks one popcount.
-// (Rounds 1-4 ran one workgroup per (tile, ENGINE), every thread walking 8 consecutive samples straight from global
-// memory: 8 reads of the filtered signals per pass, 3.8 GB per 16 utterances and 2.2 ms; now 2 reads and LDS.)
-struct dio_zc_masks { unsigned long long m[4][DIO_ZC_ROWS]; };
-
-__device__ __forceinline__ void dio_zc_tile(const double *__restrict__ f, int ny, int tile0, double *tile,
-                                            dio_zc_masks &mk) {
-  const int tid = threadIdx.x;
-  for (int q = tid; q < DIO_ZC_TILE + 2; q += KWY_THREADS) tile[q] = (tile0 + q < ny) ? f[tile0 + q] : 0.0;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < DIO_ZC_ROWS; ++j) {
-    const int q = KWY_THREADS * j + tid, i = tile0 + q;
-#pragma unroll
-    for (int kind = 0; kind < 4; ++kind) {
-      const int len = kind < 2 ? ny : ny - 1;
-      const bool e = i < len - 1 && 0.0 < dio_sig(tile, kind, q) && dio_sig(tile, kind, q + 1) <= 0.0;
-      mk.m[kind][j] = __ballot(e);
-    }
-  }
-}
-
-// grids: (tiles of the longest utterance, bands, utterances); tiles beyond an utterance's end count nothing
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_count(dio_plan P) {
-  __shared__ double tile[DIO_ZC_TILE + 2];
-  __shared__ int wc[4][KWY_WAVES];
-  const int band = blockIdx.y, utt = blockIdx.z, tid = threadIdx.x;
-  const int ny = P.u[utt].n + 1;
-  const int tile0 = blockIdx.x * DIO_ZC_TILE;
-  int *cnt = P.at<int>(utt, P.off_cnt);
-  if (tile0 >= ny) {      // (uniform)
-    if (tid < 4) cnt[(4 * band + tid) * P.ntiles_max + blockIdx.x] = 0;
-    return;
-  }
-  dio_zc_masks mk;
-  dio_zc_tile(P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band, ny, tile0, tile, mk);
-  if ((tid & 63) == 0) {
-#pragma unroll
-    for (int kind = 0; kind < 4; ++kind) {
-      int c = 0;
-#pragma unroll
-      for (int j = 0; j < DIO_ZC_ROWS; ++j) c += __popcll(mk.m[kind][j]);
-      wc[kind][tid >> 6] = c;
-    }
-  }
-  __syncthreads();
-  if (tid < 4) cnt[(4 * band + tid) * P.ntiles_max + blockIdx.x] = wc[tid][0] + wc[tid][1] + wc[tid][2] + wc[tid][3];
-}
-
-// exclusive scan of every engine's tile counts (one block per engine and utterance)
+// exclusive scan of every engine's per-block edge counts (one workgroup per engine and utterance)
 __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_scan(dio_plan P) {
   __shared__ int tot[KWY_THREADS];
   const int utt = blockIdx.y, ntiles = P.ntiles_max;
@@ -240,46 +255,20 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_scan(dio_plan P) {
   for (int i = b0; i < b1; ++i) { int v = c[i]; c[i] = run; run += v; }
 }
 
-__global__ __launch_bounds__(KWY_THREADS) void k_dio_zc_emit(dio_plan P) {
-  __shared__ double tile[DIO_ZC_TILE + 2];
-  __shared__ int rc[4][DIO_ZC_ROWS * KWY_WAVES];      // edges per (kind, row, wave)
-  const int band = blockIdx.y, utt = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// the blocks' lists strung together in order: fine[e][off .. off + c) <- list of (e, block); grid (blocks, engines, utterances)
+__global__ __launch_bounds__(64) void k_dio_zc_gather(dio_plan P) {
+  const int blk = blockIdx.x, e = blockIdx.y, utt = blockIdx.z;
   const int ny = P.u[utt].n + 1, cap = ny / 8 + 64;
-  const int tile0 = blockIdx.x * DIO_ZC_TILE;
-  if (tile0 >= ny) return;       // (uniform) nothing of this utterance in the tile
-  dio_zc_masks mk;
-  dio_zc_tile(P.at<double>(utt, P.off_filt) + (int64_t)P.ny_max * band, ny, tile0, tile, mk);
-  if (lane == 0) {
-#pragma unroll
-    for (int kind = 0; kind < 4; ++kind)
-#pragma unroll
-      for (int j = 0; j < DIO_ZC_ROWS; ++j) rc[kind][j * KWY_WAVES + wv] = __popcll(mk.m[kind][j]);
-  }
-  __syncthreads();
-  const int *cnt = P.at<int>(utt, P.off_cnt);
-  const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int kind = 0; kind < 4; ++kind) {
-    const int e = 4 * band + kind;
-    double *o = P.at<double>(utt, P.off_fine) + (int64_t)e * P.cap_max;
-    int pos = cnt[e * P.ntiles_max + blockIdx.x];        // edges of this engine in the tiles before
-#pragma unroll
-    for (int j = 0; j < DIO_ZC_ROWS; ++j) {
-      // edges of the tile before (row j, this wave): every (row, wave) slot in front of it
-      int before = 0;
-      for (int s_ = 0; s_ < j * KWY_WAVES + wv; ++s_) before += rc[kind][s_];
-      const unsigned long long m = mk.m[kind][j];
-      if ((m >> lane) & 1ull) {
-        const int at = pos + before + __popcll(m & below);
-        if (at < cap) {
-          const int q = KWY_THREADS * j + tid;
-          const double a = dio_sig(tile, kind, q), b = dio_sig(tile, kind, q + 1);
-          o[at] = (tile0 + q + 1) - a / (b - a);
-        } else {
-          atomicExch(P.u[utt].status, 1);
-        }
-      }
-    }
+  const int *cnt = P.at<int>(utt, P.off_cnt) + e * P.ntiles_max;
+  const int off = cnt[blk];
+  const int end = blk + 1 < P.ntiles_max ? cnt[blk + 1] : P.at<int>(utt, P.off_nedges)[e];
+  const int c = end - off;
+  if (c <= 0) return;
+  const double *src = P.at<double>(utt, P.off_lists) + ((int64_t)e * P.ntiles_max + blk) * P.cap_block;
+  double *o = P.at<double>(utt, P.off_fine) + (int64_t)e * P.cap_max;
+  for (int k = threadIdx.x; k < c; k += 64) {
+    if (off + k < cap) o[off + k] = src[k];
+    else atomicExch(P.u[utt].status, 1);
   }
 }
 
@@ -372,6 +361,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_trans(dio_plan p) {
     const double cur = cand[(int64_t)a * Ts + frame];
     const double past = (b < nb && behind >= 0 && behind < T) ? cand[(int64_t)b * Ts + behind] : 0.0;
     res = dio_select_best(cur, past, [&](int i) { return cand[(int64_t)i * Ts + ahead]; }, nb, p.allowed_range);
+    // (a chosen candidate that IS 0 ends the walk exactly like "none": folded here, so that the walk's dependence
+    // chain is the table look-up alone)
+    if (res != DIO_NONE && cand[(int64_t)res * Ts + ahead] == 0.0) res = DIO_NONE;
   }
   p.at<unsigned char>(utt, p.off_trans)[((int64_t)dir * Ts + frame) * RS + st] = (unsigned char)res;
 }
@@ -469,31 +461,38 @@ __global__ __launch_bounds__(KWY_THREADS) void k_dio_fix(dio_plan p) {
         const int words = min(64, T - c0) * RS / 4;
         for (int q = lane; q < words; q += 64) tr[q] = src[q];
       };
-      // the band whose candidate of `frame` equals v (v is one of them, or 0: none)
-      auto band_of = [&](double v, int frame) -> int {
-        if (v == 0.0) return nb;
-        for (int b = 0; b < nb; ++b)
-          if (cand[(int64_t)b * Ts + frame] == v) return b;
-        return nb;
-      };
       const int sections = dir == 0 ? nc : pc;
+      const int *__restrict__ list = dir == 0 ? negative_index : positive_index;
       for (int k = 0; k < sections; ++k) {
         // step 3 (dir 0): sections in frame order, forward from their last frame up to the next section's last;
         // step 4 (dir 1): sections from the last to the first, backward from their first frame
         const int i = dir == 0 ? k : pc - 1 - k;
         const int step = dir == 0 ? 1 : -1;
-        const int j0 = dir == 0 ? negative_index[i] : positive_index[i];
-        const int limit = dir == 0 ? (i == nc - 1 ? T - 1 : negative_index[i + 1]) : (i == 0 ? 1 : positive_index[i - 1]);
-        int a = band_of(f0[j0], j0), b = band_of(f0[j0 - step], j0 - step);
+        // this section's border and the next one's in one go (two lanes, one round trip)
+        const int nb_i = dir == 0 ? (i == nc - 1 ? -1 : i + 1) : (i == 0 ? -1 : i - 1);
+        const int mine = lane == 0 ? list[i] : (lane == 1 && nb_i >= 0 ? list[nb_i] : 0);
+        const int j0 = __builtin_amdgcn_readlane(mine, 0), jn = __builtin_amdgcn_readlane(mine, 1);
+        const int limit = dir == 0 ? (nb_i < 0 ? T - 1 : jn) : (nb_i < 0 ? 1 : jn);
+        // the start state: which bands' candidates ARE the two values the walk starts from.  Everything it takes is
+        // loaded at once (lanes 0..15: the candidates of frame j0, lanes 16..31: of the frame behind, every lane:
+        // the two values), so a section costs one memory round trip, not one per comparison.
+        const int fb = j0 - step;
+        const double v0 = f0[j0], v1 = f0[fb];
+        double cv = 0.0;
+        if (lane < nb) cv = cand[(int64_t)lane * Ts + j0];
+        else if (lane >= 16 && lane < 16 + nb) cv = cand[(int64_t)(lane - 16) * Ts + fb];
+        const unsigned long long ma = __ballot(lane < nb && cv == v0);
+        const unsigned long long mb = __ballot(lane >= 16 && lane < 16 + nb && cv == v1) >> 16;
+        int a = ma ? __builtin_ctzll(ma) : nb;
+        int b = (v1 != 0.0 && mb) ? __builtin_ctzll(mb) : nb;
         for (int j = j0; dir == 0 ? j < limit : j > limit; j += step) {
           const int nx = j + step;
           if ((j & ~63) != c0) stage(j);
           int n = DIO_NONE;
           if (a < nb) n = ((const unsigned char *)tr)[(j - c0) * RS + a * nbp + b];
+          if (n == DIO_NONE) { f0[nx] = 0.0; break; }
           if ((nx & ~63) != c0) stage(nx);      // (the new value is a candidate of frame nx)
-          const double v = n == DIO_NONE ? 0.0 : cc[n][nx - c0];
-          f0[nx] = v;
-          if (v == 0) break;
+          f0[nx] = cc[n][nx - c0];
           b = a;
           a = n;
         }
@@ -737,7 +736,7 @@ static size_t dio_layout(dio_plan &p) {
   auto take = [&](size_t bytes) { size_t o = off; off += kwy_pad(bytes); return (int64_t)o; };
   const int nengines = 4 * p.nbands;
   p.off_part = take(sizeof(double) * DIO_PARTS);
-  p.off_filt = take(sizeof(double) * (size_t)p.ny_max * p.nbands);
+  p.off_lists = take(sizeof(double) * (size_t)nengines * p.ntiles_max * p.cap_block);
   p.off_cnt = take(sizeof(int) * (size_t)nengines * p.ntiles_max);
   p.off_nedges = take(sizeof(int) * nengines);
   p.off_fine = take(sizeof(double) * (size_t)nengines * p.cap_max);
@@ -770,12 +769,13 @@ static int dio_prepare(kwy_ctx *ctx, int fs, double f0_floor, double f0_ceil, do
   for (int i = 0; i < DIO_MAX_BANDS; ++i) p.boundary[i] = i < f.nbands ? f.boundary[i] : 0.0;
   p.G = f.G;
   p.half = f.Lh + 2 * f.max_hal;
-  p.V = DIO_N - 2 * p.half + 1;
+  p.V = DIO_N - 2 * p.half + 1 - 2;     // outputs a block OWNS: two more are valid behind them (the edge tests' look-ahead)
   p.fs = fs; p.f0_floor = f0_floor; p.f0_ceil = f0_ceil; p.frame_period = frame_period_ms;
   p.allowed_range = allowed_range;
   p.ny_max = (int)n_max + 1;
   p.T_max = (int)kwy_dio_frames(fs, n_max, frame_period_ms);
-  p.ntiles_max = (p.ny_max + DIO_ZC_TILE - 1) / DIO_ZC_TILE;
+  p.ntiles_max = (p.ny_max + p.V - 1) / p.V;
+  p.cap_block = p.V / 8 + 64;
   p.cap_max = p.ny_max / 8 + 64;
   p.scratch = nullptr;
   *block = dio_layout(p);
@@ -800,18 +800,17 @@ static int dio_pass(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, dio_plan p,
   const kwy_c *twH, *twN;
   KWY_TRY(kwy_get_twiddles(ctx, DIO_LOG2H, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, DIO_LOG2H + 1, &twN));
-  const size_t lds = sizeof(kwy_c) * (DIO_H + 1 + DIO_H / 8) + sizeof(double) * (DIO_PARTS + 8);
+  const size_t lds = sizeof(kwy_c) * (DIO_H + 1 + DIO_H / 8) + sizeof(double) * (DIO_PARTS + 8) + sizeof(int) * 4 * 128;
   KWY_HIP(hipFuncSetAttribute((const void *)k_dio_filter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nengines = 4 * p.nbands;
-  const unsigned nblocks = (unsigned)((p.ny_max + p.V - 1) / p.V);
+  const unsigned nblocks = (unsigned)p.ntiles_max;
   hipLaunchKernelGGL(k_dio_sum, dim3(DIO_PARTS, count), dim3(KWY_THREADS), 0, ctx->stream, p);
   KWY_PROF(ctx, "k_dio_filter", hipLaunchKernelGGL(k_dio_filter, dim3(nblocks, count), dim3(DIO_NT), lds, ctx->stream,
                                                    p, twH, twN));
   {
     kwy_prof_scope ps_(ctx, "k_dio_zc");
-    hipLaunchKernelGGL(k_dio_zc_count, dim3(p.ntiles_max, p.nbands, count), dim3(KWY_THREADS), 0, ctx->stream, p);
     hipLaunchKernelGGL(k_dio_zc_scan, dim3(nengines, count), dim3(KWY_THREADS), 0, ctx->stream, p);
-    hipLaunchKernelGGL(k_dio_zc_emit, dim3(p.ntiles_max, p.nbands, count), dim3(KWY_THREADS), 0, ctx->stream, p);
+    hipLaunchKernelGGL(k_dio_zc_gather, dim3(nblocks, nengines, count), dim3(64), 0, ctx->stream, p);
   }
   KWY_PROF(ctx, "k_dio_candidates", hipLaunchKernelGGL(k_dio_candidates, dim3((p.T_max + 255) / 256, p.nbands, count),
                                                        dim3(256), 0, ctx->stream, p));

@@ -309,6 +309,7 @@ def test_cheaptrick_mcep_entry_and_fused_lockstep_step():
     dev = [tuple(_dev(a) for a in u) for u in utts]
     outs = [torch.full((len(u[1]), order + 1), float('nan'), dtype=torch.float64, device='cuda') for u in utts]
     arr = _lib.utterance_array([(d[0], d[2], d[1], o) for d, o in zip(dev, outs)])
+    torch.cuda.synchronize()          # (torch filled `outs` on its stream; the library runs on the context's)
     _lib.check(ctx, lib.kwy_cheaptrick_mcep_batch_dev(ctx.handle, arr, len(utts), fs, -0.15, 71.0, 2048, float(fs), order, alpha))
     ctx.sync()
     for i in (0, 5, 17):

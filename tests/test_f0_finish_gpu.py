@@ -35,6 +35,7 @@ def _batch_f0(ctx, waves, fs, frame_period=5.0):
     f0 = [torch.empty(n, dtype=torch.float64, device='cuda') for n in T]
     refined = [torch.empty(n, dtype=torch.float64, device='cuda') for n in T]
     status = torch.full((len(waves),), 7, dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()          # (torch filled these on ITS stream; the library runs on the context's)
     world.dio_batch_dev(ctx, dx, fs, t, f0, status, frame_period=frame_period)
     world.stonemask_batch_dev(ctx, dx, t, f0, fs, refined)
     ctx.sync()
@@ -111,6 +112,7 @@ def test_dio_dev_single_and_status_word():
     t = torch.empty(T, dtype=torch.float64, device='cuda')
     f0 = torch.empty(T, dtype=torch.float64, device='cuda')
     st = torch.full((1,), 5, dtype=torch.int32, device='cuda')
+    torch.cuda.synchronize()
     _lib.check(ctx, lib.kwy_dio_dev(ctx.handle, c_vp(dx.data_ptr()), len(a), fs, 71.0, 800.0, 2.0, 5.0, 1, 0.1,
                                     c_vp(t.data_ptr()), c_vp(f0.data_ptr()), c_vp(st.data_ptr())))
     out = torch.empty(T, dtype=torch.float64, device='cuda')
@@ -142,6 +144,7 @@ def _device_pcm(ctx, ys, frame_lens, fs, **kw):
     dy = [_dev(y) for y in ys]
     keep = [y.clone() for y in dy]
     pcm = [torch.full((len(y),), -7, dtype=torch.int16, device='cuda') for y in ys]
+    torch.cuda.synchronize()
     finish.pcm16_batch_dev(ctx, dy, frame_lens, fs, pcm, **kw)
     ctx.sync()
     for a, b in zip(dy, keep):
@@ -257,6 +260,7 @@ def test_mlsa_filter_batch_equals_single_calls():
         y = torch.full((n,), 9.0, dtype=torch.float64, device='cuda')
         keep.append((x, mc, y))
         jobs.append((x, n, mc, T, y))
+    torch.cuda.synchronize()
     for ignore in (1, 0):
         arr = _lib.job_array(_lib.MlsaJob, jobs)
         _lib.check(ctx, lib.kwy_mlsa_filter_batch_dev(ctx.handle, arr, len(jobs), order, alpha, pd, hop, ignore))
@@ -267,6 +271,7 @@ def test_mlsa_filter_batch_equals_single_calls():
                 m2[:, 0] = 0.0
             b = torch.empty_like(m2)
             y1 = torch.empty_like(y)
+            torch.cuda.synchronize()          # (torch prepared m2 on ITS stream; the library runs on the context's)
             _lib.check(ctx, lib.kwy_mc2b_dev(ctx.handle, c_vp(m2.data_ptr()), T, order, alpha, c_vp(b.data_ptr())))
             _lib.check(ctx, lib.kwy_mlsa_synthesis_dev(ctx.handle, c_vp(x.data_ptr()), n, c_vp(b.data_ptr()), T, order, alpha,
                                                        pd, hop, c_vp(y1.data_ptr())))
@@ -294,6 +299,7 @@ def test_convert_batch_diff_outputs():
     for i, a in enumerate(an):
         mc = torch.from_numpy(np.ascontiguousarray(a.mel_cepstrum.data)).cuda()
         out = torch.empty_like(mc)
+        torch.cuda.synchronize()
         _lib.check(ctx, lib.kwy_convert_mcep_dev(ctx.handle, c_vp(mc.data_ptr()), len(mc), 24, dg.M,
                                                  c_vp(dg.model(diff=True).data_ptr()), c_vp(out.data_ptr())))
         ctx.sync()
