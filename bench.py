@@ -49,7 +49,7 @@ if _argv_value('--driver', 'batch') == 'streams' or (_argv_value('--workload', '
 FS = 48000
 FRAME_PERIOD = 5.0
 # counter summaries of the current kernels (tools/final_measure.sh + tools/collect_profiles.sh)
-PMC_TRAFFIC, PMC_SQ = 'r4_pmc_traffic.json', 'r4_pmc_sq_summary.json'
+PMC_TRAFFIC, PMC_SQ = 'r5_pmc_traffic.json', 'r5_pmc_sq_summary.json'
 METRIC = 'frames/sec end-to-end analyse->align->convert->synth, 48 kHz 5 ms hop'
 
 
@@ -427,7 +427,7 @@ def main_lockstep(args):
     #      cannot be recorded inside a captured graph here), the library's events around its tracked kernels
     names = ['k_cheaptrick', 'k_d4c_lovetrain', 'k_d4c_body', 'k_d4c_bands', 'k_syn_phase', 'k_syn_pulse', 'k_syn_ola', 'k_sp2mc',
              'k_mc2sp', 'k_dtw_dist', 'k_dtw_values', 'k_dtw_codes', 'k_dtw_trace', 'k_dtw_small', 'k_gmm_logp', 'k_mlpg_chunks',
-             'k_mlpg_finish', 'k_np_words', 'k_np_jump', 'k_np_words_seg', 'k_np_emit', 'k_dio_filter', 'k_dio_zc',
+             'k_mlpg_finish', 'k_np_words', 'k_np_jump', 'k_np_words_seg', 'k_np_emit', 'k_cep2mc', 'k_dio_filter', 'k_dio_zc',
              'k_dio_candidates', 'k_dio_fix', 'k_stonemask', 'k_finish']
     pipe.profile(True)
     for _ in range(min(args.steps, 3)):

@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh [round, default r4] [source dir, default gpurun_out/final]
 set -e
 cd "$(dirname "$0")/.."
-RND=${1:-r4}
+RND=${1:-r5}
 S=${2:-gpurun_out/final}
 P=profiles
 newest() { ls -t $1 2>/dev/null | head -1; }
@@ -16,6 +16,8 @@ keep $S/bench_serial.json $P/${RND}_pair_serial_bench.json
 keep $S/bench_streams.json $P/${RND}_pair_streams_bench.json
 keep $S/bench_utt_b1.json $P/${RND}_utterance_b1_bench.json
 keep $S/bench_config4.json $P/${RND}_config4_bench.json
+keep $S/bench_wav.json $P/${RND}_wav_in_pcm_out_bench.json
+keep $S/bench_corpus_profiled.json $P/${RND}_corpus_profiled_bench.json
 keep $S/bench_fit.json $P/${RND}_fit_bench.json
 keep $S/bench_fit_1rank_nccl.json $P/${RND}_fit_1rank_nccl_bench.json
 keep $S/bench_corpus.json $P/${RND}_corpus_bench.json
@@ -33,6 +35,9 @@ if [ -n "$F" ] && [ -n "$W" ]; then
   python $P/make_pmc_traffic.py "$F" "$W" $RND 33616 \
     "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace (two separate passes) -- python bench.py --driver serial --batch 16 --steps 2 --warmup 1 --no-graph --no-variants --no-cpu-baseline" > /dev/null
 fi
+[ -f $S/wav_serial_kernel_stats.csv ] && cp $S/wav_serial_kernel_stats.csv $P/${RND}_wav_serial_kernel_stats.csv
+[ -f $S/diff_batch_kernel_stats.csv ] && cp $S/diff_batch_kernel_stats.csv $P/${RND}_diff_batch_kernel_stats.csv
+[ -f $S/diff_batch.log ] && tail -n 1 $S/diff_batch.log > $P/${RND}_diff_batch_bench.json
 [ -f $S/kat_envelopes.hip.json ] && cp $S/kat_envelopes.hip.json $P/${RND}_kat_envelopes_hip.json
 if [ -d $S/pmc_sq ]; then
   cp "$(newest "$S/pmc_sq/pass1/*/*counter_collection.csv")" $P/${RND}_pmc_sq_pass1_counter_collection.csv

@@ -19,20 +19,21 @@ if [ "$PART" = a ]; then
   python $R/bench.py --driver streams --no-cpu-baseline > $O/bench_streams.json 2>/dev/null
   python $R/bench.py --workload utterance --batch 1 > $O/bench_utt_b1.json 2>/dev/null
   python $R/bench.py --workload utterance --utterances 256 --steps 3 --warmup 1 > $O/bench_config4.json 2> $O/bench_config4.err
+  # round 5: the same step from waveforms to 16-bit samples (DIO + StoneMask and the post-step inside it)
+  python $R/bench.py --workload wav --no-variants --config4 off > $O/bench_wav.json 2> $O/bench_wav.err
   echo done > $O/DONE_A
 elif [ "$PART" = b ]; then
   python $R/bench_fit.py > $O/bench_fit.json 2>/dev/null
   python $R/bench_corpus.py > $O/bench_corpus.json 2> $O/bench_corpus.err
+  python $R/bench_corpus.py --profile-fit > $O/bench_corpus_profiled.json 2>/dev/null
   python $R/bench_corpus.py --em-iters 10 > $O/bench_corpus_em10.json 2>/dev/null
   python $R/bench_corpus.py --driver streams --distinct 8 --em-iters 10 > $O/bench_corpus_streams.json 2>/dev/null
-  # the N-rank paths rehearsed on this one GPU: two ranks, gloo for the collectives, started by torchrun from the shell
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
-    $R/bench_fit.py --backend gloo --frames 200000 > $O/bench_fit_2rank_gloo.json 2> $O/bench_fit_2rank_gloo.err
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 \
-    $R/bench_corpus.py --backend gloo --pairs 64 --seconds 2 --em-iters 10 > $O/bench_corpus_2rank_gloo.json 2> $O/bench_corpus_2rank_gloo.err
+  # the N-rank paths rehearsed on this one GPU: two ranks started by the benches' OWN --gpus flag (bench_launch.py),
+  # gloo for the collectives
+  python $R/bench_fit.py --gpus 2 --backend gloo --frames 200000 > $O/bench_fit_2rank_gloo.json 2> $O/bench_fit_2rank_gloo.err
+  python $R/bench_corpus.py --gpus 2 --backend gloo --pairs 64 --seconds 2 --em-iters 10 > $O/bench_corpus_2rank_gloo.json 2> $O/bench_corpus_2rank_gloo.err
   python $R/bench_corpus.py --pairs 64 --seconds 2 --em-iters 10 > $O/bench_corpus_1rank_64.json 2>/dev/null
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29543 \
-    $R/bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --no-cpu-baseline --no-variants > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
+  python $R/bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --config4-utterances 32 --no-cpu-baseline --no-variants > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
   # RCCL itself: a one-rank 'nccl' group on the one GPU
   python $R/bench_fit.py --backend nccl --force-group > $O/bench_fit_1rank_nccl.json 2> $O/bench_fit_1rank_nccl.err
   echo done > $O/DONE_B
@@ -42,5 +43,13 @@ else
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $SERIAL > $O/pmc_write.log 2>&1
   KWY_MEASURE_OUT=$O/pmc_sq bash $R/tools/pmc_sq.sh
   bash $R/tools/prof_fit.sh
+  # round 5: per-kernel durations of the wav-in / pcm-out step (k_dio_*, k_stonemask, k_fin_*) and of the batch path's
+  # differential outputs (k_mlsa_filter, k_mc2b)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/wav_serial -- python $R/bench.py --workload wav --driver serial --no-variants --no-cpu-baseline --config4 off > $O/wav_serial.log 2>&1
+  cp "$(ls -t $O/wav_serial/*/*kernel_stats.csv | head -1)" $O/wav_serial_kernel_stats.csv
+  rm -f $O/wav_serial/*/*kernel_trace.csv
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/diff_batch -- python $R/tools/diff_batch_run.py > $O/diff_batch.log 2>&1
+  cp "$(ls -t $O/diff_batch/*/*kernel_stats.csv | head -1)" $O/diff_batch_kernel_stats.csv
+  rm -f $O/diff_batch/*/*kernel_trace.csv
   echo done > $O/DONE_C
 fi
