@@ -130,6 +130,17 @@ class HipStats:
         idx = self.torch.from_numpy(np.asarray(labels, dtype=np.int64)).to(self.dev)
         self.resp[self.torch.arange(self.n, device=self.dev), idx] = 1.0
 
+    def sort_rows_by_component(self):
+        """Reorder the local rows so that the frames of a component sit together (stable sort by the component of
+        largest responsibility: right after k-means, its cluster).  The fit does not depend on the order of its rows
+        beyond the rounding of its sums, and the covariance kernel skips whole tiles of frames that carry no weight
+        for a component (kwy_gmm_em_cov_stats_dev): with the rows grouped that is nearly all of them.  The caller's
+        matrix is left alone (a sorted copy takes its place here)."""
+        torch = self.torch
+        order = torch.argsort(self.resp.argmax(dim=1), stable=True)
+        self.X = self.X.index_select(0, order)
+        self.resp = self.resp.index_select(0, order)
+
     def set_params(self, weights, means, covs):
         for dst, src in ((self.weights, weights), (self.means, means), (self.covs, covs)):
             dst.copy_(self.torch.from_numpy(np.ascontiguousarray(src, dtype=np.float64)))
@@ -510,12 +521,13 @@ class GaussianMixtureHIP:
     covariance_type = 'full'
 
     def __init__(self, n_components=1, covariance_type='full', tol=1e-3, reg_covar=1e-6, max_iter=100,
-                 n_init=1, init_params='kmeans', random_state=None, verbose=0, device_index=0, **unused):
+                 n_init=1, init_params='kmeans', random_state=None, verbose=0, device_index=0, sort_rows=True, **unused):
         if covariance_type != 'full' or n_init != 1 or init_params != 'kmeans':
             raise NotImplementedError('GaussianMixtureHIP implements the configuration the reference uses: '
                                       "covariance_type='full', n_init=1, init_params='kmeans'")
         self.n_components, self.tol, self.reg_covar, self.max_iter = n_components, tol, reg_covar, max_iter
         self.random_state, self.verbose, self.device_index = random_state, verbose, device_index
+        self.sort_rows = sort_rows        # group the rows by their k-means cluster before EM (HipStats.sort_rows_by_component)
 
     def fit(self, X, y=None, stats=None, labels=None):
         """X: the local shard, (n, D) numpy array or a float64 device tensor.  labels: optional initial hard
@@ -538,6 +550,9 @@ class GaussianMixtureHIP:
         else:
             self.kmeans_n_iter_, self.kmeans_centers_ = kmeans_init(stats, self.n_components, self.random_state,
                                                                     verbose=self.verbose > 1)
+        if self.sort_rows and hasattr(stats, 'sort_rows_by_component'):
+            with stats.scope():
+                stats.sort_rows_by_component()
         self.lower_bound_, self.converged_, self.n_iter_ = em_fit(
             stats, n_total, self.max_iter, self.tol, self.reg_covar, self.verbose > 1)
         if self.verbose:

@@ -397,11 +397,45 @@ __device__ __forceinline__ void fit_cov_store(double *__restrict__ out, int D, i
   });
 }
 
+// act[m][tile]: does any of the tile's FIT_COV_TILE frames carry a responsibility >= r_min for mixture m?  One
+// workgroup per FIT_ACT_TILES tiles (resp is read once, coalesced); k_fit_cov fetches, stages and multiplies only the
+// tiles that do -- in a fitted mixture most tiles of most components do not.
+#define FIT_ACT_TILES 8
+__global__ __launch_bounds__(KWY_THREADS) void k_fit_active(const double *__restrict__ resp, int64_t n, int D, int M,
+                                                           const double *__restrict__ stats, int64_t ntiles,
+                                                           unsigned char *__restrict__ act) {
+  __shared__ unsigned char f[KWY_THREADS];
+  const int tid = threadIdx.x;
+  const int per = KWY_THREADS / M > 0 ? KWY_THREADS / M : 1;     // row groups side by side (M <= 256)
+  const int m = tid % M, rg = tid / M;
+  const double r_min = fmax(FIT_R_MIN, stats ? stats[(size_t)m * (D + 1)] * FIT_R_REL : 0.0);
+  for (int q = 0; q < FIT_ACT_TILES; ++q) {
+    const int64_t tile = (int64_t)blockIdx.x * FIT_ACT_TILES + q;
+    if (tile >= ntiles) return;      // (uniform)
+    const int64_t t0 = tile * FIT_COV_TILE;
+    bool any = false;
+    if (rg < per)
+      for (int r = rg; r < FIT_COV_TILE; r += per) {
+        const int64_t t = t0 + r;
+        if (t < n && resp[t * M + m] >= r_min) any = true;
+      }
+    f[tid] = any ? 1 : 0;
+    __syncthreads();
+    if (tid < M) {
+      unsigned char o = 0;
+      for (int g = 0; g < per; ++g) o |= f[tid + M * g];
+      act[(size_t)tid * ntiles + tile] = o;
+    }
+    __syncthreads();
+  }
+}
+
 template <int NBLK>
 __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__restrict__ X, const double *__restrict__ resp,
                                                            int64_t n, int D, int M, int nsplit,
                                                            const double *__restrict__ means,
                                                            const double *__restrict__ stats,
+                                                           const unsigned char *__restrict__ act, int64_t ntiles,
                                                            double *__restrict__ cpart) {
   constexpr int NP = 16 * NBLK, ZS = NP + 1, CMAX = (NBLK * (NBLK + 1) / 2 + 3) / 4;
   constexpr int ROWS = FIT_COV_TILE / 4;   // rows of a tile staged by one wavefront
@@ -420,7 +454,7 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
     m = blockIdx.x % M;
     split = blockIdx.x / M;
   }
-  const int64_t rows = (n + nsplit - 1) / nsplit;
+  const int64_t rows = ((n + nsplit - 1) / nsplit + FIT_COV_TILE - 1) / FIT_COV_TILE * FIT_COV_TILE;   // whole tiles
   const int64_t r0 = split * rows, r1 = min(n, r0 + rows);
   const double *mu = means + (size_t)m * D;
   const double r_min = fmax(FIT_R_MIN, stats ? stats[(size_t)m * (D + 1)] * FIT_R_REL : 0.0);
@@ -455,13 +489,23 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
       }
     if (tid < FIT_COV_TILE) rs[buf * FIT_COV_TILE + tid] = rv;
   };
-  if (r0 < r1) {
-    fetch(r0);
+  // tiles of this split that carry any weight for this mixture (act, k_fit_active), in order: the next one is fetched
+  // while the current one is multiplied
+  const unsigned char *__restrict__ am = act + (size_t)m * ntiles;
+  const int64_t tile1 = (r1 + FIT_COV_TILE - 1) / FIT_COV_TILE;
+  auto next_active = [&](int64_t t) {
+    while (t < tile1 && !am[t]) ++t;
+    return t;
+  };
+  int64_t cur = r0 < r1 ? next_active(r0 / FIT_COV_TILE) : tile1;
+  if (cur < tile1) {
+    fetch(cur * FIT_COV_TILE);
     stage(0);
     __syncthreads();
     int buf = 0;
-    for (int64_t b0 = r0; b0 < r1; b0 += FIT_COV_TILE) {
-      fetch(b0 + FIT_COV_TILE);   // in flight during the MFMAs below
+    while (cur < tile1) {
+      const int64_t nxt = next_active(cur + 1);
+      if (nxt < tile1) fetch(nxt * FIT_COV_TILE);   // in flight during the MFMAs below
       const double *tile = ds + buf * FIT_COV_TILE * ZS, *rt = rs + buf * FIT_COV_TILE;
       switch (wv) {
         case 0: fit_cov_tile<NBLK, 0, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
@@ -469,9 +513,10 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
         case 2: fit_cov_tile<NBLK, 2, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
         default: fit_cov_tile<NBLK, 3, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
       }
-      stage(buf ^ 1);             // last read two tiles ago, before the previous barrier
+      if (nxt < tile1) stage(buf ^ 1);              // last read two tiles ago, before the previous barrier
       __syncthreads();
       buf ^= 1;
+      cur = nxt;
     }
   }
   // lower-triangle blocks only (diagonal blocks in full); k_fit_reduce_sym mirrors them
@@ -670,10 +715,11 @@ static int fit_cov_splits(int64_t n, int M) {
 
 template <int NBLK>
 static int fit_cov_launch(kwy_ctx *ctx, const double *X, const double *resp, int64_t n, int D, int M,
-                          const double *means, const double *stats, double *cpart, int nsplit) {
+                          const double *means, const double *stats, const unsigned char *act, int64_t ntiles,
+                          double *cpart, int nsplit) {
   const size_t lds = sizeof(double) * (2 * (size_t)FIT_COV_TILE * (16 * NBLK + 1) + 2 * FIT_COV_TILE);
   KWY_HIP(hipFuncSetAttribute((const void *)k_fit_cov<NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<NBLK>, dim3((unsigned)(M * nsplit)), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, nsplit, means, stats, cpart));
+  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<NBLK>, dim3((unsigned)(M * nsplit)), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, nsplit, means, stats, act, ntiles, cpart));
   return KWY_OK;
 }
 
@@ -692,20 +738,25 @@ extern "C" int kwy_gmm_em_cov_stats_dev(kwy_ctx *ctx, const double *X, int64_t n
   KWY_HIP(hipSetDevice(ctx->device));
   const int64_t len = (int64_t)M * D * D;
   const int nsplit = fit_cov_splits(n, M);
-  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)nsplit * len)));
+  const int64_t ntiles = (n + FIT_COV_TILE - 1) / FIT_COV_TILE;
+  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)nsplit * len) + kwy_pad((size_t)M * ntiles)));
   double *cpart = kwy_arena<double>(ctx, (size_t)nsplit * len);
-  if (!cpart) { ctx->err = "gmm_em_cov: scratch"; return KWY_ENOMEM; }
+  unsigned char *act = (unsigned char *)kwy_arena_alloc(ctx, (size_t)M * ntiles);
+  if (!cpart || !act) { ctx->err = "gmm_em_cov: scratch"; return KWY_ENOMEM; }
+  hipLaunchKernelGGL(k_fit_active, dim3((unsigned)((ntiles + FIT_ACT_TILES - 1) / FIT_ACT_TILES)), dim3(KWY_THREADS), 0,
+                     ctx->stream, resp, n, D, M, stats, ntiles, act);
+  KWY_HIP(hipGetLastError());
   switch ((D + 15) / 16) {
-    case 1: KWY_TRY(fit_cov_launch<1>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 2: KWY_TRY(fit_cov_launch<2>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 3: KWY_TRY(fit_cov_launch<3>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 4: KWY_TRY(fit_cov_launch<4>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 5: KWY_TRY(fit_cov_launch<5>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 6: KWY_TRY(fit_cov_launch<6>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 7: KWY_TRY(fit_cov_launch<7>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 8: KWY_TRY(fit_cov_launch<8>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    case 9: KWY_TRY(fit_cov_launch<9>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
-    default: KWY_TRY(fit_cov_launch<10>(ctx, X, resp, n, D, M, means, stats, cpart, nsplit)); break;
+    case 1: KWY_TRY(fit_cov_launch<1>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 2: KWY_TRY(fit_cov_launch<2>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 3: KWY_TRY(fit_cov_launch<3>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 4: KWY_TRY(fit_cov_launch<4>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 5: KWY_TRY(fit_cov_launch<5>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 6: KWY_TRY(fit_cov_launch<6>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 7: KWY_TRY(fit_cov_launch<7>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 8: KWY_TRY(fit_cov_launch<8>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 9: KWY_TRY(fit_cov_launch<9>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    default: KWY_TRY(fit_cov_launch<10>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
   }
   hipLaunchKernelGGL(k_fit_reduce_sym, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, cpart, nsplit, D,
                      M, sxx);
