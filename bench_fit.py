@@ -109,6 +109,9 @@ def main():
                           'kmeans_init_ms': km_s * 1e3, 'kmeans_lloyd_iterations': km_iters,
                           'k_fit_logprob_ms': lp_ms, 'k_fit_cov_ms': cv_ms,
                           'logprob_tflops': lp_tf, 'cov_tflops': cv_tf,
+                          'cov_note': 'cov_tflops counts the DENSE product 2 n M D(D+1)/2; since round 5 the kernel skips frame groups '
+                                      'and tiles whose responsibilities are below max(2^-200, 2^-70 nk) (kwy_gmm_em_cov_stats_dev), so the '
+                                      'figure is a dense-equivalent rate and may exceed the matrix peak; k_fit_logprob skips nothing',
                           'roofline': {'bound': 'mfma', 'kernel': 'k_fit_logprob', 'achieved': lp_tf, 'peak': peak,
                                        'unit': 'TFLOP/s', 'frac': lp_tf / peak if lp_tf else None, 'traffic': None,
                                        'note': 'useful flops 2 n M D(D+1)/2 per kernel (the padded 16x16 blocks on the '

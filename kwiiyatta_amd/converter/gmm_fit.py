@@ -355,13 +355,17 @@ def _kmeans_init(stats, n_components, random_state, max_iter, tol, verbose):
     for n_iter in range(1, max_iter + 1):
         changed = comm.all_reduce(stats.km_assign(centers).clone())
         st = comm.all_reduce(stats.km_sums())
-        empty = (st[:, 0] == 0).nonzero().flatten()
-        if len(empty):
-            _relocate_empty_clusters(stats, comm, st, centers, empty, row0)
+        # ONE host round trip per iteration: the centres are updated as if no cluster were empty (the usual case) and
+        # {empty clusters, changed labels, centre shift} come back together; an empty cluster -- sklearn relocates it
+        # BEFORE the update -- makes the iteration redo its update (km_update is a pure function of `st` and the old centres)
         shift2 = stats.km_update(st, centers, centers_new)
+        n_empty, n_changed, shift_tot = torch.stack(((st[:, 0] == 0).sum().to(torch.float64),
+                                                     changed.reshape(()).to(torch.float64), shift2.sum())).tolist()
+        if n_empty > 0:
+            _relocate_empty_clusters(stats, comm, st, centers, (st[:, 0] == 0).nonzero().flatten(), row0)
+            shift_tot = float(stats.km_update(st, centers, centers_new).sum().item())
         centers, centers_new = centers_new, centers
-        n_changed = int(changed.item())
-        shift_tot = float(shift2.sum().item())
+        n_changed = int(n_changed)
         if verbose:
             print(f'  k-means iteration {n_iter}: {n_changed} labels changed, centre shift {shift_tot:.3e}')
         if n_changed == 0:

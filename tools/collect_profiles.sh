@@ -37,7 +37,7 @@ if [ -n "$F" ] && [ -n "$W" ]; then
 fi
 [ -f $S/wav_serial_kernel_stats.csv ] && cp $S/wav_serial_kernel_stats.csv $P/${RND}_wav_serial_kernel_stats.csv
 [ -f $S/diff_batch_kernel_stats.csv ] && cp $S/diff_batch_kernel_stats.csv $P/${RND}_diff_batch_kernel_stats.csv
-[ -f $S/diff_batch.log ] && tail -n 1 $S/diff_batch.log > $P/${RND}_diff_batch_bench.json
+[ -f $S/diff_batch.log ] && grep "^{" $S/diff_batch.log | tail -n 1 > $P/${RND}_diff_batch_bench.json
 [ -f $S/kat_envelopes.hip.json ] && cp $S/kat_envelopes.hip.json $P/${RND}_kat_envelopes_hip.json
 if [ -d $S/pmc_sq ]; then
   cp "$(newest "$S/pmc_sq/pass1/*/*counter_collection.csv")" $P/${RND}_pmc_sq_pass1_counter_collection.csv
