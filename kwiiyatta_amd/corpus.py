@@ -446,9 +446,10 @@ class ConvertWave:
     /root/reference/kwiiyatta/convert_voice.py:19,39-40, filter/mlsa.py:9-30 -- as `wave_diff[i]` (and `pcm_diff[i]`:
     Wavdata.save's normalisation only, a filtered waveform has no synthesis post-step)."""
 
-    def __init__(self, ls, fs, utterances, gmm=None, order=24, frame_period=5.0, pcm=False, diff=False):
+    def __init__(self, ls, fs, utterances, gmm=None, order=24, frame_period=5.0, pcm=False, diff=False, defer_mlsa=False):
         self.ls, self.fs, self.order, self.frame_period = ls, int(fs), int(order), float(frame_period)
         self.diff = bool(diff) and gmm is not None
+        self.defer_mlsa = bool(defer_mlsa)       # the caller launches the MLSA recursions of several waves together
         self.wav_in = len(utterances) > 0 and not isinstance(utterances[0], (tuple, list))
         dev = ls.dev
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
@@ -515,7 +516,8 @@ class ConvertWave:
                 xo = np.concatenate(([0], np.cumsum([v.numel() for v in self.x]))).astype(np.int64)
                 self.wave_diff_all = torch.empty(int(xo[-1]), **f64)
                 self.wave_diff = [cut(self.wave_diff_all, xo, i) for i in range(n)]
-                self.j_mlsa = _lib.job_array(_lib.MlsaJob, [(self.x[i], self.x[i].numel(), cut(self.mc_diff, off, i), self.T[i],
+                self.mc_diff_rows = [cut(self.mc_diff, off, i) for i in range(n)]
+                self.j_mlsa = _lib.job_array(_lib.MlsaJob, [(self.x[i], self.x[i].numel(), self.mc_diff_rows[i], self.T[i],
                                                             self.wave_diff[i]) for i in range(n)])
                 self.hop = int(self.fs * (self.frame_period * 0.001))
                 self.pcm_diff = None
@@ -557,19 +559,35 @@ class ConvertWave:
                 # the differential conversion of the same mel-cepstra, its filter over the INPUT waveforms: all
                 # utterances' recursions side by side (one wavefront each)
                 chk(lib.kwy_convert_mcep_batch_dev(h, self.j_conv_diff, n, order, self.gmm.M, _p(self.model_diff)))
-                chk(lib.kwy_mlsa_filter_batch_dev(h, self.j_mlsa, n, order, self.alpha, 4, self.hop, 1))
-                if self.pcm_diff is not None:
-                    chk(lib.kwy_finish_pcm16_batch_dev(h, self.j_fin_diff, n, fs, 0, PIECE_CEILING, 1, PIECE_CEILING))
+                if not self.defer_mlsa:
+                    self.run_mlsa(ls.ctx)
+
+    def mlsa_rows(self):
+        """the wave's MLSA jobs as rows (for ONE launch over the utterances of several waves: a recursion occupies one
+        wavefront for 0.6 us per sample whatever else runs, so all files of a batch should recurse side by side)"""
+        return [(self.x[i], self.x[i].numel(), self.mc_diff_rows[i], self.T[i], self.wave_diff[i]) for i in range(self.n)]
+
+    def run_mlsa(self, ctx):
+        from .pipeline import PIECE_CEILING
+        chk = lambda rc: _lib.check(ctx, rc)  # noqa: E731
+        chk(lib.kwy_mlsa_filter_batch_dev(ctx.handle, self.j_mlsa, self.n, self.order, self.alpha, 4, self.hop, 1))
+        self.finish_diff(ctx)
+
+    def finish_diff(self, ctx):
+        from .pipeline import PIECE_CEILING
+        if self.pcm_diff is not None:
+            _lib.check(ctx, lib.kwy_finish_pcm16_batch_dev(ctx.handle, self.j_fin_diff, self.n, self.fs, 0, PIECE_CEILING, 1,
+                                                           PIECE_CEILING))
 
 
 def _lockstep_batch(utterances, fs, device_index, gmm, order, frame_period, ls, keep, wave_size=16, pcm=False, diff=False):
     """utterances in waves of `wave_size` through ConvertWave; keep(i, waveform view[, pcm view]) on the main stream.
     Bare waveforms get their f0 on the device; the DIO status words of all waves are read back ONCE at the end."""
     ls = ls if ls is not None else _Lockstep(device_index)
-    held, status = [], []
+    held, status, waves_diff = [], [], []
     for w0 in range(0, len(utterances), wave_size):
         wv = ConvertWave(ls, fs, utterances[w0:w0 + wave_size], gmm=gmm, order=order, frame_period=frame_period, pcm=pcm,
-                         diff=diff)
+                         diff=diff, defer_mlsa=diff)
         wv.run()
         with torch.cuda.stream(ls.main):
             for i in range(wv.n):
@@ -581,9 +599,27 @@ def _lockstep_batch(utterances, fs, device_index, gmm, order, frame_period, ls, 
                     keep(w0 + i, wv.wave[i])
         if wv.f0_status is not None:
             status.append(wv.f0_status)
+        if diff:
+            waves_diff.append(wv)            # (kept: its inputs and mel-cepstra feed the filter launch below)
         held.append(wv)
         while len(held) > 2:
             held.pop(0)
+    if waves_diff:
+        # the differential outputs of ALL files: one pass of launches over every recursion (64 per launch; two contexts
+        # alternate so that consecutive launches overlap), then their post-step
+        rows = [r for wv in waves_diff for r in wv.mlsa_rows()]
+        wv0 = waves_diff[0]
+        ls.side.wait_stream(ls.main)
+        for k, c0 in enumerate(range(0, len(rows), 64)):
+            ctx = (ls.ctx, ls.side_ctx)[k % 2]
+            with torch.cuda.stream((ls.main, ls.side)[k % 2]):
+                chunk = rows[c0:c0 + 64]
+                _lib.check(ctx, lib.kwy_mlsa_filter_batch_dev(ctx.handle, _lib.job_array(_lib.MlsaJob, chunk), len(chunk), order,
+                                                              wv0.alpha, 4, wv0.hop, 1))
+        ls.main.wait_stream(ls.side)
+        with torch.cuda.stream(ls.main):
+            for wv in waves_diff:
+                wv.finish_diff(ls.ctx)
     ls.sync()
     if status and bool(torch.cat(status).any().item()):
         bad = torch.nonzero(torch.cat(status)).flatten().tolist()
