@@ -553,7 +553,7 @@ class PairBatchPipeline(_Graphed):
                 # The f0 tracks of ALL waves first, on the origin stream, then the fork.  (With the extraction at the
                 # head of every wave's own stream -- forks of the graph at two different depths -- hipStreamEndCapture
                 # crashed on ROCm 7.2 as soon as there were two waves, whatever ran on the second one:
-                # scratch/capture_probe2.py.  The kernels are chip-wide anyway.)
+                # tools/capture_probe.py.  The kernels are chip-wide anyway.)
                 c0 = self.waves[0].ctx
                 for wv in self.waves:
                     _lib.check(c0, lib.kwy_dio_batch_dev(c0.handle, wv.j_dio, 2 * wv.n, fs, 71.0, 800.0, 2.0,
