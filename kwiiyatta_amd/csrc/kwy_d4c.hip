@@ -293,12 +293,17 @@ struct d4c_params {
 // table thread t jumps to draw c*t and produces c = ceil(wl/NT) draws, which travel through
 // Bd (N doubles of LDS, free on entry) to the threads that use them.  `normalise` scales to
 // unit power (GetCentroid).
+// wcos / wmode: the window's cosine c1(i) is the same for the frame's three windows (one f0, ratio 4 for the Blackman
+// and the Hanning window alike, and exactly even around the centre), so the first window leaves it in LDS (wmode 1:
+// slot min(i, wl - 1 - i) of wcos, <= N/4 + 1 doubles) and the other two read it (wmode 2) instead of evaluating the
+// polynomial again -- ~45 instructions per element, a tenth of the kernel.  wmode 0: evaluate, no cache (the frames
+// whose draws lie beyond the table build their jump table where the cache lives).
 template <int N, int NT>
 __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, int x_length, const d4c_params &p, double cf0,
                                                  double pos, int type, uint64_t dpos, const kwy_randn_src &rs,
                                                  const uint4 *__restrict__ poly, uint32_t *e, uint4 *jtab,
                                                  double *Bd, bool normalise, double *red,
-                                                 double (&av)[N / NT]) {
+                                                 double (&av)[N / NT], double *wcos, int wmode) {
   constexpr int E = N / NT;
   const int tid = kwy_tid_opaque();
   // The window function is the same for the two centroid windows; left alone, the compiler
@@ -346,7 +351,15 @@ __device__ __forceinline__ void d4c_frame_window(const double *__restrict__ x, i
     const int i = tid + NT * r;
     double v = 0.0;
     if (i < wl) {
-      const double w = d4c_window(type, i, half, 4.0, p.fs, cf0);
+      const int slot = i <= half ? i : wl - 1 - i;
+      double c1;
+      if (wmode == 2) {
+        c1 = wcos[slot];
+      } else {
+        c1 = kwy_cos_pi_range(KWY_PI * ((2.0 * (i - half) / 4.0) / p.fs) * cf0);
+        if (wmode == 1) wcos[slot] = c1;
+      }
+      const double w = type == D4C_HANNING ? 0.5 * c1 + 0.5 : 0.42 + 0.5 * c1 + 0.08 * (2.0 * c1 * c1 - 1.0);
       v = __builtin_fma(kwy_randn_from_raw(raw[r]), D4C_SAFE, xv[r] * w);
       Bd[i] = w;                       // kept for the DC removal below (only this thread reads it)
       s1 += v; s2 += w;
@@ -519,6 +532,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   // stream positions of the frame's three windows: the body's noise continues where the LoveTrain pass stopped
   const uint64_t dbase = *draws_before;
   const uint64_t dpos0 = dbase + offs3[3 * frame], dpos1 = dbase + offs3[3 * frame + 1], dpos2 = dbase + offs3[3 * frame + 2];
+  // (the window cosine cache lives in A0, where a frame beyond the noise table builds its jump table: no cache then)
+  const bool cache = dpos2 + (uint64_t)(2 * kwy_matlab_round(4.0 * p.fs / cf0 / 2.0) + 1) <= rs.n;
 
   D4C_STAMP(1);
   // ---- static centroid: two temporal centroids at pos -+ 0.25/f0, each Re(X2 conj X1) of the
@@ -539,7 +554,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
     for (int which = 0; which < 2; ++which) {
       const int tid = kwy_tid_opaque();
       double cpos = which == 0 ? pos - 0.25 / cf0 : pos + 0.25 / cf0;
-      d4c_frame_window<N, NT>(x, x_length, p, cf0, cpos, D4C_BLACKMAN, which == 0 ? dpos0 : dpos1, rs, poly, e, jtab, Bd, true, red, av);
+      d4c_frame_window<N, NT>(x, x_length, p, cf0, cpos, D4C_BLACKMAN, which == 0 ? dpos0 : dpos1, rs, poly, e, jtab, Bd, true, red, av,
+                              A0, cache ? 1 + which : 0);
       __syncthreads();      // (the window code keeps per-thread values in Bd until here)
       // even samples: z[m] = a[2m] + j b[2m] -- sample i = tid + NT r has the parity of tid
       if (!(tid & 1)) {
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
 
     D4C_STAMP(6);
     // ---- smoothed power spectrum (the centroid sum waits in registers)
-    d4c_frame_window<N, NT>(x, x_length, p, cf0, pos, D4C_HANNING, dpos2, rs, poly, e, jtab, Bd, false, red, av);
+    d4c_frame_window<N, NT>(x, x_length, p, cf0, pos, D4C_HANNING, dpos2, rs, poly, e, jtab, Bd, false, red, av, A0, cache ? 2 : 0);
 #pragma unroll
     for (int r = 0; r < E; ++r) Bd[tid + NT * r] = av[r];
     __syncthreads();
