@@ -100,17 +100,29 @@ __global__ __launch_bounds__(64) void k_mlsa_filter(mlsa_jobs J, int m, double a
     const double curb = (lane <= m) ? b[f * (m + 1) + lane] : 0.0;
     const double slope = (curb - prevb) / hop;
     double cur = prevb;
-    for (int j = lane; j < hop; j += 64) sx[j] = x[s0 + j];
+    // The input scale exp(b[0]) of every sample of the frame, off the serial loop: b[0] at sample j is prevb[0] plus j
+    // additions of the slope (the very sums the loop below forms for its coefficients), so every lane runs those
+    // additions and keeps the values of "its" samples j = lane + 64 r -- then exp and the product in parallel, the
+    // same numbers the loop used to compute one sample at a time (~40 instructions of each sample's ~280).
+    {
+      const double p0 = kwy_readlane_f64(prevb, 0), sl0 = kwy_readlane_f64(slope, 0);
+      double v = p0;
+      for (int t = 0; t < lane; ++t) v += sl0;                  // sample j = lane
+      for (int j = lane; j < hop; j += 64) {
+        sx[j] = x[s0 + j] * exp(v);
+        for (int t = 0; t < 64; ++t) v += sl0;                  // 64 samples on
+      }
+    }
     if (lane <= m) sb[par * 72 + lane] = cur;
     __syncthreads();
     for (int j = 0; j < hop; ++j) {
       // one wavefront: the LDS executes its accesses in issue order, no barrier between the
       // store of a coefficient and its broadcast load
       const double *__restrict__ bc = sb + par * 72;
-      const double b0 = bc[0], b1 = bc[1];
+      const double b1 = bc[1];
       cur += slope;
       if (lane <= m) sb[(par ^ 1) * 72 + lane] = cur;   // the coefficients of the next sample
-      double xv = sx[j] * exp(b0);
+      double xv = sx[j];                                 // (already times exp(b[0]) of this sample)
       // ---- mlsadf1 (uniform)
       double out = 0.0;
 #pragma unroll
