@@ -685,12 +685,13 @@ static constexpr size_t d4c_bands_lds() {
 template <int LOG2N, bool SPARSE>
 __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d4c_bands(
     d4c_batch batch, d4c_params p, const kwy_c *__restrict__ twH,
-    const kwy_c *__restrict__ twN, const double *__restrict__ nuttall) {
+    const kwy_c *__restrict__ twN, const double *__restrict__ nuttall, long long *__restrict__ dbg) {
   constexpr int N = 1 << LOG2N, H = N / 2;
   constexpr int NT = d4c_nt<LOG2N>::value;
   constexpr int E = N / NT;
   constexpr int RK = (H + 1 + NT - 1) / NT;
   constexpr int HEX = 16 * NT / N;
+#define D4C_STAMP(n) do { if (dbg && threadIdx.x == 0 && blockIdx.x == (unsigned)dbg[63]) dbg[n] = clock64(); } while (0)
   extern __shared__ double smem[];
   double *red = smem;                        // 16
   double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
@@ -710,6 +711,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
   const kwy_c twb = twN[tid];
   const double *Dv = dvbuf + (size_t)frame * p.dv_stride;
+  D4C_STAMP(16);
 
   const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
   const int half_window_length = p.window_length / 2;
@@ -737,6 +739,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
     const int tid = kwy_tid_opaque();
     const double *Dc = Dv + ((int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs) - half_window_length);
     const double c0 = nx0, c1 = nx1;
+    if (b == 1) D4C_STAMP(17);
     {
       const double *Dn = Dv + ((int)(D4C_FREQ_INTERVAL * (b + 2) * N / p.fs) - half_window_length);
       const bool more = b + 1 < p.nbands;
@@ -749,6 +752,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
       if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * ns2;
       kwy_fft_pass8_first_sparse_core<LOG2N - 1, NT, false>(B, kwy_tw_reg{tw4[0]}, a0, a1);
       kwy_fft_inplace_rest_w<LOG2N - 1, NT, false>(B, tw4);
+      if (b == 1) D4C_STAMP(18);
     } else {
 #pragma unroll
       for (int r = 0; r < E; ++r) {
@@ -770,8 +774,12 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
       }
     }
     __syncthreads();
+    if (b == 1) D4C_STAMP(19);
     double nsmall, nall;
     kwy_block_smallest_sum<RK, NT>(key, H + 1, H - boundary, hist, red, &nsmall, &nall);
+    if (b == 1) D4C_STAMP(20);
+    if (dbg && tid == 0 && blockIdx.x == (unsigned)dbg[63])
+      for (int q = 0; q < 12; ++q) dbg[24 + 12 * (b & 1) + q] = hist[2 * KWY_SELECT_BINS + q];
     if (tid == 0) {
       double cv = 10 * log10(nsmall / nall);
       cv = cv + (cf0 - 100) / 50.0;
@@ -779,6 +787,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
     }
     __syncthreads();
   }
+  D4C_STAMP(21);
   if (tid == 0) {
     coarse[0] = -60.0;
     coarse[p.nbands + 1] = -D4C_SAFE;
@@ -802,6 +811,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
     double v = coarse[seg - 1] + sfrac * (coarse[seg] - coarse[seg - 1]);
     o[k] = exp10(v / 20.0);
   }
+  D4C_STAMP(22);
+#undef D4C_STAMP
 }
 
 // ------------------------------------------------------------------ host side
@@ -843,12 +854,12 @@ static int launch_body(kwy_ctx *ctx, const d4c_batch &b, const d4c_params &p, co
     KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_bands<LOG2N, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, true>), dim3(grid), dim3(NT), lds_b, ctx->stream,
-                       b, p, twH, twN, nuttall));
+                       b, p, twH, twN, nuttall, (long long *)ctx->dbg));
   } else {
     KWY_HIP(hipFuncSetAttribute((const void *)k_d4c_bands<LOG2N, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
     KWY_PROF(ctx, "k_d4c_bands", hipLaunchKernelGGL((k_d4c_bands<LOG2N, false>), dim3(grid), dim3(NT), lds_b, ctx->stream,
-                       b, p, twH, twN, nuttall));
+                       b, p, twH, twN, nuttall, (long long *)ctx->dbg));
   }
   KWY_HIP(hipGetLastError());
   return KWY_OK;

@@ -430,147 +430,262 @@ __device__ __forceinline__ void kwy_block_sum2(double a, double b, double *red, 
   *ta = sa; *tb = sb;
 }
 
-// Sum of the m smallest of n non-negative doubles, and the sum of all of them,
-// without sorting.  Thread t holds the IEEE bit patterns of elements t, t+NT, ...
-// in key[] (~0 for slots beyond n).  An MSB-first radix select (KWY_SELECT_BITS bits a
-// round; the patterns order like the values for x >= 0) finds the m-th smallest
-// value v*; then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.  Two barriers per
-// round: the histogram and the control words are double-buffered.
-// hist: KWY_SELECT_WORDS uint32 of LDS (8-byte aligned) that no thread touches
-// any more when the call starts; red: >= 2*NT/64 doubles.
-// Digit width: KWY_SELECT_BITS bits per round.  8 (256 bins) is what the kernels use.  11 bits -- the whole
-// exponent of a non-negative IEEE double in the first round, then 11 mantissa bits: two or three rounds instead of
-// four on a 2049-bin spectrum -- was measured and is SLOWER (k_d4c_body 0.44 ms against 0.39 ms per launch): what
-// the rounds save in barriers is lost clearing and scanning 2048 bins per round.
+// Sum of the m smallest of n non-negative doubles, and the sum of all of them, without sorting.  Thread t holds the
+// IEEE bit patterns of elements t, t+NT, ... in key[] (~0 for slots beyond n); the patterns order like the values
+// for x >= 0.  The m-th smallest value v* is found, then sum_small = sum(v < v*) + (m - #{v < v*}) * v*.
+//   hist: KWY_SELECT_WORDS uint32 of LDS (16-byte aligned) that no thread touches any more when the call starts;
+//   red: >= 2*NT/64 doubles.
+// Two ways to v*:
+//  (1) FROM THE TOP, one histogram: bin = distance of the key's high word from the block's largest high word in
+//      quarter binades (256 bins = 64 binades below the maximum, everything lower in the last bin).  The bin that
+//      holds the wanted rank -- counted from the largest value -- is left with a few dozen keys of a 2 049-bin
+//      spectrum; they are listed in LDS and ranked against each other with full keys.  Only the maximum is reduced,
+//      the keys stay as they are, three barriers + the ranking.  D4C asks for the 66th largest of 2 049: always here.
+//  (2) GENERAL, MSB-first radix select (KWY_SELECT_BITS bits a round) on key - min(key), starting at the highest bit
+//      in which the block's keys differ; two barriers per round, histogram and control words double-buffered; a
+//      round that leaves <= 124 keys hands over to the same ranking.  Taken when (1) ends in its last bin or with a
+//      crowded one (flat data, ties by the hundred, a rank far from the top).
+// Digit width 8 (256 bins) is what the kernels use.  11 bits -- the whole exponent of a non-negative IEEE double in
+// the first round -- was measured and is SLOWER (what the rounds save in barriers is lost clearing and scanning
+// 2048 bins per round).  Wave-aggregated atomics (the lanes that share the first live lane's digit counted with one
+// atomic) were measured too: on real group-delay spectra the ballots cost more issue slots than the same-address
+// atomics they save (3 280 against 1 936 clocks for the nine slots of a round): KWY_SELECT_AGG=1 keeps that form.
 #ifndef KWY_SELECT_BITS
 #define KWY_SELECT_BITS 8
 #endif
 #define KWY_SELECT_BINS (1 << KWY_SELECT_BITS)
-#define KWY_SELECT_WORDS(NT) (2 * KWY_SELECT_BINS + 16)
-// The digits are taken from key - min(key), starting at the highest bit in which the block's keys differ: a power
-// spectrum spans a few dozen binades, so the sign and the leading exponent bits are the same in every key and a round
-// spent on them would select nothing (one round saved of typically three).  key[] is rewritten (relative keys).
+#ifndef KWY_SELECT_AGG
+#define KWY_SELECT_AGG 0
+#endif
+#define KWY_SELECT_WORDS(NT) (2 * KWY_SELECT_BINS + 32)
+#define KWY_SELECT_LIST (KWY_SELECT_BINS / 2 - 4)         // keys the ranking takes (the other histogram's words)
+
+__device__ __forceinline__ uint32_t kwy_wave_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x101, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x102, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0xf, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x108, 0xf, 0xf, false));
+  return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+             max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
+// wavefront 0: the bin of h[0 .. BINS) that holds rank kk (1-based, bins taken in index order) -> ctl[0] = bin,
+// ctl[1] = rank inside it, ctl[2] = its population, ctl[3] = keys in the bins before it
+__device__ __forceinline__ void kwy_select_scan(const uint32_t *h, int kk, uint32_t *ctl, int lane) {
+  constexpr int PERLANE = KWY_SELECT_BINS / 64;           // bins scanned per lane
+  static_assert(PERLANE % 4 == 0 && PERLANE >= 4, "bins per lane must be a multiple of 4");
+  // lane l owns bins [PERLANE l, PERLANE (l + 1)): their total first, then only the lane whose range holds the
+  // wanted rank walks its bins again (the counts are not kept in registers)
+  const uint4 *hp = (const uint4 *)h + lane * (PERLANE / 4);
+  uint32_t tot = 0;
+#pragma unroll
+  for (int q = 0; q < PERLANE / 4; ++q) {
+    const uint4 c4 = hp[q];
+    tot += (c4.x + c4.y) + (c4.z + c4.w);
+  }
+  uint32_t before = kwy_wave_scan_u32(tot) - tot;
+  if ((uint32_t)kk > before && (uint32_t)kk <= before + tot) {
+    const uint32_t *hb = h + PERLANE * lane;
+    for (int q = 0; q < PERLANE; ++q) {
+      const uint32_t c = hb[q];
+      if ((uint32_t)kk <= before + c) {
+        ctl[0] = PERLANE * lane + q;
+        ctl[1] = (uint32_t)kk - before;
+        ctl[2] = c;
+        ctl[3] = before;
+        break;
+      }
+      before += c;
+    }
+  }
+}
+
+// the listed keys list[0 .. pop) ranked against each other (pop <= KWY_SELECT_LIST; four entries behind the list
+// must be readable).  DESCENDING: the key with `rank - 1` listed keys in front of it when sorted from the largest.
+// Thread tid < pop looks at entry tid; the one that holds the wanted key publishes it with out_count[0] = the number
+// of listed keys in front of it (strictly) and out_count[1] = the listed keys equal to it.  Ascending order: the same
+// with the comparison turned round.
+template <bool DESCENDING>
+__device__ __forceinline__ void kwy_select_rank(const unsigned long long *list, int pop, int rank, int tid,
+                                                unsigned long long *out_key, uint32_t *out_count) {
+  if (tid < pop) {
+    const unsigned long long mine = list[tid];
+    int front = 0, tie_front = 0, ties = 0;
+    for (int j = 0; j < pop; j += 4) {                       // four keys a trip: two 16-byte reads in flight
+      const ulonglong2 o01 = *(const ulonglong2 *)(list + j), o23 = *(const ulonglong2 *)(list + j + 2);
+      const unsigned long long o[4] = {o01.x, o01.y, o23.x, o23.y};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool in = j + q < pop;
+        front += in & (DESCENDING ? o[q] > mine : o[q] < mine);
+        const bool eq = in & (o[q] == mine);
+        ties += eq;
+        tie_front += eq & (j + q < tid);
+      }
+    }
+    if (front + tie_front == rank - 1) { *out_key = mine; out_count[0] = (uint32_t)front; out_count[1] = (uint32_t)ties; }
+  }
+}
+
 template <int RMAX, int NT = KWY_THREADS>
 __device__ inline void kwy_block_smallest_sum(unsigned long long (&key)[RMAX], int n, int m,
                                               uint32_t *hist, double *red, double *sum_small,
                                               double *sum_all) {
   constexpr int BITS = KWY_SELECT_BITS, BINS = 1 << BITS;
-  constexpr int PERLANE = BINS / 64;                      // bins scanned per lane of wavefront 0
-  static_assert(PERLANE % 4 == 0 && PERLANE >= 4, "bins per lane must be a multiple of 4");
+  constexpr int TOP_SHIFT = 18;                           // high word: 20 mantissa bits -> quarter binades
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  uint32_t *ctlb = hist + 2 * BINS;  // 2 x {digit, new rank, population}, then one 64-bit key
-  // ---- the block's smallest and largest key (non-negative doubles order like their bit patterns)
-  double lo = INFINITY, hi = 0.0;
+  uint32_t *ctlb = hist + 2 * BINS;  // 2 x {digit, rank, population, before}; [8..9] one 64-bit key; [10] list
+                                     // length; [11..12] two counts; [16 ..] one word per wavefront
+  unsigned long long *k64 = (unsigned long long *)(ctlb + 8);
+  unsigned long long *list = (unsigned long long *)(hist + BINS);
+  unsigned long long vkey;           // bit pattern of v*
+  int copies;                        // how many keys equal to v* belong to the m smallest
+
+  // ---- (1) from the top
+  uint32_t hmax = 0;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+    if (tid + NT * r < n) hmax = max(hmax, (uint32_t)(key[r] >> 32));
+  hmax = kwy_wave_max_u32(hmax);
+  if (lane == 0) ctlb[16 + wv] = hmax;
+  for (int i = tid; i < BINS; i += NT) hist[i] = 0;
+  if (tid == 0) ctlb[10] = 0;
+  __syncthreads();
+  hmax = ctlb[16];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) hmax = max(hmax, ctlb[16 + i]);
+  uint32_t dg[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    dg[r] = BINS;                                         // (no bin: slot beyond n)
+    if (NT * r + (tid & ~63) >= n) continue;              // nothing in this slot for the whole wavefront
+    if (tid + NT * r < n) {
+      dg[r] = min((hmax - (uint32_t)(key[r] >> 32)) >> TOP_SHIFT, (uint32_t)(BINS - 1));
+      atomicAdd(&hist[dg[r]], 1u);
+    }
+  }
+  __syncthreads();
+  if (wv == 0) kwy_select_scan(hist, n - m + 1, ctlb, lane);
+  __syncthreads();
+  const uint32_t chosen = ctlb[0], pop = ctlb[2];
+  if (chosen < (uint32_t)(BINS - 1) && pop <= (uint32_t)KWY_SELECT_LIST) {
+    const int rank = (int)ctlb[1], above = (int)ctlb[3];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (dg[r] == chosen) list[atomicAdd(&ctlb[10], 1u)] = key[r];
+    __syncthreads();
+    kwy_select_rank<true>(list, (int)pop, rank, tid, k64, &ctlb[11]);
+    __syncthreads();
+    vkey = *k64;
+    copies = m - (n - above - (int)ctlb[11] - (int)ctlb[12]);   // keys >= v*: above + listed in front + ties
+  } else {
+    // ---- (2) general: the block's smallest and largest key, relative keys, radix rounds
+    double lo = INFINITY, hi = 0.0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      if (tid + NT * r < n) {
+        const double x = __longlong_as_double((long long)key[r]);
+        lo = fmin(lo, x); hi = fmax(hi, x);
+      }
+    }
+    lo = kwy_wave_min_f64(lo);
+    hi = kwy_wave_max_f64(hi);
+    if (lane == 0) { red[wv] = lo; red[NT / 64 + wv] = hi; }
+    for (int i = tid; i < BINS; i += NT) hist[i] = 0;
+    if (tid == 0) ctlb[10] = 0;
+    __syncthreads();
+    lo = red[0]; hi = red[NT / 64];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) { lo = fmin(lo, red[i]); hi = fmax(hi, red[NT / 64 + i]); }
+    const unsigned long long kmin = (unsigned long long)__double_as_longlong(lo);
+    const unsigned long long range = (unsigned long long)__double_as_longlong(hi) - kmin;
+    const int top0 = range ? 64 - __clzll((long long)range) : 0;     // one past the highest differing bit
+    const int rounds = (top0 + BITS - 1) / BITS;                    // 0: all keys equal
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) key[r] -= kmin;                  // (slots beyond n are never looked at)
+    unsigned long long prefix = 0ull;
+    int kk = m;  // 1-based rank of the wanted element among the still-matching keys
+    bool alive[RMAX];  // key still carries the prefix found so far
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) alive[r] = tid + NT * r < n;
+    for (int round = 0; round < rounds; ++round) {
+      // digits are taken from bit top0 - 1 downwards; the last one may be narrower
+      const int top = top0 - BITS * round;                  // one past the digit's highest bit
+      const int shift = top - BITS > 0 ? top - BITS : 0;
+      const unsigned long long mask = (1ull << (top - shift)) - 1ull;
+      uint32_t *h = hist + (round & 1) * BINS, *hn = hist + ((round + 1) & 1) * BINS;
+      uint32_t *ctl = ctlb + (round & 1) * 4;
+      for (int i = tid; i < BINS; i += NT) hn[i] = 0;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        if (NT * r + (tid & ~63) >= n) continue;  // nothing in this slot for the whole wavefront
+        const int d = (int)((key[r] >> shift) & mask);
+#if KWY_SELECT_AGG
+        const unsigned long long mm = __ballot(alive[r]);
+        if (mm != 0ull) {
+          const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
+          const int d0 = __builtin_amdgcn_readlane(d, leader);
+          const bool same = alive[r] && d == d0;
+          const unsigned long long ms = __ballot(same);
+          if (lane == leader) atomicAdd(&h[d0], (uint32_t)__popcll(ms));
+          if (alive[r] && !same) atomicAdd(&h[d], 1u);
+        }
+#else
+        if (alive[r]) atomicAdd(&h[d], 1u);
+#endif
+      }
+      __syncthreads();
+      if (wv == 0) kwy_select_scan(h, kk, ctl, lane);
+      __syncthreads();
+      const int chosen_d = (int)ctl[0];
+      prefix |= (unsigned long long)chosen_d << shift;
+      kk = (int)ctl[1];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) alive[r] = alive[r] && (int)((key[r] >> shift) & mask) == chosen_d;
+      const uint32_t left = ctl[2];
+      if (left == 1u && round < rounds - 1) {
+        // exactly one key carries this prefix: it IS the wanted element, skip the remaining rounds
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+          if (alive[r]) *k64 = key[r];
+        __syncthreads();
+        prefix = *k64;
+        kk = 1;
+        break;
+      }
+      if (left <= (uint32_t)KWY_SELECT_LIST && round < rounds - 1) {
+        // a handful of keys carry this prefix: listed in the other histogram's words and ranked against each other
+        unsigned long long *lst = (unsigned long long *)hn;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+          if (alive[r]) lst[atomicAdd(&ctlb[10], 1u)] = key[r];
+        __syncthreads();
+        kwy_select_rank<false>(lst, (int)left, kk, tid, k64, &ctlb[11]);
+        __syncthreads();
+        prefix = *k64;
+        kk -= (int)ctlb[11];                                // copies of v* among the m smallest
+        break;
+      }
+    }
+    // (all keys equal: no round ran, prefix = 0 = every relative key, kk = m of them)
+    vkey = prefix + kmin;
+    copies = kk;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) key[r] += kmin;
+  }
+  const double vstar = __longlong_as_double((long long)vkey);
+  double s_less = 0.0, s_all = 0.0;
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
     if (tid + NT * r < n) {
       const double x = __longlong_as_double((long long)key[r]);
-      lo = fmin(lo, x); hi = fmax(hi, x);
-    }
-  }
-  lo = kwy_wave_min_f64(lo);
-  hi = kwy_wave_max_f64(hi);
-  if (lane == 0) { red[wv] = lo; red[NT / 64 + wv] = hi; }
-  for (int i = tid; i < BINS; i += NT) hist[i] = 0;
-  __syncthreads();
-  lo = red[0]; hi = red[NT / 64];
-#pragma unroll
-  for (int i = 1; i < NT / 64; ++i) { lo = fmin(lo, red[i]); hi = fmax(hi, red[NT / 64 + i]); }
-  const unsigned long long kmin = (unsigned long long)__double_as_longlong(lo);
-  const unsigned long long range = (unsigned long long)__double_as_longlong(hi) - kmin;
-  const int top0 = range ? 64 - __clzll((long long)range) : 0;       // one past the highest differing bit
-  const int rounds = (top0 + BITS - 1) / BITS;                      // 0: all keys equal
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) key[r] -= kmin;                    // (slots beyond n are never looked at)
-  unsigned long long prefix = 0ull;
-  int kk = m;  // 1-based rank of the wanted element among the still-matching keys
-  bool alive[RMAX];  // key still carries the prefix found so far
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) alive[r] = tid + NT * r < n;
-  for (int round = 0; round < rounds; ++round) {
-    // digits are taken from bit top0 - 1 downwards; the last one may be narrower
-    const int top = top0 - BITS * round;                  // one past the digit's highest bit
-    const int shift = top - BITS > 0 ? top - BITS : 0;
-    const unsigned long long mask = (1ull << (top - shift)) - 1ull;
-    uint32_t *h = hist + (round & 1) * BINS, *hn = hist + ((round + 1) & 1) * BINS;
-    uint32_t *ctl = ctlb + (round & 1) * 4;
-    for (int i = tid; i < BINS; i += NT) hn[i] = 0;
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      if (NT * r + (tid & ~63) >= n) continue;  // nothing in this slot for the whole wavefront
-      // spectra are smooth: most lanes of a wavefront carry the same leading digits, and 64
-      // atomics on one LDS word serialise.  The lanes that share the first live lane's digit
-      // are counted with one atomic, the others go one by one.
-      const int d = (int)((key[r] >> shift) & mask);
-      const unsigned long long mm = __ballot(alive[r]);
-      if (mm != 0ull) {
-        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)mm) - 1);
-        const int d0 = __builtin_amdgcn_readlane(d, leader);
-        const bool same = alive[r] && d == d0;
-        const unsigned long long ms = __ballot(same);
-        if (lane == leader) atomicAdd(&h[d0], (uint32_t)__popcll(ms));
-        if (alive[r] && !same) atomicAdd(&h[d], 1u);
-      }
-    }
-    __syncthreads();
-    if (wv == 0) {
-      // lane l owns bins [PERLANE l, PERLANE (l + 1)): their total first, then only the lane whose range holds the
-      // wanted rank walks its bins again (the counts are not kept in registers)
-      const uint4 *hp = (const uint4 *)h + lane * (PERLANE / 4);
-      uint32_t tot = 0;
-#pragma unroll
-      for (int q = 0; q < PERLANE / 4; ++q) {
-        const uint4 c4 = hp[q];
-        tot += (c4.x + c4.y) + (c4.z + c4.w);
-      }
-      uint32_t before = kwy_wave_scan_u32(tot) - tot;
-      if ((uint32_t)kk > before && (uint32_t)kk <= before + tot) {
-        const uint32_t *hb = h + PERLANE * lane;
-        for (int q = 0; q < PERLANE; ++q) {
-          const uint32_t c = hb[q];
-          if ((uint32_t)kk <= before + c) {
-            ctl[0] = PERLANE * lane + q;
-            ctl[1] = (uint32_t)kk - before;
-            ctl[2] = c;  // population of the chosen bin
-            break;
-          }
-          before += c;
-        }
-      }
-    }
-    __syncthreads();
-    const int chosen = (int)ctl[0];
-    prefix |= (unsigned long long)chosen << shift;
-    kk = (int)ctl[1];
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) alive[r] = alive[r] && (int)((key[r] >> shift) & mask) == chosen;
-    if (ctl[2] == 1u && round < rounds - 1) {
-      // exactly one key carries this prefix: it IS the wanted element, skip the remaining rounds
-      unsigned long long *k64 = (unsigned long long *)(ctlb + 8);
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (alive[r]) *k64 = key[r];
-      __syncthreads();
-      prefix = *k64;
-      kk = 1;
-      break;
-    }
-  }
-  // (all keys equal: no round ran, prefix = 0 = every relative key, kk = m of them)
-  const double vstar = __longlong_as_double((long long)(prefix + kmin));
-  double s_less = 0.0, s_all = 0.0;
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    int i = tid + NT * r;
-    if (i < n) {
-      double x = __longlong_as_double((long long)(key[r] + kmin));
       s_all += x;
-      if (key[r] < prefix) s_less += x;
+      if (key[r] < vkey) s_less += x;
     }
   }
   double t_less, t_all;
   kwy_block_sum2<NT>(s_less, s_all, red, &t_less, &t_all);
-  *sum_small = t_less + (double)kk * vstar;
+  *sum_small = t_less + (double)copies * vstar;
   *sum_all = t_all;
 }
 

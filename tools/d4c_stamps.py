@@ -17,3 +17,9 @@ print('frame', frame, 'f0', f0[frame])
 for i in range(1,16):
     print(names[i].ljust(16), d[i]-d[i-1])
 print('total', d[15]-d[0])
+names2 = ['bands start','band1 head','band1 fft','band1 bins','band1 select','bands loop end','output']
+for i in range(17,23):
+    print(names2[i-16].ljust(16), d[i]-d[i-1])
+print('bands total', d[22]-d[16])
+print('select ctl words (band 0/2/4, band 1/3):', d[24:36], d[36:48])
+print('select phases (min/max+setup, slots r0, barrier, scan, barrier, finish, sums):', np.diff(d[48:56]))
