@@ -345,7 +345,7 @@ def main_lockstep(args):
     rng = DeviceRandomState.from_seed(seed, device_index=local_rank)
     wav = args.workload == 'wav'            # wav in -> int16 out: DIO + StoneMask and the post-step inside the step
     pipe = pl.PairBatchPipeline(local_rank, FS, pairs, dgmm, waves=1 if serial else args.waves, rng=rng, serial=serial,
-                                wav_in=wav, pcm=wav)
+                                wav_in=wav, pcm=wav, chain_priority=args.chain_priority == 'on')
     torch.cuda.synchronize()
 
     def sync_all():
@@ -672,6 +672,9 @@ def main():
                      help='pair workload: batch = lockstep through the batched entries (default); streams = one stream and '
                           'one graph per pair (round 3); serial = one wave of the lockstep driver on one stream')
     ap_.add_argument('--waves', type=int, default=2, help='lockstep driver: waves of <= 16 pairs side by side')
+    ap_.add_argument('--chain-priority', choices=('on', 'off'), default='off',
+                     help='lockstep driver: the streams of the serial chain (alignment, conversion, rendering) get a '
+                          'higher stream priority than the aperiodicity streams')
     ap_.add_argument('--no-variants', action='store_true', help='lockstep driver: skip the pads-replayed and PCIe variants')
     ap_.add_argument('--no-cpu-baseline', action='store_true')
     ap_.add_argument('--distinct', type=int, default=32,

@@ -807,61 +807,112 @@ __global__ __launch_bounds__(KWY_THREADS) void k_syn_pulse_emit(syn_plan_batch b
   syn_pulse_emit_body(v.wrap, v.p.y_length, v.p.fs, v.pl.tile_cnt, v.cap, v.pl.pidx, v.pl.pshift);
 }
 
-// Minimum-phase spectrum (common.cpp GetMinimumPhaseSpectrum), in place: buf holds the half
-// log-spectrum L[0..H] as reals on entry and M[0..H] on return.  (The ~1e-17 imaginary rounding
-// residue of the real cepstrum that the CPU code carries along is dropped.)
+// The pulse kernel runs with as many threads as a radix-8 pass of its transform has butterflies (N/16: 128 at 48 kHz)
+// -- every wavefront works in every pass, and the registers of the idle half buy two more workgroups per CU -- but
+// keeps the arithmetic of the 256-thread form it replaced, bit for bit: thread t stands for the V = 256/NT "virtual"
+// threads t + NT g.  Pair twiddles: exp(-2 pi i k / N) for k = t + NT r as base[r % V] times an 8th root of unity,
+// base[g] = exp(-2 pi i (t + NT g) / N); block sums: the partial sums of the virtual threads, wavefront by
+// wavefront (syn_block_sum_v).
 template <int LOG2N>
-__device__ inline void syn_min_phase(kwy_c *buf, const kwy_c *__restrict__ twl, kwy_c twb,
-                                     const kwy_c *__restrict__ twN) {
-  constexpr int N = 1 << LOG2N, H = N / 2;
-  constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
-  double *L = (double *)buf;
+struct syn_pulse_nt { static constexpr int value = LOG2N <= 10 ? 64 : (LOG2N == 11 ? 128 : 256); };
+
+template <int LOG2H, int NT, int V>
+__device__ __forceinline__ kwy_c syn_pair_twiddle(const kwy_c (&base)[V], int r) {
+  constexpr int N = 2 << LOG2H;
+  constexpr int OCT = 8 * (NT * V) / N;                     // >= 1: N <= 2048 here, or V = 1 and NT >= N/8
+  return kwy_tw_octant(base[r % V], OCT * (r / V));
+}
+
+template <int LOG2H, int NT, int V>
+__device__ inline void syn_rfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw, const kwy_c (&base)[V],
+                                        const kwy_c *__restrict__ twN) {
+  constexpr int H = 1 << LOG2H, N = 2 * H;
+  constexpr bool TABLE = 8 * (NT * V) / N < 1;              // the long transforms read the pair twiddles
+  kwy_fft_inplace<LOG2H, NT, false>(z, tw);
+  const int tid = kwy_tid_opaque();
+#pragma unroll
+  for (int r = 0; r * NT <= H / 2; ++r) {
+    const int k = tid + NT * r;
+    if (k > H / 2) continue;
+    if (k == 0) {
+      const kwy_c z0 = z[0];
+      z[0] = {z0.x + z0.y, 0.0};
+      z[H] = {z0.x - z0.y, 0.0};
+    } else {
+      kwy_c w;
+      if constexpr (TABLE) w = twN[k]; else w = syn_pair_twiddle<LOG2H, NT, V>(base, r);
+      const kwy_c A = z[k], Bc = z[H - k];
+      const double er = 0.5 * (A.x + Bc.x), ei = 0.5 * (A.y - Bc.y);
+      const double dr = 0.5 * (A.x - Bc.x), di = 0.5 * (A.y + Bc.y);
+      const double orr = di, oi = -dr;
+      const double pr = __builtin_fma(orr, w.x, -(oi * w.y)), pi = __builtin_fma(orr, w.y, oi * w.x);
+      z[k] = {er + pr, ei + pi};
+      if (k != H - k) z[H - k] = {er - pr, -(ei - pi)};
+    }
+  }
+  __syncthreads();
+}
+
+template <int LOG2H, int NT, int V>
+__device__ inline void syn_irfft_inplace(kwy_c *z, const kwy_c *__restrict__ tw, const kwy_c (&base)[V],
+                                         const kwy_c *__restrict__ twN) {
+  constexpr int H = 1 << LOG2H, N = 2 * H;
+  constexpr bool TABLE = 8 * (NT * V) / N < 1;
   const int tid = kwy_tid_opaque();
   __syncthreads();
-  for (int i = H + 1 + tid; i < N; i += KWY_THREADS) L[i] = L[N - i];
-  __syncthreads();
-  kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
-  // causal cepstrum: c[0], 2 c[1..H-1], c[H], zeros -- packed reals over the complex bins they came from
-  double cv[RK];
 #pragma unroll
-  for (int r = 0; r < RK; ++r) {
-    const int n = tid + KWY_THREADS * r;
-    double v = 0.0;
-    if (n <= H) {
-      v = buf[n].x;
-      if (n >= 1 && n < H) v *= 2.0;
+  for (int r = 0; r * NT <= H / 2; ++r) {
+    const int k = tid + NT * r;
+    if (k > H / 2) continue;
+    if (k == 0) {
+      const double ar = z[0].x, br = z[H].x;
+      z[0] = {ar + br, ar - br};
+    } else {
+      kwy_c w;
+      if constexpr (TABLE) w = twN[k]; else w = syn_pair_twiddle<LOG2H, NT, V>(base, r);
+      const kwy_c A = z[k], Bc = z[H - k];
+      const double er = A.x + Bc.x, ei = A.y - Bc.y;
+      const double dr = A.x - Bc.x, di = A.y + Bc.y;
+      const double wr = w.x, wi = -w.y;
+      const double orr = __builtin_fma(dr, wr, -(di * wi)), oi = __builtin_fma(dr, wi, di * wr);
+      z[k] = {er - oi, ei + orr};
+      if (k != H - k) z[H - k] = {er + oi, -(ei - orr)};
     }
-    cv[r] = v;
   }
   __syncthreads();
+  kwy_fft_inplace<LOG2H, NT, true>(z, tw);
+}
+
+// sum over the workgroup of the V partial sums every thread carries, in the order of a 256-thread workgroup whose
+// thread t + NT g carries part[g]: wavefront sums, then the four of them left to right.  red: >= 4 doubles.
+template <int NT, int V>
+__device__ __forceinline__ double syn_block_sum_v(const double (&part)[V], double *red) {
+  double ws[V];
 #pragma unroll
-  for (int r = 0; r < RK; ++r) {
-    const int n = tid + KWY_THREADS * r;
-    if (n <= H) L[n] = cv[r];
-  }
-  for (int n = H + 1 + tid; n < N; n += KWY_THREADS) L[n] = 0.0;
+  for (int g = 0; g < V; ++g) ws[g] = kwy_wave_sum(part[g]);
   __syncthreads();
-  kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
-  for (int k = tid; k <= H; k += KWY_THREADS) {
-    const kwy_c R = buf[k];
-    const double tmp = exp(R.x / N);
-    const double ph = R.y / N;
-    double sn, cs;
-    sincos(ph, &sn, &cs);       // one argument reduction for both
-    buf[k] = {tmp * cs, tmp * sn};
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int g = 0; g < V; ++g) red[(threadIdx.x >> 6) + (NT / 64) * g] = ws[g];
   }
   __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int i = 1; i < NT * V / 64; ++i) s += red[i];
+  return s;
 }
 
 __device__ __forceinline__ double syn_safe_ap(double x) {
   return fmax(0.001, fmin(0.999999999999, x));
 }
 
-// One pulse per workgroup iteration; its response goes to slot (pulse - first_pulse) of `resp`.  LDS: one FFT buffer (in-place transforms), the
-// interpolated envelope / aperiodic ratio rows, the periodic response, a small twiddle table -- 51 KB at 48 kHz, three
-// workgroups per CU.  The noise spectrum waits in registers (bins tid + 256 r) while the
-// buffer computes the aperiodic minimum-phase response.
-// (workgroups per CU by LDS: three up to 2048 points, two at 4096, one at 8192 -- the register budget follows)
+// One pulse per workgroup iteration; its response goes to slot (pulse - first_pulse) of `resp`.  LDS: one FFT buffer
+// (in-place transforms), the half log-spectrum of the aperiodic part (formed with the periodic one's in the single pass
+// over the interpolated envelope / aperiodicity rows, which are not kept), a small twiddle table -- 27 KB at 48 kHz:
+// five workgroups of two wavefronts per CU, all ten at work in every pass (the 256-thread form of rounds 1-4 held
+// 51 KB and kept half of its twelve wavefronts per CU idle through the seven transforms of a pulse).  What is kept
+// of the periodic response (H samples and a scalar) takes the place of the aperiodic log-spectrum when that moves
+// into the FFT buffer; the minimum-phase spectrum waits in registers while the noise is transformed.
 // One utterance of a rendering launch (descriptors by value in the kernel arguments, as for the analysis kernels):
 // a launch renders the pulses of up to KWY_BATCH_MAX utterances, each with its own slice of the grid.
 struct syn_view {
@@ -877,10 +928,14 @@ struct syn_view {
 typedef kwy_batch<syn_view> syn_batch;
 
 template <int LOG2N, bool DIRECT>
-__global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1)) void k_syn_pulse(
+__global__ __launch_bounds__(syn_pulse_nt<LOG2N>::value, LOG2N <= 12 ? 2 : 1) void k_syn_pulse(
     syn_batch batch, kwy_randn_src rs, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
-    const double *__restrict__ dc_remover) {
+    const double *__restrict__ dc_remover, long long *__restrict__ dbg) {
+  constexpr int NT = syn_pulse_nt<LOG2N>::value, V = KWY_THREADS / NT;
+  // diagnostic stamps (tools/syn_pulse_stamps.py): the first voiced pulse that a workgroup from dbg[63] on reaches
+  bool stamping = false;
+#define SYN_STAMP(n) do { if (stamping && threadIdx.x == 0) dbg[n] = clock64(); } while (0)
   const int utt = batch.find(blockIdx.x);
   const int lblock = (int)blockIdx.x - batch.start[utt], lgrid = batch.start[utt + 1] - batch.start[utt];
   const double *__restrict__ sp = batch.u[utt].sp, *__restrict__ ap = batch.u[utt].ap;
@@ -895,25 +950,21 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
   double *__restrict__ resp = batch.u[utt].resp;
   double *__restrict__ y = batch.u[utt].y;
   constexpr int N = 1 << LOG2N, H = N / 2, K = H + 1;
-  constexpr int C = N / KWY_THREADS;  // draws / output samples per thread
-  constexpr int RK = (H + 1 + KWY_THREADS - 1) / KWY_THREADS;
+  constexpr int C = N / NT;                // draws / output samples per thread: sample tid + NT m
+  constexpr int RK = (H + 1 + NT - 1) / NT;
   constexpr int TWL = (H / 8 > 1) ? H / 8 : 1;
   extern __shared__ double smem[];
   double *red = smem;                      // 8
   uint32_t *e = (uint32_t *)(red + 8);     // KWY_EBASE_WORDS
   kwy_c *twl = (kwy_c *)(e + KWY_EBASE_WORDS);  // exp(-2 pi i k / H), k < H/8
   kwy_c *buf = twl + TWL;                  // H+1 complex
-  double *env = (double *)(buf + (H + 1)); // K
-  double *ratio = env + K + 1;             // K
-  // Up to 2048 points the periodic response waits in LDS (N doubles) rather than in 2 C registers per thread while the
-  // FFT buffer computes the aperiodic one: the kernel is at its register cap there (3 workgroups per CU either way);
-  // the longer transforms have registers to spare and no LDS for it.
-  constexpr bool PER_LDS = LOG2N <= 11;
-  double *perl = ratio + K + 1;            // N (PER_LDS)
+  double *lap = (double *)(buf + (H + 1)); // K: half log-spectrum of the aperiodic part
 
   const int tid = threadIdx.x;
-  for (int i = tid; i < TWL; i += KWY_THREADS) twl[i] = twH[i];
-  const kwy_c twb = twN[tid];
+  for (int i = tid; i < TWL; i += NT) twl[i] = twH[i];
+  kwy_c twb[V];
+#pragma unroll
+  for (int g = 0; g < V; ++g) twb[g] = twN[tid + NT * g];
   const int P = min(npulse[0], cap);
   const int pend = min(P, first_pulse + slots);    // this round's pulses
   for (int pp = first_pulse + lblock; pp < pend; pp += lgrid) {
@@ -928,7 +979,7 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
     const double current_time = idx / (double)p.fs;
     const double shift = pshift[pp];
 
-    // ---- spectral envelope / aperiodic ratio at the pulse time
+    // ---- spectral envelope / aperiodic ratio at the pulse time -> the two half log-spectra
     int fl = (int)floor(current_time / p.frame_period);
     int ce = (int)ceil(current_time / p.frame_period);
     if (fl > p.T - 1) fl = (int)p.T - 1;
@@ -936,125 +987,214 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
     const double interpolation = current_time / p.frame_period - fl;
     const double *s0 = sp + (int64_t)fl * K, *s1 = sp + (int64_t)ce * K;
     const double *a0 = ap + (int64_t)fl * K, *a1 = ap + (int64_t)ce * K;
-    for (int k = tid; k < K; k += KWY_THREADS) {
-      double ev, rv;
-      if (fl == ce) {
-        ev = fabs(s0[k] * p.sp_mul);
-        rv = syn_safe_ap(a0[k]);
-      } else {
-        ev = (1.0 - interpolation) * fabs(s0[k] * p.sp_mul) + interpolation * fabs(s1[k] * p.sp_mul);
-        rv = (1.0 - interpolation) * syn_safe_ap(a0[k]) + interpolation * syn_safe_ap(a1[k]);
-      }
-      env[k] = ev;
-      ratio[k] = rv * rv;
-    }
-    __syncthreads();
-
-    // ---- periodic response (sample i = tid + 256*m, parked in LDS; only this thread touches its elements)
-    const bool has_periodic = current_vuv > 0.5 && !(ratio[0] > 0.999);
-    double per[PER_LDS ? 1 : C];
-#pragma unroll
-    for (int m = 0; m < (PER_LDS ? 1 : C); ++m) per[m] = 0.0;
-    if (has_periodic) {
-      double *L = (double *)buf;
-      for (int k = tid; k <= H; k += KWY_THREADS)
-        L[k] = log(env[k] * (1.0 - ratio[k]) + SYN_SAFE) / 2.0;
-      syn_min_phase<LOG2N>(buf, twl, twb, twN);
-      const double coefficient = 2.0 * KWY_PI * shift * p.fs / N;
-      for (int k = tid; k <= H; k += KWY_THREADS) {
-        const double re = buf[k].x, im = buf[k].y;
-        const double re2 = kwy_cos_pi_range(coefficient * k);   // shift * fs < 1: the argument stays in [0, pi]
-        const double im2 = sqrt(1.0 - re2 * re2);
-        buf[k] = {__builtin_fma(re, re2, im * im2), __builtin_fma(im, re2, -(re * im2))};
-      }
-      kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
-      const double *w = (const double *)buf;
-      double part = 0.0;
-      for (int i = tid; i < H; i += KWY_THREADS) part += w[i];
-      const double dc_component = kwy_block_sum(part, red);
-#pragma unroll
-      for (int m = 0; m < C; ++m) {
-        int i = tid + KWY_THREADS * m;
-        double v = (i < H) ? -dc_component * dc_remover[i] : w[i - H] - dc_component * dc_remover[i];
-        if constexpr (PER_LDS) perl[i] = v;
-        else per[PER_LDS ? 0 : m] = v;
-      }
-      __syncthreads();
-    }
-
-    // ---- aperiodic response
+    double rv0 = syn_safe_ap(a0[0]);
+    if (fl != ce) rv0 = (1.0 - interpolation) * rv0 + interpolation * syn_safe_ap(a1[0]);
+    const bool has_periodic = current_vuv > 0.5 && !(rv0 * rv0 > 0.999);
+    stamping = dbg && threadIdx.x == 0 && has_periodic && blockIdx.x >= (unsigned)dbg[63] && dbg[62] == 0 &&
+               atomicCAS((unsigned long long *)&dbg[62], 0ull, 1ull) == 0ull;
+    SYN_STAMP(0);
     {
-      const int tid = kwy_tid_opaque();
-      // The minimum-phase spectrum first, pulled into registers (bins tid + 256 r); the noise spectrum is formed in the
-      // buffer afterwards and multiplied in place -- so the RK complex registers are alive across one transform (the
-      // noise's), not across the two of the minimum-phase construction.
-      {
-        double *L = (double *)buf;
-        if (current_vuv != 0.0) {
-          for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k] * ratio[k]) / 2.0;
+      double *L = (double *)buf;
+      // (the rows first, all loads of a thread in flight together, then the logarithms)
+      double evs[RK], rts[RK];
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const int k = min(tid + NT * r, H);
+        double ev, rv;
+        if (fl == ce) {
+          ev = fabs(s0[k] * p.sp_mul);
+          rv = syn_safe_ap(a0[k]);
         } else {
-          for (int k = tid; k <= H; k += KWY_THREADS) L[k] = log(env[k]) / 2.0;
+          ev = (1.0 - interpolation) * fabs(s0[k] * p.sp_mul) + interpolation * fabs(s1[k] * p.sp_mul);
+          rv = (1.0 - interpolation) * syn_safe_ap(a0[k]) + interpolation * syn_safe_ap(a1[k]);
+        }
+        evs[r] = ev;
+        rts[r] = rv * rv;
+      }
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const int k = tid + NT * r;
+        if (k <= H) {
+          lap[k] = (current_vuv != 0.0) ? log(evs[r] * rts[r]) / 2.0 : log(evs[r]) / 2.0;
+          if (has_periodic) L[k] = log(evs[r] * (1.0 - rts[r]) + SYN_SAFE) / 2.0;
         }
       }
-      syn_min_phase<LOG2N>(buf, twl, twb, twN);
+    }
+
+    // ---- the two responses, periodic (part 0, voiced pulses only) then aperiodic (part 1), through ONE copy of the
+    // code: a pulse is seven transforms and the element-wise steps between them -- written out one after the other
+    // that was 68 KB of instructions, more than the 64 KB instruction cache two CUs share, run through once per
+    // pulse by workgroups that are each somewhere else in it.  As loops (one forward, one inverse transform in the
+    // binary) it is a third of that.
+    //   part: [mirror -> rfft] [causal fold -> rfft -> exp] ([noise -> rfft]) -> product -> irfft
+    // Of the periodic response dc_component and the H samples w[0 .. H) of the inverse transform are needed later
+    // (sample i is -dc * dc_remover[i] below H, w[i - H] - dc * dc_remover[i] from H on): they change places with the
+    // aperiodic half log-spectrum -- w to `lap`, the log-spectrum into the FFT buffer.
+    double dc_component = 0.0;
+    SYN_STAMP(1);
+#pragma nounroll
+    for (int part = has_periodic ? 0 : 1; part < 2; ++part) {
+      const int tid = kwy_tid_opaque();
+      double *L = (double *)buf;
+      if (part == 1) {
+        double la[RK], wv[RK];
+#pragma unroll
+        for (int r = 0; r < RK; ++r) {
+          const int k = tid + NT * r;
+          la[r] = k <= H ? lap[k] : 0.0;
+          wv[r] = (has_periodic && k < H) ? L[k] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RK; ++r) {
+          const int k = tid + NT * r;
+          if (k <= H) { L[k] = la[r]; lap[k] = wv[r]; }
+        }
+      }
+      // minimum-phase spectrum (common.cpp GetMinimumPhaseSpectrum) of the half log-spectrum in the buffer, then, for
+      // the aperiodic part, the spectrum of the pulse's noise while the minimum-phase one waits in registers
       kwy_c mp[RK];
 #pragma unroll
-      for (int r = 0; r < RK; ++r) {
-        const int k = tid + KWY_THREADS * r;
-        mp[r] = k <= H ? buf[k] : kwy_c{0.0, 0.0};
-      }
-      __syncthreads();
-      // the pulse's noise: draws [dpos, dpos + noise_size) of the stream, dpos = idx - idx[0] (the serial code draws
-      // noise_size numbers per pulse); sample d = tid + 256 j takes draw d -- from the table, or beyond it from the
-      // generator (jump table of the pulse's stream position in the currently idle FFT buffer, thread t makes the C
-      // consecutive draws from C t on, which travel through LDS)
-      const uint64_t dpos = (uint64_t)(idx - pidx[0]);
-      uint32_t raw[C];
-      if (dpos + (uint64_t)ns_used <= rs.n) {
-#pragma unroll
-        for (int j = 0; j < C; ++j) raw[j] = (tid + KWY_THREADS * j < ns_used) ? rs.tab[dpos + tid + KWY_THREADS * j] : 0u;
-      } else {
-        kwy_rng_block_ebase(dpos, rs.pow2, e);
-        kwy_rng rng;
-        if constexpr (sizeof(kwy_c) * (H + 1) >= 8192) {
-          kwy_rng_build_table<KWY_THREADS>(e, (uint4 *)buf);
+      for (int r = 0; r < RK; ++r) mp[r] = {0.0, 0.0};
+#pragma nounroll
+      for (int it = 0; it < 2 + part; ++it) {
+        const int tid = kwy_tid_opaque();
+        if (it == 0) {
           __syncthreads();
-          rng = kwy_rng_combine_table((const uint4 *)buf, poly[tid]);
+          for (int i = H + 1 + tid; i < N; i += NT) L[i] = L[N - i];
+          __syncthreads();
+        } else if (it == 1) {
+          // causal cepstrum: c[0], 2 c[1..H-1], c[H], zeros -- packed reals over the complex bins they came from
+          double cv[RK];
+#pragma unroll
+          for (int r = 0; r < RK; ++r) {
+            const int n = tid + NT * r;
+            double v = 0.0;
+            if (n <= H) {
+              v = buf[n].x;
+              if (n >= 1 && n < H) v *= 2.0;
+            }
+            cv[r] = v;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < RK; ++r) {
+            const int n = tid + NT * r;
+            if (n <= H) L[n] = cv[r];
+          }
+          for (int n = H + 1 + tid; n < N; n += NT) L[n] = 0.0;
           __syncthreads();
         } else {
-          rng = kwy_rng_combine(e, poly[tid]);
+#pragma unroll
+          for (int r = 0; r < RK; ++r) {
+            const int k = tid + NT * r;
+            mp[r] = k <= H ? buf[k] : kwy_c{0.0, 0.0};
+          }
+          __syncthreads();
+          // the pulse's noise: draws [dpos, dpos + noise_size) of the stream, dpos = idx - idx[0] (the serial code
+          // draws noise_size numbers per pulse); sample d = tid + NT j takes draw d -- from the table, or beyond it
+          // from the generator (jump table of the pulse's stream position in the currently idle FFT buffer, thread t
+          // makes the C consecutive draws from C t on, which travel through LDS)
+          const uint64_t dpos = (uint64_t)(idx - pidx[0]);
+          uint32_t raw[C];
+          if (dpos + (uint64_t)ns_used <= rs.n) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) raw[j] = (tid + NT * j < ns_used) ? rs.tab[dpos + tid + NT * j] : 0u;
+          } else {
+            kwy_rng_block_ebase(dpos, rs.pow2, e);
+            kwy_rng rng;
+            if constexpr (sizeof(kwy_c) * (H + 1) >= 8192) {
+              kwy_rng_build_table<NT>(e, (uint4 *)buf);
+              __syncthreads();
+              rng = kwy_rng_combine_table((const uint4 *)buf, poly[tid]);
+              __syncthreads();
+            } else {
+              rng = kwy_rng_combine(e, poly[tid]);
+            }
+            uint32_t *D = (uint32_t *)buf;
+#pragma unroll
+            for (int j = 0; j < C; ++j) D[C * tid + j] = kwy_rng_randn_raw(rng);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < C; ++j) raw[j] = D[tid + NT * j];
+            __syncthreads();
+          }
+          double nv[C];
+          double sum[V];
+#pragma unroll
+          for (int g = 0; g < V; ++g) sum[g] = 0.0;
+#pragma unroll
+          for (int j = 0; j < C; ++j) {
+            const int d = tid + NT * j;
+            nv[j] = kwy_randn_from_raw(raw[j]);
+            if (d < ns_used) sum[j % V] += nv[j];             // virtual thread tid + NT (j % V), its element j / V
+          }
+          const double average = syn_block_sum_v<NT, V>(sum, red) / noise_size;
+#pragma unroll
+          for (int j = 0; j < C; ++j) {
+            const int d = tid + NT * j;
+            L[d] = (d < ns_used) ? nv[j] - average : 0.0;
+          }
+          __syncthreads();
         }
-        uint32_t *D = (uint32_t *)buf;
+        syn_rfft_inplace<LOG2N - 1, NT, V>(buf, twl, twb, twN);
+        if (it == 1) {
+          // (three bins a trip: their exp / sincos chains are independent and fill each other's issue gaps)
+          constexpr int G = 3;
+#pragma nounroll
+          for (int k0 = tid; k0 <= H; k0 += G * NT) {
+            kwy_c R[G];
 #pragma unroll
-        for (int j = 0; j < C; ++j) D[C * tid + j] = kwy_rng_randn_raw(rng);
-        __syncthreads();
+            for (int g = 0; g < G; ++g) R[g] = buf[min(k0 + g * NT, H)];
 #pragma unroll
-        for (int j = 0; j < C; ++j) raw[j] = D[tid + KWY_THREADS * j];
-        __syncthreads();
+            for (int g = 0; g < G; ++g) {
+              const double tmp = exp(R[g].x / N);
+              const double ph = R[g].y / N;
+              double sn, cs;
+              sincos(ph, &sn, &cs);       // one argument reduction for both
+              R[g] = {tmp * cs, tmp * sn};
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              if (k0 + g * NT <= H) buf[k0 + g * NT] = R[g];
+          }
+          __syncthreads();
+        }
       }
-      double *A = (double *)buf;
-      double nv[C];
-      double sum = 0.0;
+      SYN_STAMP(2 + 5 * part);
+      if (part == 0) {
+        const double coefficient = 2.0 * KWY_PI * shift * p.fs / N;
+        for (int k = tid; k <= H; k += NT) {
+          const double re = buf[k].x, im = buf[k].y;
+          const double re2 = kwy_cos_pi_range(coefficient * k);   // shift * fs < 1: the argument stays in [0, pi]
+          const double im2 = sqrt(1.0 - re2 * re2);
+          buf[k] = {__builtin_fma(re, re2, im * im2), __builtin_fma(im, re2, -(re * im2))};
+        }
+      } else {
 #pragma unroll
-      for (int j = 0; j < C; ++j) {
-        const int d = tid + KWY_THREADS * j;
-        nv[j] = kwy_randn_from_raw(raw[j]);
-        if (d < ns_used) sum += nv[j];
+        for (int r = 0; r < RK; ++r) {
+          const int k = tid + NT * r;
+          if (k <= H) buf[k] = cmulf(mp[r], buf[k]);
+        }
       }
-      const double average = kwy_block_sum(sum, red) / noise_size;
+      SYN_STAMP(3 + 5 * part);
+      syn_irfft_inplace<LOG2N - 1, NT, V>(buf, twl, twb, twN);
+      SYN_STAMP(4 + 5 * part);
+      if (part == 0) {
+        const double *w = (const double *)buf;
+        double ps[V];
 #pragma unroll
-      for (int j = 0; j < C; ++j) {
-        const int d = tid + KWY_THREADS * j;
-        A[d] = (d < ns_used) ? nv[j] - average : 0.0;
+        for (int g = 0; g < V; ++g) {
+          ps[g] = 0.0;
+          for (int i = tid + NT * g; i < H; i += KWY_THREADS) ps[g] += w[i];
+        }
+        dc_component = syn_block_sum_v<NT, V>(ps, red);
+        SYN_STAMP(5);
       }
-      __syncthreads();
-      kwy_rfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
-#pragma unroll
-      for (int r = 0; r < RK; ++r) {
-        const int k = tid + KWY_THREADS * r;
-        if (k <= H) buf[k] = cmulf(mp[r], buf[k]);
-      }
-      kwy_irfft_inplace<LOG2N - 1, KWY_THREADS>(buf, twl, twb, twN);
+    }
+    {
+      const int tid = kwy_tid_opaque();
+      SYN_STAMP(10);
       const double *w = (const double *)buf;
       const double sqrt_noise_size = sqrt((double)noise_size);
       // sample i lands at idx - H + 1 + i: into this pulse's slot, or (DIRECT: the one workgroup that takes the
@@ -1063,9 +1203,10 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
       const int64_t offset = (int64_t)idx - H + 1;
 #pragma unroll
       for (int m = 0; m < C; ++m) {
-        int i = tid + KWY_THREADS * m;
+        int i = tid + NT * m;
         double aper = (i < H) ? w[i + H] : w[i - H];
-        const double pv = PER_LDS ? (has_periodic ? perl[i] : 0.0) : per[PER_LDS ? 0 : m];
+        double pv = 0.0;
+        if (has_periodic) pv = (i < H) ? -dc_component * dc_remover[i] : lap[i - H] - dc_component * dc_remover[i];
         const double r = (pv * sqrt_noise_size + aper) / N;
         if constexpr (DIRECT) {
           const int64_t n = offset + i;
@@ -1074,8 +1215,10 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1
           slot[i] = r;
         }
       }
+      SYN_STAMP(11);
     }
   }
+#undef SYN_STAMP
 }
 
 
@@ -1157,10 +1300,11 @@ static int launch_pulse(kwy_ctx *ctx, syn_batch &batch) {
   const double *dcrem;
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N - 1, &twH));
   KWY_TRY(kwy_get_twiddles(ctx, LOG2N, &twN));
-  KWY_TRY(kwy_get_poly(ctx, 12ull * (N / KWY_THREADS), &poly));
+  KWY_TRY(kwy_get_poly(ctx, 12ull * (N / syn_pulse_nt<LOG2N>::value), &poly));
   KWY_TRY(get_dc_remover(ctx, N, &dcrem));
+  constexpr int NT = syn_pulse_nt<LOG2N>::value;
   size_t lds = sizeof(kwy_c) * ((H + 1) + (H / 8 > 1 ? H / 8 : 1)) +
-               sizeof(double) * (2 * (K + 1) + (LOG2N <= 11 ? N : 0) + 8) + sizeof(uint32_t) * KWY_EBASE_WORDS;
+               sizeof(double) * ((K + 1) + 8) + sizeof(uint32_t) * KWY_EBASE_WORDS;
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   KWY_HIP(hipFuncSetAttribute((const void *)k_syn_pulse<LOG2N, true>,
@@ -1171,16 +1315,16 @@ static int launch_pulse(kwy_ctx *ctx, syn_batch &batch) {
   int g = 0;
   for (int u = 0; u < batch.n; ++u) { batch.start[u] = g; g += std::max(1, std::min(batch.u[u].slots, share)); }
   batch.start[batch.n] = g;
-  KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL((k_syn_pulse<LOG2N, false>), dim3(g), dim3(KWY_THREADS), lds, ctx->stream, batch,
-                     kwy_randn(ctx), poly, twH, twN, dcrem));
+  KWY_PROF(ctx, "k_syn_pulse", hipLaunchKernelGGL((k_syn_pulse<LOG2N, false>), dim3(g), dim3(NT), lds, ctx->stream, batch,
+                     kwy_randn(ctx), poly, twH, twN, dcrem, (long long *)ctx->dbg));
   g = 0;
   for (int u = 0; u < batch.n; ++u) { batch.start[u] = g; g += batch.u[u].nt; }
   batch.start[batch.n] = g;
   KWY_PROF(ctx, "k_syn_ola", hipLaunchKernelGGL(k_syn_ola, dim3(g), dim3(KWY_THREADS), 0, ctx->stream, batch, N));
   // pulses beyond the slots (none for speech): one workgroup per utterance, serial, same order
   for (int u = 0; u <= batch.n; ++u) batch.start[u] = u;
-  KWY_PROF(ctx, "k_syn_pulse_more", hipLaunchKernelGGL((k_syn_pulse<LOG2N, true>), dim3(batch.n), dim3(KWY_THREADS), lds, ctx->stream,
-                     batch, kwy_randn(ctx), poly, twH, twN, dcrem));
+  KWY_PROF(ctx, "k_syn_pulse_more", hipLaunchKernelGGL((k_syn_pulse<LOG2N, true>), dim3(batch.n), dim3(NT), lds, ctx->stream,
+                     batch, kwy_randn(ctx), poly, twH, twN, dcrem, (long long *)nullptr));
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }

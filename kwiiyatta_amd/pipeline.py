@@ -310,7 +310,10 @@ class _Wave:
         dev, K, order, fs = owner.dev, owner.K, owner.order, owner.fs
         f64 = dict(dtype=torch.float64, device=dev)
         self.n = len(pairs)
-        self.stream = main_stream if main_stream is not None else torch.cuda.Stream(device=dev)
+        # the stream of the serial chain (alignment, conversion, rendering: narrow kernels between chip-wide ones) may
+        # be given priority over the aperiodicity stream (owner.chain_priority, bench.py --chain-priority)
+        self.stream = main_stream if main_stream is not None else \
+            torch.cuda.Stream(device=dev, priority=-1 if owner.chain_priority else 0)
         self.ctx = _lib.Context(dev.index, stream=self.stream.cuda_stream)
         if serial:          # one stream for everything: kernels one after the other (per-kernel timing, rocprofv3 runs)
             self.side, self.side_ctx = self.stream, self.ctx
@@ -472,8 +475,10 @@ class PairBatchPipeline(_Graphed):
     it within the rounding of one exp / log round trip (same DTW path in the tests, waveforms within 1e-9)."""
 
     def __init__(self, device_index, fs, pairs, gmm, order=24, radius=32, frame_period=5.0, waves=2, rng=None,
-                 silence=None, rng_place='side', serial=False, max_wave=16, wav_in=False, pcm=False, fused_mcep=True):
+                 silence=None, rng_place='side', serial=False, max_wave=16, wav_in=False, pcm=False, fused_mcep=True,
+                 chain_priority=False):
         self.dev = torch.device('cuda', device_index)
+        self.chain_priority = bool(chain_priority)
         self.wav_in, self.pcm, self.fused_mcep = bool(wav_in), bool(pcm), bool(fused_mcep)
         self.fs, self.order, self.radius, self.frame_period = int(fs), int(order), int(radius), float(frame_period)
         self.fft = lib.kwy_cheaptrick_fft_size(self.fs, 71.0)
@@ -490,7 +495,7 @@ class PairBatchPipeline(_Graphed):
         while (len(pairs) + nw - 1) // nw > max_wave:  # (16: a wave is one launch of the batched entries)
             nw += 1
         per = (len(pairs) + nw - 1) // nw
-        self.stream = torch.cuda.Stream(device=self.dev)
+        self.stream = torch.cuda.Stream(device=self.dev, priority=-1 if self.chain_priority else 0)
         self.waves = []
         for w in range(nw):
             chunk = pairs[w * per:(w + 1) * per]
