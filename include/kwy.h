@@ -525,6 +525,19 @@ int kwy_km_assign_dev(kwy_ctx *ctx, const double *Xc, int64_t n, int D, const do
                       int32_t *labels, double *resp, unsigned long long *changed);
 int kwy_km_update_dev(kwy_ctx *ctx, const double *stats, const double *centers_old, int M, int D,
                       double *centers_new, double *shift2);
+/* Up to `iterations` Lloyd iterations back to back WITHOUT the host (one shard: no reduction between the ranks' sums):
+ * each is kwy_km_assign_dev + kwy_gmm_em_sums_dev + kwy_km_update_dev followed by the decision sklearn's
+ * _kmeans_single_lloyd takes after an iteration, taken on the device; the kernels of the iterations enqueued behind
+ * the one that ended the loop return at once.  centers2: 2 x M x D, the centres of iteration i in buffer i & 1.
+ * state (int64[4], zeroed by the caller before the first batch): [0] 0 = running, 1 = labels unchanged (strict
+ * convergence), 2 = squared centre shift <= abs_tol (summed in numpy's order), 3 = a cluster is empty -- the
+ * iteration is left after its sums (labels, resp, stats are its own, the centres not updated) for the caller to
+ * relocate and finish, 4 = max_iter iterations done; [1] finished iterations; [2] changed labels of the last
+ * assignment.  log: 2 doubles per finished iteration (changed labels, centre shift), max_iter rows.
+ * Replaces the per-iteration host round trip of sklearn/cluster/_kmeans.py:_kmeans_single_lloyd. */
+int kwy_km_lloyd_dev(kwy_ctx *ctx, const double *Xc, int64_t n, int D, double *centers2, int M, int32_t *labels,
+                     double *resp, unsigned long long *changed, double *stats, double *shift2, double abs_tol,
+                     int iterations, int64_t max_iter, long long *state, double *log);
 
 /* ---- training-set path (device-resident) ---------------------------------------------------------
  * What the reference does per parallel pair before the converter fit (Config.load_dataset ->

@@ -261,7 +261,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_fit_resp(double *__restrict__ w
 template <int NBLK>
 __global__ __launch_bounds__(KWY_THREADS) void k_fit_sums(const double *__restrict__ X,
                                                          const double *__restrict__ resp, int64_t n, int D,
-                                                         int M, int rows_per_chunk, double *__restrict__ part) {
+                                                         int M, int rows_per_chunk, double *__restrict__ part,
+                                                         const long long *__restrict__ gate) {
+  if (gate && gate[0]) return;    // (the device-driven Lloyd loop has stopped: kwy_km_lloyd_dev)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ar = lane & 15, ak = lane >> 4;
   const int rb = 4 * blockIdx.y + wv;
   if (16 * rb >= M) return;       // no barrier in this kernel
@@ -312,7 +314,9 @@ __global__ __launch_bounds__(KWY_THREADS) void k_fit_sums(const double *__restri
 }
 
 // out[e] = sum_c part[c][e]
-__global__ void k_fit_reduce(const double *__restrict__ part, int nchunks, int64_t len, double *__restrict__ out) {
+__global__ void k_fit_reduce(const double *__restrict__ part, int nchunks, int64_t len, double *__restrict__ out,
+                             const long long *__restrict__ gate = nullptr) {
+  if (gate && gate[0]) return;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= len) return;
   double s = 0.0;
@@ -658,13 +662,13 @@ extern "C" int kwy_gmm_em_estep_dev(kwy_ctx *ctx, const double *X, int64_t n, in
 
 template <int NBLK>
 static void fit_sums_launch(kwy_ctx *ctx, const double *X, const double *resp, int64_t n, int D, int M, int rows,
-                            int nchunks, double *part) {
-  KWY_PROF(ctx, "k_fit_sums", hipLaunchKernelGGL(k_fit_sums<NBLK>, dim3(nchunks, (M + 63) / 64), dim3(KWY_THREADS), 0, ctx->stream, X, resp, n, D, M, rows, part));
+                            int nchunks, double *part, const long long *gate) {
+  KWY_PROF(ctx, "k_fit_sums", hipLaunchKernelGGL(k_fit_sums<NBLK>, dim3(nchunks, (M + 63) / 64), dim3(KWY_THREADS), 0, ctx->stream, X, resp, n, D, M, rows, part, gate));
 }
 
 // stats[m][0] = sum_t r[t][m], stats[m][1+i] = sum_t r[t][m] x[t][i]   (local shard)
-extern "C" int kwy_gmm_em_sums_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
-                                   double *stats) {
+int kwy_fit_sums_gated(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp, double *stats,
+                        const long long *gate) {
   KWY_TRY(fit_check(ctx, n, D, M));
   if (!X || !resp || !stats) { ctx->err = "gmm_em_sums: null pointer"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
@@ -675,21 +679,26 @@ extern "C" int kwy_gmm_em_sums_dev(kwy_ctx *ctx, const double *X, int64_t n, int
   double *part = kwy_arena<double>(ctx, (size_t)nchunks * len);
   if (!part) { ctx->err = "gmm_em_sums: scratch"; return KWY_ENOMEM; }
   switch ((D + 15) / 16) {
-    case 1: fit_sums_launch<1>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 2: fit_sums_launch<2>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 3: fit_sums_launch<3>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 4: fit_sums_launch<4>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 5: fit_sums_launch<5>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 6: fit_sums_launch<6>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 7: fit_sums_launch<7>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 8: fit_sums_launch<8>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    case 9: fit_sums_launch<9>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
-    default: fit_sums_launch<10>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part); break;
+    case 1: fit_sums_launch<1>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 2: fit_sums_launch<2>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 3: fit_sums_launch<3>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 4: fit_sums_launch<4>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 5: fit_sums_launch<5>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 6: fit_sums_launch<6>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 7: fit_sums_launch<7>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 8: fit_sums_launch<8>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 9: fit_sums_launch<9>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    default: fit_sums_launch<10>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
   }
   hipLaunchKernelGGL(k_fit_reduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nchunks, len,
-                     stats);
+                     stats, gate);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
+}
+
+extern "C" int kwy_gmm_em_sums_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
+                                   double *stats) {
+  return kwy_fit_sums_gated(ctx, X, n, D, M, resp, stats, nullptr);
 }
 
 // means[m][i] = stats[m][1+i] / (stats[m][0] + 10 eps)      (stats: globally reduced)
