@@ -619,19 +619,27 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
   kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
   D4C_STAMP(8);
   double pv[RK];
+  {
+    // the power spectrum in pairs (k, H - k), k = tid + NT q <= H/2 (kwy_rfft_pair_power2_w), H/2 by thread 0
+    constexpr int Q = (H / 2) / NT;
+    static_assert(RK == 2 * Q + 1, "pairs per thread");
 #pragma unroll
-  for (int r = 0; r < RK; ++r) {
-    const int k = tid + NT * r;
-    pv[r] = 0.0;
-    if (k <= H) {
-      const kwy_c v = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
-      pv[r] = __builtin_fma(v.x, v.x, v.y * v.y);
+    for (int q = 0; q < Q; ++q)
+      kwy_rfft_pair_power2_w<LOG2N - 1>(B, tid + NT * q, kwy_tw_hex(d4c_opaque(twb), HEX * q), &pv[2 * q], &pv[2 * q + 1]);
+    pv[2 * Q] = 0.0;
+    if (tid == 0) {
+      double pm;
+      kwy_rfft_pair_power2_w<LOG2N - 1>(B, H / 2, kwy_c{0.0, -1.0}, &pv[2 * Q], &pm);
     }
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RK; ++r)
-    if (tid + NT * r <= H) P[tid + NT * r] = pv[r];
+    for (int q = 0; q < Q; ++q) {
+      const int k = tid + NT * q;
+      P[k] = pv[2 * q];
+      P[H - k] = pv[2 * q + 1];
+    }
+    if (tid == 0) P[H / 2] = pv[2 * Q];
+  }
   __syncthreads();
   d4c_dc_correction<NT>(P, S, cf0, p.fs, N);
   d4c_linear_smoothing_regs<NT, RK>(P, pv, S, tot, cf0, p.fs, N);   // P is dead from here on
@@ -763,15 +771,24 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
       kwy_fft_inplace_w<LOG2N - 1, NT, false>(B, tw4);
     }
     // CPU: power spectrum, sort ascending, cumulative sum, ratio of the (H - boundary) smallest to all
+    // bins k and H - k in pairs (k = tid + NT q <= H/2; the self-paired H/2 goes to thread 0): slot 2 q and 2 q + 1 of
+    // every thread, the last slot thread 0's alone -- which keys a thread holds does not matter to the selection,
+    // only that slot r of thread t is filled exactly when t + NT r <= H
     unsigned long long key[RK];
+    constexpr int Q = (H / 2) / NT;
+    static_assert(RK == 2 * Q + 1, "pairs per thread");
 #pragma unroll
-    for (int r = 0; r < RK; ++r) {
-      const int k = tid + NT * r;
-      key[r] = ~0ull;
-      if (k <= H) {
-        const kwy_c cc = kwy_rfft_bin2_w<LOG2N - 1>(B, k, kwy_tw_hex(d4c_opaque(twb), HEX * r));
-        key[r] = (unsigned long long)__double_as_longlong(__builtin_fma(cc.x, cc.x, cc.y * cc.y));
-      }
+    for (int q = 0; q < Q; ++q) {
+      double pk, pm;
+      kwy_rfft_pair_power2_w<LOG2N - 1>(B, tid + NT * q, kwy_tw_hex(d4c_opaque(twb), HEX * q), &pk, &pm);
+      key[2 * q] = (unsigned long long)__double_as_longlong(pk);
+      key[2 * q + 1] = (unsigned long long)__double_as_longlong(pm);
+    }
+    key[2 * Q] = ~0ull;
+    if (tid == 0) {
+      double pk, pm;
+      kwy_rfft_pair_power2_w<LOG2N - 1>(B, H / 2, kwy_c{0.0, -1.0}, &pk, &pm);
+      key[2 * Q] = (unsigned long long)__double_as_longlong(pk);
     }
     __syncthreads();
     if (b == 1) D4C_STAMP(19);

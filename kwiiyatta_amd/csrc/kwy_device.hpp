@@ -1056,6 +1056,24 @@ __device__ __forceinline__ kwy_c kwy_rfft_bin2_w(const kwy_c *z, int k, kwy_c w)
   // 2 X = (er, ei) + (di, -dr) w, as two fused multiply-adds per component (see cmulf)
   return {__builtin_fma(dr, w.y, __builtin_fma(di, w.x, er)), __builtin_fma(-dr, w.x, __builtin_fma(di, w.y, ei))};
 }
+// |2 X[k]|^2 and |2 X[H - k]|^2 together (0 <= k <= H/2): the two bins are E + O w and conj(E - O w) of the same two
+// packed points -- one pair of LDS reads, one twiddle and one complex product for two powers
+template <int LOG2H>
+__device__ __forceinline__ void kwy_rfft_pair_power2_w(const kwy_c *z, int k, kwy_c w, double *pk, double *pm) {
+  constexpr int H = 1 << LOG2H;
+  if (k == 0) {
+    const double a = 2.0 * (z[0].x + z[0].y), b = 2.0 * (z[0].x - z[0].y);
+    *pk = a * a; *pm = b * b;
+    return;
+  }
+  const kwy_c A = z[k], Bz = z[H - k];
+  const double er = A.x + Bz.x, ei = A.y - Bz.y;
+  const double dr = A.x - Bz.x, di = A.y + Bz.y;
+  const double pr = __builtin_fma(dr, w.y, di * w.x), pi = __builtin_fma(-dr, w.x, di * w.y);
+  const double xr = er + pr, xi = ei + pi, yr = er - pr, yi = ei - pi;
+  *pk = __builtin_fma(xr, xr, xi * xi);
+  *pm = __builtin_fma(yr, yr, yi * yi);
+}
 template <int LOG2H>
 __device__ __forceinline__ kwy_c kwy_rfft_bin(const kwy_c *z, int k, const kwy_c *__restrict__ twN) {
   return kwy_rfft_bin_w<LOG2H>(z, k, twN[k & ((2 << LOG2H) - 1)]);

@@ -276,6 +276,36 @@ def test_hip_kmeans_matches_sklearn(n, D, M, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('batch', [1, 3, 16])
+def test_hip_lloyd_on_the_device_equals_the_host_loop(batch, monkeypatch):
+    """kwy_km_lloyd_dev (the stopping decision taken on the device, `batch` iterations per read-back) against the loop
+    with one host round trip per iteration: same iteration count, labels and centres -- on blobs, and on the data
+    whose k-means++ seeding leaves clusters empty (the iteration is handed back to the host for the relocation)."""
+    from kwiiyatta_amd.converter import gmm_fit
+    from kwiiyatta_amd.converter.gmm_fit import HipStats, kmeans_init
+    rng = np.random.default_rng(4)
+    cases = [(make_data(6000, 24, 8, seed=5), 12, 2)]
+    for seed in range(4):
+        X = np.repeat(rng.standard_normal((10, 6)) * 20, 40, axis=0) + rng.standard_normal((400, 6)) * 1e-3
+        cases.append((X, 16, seed))
+    for X, M, seed in cases:
+        monkeypatch.setattr(gmm_fit, 'LLOYD_BATCH', batch)
+        dev = HipStats(X, M)
+        it_d, c_d = kmeans_init(dev, M, seed)
+        with dev.scope():
+            lab_d = dev.labels.cpu().numpy()
+        host = HipStats(X, M)
+        monkeypatch.delattr(HipStats, 'km_lloyd')                 # hasattr fails -> the per-iteration loop
+        it_h, c_h = kmeans_init(host, M, seed)
+        monkeypatch.undo()
+        with host.scope():
+            lab_h = host.labels.cpu().numpy()
+        assert it_d == it_h
+        assert np.array_equal(lab_d, lab_h)
+        assert np.array_equal(c_d, c_h)
+
+
+@pytest.mark.gpu
 def test_hip_kmeans_blocks_match_numpy():
     """the individual k-means blocks against their numpy restatement (shard-local parts: colstats, centring,
     candidate distances, the cumulative-sum search incl. the not-mine / clipped cases, assignment, update)"""
