@@ -145,7 +145,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   double sumsq = 0.0;
   double wc, ws, wcd, wsd;
   kwy_sincos_pi_range(KWY_PI * ((tid - half) / 1.5 / fs) * cf0, &ws, &wc);   // |argument| <= pi inside the window
-  sincos(KWY_PI * (KWY_THREADS / 1.5 / fs) * cf0, &wsd, &wcd);
+  kwy_sincos_medium(KWY_PI * (KWY_THREADS / 1.5 / fs) * cf0, &wsd, &wcd);
 #pragma unroll
   for (int j = 0; j < E; ++j) {
     const int i = tid + KWY_THREADS * j;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   // ---- log spectrum, mirrored, into the other buffer
   double *Lg = S;  // N doubles in buffer X
   for (int k = tid; k <= H; k += KWY_THREADS) {
-    double v = log(P[k]);
+    double v = kwy_log(P[k]);
     Lg[k] = v;
     if (k >= 1 && k < H) Lg[N - k] = v;
   }
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
   //      (kwy_rotate) -- the general-range sin() per bin was 5 % of the kernel's instructions.
   {
     double ls, lc, lsd, lcd;
-    sincos(KWY_PI * cf0 * ((double)tid / fs), &ls, &lc);
-    sincos(KWY_PI * cf0 * ((double)KWY_THREADS / fs), &lsd, &lcd);
+    kwy_sincos_medium(KWY_PI * cf0 * ((double)tid / fs), &ls, &lc);
+    kwy_sincos_medium(KWY_PI * cf0 * ((double)KWY_THREADS / fs), &lsd, &lcd);
 #pragma unroll
     for (int r = 0; r < RK; ++r) {
       const int k = tid + KWY_THREADS * r;

@@ -230,6 +230,63 @@ __device__ __forceinline__ double kwy_cos_pi_range(double x) {
   return ((k + 1) & 2) ? -v : v;
 }
 
+// ------------------------------------------------------------------ log, and sincos beyond [-pi, pi]
+// The library's log / sincos are 98 / 155 vector instructions a call (extended tables, the Payne-Hanek path for huge
+// arguments inline): the kernels that call them once per spectral bin -- CheapTrick's log spectrum, the two half
+// log-spectra and the two minimum-phase exponentials of every synthesis pulse -- spend a tenth to a quarter of their
+// instructions there.  These are the fdlibm forms (e_log.c; k_sin.c / k_cos.c behind a two-constant fused reduction):
+// < 1 ulp for log, < 1.5 ulp for sin / cos with |x| < 2^30 (tests/test_select_gpu.py checks both against numpy).
+__device__ __forceinline__ double kwy_log(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  const bool tiny = x < 2.2250738585072014e-308;            // subnormal (or zero / negative: fixed up below)
+  const double xs = tiny ? x * 18014398509481984.0 : x;     // 2^54
+  int e;
+  double m = frexp(xs, &e);                                  // [0.5, 1)
+  e -= tiny ? 54 : 0;
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;
+  e -= low ? 1 : 0;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  double r = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  r = x == 0.0 ? -INFINITY : r;
+  r = (x < 0.0 || x != x) ? NAN : r;
+  r = x == INFINITY ? INFINITY : r;
+  return r;
+}
+
+__device__ __forceinline__ void kwy_sincos_medium(double x, double *sn_out, double *cs_out) {
+  const double kf = rint(x * 6.36619772367581382433e-01);    // x / (pi/2)
+  double y = __builtin_fma(-kf, 1.57079632679489655800e+00, x);
+  y = __builtin_fma(-kf, 6.12323399573676603587e-17, y);
+  const int q = (int)kf;
+  const double z = y * y;
+  const double rs = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sn = y + (z * y) * (-1.66666666666666324348e-01 + z * rs);
+  const double rc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 +
+                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z, w = 1.0 - hz;
+  const double cs = w + (((1.0 - w) - hz) + z * rc);
+  // (sin, cos)(y + q pi/2)
+  const double s_ = (q & 1) ? cs : sn, c_ = (q & 1) ? sn : cs;
+  *sn_out = (q & 2) ? -s_ : s_;
+  *cs_out = ((q + 1) & 2) ? -c_ : c_;
+}
+
 // sin and cos on [-pi, pi] from the same reduction (the two kernel polynomials are evaluated by the routine above
 // anyway).  A window function sampled at i = tid + NT r advances its argument by a constant per r: one call for
 // r = 0, then the rotation kwy_rotate() per further element (6 instead of ~40 instructions; the error grows by about

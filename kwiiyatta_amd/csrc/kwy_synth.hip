@@ -1015,8 +1015,8 @@ __global__ __launch_bounds__(syn_pulse_nt<LOG2N>::value, LOG2N <= 12 ? 2 : 1) vo
       for (int r = 0; r < RK; ++r) {
         const int k = tid + NT * r;
         if (k <= H) {
-          lap[k] = (current_vuv != 0.0) ? log(evs[r] * rts[r]) / 2.0 : log(evs[r]) / 2.0;
-          if (has_periodic) L[k] = log(evs[r] * (1.0 - rts[r]) + SYN_SAFE) / 2.0;
+          lap[k] = kwy_log((current_vuv != 0.0) ? evs[r] * rts[r] : evs[r]) / 2.0;
+          if (has_periodic) L[k] = kwy_log(evs[r] * (1.0 - rts[r]) + SYN_SAFE) / 2.0;
         }
       }
     }
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(syn_pulse_nt<LOG2N>::value, LOG2N <= 12 ? 2 : 1) vo
               const double tmp = exp(R[g].x / N);
               const double ph = R[g].y / N;
               double sn, cs;
-              sincos(ph, &sn, &cs);       // one argument reduction for both
+              kwy_sincos_medium(ph, &sn, &cs);   // (a minimum-phase angle: a few pi at most)
               R[g] = {tmp * cs, tmp * sn};
             }
 #pragma unroll

@@ -35,3 +35,20 @@ extern "C" int kwy_debug_smallest_sum_dev(void *stream, const double *values, in
   hipLaunchKernelGGL(k_select_selftest, dim3(problems), dim3(D4C_NT), 0, (hipStream_t)stream, values, n, m, out);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- diagnostic: kwy_log / kwy_sincos_medium of kwy_device.hpp element by element ----------------------------
+__global__ void k_devmath_selftest(const double *__restrict__ x, int n, double *__restrict__ lg, double *__restrict__ sn,
+                                   double *__restrict__ cs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  lg[i] = kwy_log(x[i]);
+  kwy_sincos_medium(x[i], &sn[i], &cs[i]);
+}
+
+extern "C" int kwy_debug_devmath_dev(void *stream, const double *x, int n, double *log_out, double *sin_out,
+                                     double *cos_out) {
+  if (!x || !log_out || !sin_out || !cos_out || n <= 0) return -1;
+  hipLaunchKernelGGL(k_devmath_selftest, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n, log_out,
+                     sin_out, cos_out);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
