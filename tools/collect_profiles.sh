@@ -17,6 +17,7 @@ keep $S/bench_streams.json $P/${RND}_pair_streams_bench.json
 keep $S/bench_utt_b1.json $P/${RND}_utterance_b1_bench.json
 keep $S/bench_config4.json $P/${RND}_config4_bench.json
 keep $S/bench_wav.json $P/${RND}_wav_in_pcm_out_bench.json
+keep $S/bench_chain_priority.json $P/${RND}_chain_priority_bench.json
 keep $S/bench_corpus_profiled.json $P/${RND}_corpus_profiled_bench.json
 keep $S/bench_fit.json $P/${RND}_fit_bench.json
 keep $S/bench_fit_1rank_nccl.json $P/${RND}_fit_1rank_nccl_bench.json

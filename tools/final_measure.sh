@@ -21,6 +21,8 @@ if [ "$PART" = a ]; then
   python $R/bench.py --workload utterance --utterances 256 --steps 3 --warmup 1 > $O/bench_config4.json 2> $O/bench_config4.err
   # round 5: the same step from waveforms to 16-bit samples (DIO + StoneMask and the post-step inside it)
   python $R/bench.py --workload wav --no-variants --config4 off > $O/bench_wav.json 2> $O/bench_wav.err
+  # the serial chain's streams at a higher stream priority (round 4's review, item 8): recorded, not the default
+  python $R/bench.py --chain-priority on --no-variants --config4 off --no-cpu-baseline > $O/bench_chain_priority.json 2>/dev/null
   echo done > $O/DONE_A
 elif [ "$PART" = b ]; then
   python $R/bench_fit.py > $O/bench_fit.json 2>/dev/null
