@@ -212,15 +212,14 @@ __global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
     int boundary = (int)(width * N / fs) + 1;
     if (boundary > H / 2) boundary = H / 2;  // guards LDS only; f0 > 3fs/8 is outside WORLD's domain
     const int L = H + boundary * 2 + 1;
-    for (int i = tid; i < L; i += KWY_THREADS) {
+    // (L <= N + 1 values over 256 threads: chunks of <= N / 256 + 1)
+    kwy_block_cumsum_of<KWY_THREADS, N / KWY_THREADS + 1>([&](int i) {
       double m;
       if (i < boundary) m = P[boundary - i];
       else if (i < H + boundary) m = P[i - boundary];
       else m = P[H - (i - (H + boundary))];
-      S[i] = m * fs / N;
-    }
-    __syncthreads();
-    kwy_block_cumsum(S, L, tot);
+      return m * fs / N;
+    }, S, L, tot);
     const double origin_of_mirroring_axis = -(boundary - 0.5) * fs / N;
     const double dfi = (double)fs / N;
     for (int k = tid; k <= H; k += KWY_THREADS) {

@@ -84,6 +84,8 @@ __device__ inline void d4c_dc_correction(double *P, double *S, double cf0, int f
   __syncthreads();
 }
 
+// chunk bound of the smoothing's prefix sum: L <= H + 2 (H/2) + 1 = N + 1 values over NT = N / 16 threads
+#define D4C_SMOOTH_CHUNK 17
 // WORLD LinearSmoothing: in[0..H] -> out[0..H] (out may alias in); S: scratch of >= H+2b+1
 // (Measured in round 3 and dropped: the same three passes -- mirrored fill, prefix sum, two interpolated reads per
 // bin -- unrolled to their compile-time maxima with the prefix sum's chunk in registers, so that the LDS reads of a
@@ -98,15 +100,13 @@ __device__ inline void d4c_linear_smoothing(const double *in, double *out, doubl
   int boundary = (int)(width * N / fs) + 1;
   if (boundary > H / 2) boundary = H / 2;  // LDS guard; outside WORLD's domain anyway
   const int L = min(H + boundary * 2 + 1, kmax + boundary * 2 + 4);
-  for (int i = threadIdx.x; i < L; i += NT) {
+  kwy_block_cumsum_of<NT, D4C_SMOOTH_CHUNK>([&](int i) {
     double m;
     if (i < boundary) m = in[boundary - i];
     else if (i < H + boundary) m = in[i - boundary];
     else m = in[H - (i - (H + boundary))];
-    S[i] = m * fs / N;
-  }
-  __syncthreads();
-  kwy_block_cumsum<NT>(S, L, tot);
+    return m * fs / N;
+  }, S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
   const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
   for (int k = threadIdx.x; k <= min(H, kmax); k += NT) {
@@ -394,15 +394,13 @@ __device__ inline void d4c_subtract_smoothed(double *io, double *S, double *tot,
   int boundary = (int)(width * N / fs) + 1;
   if (boundary > H / 2) boundary = H / 2;
   const int L = min(H + boundary * 2 + 1, kmax + boundary * 2 + 4);
-  for (int i = threadIdx.x; i < L; i += NT) {
+  kwy_block_cumsum_of<NT, D4C_SMOOTH_CHUNK>([&](int i) {
     double m;
     if (i < boundary) m = io[boundary - i];
     else if (i < H + boundary) m = io[i - boundary];
     else m = io[H - (i - (H + boundary))];
-    S[i] = m * fs / N;
-  }
-  __syncthreads();
-  kwy_block_cumsum<NT>(S, L, tot);
+    return m * fs / N;
+  }, S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
   const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
   for (int k = threadIdx.x; k <= min(H, kmax); k += NT) {
@@ -423,15 +421,13 @@ __device__ inline void d4c_linear_smoothing_regs(const double *in, double (&outv
   int boundary = (int)(width * N / fs) + 1;
   if (boundary > H / 2) boundary = H / 2;
   const int L = H + boundary * 2 + 1;
-  for (int i = threadIdx.x; i < L; i += NT) {
+  kwy_block_cumsum_of<NT, D4C_SMOOTH_CHUNK>([&](int i) {
     double m;
     if (i < boundary) m = in[boundary - i];
     else if (i < H + boundary) m = in[i - boundary];
     else m = in[H - (i - (H + boundary))];
-    S[i] = m * fs / N;
-  }
-  __syncthreads();
-  kwy_block_cumsum<NT>(S, L, tot);
+    return m * fs / N;
+  }, S, L, tot);
   const double origin = -(boundary - 0.5) * fs / N;
   const double inv_dfi = (double)N / fs, inv_width = 1.0 / width;
 #pragma unroll

@@ -440,6 +440,45 @@ __device__ inline void kwy_block_cumsum(double *buf, int L, double *tot) {
   __syncthreads();
 }
 
+// The same prefix sum of values that are COMPUTED (value(i), i < L), left in buf: the thread's chunk stays in registers
+// between its running sum and the addition of the offset, so the values are never stored, read back, summed in place
+// and read again -- 2 LDS accesses per element instead of 6 and one barrier fewer than fill + kwy_block_cumsum.
+// Same additions in the same order (bit-identical).  CH: compile-time bound of the chunk ceil(L / NT).
+template <int NT, int CH, class F>
+__device__ inline void kwy_block_cumsum_of(F value, double *buf, int L, double *tot) {
+  constexpr int PER = NT / 64;
+  const int t = threadIdx.x;
+  const int chunk = (L + NT - 1) / NT;
+  const int b0 = t * chunk;
+  const int b1 = min(L, b0 + chunk);
+  double r[CH];
+  double run = 0.0;
+#pragma unroll
+  for (int q = 0; q < CH; ++q) {
+    r[q] = 0.0;
+    if (q < chunk && b0 + q < b1) { run += value(b0 + q); r[q] = run; }
+  }
+  tot[t] = run;
+  __syncthreads();
+  if (t < 64) {  // wave 0 scans the NT chunk totals, PER per lane
+    double a[PER];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { acc += tot[PER * t + q]; a[q] = acc; }
+    const double inc = kwy_wave_scan_f64(acc);
+    const double excl = inc - acc;  // sum of the lanes before this one
+    tot[PER * t] = excl;
+#pragma unroll
+    for (int q = 1; q < PER; ++q) tot[PER * t + q] = excl + a[q - 1];
+  }
+  __syncthreads();
+  const double off = tot[t];
+#pragma unroll
+  for (int q = 0; q < CH; ++q)
+    if (q < chunk && b0 + q < b1) buf[b0 + q] = t > 0 ? r[q] + off : r[q];
+  __syncthreads();
+}
+
 // offsets[i] = sum_{j<i} count(j) for i <= n, the counts given by a function of the index (evaluated twice: once for
 // the chunk totals, once for the offsets) -- counting and scanning in ONE single-workgroup launch.  tot: NT uint64 of LDS.
 template <int NT, class F>
