@@ -62,7 +62,7 @@ __device__ __forceinline__ double ct_interp1q(double x0, double shift, const dou
 // logarithm and transform of that row: the first ncut coefficients (c[0] halved, minus log(out_div) for the
 // division of world.py:50) go to a scratch row and k_cep2mc applies the frequency transform as a matrix product.
 template <int LOG2N, bool MCEP>
-__global__ __launch_bounds__(KWY_THREADS) void k_cheaptrick(
+__global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 5 : 4) void k_cheaptrick(
     ct_batch batch, int fs, double q1, double f0_floor_eff, kwy_randn_src rs, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN, double out_div, ct_mcep mcep) {
   constexpr int N = 1 << LOG2N;
