@@ -928,7 +928,7 @@ struct syn_view {
 typedef kwy_batch<syn_view> syn_batch;
 
 template <int LOG2N, bool DIRECT>
-__global__ __launch_bounds__(syn_pulse_nt<LOG2N>::value, LOG2N <= 12 ? 2 : 1) void k_syn_pulse(
+__global__ __launch_bounds__(syn_pulse_nt<LOG2N>::value, LOG2N <= 11 ? 3 : (LOG2N == 12 ? 2 : 1)) void k_syn_pulse(
     syn_batch batch, kwy_randn_src rs, const uint4 *__restrict__ poly,
     const kwy_c *__restrict__ twH, const kwy_c *__restrict__ twN,
     const double *__restrict__ dc_remover, long long *__restrict__ dbg) {
