@@ -401,37 +401,66 @@ __device__ __forceinline__ void fit_cov_store(double *__restrict__ out, int D, i
   });
 }
 
-// act[m][tile]: does any of the tile's FIT_COV_TILE frames carry a responsibility >= r_min for mixture m?  One
-// workgroup per FIT_ACT_TILES tiles (resp is read once, coalesced); k_fit_cov fetches, stages and multiplies only the
-// tiles that do -- in a fitted mixture most tiles of most components do not.
-#define FIT_ACT_TILES 8
+// act[m][g]: does any of the four frames 4 g .. 4 g + 3 (one matrix instruction's worth) carry a responsibility >= r_min
+// for mixture m?  A workgroup takes FIT_ACT_GROUPS groups x all mixtures: resp is read once, coalesced along the
+// mixtures, the flags leave through LDS so that they are written coalesced along the groups.
+#define FIT_ACT_GROUPS 64
 __global__ __launch_bounds__(KWY_THREADS) void k_fit_active(const double *__restrict__ resp, int64_t n, int D, int M,
-                                                           const double *__restrict__ stats, int64_t ntiles,
+                                                           const double *__restrict__ stats, int64_t ngroups,
                                                            unsigned char *__restrict__ act) {
-  __shared__ unsigned char f[KWY_THREADS];
+  extern __shared__ unsigned char fl[];          // M x FIT_ACT_GROUPS
   const int tid = threadIdx.x;
-  const int per = KWY_THREADS / M > 0 ? KWY_THREADS / M : 1;     // row groups side by side (M <= 256)
-  const int m = tid % M, rg = tid / M;
-  const double r_min = fmax(FIT_R_MIN, stats ? stats[(size_t)m * (D + 1)] * FIT_R_REL : 0.0);
-  for (int q = 0; q < FIT_ACT_TILES; ++q) {
-    const int64_t tile = (int64_t)blockIdx.x * FIT_ACT_TILES + q;
-    if (tile >= ntiles) return;      // (uniform)
-    const int64_t t0 = tile * FIT_COV_TILE;
+  const int64_t g0 = (int64_t)blockIdx.x * FIT_ACT_GROUPS;
+  for (int idx = tid; idx < M * FIT_ACT_GROUPS; idx += KWY_THREADS) {
+    const int m = idx % M, q = idx / M;
+    const int64_t g = g0 + q;
     bool any = false;
-    if (rg < per)
-      for (int r = rg; r < FIT_COV_TILE; r += per) {
-        const int64_t t = t0 + r;
+    if (g < ngroups) {
+      const double r_min = fmax(FIT_R_MIN, stats ? stats[(size_t)m * (D + 1)] * FIT_R_REL : 0.0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t t = 4 * g + r;
         if (t < n && resp[t * M + m] >= r_min) any = true;
       }
-    f[tid] = any ? 1 : 0;
-    __syncthreads();
-    if (tid < M) {
-      unsigned char o = 0;
-      for (int g = 0; g < per; ++g) o |= f[tid + M * g];
-      act[(size_t)tid * ntiles + tile] = o;
     }
-    __syncthreads();
+    fl[m * FIT_ACT_GROUPS + q] = any ? 1 : 0;
   }
+  __syncthreads();
+  for (int idx = tid; idx < M * FIT_ACT_GROUPS; idx += KWY_THREADS) {
+    const int m = idx / FIT_ACT_GROUPS, q = idx % FIT_ACT_GROUPS;
+    if (g0 + q < ngroups) act[(size_t)m * ngroups + g0 + q] = fl[idx];
+  }
+}
+
+// The active groups of every mixture as a LIST (ascending): one workgroup per mixture counts and scans its flags and
+// writes list[m][0 .. count[m]).  k_fit_cov builds its 32-frame tiles from eight LISTED groups each -- wherever they
+// lie -- and gives every split of a mixture an equal run of consecutive tiles: every matrix instruction issued has at
+// least one frame that counts, and the splits of a mixture have the same amount to do.  (Until round 5's last day a split owned a
+// row range and visited the 32-row tiles of it that had any weight: on rows in arbitrary order 40 % of all tiles for one
+// live group each, on rows grouped by cluster one split per component did all the work.)
+__global__ __launch_bounds__(KWY_THREADS) void k_fit_active_list(const unsigned char *__restrict__ act, int64_t ntiles,
+                                                                int32_t *__restrict__ list, int32_t *__restrict__ count) {   // (ntiles: entries per mixture = groups)
+  __shared__ uint64_t tot[KWY_THREADS];
+  __shared__ uint64_t total;
+  const int m = blockIdx.x, t = threadIdx.x;
+  const unsigned char *am = act + (size_t)m * ntiles;
+  int32_t *lm = list + (size_t)m * ntiles;
+  const int64_t chunk = (ntiles + KWY_THREADS - 1) / KWY_THREADS;
+  const int64_t b0 = t * chunk, b1 = min(ntiles, b0 + chunk);
+  uint64_t run = 0;
+  for (int64_t i = b0; i < b1; ++i) run += am[i] ? 1 : 0;
+  tot[t] = run;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t acc = 0;
+    for (int i = 0; i < KWY_THREADS; ++i) { const uint64_t c = tot[i]; tot[i] = acc; acc += c; }
+    total = acc;
+  }
+  __syncthreads();
+  uint64_t at = tot[t];
+  for (int64_t i = b0; i < b1; ++i)
+    if (am[i]) lm[at++] = (int32_t)i;
+  if (t == 0) count[m] = (int32_t)total;
 }
 
 template <int NBLK>
@@ -439,7 +468,8 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
                                                            int64_t n, int D, int M, int nsplit,
                                                            const double *__restrict__ means,
                                                            const double *__restrict__ stats,
-                                                           const unsigned char *__restrict__ act, int64_t ntiles,
+                                                           const int32_t *__restrict__ list,
+                                                           const int32_t *__restrict__ count, int64_t ntiles,
                                                            double *__restrict__ cpart) {
   constexpr int NP = 16 * NBLK, ZS = NP + 1, CMAX = (NBLK * (NBLK + 1) / 2 + 3) / 4;
   constexpr int ROWS = FIT_COV_TILE / 4;   // rows of a tile staged by one wavefront
@@ -458,8 +488,6 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
     m = blockIdx.x % M;
     split = blockIdx.x / M;
   }
-  const int64_t rows = ((n + nsplit - 1) / nsplit + FIT_COV_TILE - 1) / FIT_COV_TILE * FIT_COV_TILE;   // whole tiles
-  const int64_t r0 = split * rows, r1 = min(n, r0 + rows);
   const double *mu = means + (size_t)m * D;
   const double r_min = fmax(FIT_R_MIN, stats ? stats[(size_t)m * (D + 1)] * FIT_R_REL : 0.0);
   double muv[FIT_LP_COLS];
@@ -470,17 +498,35 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
   for (int a = 0; a < CMAX; ++a) acc[a] = fit_v4f64{0.0, 0.0, 0.0, 0.0};
   // this wavefront stages rows ROWS*w .. ROWS*w+ROWS-1 of every tile: fetched one tile ahead into registers
   double xv[ROWS][FIT_LP_COLS], rv = 0.0;
-  auto fetch = [&](int64_t b0) {
+  // tile j of the mixture = the listed groups 8 j .. 8 j + 7 (four frames each; entries beyond the list: no frames)
+  const int32_t *__restrict__ lm = list + (size_t)m * ntiles;
+  const int cnt = count[m];                      // listed groups
+  const int ntl = (cnt + 7) / 8;                 // tiles
+  // (the list entries of a tile are read one tile AHEAD of its rows: the rows' addresses depend on them, and two
+  // dependent trips to memory per tile are more than a tile's 2.4 us of matrix instructions cover)
+  int ea = 0, eb = 0, er = 0;                    // first frames' groups of this wavefront's rows / of row tid
+  auto entries = [&](int j) {
+    const int e0 = 8 * j + 2 * wv, e2 = 8 * j + ((tid & (FIT_COV_TILE - 1)) >> 2);
+    ea = e0 < cnt ? lm[e0] : -1;
+    eb = e0 + 1 < cnt ? lm[e0 + 1] : -1;
+    er = e2 < cnt ? lm[e2] : -1;
+  };
+  auto fetch = [&]() {                           // the rows of the tile whose entries are in (ea, eb, er)
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r)
+    for (int r = 0; r < ROWS; ++r) {
+      const int g = (r < 4) ? ea : eb;
+      const int64_t t = g >= 0 ? 4 * (int64_t)g + (r & 3) : n;
 #pragma unroll
       for (int c = 0; c < FIT_LP_COLS; ++c) {
         const int i = lane + 64 * c;
-        const int64_t t = b0 + ROWS * wv + r;
-        xv[r][c] = (t < r1 && i < D) ? X[t * D + i] : muv[c];
+        xv[r][c] = (t < n && i < D) ? X[t * D + i] : muv[c];
       }
-    const int64_t t = b0 + tid;
-    rv = (tid < FIT_COV_TILE && t < r1) ? resp[t * M + m] : 0.0;
+    }
+    rv = 0.0;
+    if (tid < FIT_COV_TILE) {
+      const int64_t t = er >= 0 ? 4 * (int64_t)er + (tid & 3) : n;
+      if (t < n) rv = resp[t * M + m];
+    }
   };
   auto stage = [&](int buf) {
     double *dt = ds + buf * FIT_COV_TILE * ZS;
@@ -493,23 +539,26 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
       }
     if (tid < FIT_COV_TILE) rs[buf * FIT_COV_TILE + tid] = rv;
   };
-  // tiles of this split that carry any weight for this mixture (act, k_fit_active), in order: the next one is fetched
-  // while the current one is multiplied
-  const unsigned char *__restrict__ am = act + (size_t)m * ntiles;
-  const int64_t tile1 = (r1 + FIT_COV_TILE - 1) / FIT_COV_TILE;
-  auto next_active = [&](int64_t t) {
-    while (t < tile1 && !am[t]) ++t;
-    return t;
-  };
-  int64_t cur = r0 < r1 ? next_active(r0 / FIT_COV_TILE) : tile1;
-  if (cur < tile1) {
-    fetch(cur * FIT_COV_TILE);
+  // split s takes the tiles [ntl s / nsplit, ntl (s + 1) / nsplit) of the mixture -- equal shares, and CONSECUTIVE ones:
+  // where the posteriors are broad the same rows are live for many mixtures, and the workgroups of a split (one XCD)
+  // then read them from that XCD's L2 as they did when a split owned a row range (dealing the tiles out round-robin
+  // instead was measured: 7.7 against 5.2 ms per launch on config 5's corpus -- every workgroup fetched its own rows).
+  // The next tile is fetched while the current one is multiplied.
+  int j = (int)((int64_t)ntl * split / nsplit);
+  const int jend = (int)((int64_t)ntl * (split + 1) / nsplit);
+  if (j < jend) {
+    entries(j);
+    fetch();
+    if (j + 1 < jend) entries(j + 1);
     stage(0);
     __syncthreads();
     int buf = 0;
-    while (cur < tile1) {
-      const int64_t nxt = next_active(cur + 1);
-      if (nxt < tile1) fetch(nxt * FIT_COV_TILE);   // in flight during the MFMAs below
+    while (j < jend) {
+      const int jn = j + 1;
+      if (jn < jend) {
+        fetch();                                             // rows of tile jn: in flight during the MFMAs below
+        if (jn + 1 < jend) entries(jn + 1);
+      }
       const double *tile = ds + buf * FIT_COV_TILE * ZS, *rt = rs + buf * FIT_COV_TILE;
       switch (wv) {
         case 0: fit_cov_tile<NBLK, 0, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
@@ -517,10 +566,10 @@ __global__ __launch_bounds__(KWY_THREADS, 2) void k_fit_cov(const double *__rest
         case 2: fit_cov_tile<NBLK, 2, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
         default: fit_cov_tile<NBLK, 3, CMAX>(tile, rt, ZS, ar, ak, r_min, acc); break;
       }
-      if (nxt < tile1) stage(buf ^ 1);              // last read two tiles ago, before the previous barrier
+      if (jn < jend) stage(buf ^ 1);                         // last read two tiles ago, before the previous barrier
       __syncthreads();
       buf ^= 1;
-      cur = nxt;
+      j = jn;
     }
   }
   // lower-triangle blocks only (diagonal blocks in full); k_fit_reduce_sym mirrors them
@@ -724,11 +773,11 @@ static int fit_cov_splits(int64_t n, int M) {
 
 template <int NBLK>
 static int fit_cov_launch(kwy_ctx *ctx, const double *X, const double *resp, int64_t n, int D, int M,
-                          const double *means, const double *stats, const unsigned char *act, int64_t ntiles,
-                          double *cpart, int nsplit) {
+                          const double *means, const double *stats, const int32_t *list, const int32_t *count,
+                          int64_t ntiles, double *cpart, int nsplit) {
   const size_t lds = sizeof(double) * (2 * (size_t)FIT_COV_TILE * (16 * NBLK + 1) + 2 * FIT_COV_TILE);
   KWY_HIP(hipFuncSetAttribute((const void *)k_fit_cov<NBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<NBLK>, dim3((unsigned)(M * nsplit)), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, nsplit, means, stats, act, ntiles, cpart));
+  KWY_PROF(ctx, "k_fit_cov", hipLaunchKernelGGL(k_fit_cov<NBLK>, dim3((unsigned)(M * nsplit)), dim3(KWY_THREADS), lds, ctx->stream, X, resp, n, D, M, nsplit, means, stats, list, count, ntiles, cpart));
   return KWY_OK;
 }
 
@@ -747,25 +796,29 @@ extern "C" int kwy_gmm_em_cov_stats_dev(kwy_ctx *ctx, const double *X, int64_t n
   KWY_HIP(hipSetDevice(ctx->device));
   const int64_t len = (int64_t)M * D * D;
   const int nsplit = fit_cov_splits(n, M);
-  const int64_t ntiles = (n + FIT_COV_TILE - 1) / FIT_COV_TILE;
-  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)nsplit * len) + kwy_pad((size_t)M * ntiles)));
+  const int64_t ntiles = (n + 3) / 4;            // list entries per mixture: groups of four frames
+  KWY_TRY(kwy_arena_begin(ctx, kwy_pad(sizeof(double) * (size_t)nsplit * len) + kwy_pad((size_t)M * ntiles) +
+                               kwy_pad(sizeof(int32_t) * (size_t)M * ntiles) + kwy_pad(sizeof(int32_t) * (size_t)M)));
   double *cpart = kwy_arena<double>(ctx, (size_t)nsplit * len);
   unsigned char *act = (unsigned char *)kwy_arena_alloc(ctx, (size_t)M * ntiles);
-  if (!cpart || !act) { ctx->err = "gmm_em_cov: scratch"; return KWY_ENOMEM; }
-  hipLaunchKernelGGL(k_fit_active, dim3((unsigned)((ntiles + FIT_ACT_TILES - 1) / FIT_ACT_TILES)), dim3(KWY_THREADS), 0,
-                     ctx->stream, resp, n, D, M, stats, ntiles, act);
+  int32_t *list = kwy_arena<int32_t>(ctx, (size_t)M * ntiles);
+  int32_t *count = kwy_arena<int32_t>(ctx, (size_t)M);
+  if (!cpart || !act || !list || !count) { ctx->err = "gmm_em_cov: scratch"; return KWY_ENOMEM; }
+  hipLaunchKernelGGL(k_fit_active, dim3((unsigned)((ntiles + FIT_ACT_GROUPS - 1) / FIT_ACT_GROUPS)), dim3(KWY_THREADS),
+                     (size_t)M * FIT_ACT_GROUPS, ctx->stream, resp, n, D, M, stats, ntiles, act);
+  hipLaunchKernelGGL(k_fit_active_list, dim3((unsigned)M), dim3(KWY_THREADS), 0, ctx->stream, act, ntiles, list, count);
   KWY_HIP(hipGetLastError());
   switch ((D + 15) / 16) {
-    case 1: KWY_TRY(fit_cov_launch<1>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 2: KWY_TRY(fit_cov_launch<2>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 3: KWY_TRY(fit_cov_launch<3>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 4: KWY_TRY(fit_cov_launch<4>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 5: KWY_TRY(fit_cov_launch<5>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 6: KWY_TRY(fit_cov_launch<6>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 7: KWY_TRY(fit_cov_launch<7>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 8: KWY_TRY(fit_cov_launch<8>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    case 9: KWY_TRY(fit_cov_launch<9>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
-    default: KWY_TRY(fit_cov_launch<10>(ctx, X, resp, n, D, M, means, stats, act, ntiles, cpart, nsplit)); break;
+    case 1: KWY_TRY(fit_cov_launch<1>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 2: KWY_TRY(fit_cov_launch<2>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 3: KWY_TRY(fit_cov_launch<3>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 4: KWY_TRY(fit_cov_launch<4>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 5: KWY_TRY(fit_cov_launch<5>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 6: KWY_TRY(fit_cov_launch<6>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 7: KWY_TRY(fit_cov_launch<7>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 8: KWY_TRY(fit_cov_launch<8>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    case 9: KWY_TRY(fit_cov_launch<9>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
+    default: KWY_TRY(fit_cov_launch<10>(ctx, X, resp, n, D, M, means, stats, list, count, ntiles, cpart, nsplit)); break;
   }
   hipLaunchKernelGGL(k_fit_reduce_sym, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, cpart, nsplit, D,
                      M, sxx);
