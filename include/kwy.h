@@ -532,12 +532,17 @@ int kwy_km_update_dev(kwy_ctx *ctx, const double *stats, const double *centers_o
  * state (int64[4], zeroed by the caller before the first batch): [0] 0 = running, 1 = labels unchanged (strict
  * convergence), 2 = squared centre shift <= abs_tol (summed in numpy's order), 3 = a cluster is empty -- the
  * iteration is left after its sums (labels, resp, stats are its own, the centres not updated) for the caller to
- * relocate and finish, 4 = max_iter iterations done; [1] finished iterations; [2] changed labels of the last
+ * relocate and finish (resp is NOT up to date: kwy_km_onehot_dev), 4 = max_iter iterations done; [1] finished iterations; [2] changed labels of the last
  * assignment.  log: 2 doubles per finished iteration (changed labels, centre shift), max_iter rows.
  * Replaces the per-iteration host round trip of sklearn/cluster/_kmeans.py:_kmeans_single_lloyd. */
 int kwy_km_lloyd_dev(kwy_ctx *ctx, const double *Xc, int64_t n, int D, double *centers2, int M, int32_t *labels,
                      double *resp, unsigned long long *changed, double *stats, double *shift2, double abs_tol,
                      int iterations, int64_t max_iter, long long *state, double *log);
+/* resp[t][:] = the one-hot row of labels[t] (n x M): kwy_km_lloyd_dev sums the centroids from the labels and leaves
+ * `resp` alone (4 bytes per frame and iteration instead of M doubles written and read); the caller that wants
+ * scikit-learn's `resp` of the k-means initialisation (sklearn/mixture/_base.py:_initialize_parameters) asks for it
+ * once, after the loop. */
+int kwy_km_onehot_dev(kwy_ctx *ctx, const int32_t *labels, int64_t n, int M, double *resp);
 
 /* ---- training-set path (device-resident) ---------------------------------------------------------
  * What the reference does per parallel pair before the converter fit (Config.load_dataset ->

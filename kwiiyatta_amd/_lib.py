@@ -141,6 +141,7 @@ SIGNATURES = {
     'kwy_km_pp_pick_dev': (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     'kwy_km_assign_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     'kwy_km_update_dev': (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    'kwy_km_onehot_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp]),
     'kwy_km_lloyd_dev': (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_int, c_i64,
                          c_vp, c_vp]),
     'kwy_gmm_mlpg': (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),

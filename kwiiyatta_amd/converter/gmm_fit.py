@@ -275,6 +275,11 @@ class HipStats:
                                                  float(abs_tol), int(iterations), int(max_iter), self._p(state),
                                                  self._p(log)))
 
+    def km_onehot(self):
+        """resp <- the one-hot rows of the labels (the device loop does not keep them up to date)"""
+        self._chk(self._lib.lib.kwy_km_onehot_dev(self.ctx.handle, self._p(self.labels), self.n, self.M,
+                                                  self._p(self.resp)))
+
     def km_labels_of(self, i):
         return self.labels[i]
 
@@ -376,6 +381,7 @@ def _kmeans_init(stats, n_components, random_state, max_iter, tol, verbose):
             stats.km_lloyd(c2, abs_tol, min(LLOYD_BATCH, max_iter - n_iter), max_iter, state, log)
             code, n_iter, n_changed = state.tolist()[:3]
             if code == 3:
+                stats.km_onehot()
                 st = stats.stats
                 cur = n_iter & 1
                 _relocate_empty_clusters(stats, comm, st, c2[cur], (st[:, 0] == 0).nonzero().flatten(), row0)
@@ -392,6 +398,8 @@ def _kmeans_init(stats, n_components, random_state, max_iter, tol, verbose):
                 strict = code == 1
                 break
         centers = c2[n_iter & 1].clone()
+        if strict:
+            stats.km_onehot()               # (not strict: the assignment below writes them)
     else:
         centers_new = torch.empty_like(centers)
         for n_iter in range(1, max_iter + 1):

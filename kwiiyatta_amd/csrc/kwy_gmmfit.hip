@@ -262,7 +262,10 @@ template <int NBLK>
 __global__ __launch_bounds__(KWY_THREADS) void k_fit_sums(const double *__restrict__ X,
                                                          const double *__restrict__ resp, int64_t n, int D,
                                                          int M, int rows_per_chunk, double *__restrict__ part,
-                                                         const long long *__restrict__ gate) {
+                                                         const long long *__restrict__ gate,
+                                                         const int *__restrict__ labels) {
+  // labels (k-means): the weights are the one-hot rows of the labels, formed here -- 4 bytes per frame instead of a
+  // row of M doubles written by the assignment and read back (the same products and sums: x times 1.0 or 0.0)
   if (gate && gate[0]) return;    // (the device-driven Lloyd loop has stopped: kwy_km_lloyd_dev)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, ar = lane & 15, ak = lane >> 4;
   const int rb = 4 * blockIdx.y + wv;
@@ -283,7 +286,8 @@ __global__ __launch_bounds__(KWY_THREADS) void k_fit_sums(const double *__restri
     const double *px = X + tc * D;
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) xq[b] = px[b == NBLK - 1 ? clast : 16 * b + ar];
-    aq = (t < r1 && mok) ? resp[tc * M + mrow] : 0.0;
+    if (labels) aq = (t < r1 && mok && labels[tc] == mrow) ? 1.0 : 0.0;
+    else aq = (t < r1 && mok) ? resp[tc * M + mrow] : 0.0;
   };
 #pragma unroll
   for (int p = 0; p < FIT_SUM_PF; ++p) load(xs[p], as[p], p);
@@ -711,15 +715,15 @@ extern "C" int kwy_gmm_em_estep_dev(kwy_ctx *ctx, const double *X, int64_t n, in
 
 template <int NBLK>
 static void fit_sums_launch(kwy_ctx *ctx, const double *X, const double *resp, int64_t n, int D, int M, int rows,
-                            int nchunks, double *part, const long long *gate) {
-  KWY_PROF(ctx, "k_fit_sums", hipLaunchKernelGGL(k_fit_sums<NBLK>, dim3(nchunks, (M + 63) / 64), dim3(KWY_THREADS), 0, ctx->stream, X, resp, n, D, M, rows, part, gate));
+                            int nchunks, double *part, const long long *gate, const int *labels) {
+  KWY_PROF(ctx, "k_fit_sums", hipLaunchKernelGGL(k_fit_sums<NBLK>, dim3(nchunks, (M + 63) / 64), dim3(KWY_THREADS), 0, ctx->stream, X, resp, n, D, M, rows, part, gate, labels));
 }
 
 // stats[m][0] = sum_t r[t][m], stats[m][1+i] = sum_t r[t][m] x[t][i]   (local shard)
 int kwy_fit_sums_gated(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp, double *stats,
-                        const long long *gate) {
+                        const long long *gate, const int *labels) {
   KWY_TRY(fit_check(ctx, n, D, M));
-  if (!X || !resp || !stats) { ctx->err = "gmm_em_sums: null pointer"; return KWY_EINVAL; }
+  if (!X || (!resp && !labels) || !stats) { ctx->err = "gmm_em_sums: null pointer"; return KWY_EINVAL; }
   KWY_HIP(hipSetDevice(ctx->device));
   const int rows_per_chunk = fit_sum_rows(n);
   const int nchunks = (int)((n + rows_per_chunk - 1) / rows_per_chunk);
@@ -728,16 +732,16 @@ int kwy_fit_sums_gated(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, c
   double *part = kwy_arena<double>(ctx, (size_t)nchunks * len);
   if (!part) { ctx->err = "gmm_em_sums: scratch"; return KWY_ENOMEM; }
   switch ((D + 15) / 16) {
-    case 1: fit_sums_launch<1>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 2: fit_sums_launch<2>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 3: fit_sums_launch<3>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 4: fit_sums_launch<4>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 5: fit_sums_launch<5>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 6: fit_sums_launch<6>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 7: fit_sums_launch<7>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 8: fit_sums_launch<8>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    case 9: fit_sums_launch<9>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
-    default: fit_sums_launch<10>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate); break;
+    case 1: fit_sums_launch<1>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 2: fit_sums_launch<2>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 3: fit_sums_launch<3>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 4: fit_sums_launch<4>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 5: fit_sums_launch<5>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 6: fit_sums_launch<6>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 7: fit_sums_launch<7>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 8: fit_sums_launch<8>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    case 9: fit_sums_launch<9>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
+    default: fit_sums_launch<10>(ctx, X, resp, n, D, M, rows_per_chunk, nchunks, part, gate, labels); break;
   }
   hipLaunchKernelGGL(k_fit_reduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream, part, nchunks, len,
                      stats, gate);
@@ -747,7 +751,7 @@ int kwy_fit_sums_gated(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, c
 
 extern "C" int kwy_gmm_em_sums_dev(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp,
                                    double *stats) {
-  return kwy_fit_sums_gated(ctx, X, n, D, M, resp, stats, nullptr);
+  return kwy_fit_sums_gated(ctx, X, n, D, M, resp, stats, nullptr, nullptr);
 }
 
 // means[m][i] = stats[m][1+i] / (stats[m][0] + 10 eps)      (stats: globally reduced)

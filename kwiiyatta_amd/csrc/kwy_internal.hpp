@@ -91,9 +91,10 @@ int kwy_get_twiddles(kwy_ctx *ctx, int log2n, const kwy_c **out);
 int kwy_get_poly(kwy_ctx *ctx, uint64_t stride_steps, const uint4 **out);
 // pysptk.sp2mc's frequency transform for transform length N as a matrix [ncut][64] (kwy_mcep.hip): mc[j] = sum_n F[n][j] c[n]
 int kwy_get_sp2mc_matrix(kwy_ctx *ctx, int N, int order, double alpha, const double **out, int *ncut);
-// kwy_gmm_em_sums_dev whose kernels return at once when gate[0] != 0 (gate may be NULL): kwy_gmmfit.hip
+// kwy_gmm_em_sums_dev whose kernels return at once when gate[0] != 0 (gate may be NULL); with `labels` the weights are
+// the one-hot rows of the labels (resp is not read): kwy_gmmfit.hip
 int kwy_fit_sums_gated(kwy_ctx *ctx, const double *X, int64_t n, int D, int M, const double *resp, double *stats,
-                       const long long *gate);
+                       const long long *gate, const int *labels);
 // [max_c][nthreads] table: row c-1 holds x^(12*c*t) mod P, t < nthreads (chunk of c draws per thread)
 int kwy_get_poly_multi(kwy_ctx *ctx, int max_c, int nthreads, const uint4 **out);
 

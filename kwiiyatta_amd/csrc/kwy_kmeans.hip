@@ -689,20 +689,43 @@ extern "C" int kwy_km_lloyd_dev(kwy_ctx *ctx, const double *Xc, int64_t n, int D
                                 double *shift2, double abs_tol, int iterations, int64_t max_iter, long long *state,
                                 double *log) {
   KWY_TRY(km_check(ctx, n, D));
-  if (!Xc || !centers2 || !labels || !resp || !changed || !stats || !shift2 || !state || !log || M < 1 || M > 256 ||
+  (void)resp;    // (the one-hot rows are not kept up to date by the loop: kwy_km_onehot_dev after it)
+  if (!Xc || !centers2 || !labels || !changed || !stats || !shift2 || !state || !log || M < 1 || M > 256 ||
       iterations < 1 || max_iter < 1) {
     ctx->err = "km_lloyd: null pointer, M outside 1..256 or no iterations";
     return KWY_EINVAL;
   }
   KWY_HIP(hipSetDevice(ctx->device));
   for (int it = 0; it < iterations; ++it) {
-    KWY_TRY(km_assign_core(ctx, Xc, n, D, centers2, M, labels, resp, changed, state));
-    KWY_TRY(kwy_fit_sums_gated(ctx, Xc, n, D, M, resp, stats, state));
+    KWY_TRY(km_assign_core(ctx, Xc, n, D, centers2, M, labels, nullptr, changed, state));
+    KWY_TRY(kwy_fit_sums_gated(ctx, Xc, n, D, M, nullptr, stats, state, labels));
     hipLaunchKernelGGL(k_km_update_gated, dim3(M), dim3(KWY_THREADS), 0, ctx->stream, stats, centers2, M, D, shift2,
                        state);
     hipLaunchKernelGGL(k_km_decide, dim3(1), dim3(64), 0, ctx->stream, stats, changed, shift2, M, D, abs_tol,
                        (long long)max_iter, state, log);
   }
+  KWY_HIP(hipGetLastError());
+  return KWY_OK;
+}
+
+// resp[t][:] = the one-hot row of labels[t] (what kwy_km_assign_dev writes beside the labels)
+__global__ __launch_bounds__(KWY_THREADS) void k_km_onehot(const int *__restrict__ labels, int64_t n, int M,
+                                                          double *__restrict__ resp) {
+  const int c = threadIdx.x & 15, f = threadIdx.x >> 4;
+  for (int pass = 0; pass < KWY_THREADS / 16; ++pass) {
+    const int64_t t = (int64_t)blockIdx.x * KWY_THREADS + 16 * pass + f;
+    if (t >= n) continue;
+    const int bi = labels[t];
+    for (int m = c; m < M; m += 16) resp[t * M + m] = (m == bi) ? 1.0 : 0.0;
+  }
+}
+
+extern "C" int kwy_km_onehot_dev(kwy_ctx *ctx, const int *labels, int64_t n, int M, double *resp) {
+  if (!ctx) return KWY_EINVAL;
+  if (!labels || !resp || n <= 0 || M < 1) { ctx->err = "km_onehot: null pointer or empty"; return KWY_EINVAL; }
+  KWY_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_km_onehot, dim3((unsigned)((n + KWY_THREADS - 1) / KWY_THREADS)), dim3(KWY_THREADS), 0,
+                     ctx->stream, labels, n, M, resp);
   KWY_HIP(hipGetLastError());
   return KWY_OK;
 }
