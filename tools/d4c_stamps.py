@@ -12,14 +12,13 @@ lib.kwy_ctx_debug_buffer.argtypes = [c_vp, c_vp]   # diagnostic hook, not in inc
 lib.kwy_ctx_debug_buffer(p.ctx.handle, c_vp(dbg.data_ptr()))
 p.run(); p.sync(); p.run(); p.sync()
 d = dbg.cpu().numpy()
-names = ['start','rng','win0','fft+cen0','win1','fft+cen1','dccorr','win2','fft2','pow+smooth','gd smooth x2','band0 fill','band0 fft','band0 select','bands end','output']
+names = ['start','rng','win0','fft+cen0','win1','fft+cen1','dccorr','win2','fft2','pow+smooth','gd smooth x2']
 print('frame', frame, 'f0', f0[frame])
-for i in range(1,16):
+for i in range(1,11):
     print(names[i].ljust(16), d[i]-d[i-1])
-print('total', d[15]-d[0])
+print('body total', d[15]-d[0])
 names2 = ['bands start','band1 head','band1 fft','band1 bins','band1 select','bands loop end','output']
 for i in range(17,23):
     print(names2[i-16].ljust(16), d[i]-d[i-1])
 print('bands total', d[22]-d[16])
 print('select ctl words (band 0/2/4, band 1/3):', d[24:36], d[36:48])
-print('select phases (min/max+setup, slots r0, barrier, scan, barrier, finish, sums):', np.diff(d[48:56]))
