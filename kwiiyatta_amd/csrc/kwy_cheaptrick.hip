@@ -222,11 +222,15 @@ __global__ __launch_bounds__(KWY_THREADS, LOG2N <= 11 ? 5 : 4) void k_cheaptrick
     }, S, L, tot);
     const double origin_of_mirroring_axis = -(boundary - 0.5) * fs / N;
     const double dfi = (double)fs / N;
+    // The bins are equidistant: position and weight of a bin's two interpolated reads are those of bin 0 shifted by k,
+    // formed once (uniform) instead of per bin with a division each (kwy_d4c.hip: d4c_smoothing_taps).
+    const double rl = (-width / 2.0 - origin_of_mirroring_axis) / dfi, rh = (-width / 2.0 + width - origin_of_mirroring_axis) / dfi;
+    const int cl = __builtin_amdgcn_readfirstlane((int)rl), ch = __builtin_amdgcn_readfirstlane((int)rh);
+    const double fl = kwy_uniform(rl - (double)(int)rl), fh = kwy_uniform(rh - (double)(int)rh);
     for (int k = tid; k <= H; k += KWY_THREADS) {
-      double fa = (double)k / N * fs - width / 2.0;
-      double low = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
-      fa += width;
-      double high = ct_interp1q(origin_of_mirroring_axis, dfi, S, L, fa);
+      const int b0 = k + cl, b1 = k + ch;
+      const double l0 = S[b0], l1 = S[min(b0 + 1, L - 1)], h0 = S[b1], h1 = S[min(b1 + 1, L - 1)];
+      const double low = __builtin_fma(l1 - l0, fl, l0), high = __builtin_fma(h1 - h0, fh, h0);
       // the serial CPU cumulative sum is monotone, so its differences are >= 0; the block-parallel one can
       // come out an ulp of the running total below zero in bins that carry no energy at all
       P[k] = fmax((high - low) / width, 0.0);
