@@ -818,11 +818,9 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   const int nn = p.nbands + 2;
   for (int k = tid; k < p.K; k += NT) {
     double xi = (double)k * p.fs / p.fft_size;
-    int seg = 0;  // number of nodes <= xi
-    for (int j = 0; j < nn; ++j) {
-      double xj = (j <= p.nbands) ? j * D4C_FREQ_INTERVAL : p.fs / 2.0;
-      if (xj <= xi) seg = j + 1;
-    }
+    // number of nodes <= xi: the nodes are the multiples of the band interval up to nbands, then fs / 2 (the quotient
+    // of an exact multiple is exact, so the floor agrees with the comparisons it replaces)
+    int seg = min((int)(xi / D4C_FREQ_INTERVAL) + 1, p.nbands + 1);
     if (seg < 1) seg = 1;
     if (seg > nn - 1) seg = nn - 1;
     double xa = (seg - 1 <= p.nbands) ? (seg - 1) * D4C_FREQ_INTERVAL : p.fs / 2.0;
