@@ -145,8 +145,8 @@ int kwy_stonemask(kwy_ctx *ctx, const double *x, int64_t x_length, int fs,
                   double *refined_f0);
 /* The f0 track without the host (round 5): what Analyzer.extract_f0 does in front of every analysis,
  * kwiiyatta/vocoder/world.py:33-41, on DEVICE pointers, enqueued on the context's stream and not synchronised; the
- * batch forms take the utterances of a wave in one pass of launches (<= 16 per pass), as kwy_cheaptrick_batch_dev
- * does.  Every job's result equals the host entry's bit for bit (the host entries run the same pass on staged copies).
+ * batch forms take the utterances of a wave in one pass of launches (DIO <= 32 per pass: the two sides of a wave of 16
+ * pairs share the single-wavefront contour repair; StoneMask <= 16), as kwy_cheaptrick_batch_dev does.  Every job's result equals the host entry's bit for bit (the host entries run the same pass on staged copies).
  * status (one int32 on the device per utterance, or NULL): cleared by the call, set to 1 when an engine's
  * zero-crossing buffer overflowed (kwy_dio reports that as KWY_EHIP); a driver reads the words back once per wave. */
 typedef struct kwy_f0_job {

@@ -44,7 +44,11 @@
 #define DIO_NT 512                   // threads of the filter kernel: one radix-8 butterfly per thread and pass
 #define DIO_PARTS 256                // partial sums of the mean
 
-// ---- one pass of launches over <= KWY_BATCH_MAX utterances -------------------------------------------
+// A pass takes up to 32 utterances (twice the other batch entries' 16: 40 bytes of descriptor each, by value): the
+// contour repair is ONE wavefront per utterance walking ~2 000 dependent look-ups -- 0.49 ms however many utterances
+// walk side by side, alone on the chip inside a step's stream -- so the 32 utterances of a wave of 16 pairs share it.
+#define DIO_BATCH 32
+// ---- one pass of launches over <= DIO_BATCH utterances -------------------------------------------
 // Everything a kernel needs travels by value in this struct (no descriptor in device memory: capturable in a HIP
 // graph).  Scratch: one block per utterance at scratch + u * stride, laid out for the LONGEST utterance of the pass.
 struct dio_utt {
@@ -65,7 +69,7 @@ struct dio_plan {
   char *scratch;
   int64_t stride;
   int64_t off_part, off_lists, off_cnt, off_nedges, off_fine, off_cand, off_score, off_w1, off_w2, off_idx, off_trans;
-  dio_utt u[KWY_BATCH_MAX];
+  dio_utt u[DIO_BATCH];
   template <class T>
   __device__ __forceinline__ T *at(int utt, int64_t off) const { return (T *)(scratch + utt * stride + off); }
 };
@@ -783,12 +787,12 @@ static int dio_prepare(kwy_ctx *ctx, int fs, double f0_floor, double f0_ceil, do
   return KWY_OK;
 }
 
-// One pass of launches over jobs[0 .. count), count <= KWY_BATCH_MAX (device pointers); scratch: `count` blocks of
+// One pass of launches over jobs[0 .. count), count <= DIO_BATCH (device pointers); scratch: `count` blocks of
 // the plan's stride; a job without a status word gets spare[u].
 static int dio_pass(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, dio_plan p, char *scratch, int *spare) {
   p.count = count;
   p.scratch = scratch;
-  for (int u = 0; u < KWY_BATCH_MAX; ++u) {
+  for (int u = 0; u < DIO_BATCH; ++u) {
     if (u < count) {
       const kwy_f0_job &q = jobs[u];
       p.u[u] = dio_utt{q.x, q.temporal_positions, q.f0, q.status ? (int *)q.status : spare + u, (int)q.x_length,
@@ -825,7 +829,7 @@ static int dio_pass(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, dio_plan p,
   return KWY_OK;
 }
 
-// pyworld.dio for `count` utterances (device pointers, not synchronised): passes of <= KWY_BATCH_MAX utterances
+// pyworld.dio for `count` utterances (device pointers, not synchronised): passes of <= DIO_BATCH utterances
 extern "C" int kwy_dio_batch_dev(kwy_ctx *ctx, const kwy_f0_job *jobs, int count, int fs, double f0_floor,
                                  double f0_ceil, double channels_in_octave, double frame_period_ms, int speed,
                                  double allowed_range) {
@@ -844,14 +848,14 @@ extern "C" int kwy_dio_batch_dev(kwy_ctx *ctx, const kwy_f0_job *jobs, int count
   size_t block;
   KWY_TRY(dio_prepare(ctx, fs, f0_floor, f0_ceil, channels_in_octave, frame_period_ms, speed, allowed_range, n_max,
                       &p, &block));
-  const int per_pass = count < KWY_BATCH_MAX ? count : KWY_BATCH_MAX;
-  KWY_TRY(kwy_arena_begin(ctx, block * per_pass + kwy_pad(sizeof(int) * KWY_BATCH_MAX)));
+  const int per_pass = count < DIO_BATCH ? count : DIO_BATCH;
+  KWY_TRY(kwy_arena_begin(ctx, block * per_pass + kwy_pad(sizeof(int) * DIO_BATCH)));
   char *scratch = (char *)kwy_arena_alloc(ctx, block * per_pass);
-  int *spare = kwy_arena<int>(ctx, KWY_BATCH_MAX);
+  int *spare = kwy_arena<int>(ctx, DIO_BATCH);
   if (!scratch || !spare) { ctx->err = "dio: scratch arena too small"; return KWY_ENOMEM; }
   // (the passes of a call share the scratch: they run one after the other on the context's stream)
-  for (int i0 = 0; i0 < count; i0 += KWY_BATCH_MAX)
-    KWY_TRY(dio_pass(ctx, jobs + i0, count - i0 < KWY_BATCH_MAX ? count - i0 : KWY_BATCH_MAX, p, scratch, spare));
+  for (int i0 = 0; i0 < count; i0 += DIO_BATCH)
+    KWY_TRY(dio_pass(ctx, jobs + i0, count - i0 < DIO_BATCH ? count - i0 : DIO_BATCH, p, scratch, spare));
   return KWY_OK;
 }
 
