@@ -1177,8 +1177,19 @@ static int fastdtw_core(kwy_ctx *ctx, const dtw_pair *pairs, int n, int dim, int
     if (!small_dist)
       KWY_PROF(ctx, "k_dtw_dist", hipLaunchKernelGGL(k_dtw_dist, dim3((unsigned)lv_units, n), dim3(KWY_THREADS), 0, ctx->stream, b, l));
     if (small) {
-      b.lds_bytes = (int)big_lds;
-      KWY_PROF(ctx, "k_dtw_small", hipLaunchKernelGGL(k_dtw_small, dim3(n), dim3(64 * DTW_WAVES), big_lds, ctx->stream, b, l,
+      // A single-strip level asks for the LDS it can use, not for a whole CU's: the series (when it computes the
+      // distances itself), the boundary rows, the codes' places and planes of <= 64 rows, the trace's tables -- a few
+      // dozen KB for the coarse levels, so that its sixteen workgroups find room beside the resident workgroups of a
+      // chip-wide kernel instead of waiting for a CU to drain (0.9 ms per launch inside a step against 0.05 alone).
+      const size_t dist_b = small_dist ? sizeof(double) * (size_t)(len_x + len_y) * (size_t)(dim | 1) : 0;
+      const size_t bnd_b = sizeof(double) * DTW_WAVES * ((size_t)len_y + 2);
+      const size_t groups = 64 * ((size_t)len_y / 64 + 2);                     // 64-column plane groups of 64 rows
+      const size_t codes_b = (size_t)64 * 4 * (size_t)std::min<int64_t>(len_y, 8 * (int64_t)radius + 128) + 32 * groups;
+      const size_t trace_b = 16 * ((size_t)len_x + 2) + 8 * DTW_TRACE_NT + 16 * groups + 256;
+      size_t need = std::max(std::max(dist_b, bnd_b), std::max(codes_b, trace_b)) + 4096;
+      need = std::min(big_lds, (need + 1023) & ~(size_t)1023);
+      b.lds_bytes = (int)need;
+      KWY_PROF(ctx, "k_dtw_small", hipLaunchKernelGGL(k_dtw_small, dim3(n), dim3(64 * DTW_WAVES), need, ctx->stream, b, l,
                                                        small_dist ? 1 : 0));
       continue;
     }
