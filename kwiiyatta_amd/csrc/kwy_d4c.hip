@@ -686,7 +686,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 1 : 3) void k_d
 template <int LOG2N>
 static constexpr size_t d4c_bands_lds() {
   constexpr int N = 1 << LOG2N, H = N / 2, NT = d4c_nt<LOG2N>::value;
-  return sizeof(double) * (16 + D4C_MAX_BANDS + 2) + sizeof(double) * ((2 * H + 2) + 2) +
+  return sizeof(double) * (16 + D4C_MAX_BANDS + 2 + 2 * NT) + sizeof(double) * ((2 * H + 2) + 2) +
          ((sizeof(uint32_t) * KWY_SELECT_WORDS(NT) > sizeof(double) * (2 * H + 4))
               ? sizeof(uint32_t) * KWY_SELECT_WORDS(NT) - sizeof(double) * (2 * H + 4) : 0);
 }
@@ -706,7 +706,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   extern __shared__ double smem[];
   double *red = smem;                        // 16
   double *coarse = red + 16;                 // D4C_MAX_BANDS + 2
-  kwy_c *B = (kwy_c *)(coarse + D4C_MAX_BANDS + 2);   // H+1 complex (+2 doubles)
+  double *wns = coarse + D4C_MAX_BANDS + 2;  // 2 NT: the thread's two window values (sparse path), parked between bands
+  kwy_c *B = (kwy_c *)(wns + 2 * NT);        // H+1 complex (+2 doubles)
   double *Bd = (double *)B;
   uint32_t *hist = (uint32_t *)B;
 
@@ -718,13 +719,11 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   const double f0v = kwy_uniform(batch.u[utt].f0[frame]);
   if (f0v == 0.0 || kwy_uniform(batch.u[utt].ap0[frame]) <= p.threshold) return;   // the body wrote the frame's row
   const double cf0 = kwy_uniform(f0v > D4C_FLOOR_F0 ? f0v : D4C_FLOOR_F0);
-  kwy_c tw4[4];
-  kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH, tw4);
-  const kwy_c twb = twN[tid];
   const double *Dv = dvbuf + (size_t)frame * p.dv_stride;
   D4C_STAMP(16);
 
-  const int boundary = kwy_matlab_round(N * 8.0 / p.window_length);
+  // (uniform values formed in vector registers: moved to scalar ones, the kernel sits at its register cap)
+  const int boundary = __builtin_amdgcn_readfirstlane(kwy_matlab_round(N * 8.0 / p.window_length));
   const int half_window_length = p.window_length / 2;
   constexpr bool sparse = SPARSE;
   // the Nuttall window stays in registers: elements 2 tid, 2 tid + 1 (and the last one) for the copy-only first
@@ -733,7 +732,7 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   if constexpr (sparse) {
     if (2 * tid < p.window_length) ns0 = nuttall[2 * tid];
     if (2 * tid + 1 < p.window_length) ns1 = nuttall[2 * tid + 1];
-    if (2 * (H / 8) < p.window_length) ns2 = nuttall[2 * (H / 8)];
+    wns[2 * tid] = ns0; wns[2 * tid + 1] = ns1;      // (read back by the same thread: no barrier)
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -748,6 +747,12 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
   double nx1 = (mine1 && p.nbands > 0) ? Dfirst[2 * tid + 1] : 0.0;
   for (int b = 0; b < p.nbands; ++b) {
     const int tid = kwy_tid_opaque();
+    // the thread's pass factors and bin twiddle are fetched again for every band (five 16-byte loads from L1 / L2,
+    // through the opaque thread index so that they are not hoisted) instead of living in 20 registers across the
+    // selection, where the kernel is at its cap of 128
+    kwy_c tw4[4];
+    kwy_fft_thread_twiddles<LOG2N - 1, NT>(twH + (tid - (int)threadIdx.x), tw4);
+    const kwy_c twb = twN[tid];
     const double *Dc = Dv + ((int)(D4C_FREQ_INTERVAL * (b + 1) * N / p.fs) - half_window_length);
     const double c0 = nx0, c1 = nx1;
     if (b == 1) D4C_STAMP(17);
@@ -759,8 +764,8 @@ __global__ __launch_bounds__(d4c_nt<LOG2N>::value, LOG2N >= 13 ? 2 : 4) void k_d
     }
     if constexpr (sparse) {
       // only the first H/8 (+1) packed points are non-zero: the first pass needs no input buffer
-      kwy_c a0 = {c0 * ns0, c1 * ns1}, a1 = {0.0, 0.0};
-      if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * ns2;
+      kwy_c a0 = {c0 * wns[2 * tid], c1 * wns[2 * tid + 1]}, a1 = {0.0, 0.0};
+      if (tid == 0 && 2 * (H / 8) < p.window_length) a1.x = Dc[2 * (H / 8)] * nuttall[2 * (H / 8)];
       kwy_fft_pass8_first_sparse_core<LOG2N - 1, NT, false>(B, kwy_tw_reg{tw4[0]}, a0, a1);
       kwy_fft_inplace_rest_w<LOG2N - 1, NT, false>(B, tw4);
       if (b == 1) D4C_STAMP(18);
